@@ -1,0 +1,165 @@
+/*
+ * toist_hip.h -- C ABI of the MI355X-native (gfx950) TOIST/MDETR hot path.
+ *
+ * The reference (AIR-DISCOVER/TOIST) has no FFI/plugin interface of its own: its hot path is stock
+ * torch ops called from Python.  This header is therefore the boundary a
+ * maintainer binds from Python with ctypes: plain pointers and sizes, no torch
+ * types.  Each entry point names the reference call site it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller unless marked "host";
+ *    the library never allocates or frees device memory and keeps no mutable global state;
+ *  - every entry point only enqueues work on `stream` (a hipStream_t passed as void*) and never
+ *    synchronises with the host;
+ *  - return value: TOIST_OK (0) or a negative TOIST_E* code; the message for the last error of the
+ *    calling thread is available from toist_last_error();
+ *  - bf16 tensors are raw uint16 (upper half of an IEEE fp32), activations are row-major with the
+ *    channel / feature axis innermost (NHWC for feature maps, [tokens, d] for sequences).
+ */
+#ifndef TOIST_HIP_H
+#define TOIST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOIST_OK 0
+#define TOIST_EINVAL (-1) /* bad shape / alignment / unsupported combination */
+#define TOIST_EHIP (-2)   /* a HIP runtime call or kernel launch failed */
+
+#define TOIST_ABI_VERSION 1
+
+int toist_version(void);
+/* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
+int toist_last_error(char* buf, size_t cap);
+
+/* ------------------------------------------------------------------------------------------------
+ * Hungarian matcher.  Replaces HungarianMatcher.forward, /root/reference/models/matcher.py:39-87
+ * (softmax + class/L1/GIoU cost, `.cpu()` sync, per-image scipy.optimize.linear_sum_assignment),
+ * for L decoder layers x B images in one launch.
+ *   logits   [L,B,Q,K] f32      boxes    [L,B,Q,4] f32 (cxcywh)
+ *   tgt_boxes[Ttot,4]  f32      pos_map  [Ttot,K]  f32
+ *   tgt_off  [B+1] i32 prefix sums of T_b          match_off [B+1] i32 prefix sums of min(Q,T_b)
+ *   max_T    host value, max_b T_b (sizes the LDS)
+ *   src_idx / tgt_idx [L, match_off[B]] i64: for image b the slice [match_off[b], match_off[b+1])
+ *            holds the matched query indices (ascending) and their target indices (image-local),
+ *            exactly the pair linear_sum_assignment returns for the [Q,T_b] block.
+ *   status   [L*B] i32: 0 ok, 1 = cost block holds NaN/-inf (SciPy: "matrix contains invalid numeric
+ *            entries"), 2 = infeasible.
+ *   cost_out optional [L, B*Q, Ttot] f32 (only the per-image diagonal blocks are written).
+ */
+int toist_matcher(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
+                  const int32_t* tgt_off, const int32_t* match_off, int L, int B, int Q, int K, int max_T,
+                  float w_class, float w_bbox, float w_giou, int64_t* src_idx, int64_t* tgt_idx,
+                  int32_t* status, float* cost_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM family:  C[z][m][n] = epilogue( sum_k A[z][m][k] * B[z][n][k] ).
+ * One descriptor covers nn.Linear forward/dgrad/wgrad (transformer.py:273-304,362-408, HF RoBERTa),
+ * the attention batched products, and ResNet convolutions as im2col-free implicit GEMM on NHWC
+ * activations (backbone.py:75 -> torchvision ResNet body; FrozenBatchNorm2d, backbone.py:48-58, is
+ * the per-channel scale/shift of the epilogue).
+ */
+enum {
+    TOIST_A_ROWK = 0,  /* A[m][k] at a + m*lda + k                                  (k contiguous) */
+    TOIST_A_KROW = 1,  /* A[m][k] at a + k*lda + m                                  (m contiguous) */
+    TOIST_A_CONV = 2,  /* m = output pixel (n,oy,ox), k = (r,s,c): gather from NHWC source         */
+    TOIST_A_CONVT = 3  /* m = input pixel (n,iy,ix),  k = (r,s,co): transposed-conv gather (dgrad) */
+};
+enum {
+    TOIST_B_ROWK = 0, /* B[n][k] at b + n*ldb + k */
+    TOIST_B_KROW = 1, /* B[n][k] at b + (k % kin)*ldb + (k / kin)*tap_stride + n */
+    TOIST_B_CONVX = 2 /* n = (r,s,c), k = output pixel: gather from NHWC source (conv wgrad) */
+};
+enum {
+    TOIST_ACT_NONE = 0,
+    TOIST_ACT_RELU = 1,
+    TOIST_ACT_GELU = 2,        /* exact erf GELU */
+    TOIST_ACT_SIGMOID = 3,
+    TOIST_ACT_MASK_POS = 4,    /* v = aux > 0 ? v : 0           (ReLU backward)       */
+    TOIST_ACT_GELU_BWD = 5,    /* v *= gelu'(aux)               (aux = pre-activation) */
+    TOIST_ACT_SIGMOID_BWD = 6  /* v *= aux * (1 - aux)          (aux = sigmoid output) */
+};
+
+typedef struct toist_operand {
+    const void* ptr;     /* bf16 */
+    int64_t bs_outer;    /* element stride of batch index z / batch_inner */
+    int64_t bs_inner;    /* element stride of batch index z % batch_inner */
+    int32_t ld;          /* leading dimension in elements */
+    int32_t kin;         /* B_KROW two-level k (0 = plain) */
+    int64_t tap_stride;  /* B_KROW two-level k */
+    /* gather geometry (CONV / CONVT / CONVX) */
+    int32_t SH, SW, SC;  /* source tensor [N,SH,SW,SC] */
+    int32_t PH, PW;      /* pixel space enumerated by the row (A) or k (B) index: [N,PH,PW] */
+    int32_t R, S, stride, pad, dil;
+} toist_operand;
+
+typedef struct toist_epilogue {
+    float alpha;          /* v = acc * alpha */
+    const float* scale;   /* [N] f32 or NULL: v = v * scale[n] */
+    const float* shift;   /* [N] f32 or NULL: v = v + shift[n] */
+    const void* res;      /* bf16 residual, same row map as C, or NULL */
+    int32_t ldr;
+    const void* aux;      /* bf16 operand of the *_BWD / MASK_POS activations */
+    int32_t ldaux;
+    int32_t act;          /* TOIST_ACT_* */
+    void* pre_out;        /* optional bf16 copy of v before the activation (ld = ldc) */
+    int32_t out_f32;      /* C is f32 instead of bf16 */
+    int32_t accumulate;   /* C += v with f32 atomics (requires out_f32); implied by split_k > 1 */
+    /* optional row scatter of C/res/aux: m = (n,oy,ox) in [*,cOH,cOW] -> ((n*cH + oy*cst)*cW + ox*cst) */
+    int32_t cmap, cH, cW, cOH, cOW, cst;
+    /* dropout: where = 0 none, 1 = before the residual add, 2 = after the activation */
+    int32_t drop_where;
+    float drop_p;
+    uint64_t drop_seed;
+} toist_epilogue;
+
+typedef struct toist_gemm {
+    int32_t M, N, K;
+    int32_t a_kind, b_kind;
+    toist_operand a, b;
+    void* c;
+    int32_t ldc;
+    int64_t cs_outer, cs_inner; /* batch strides of C (and res/aux/pre_out) */
+    int32_t batch, batch_inner; /* z in [0,batch): outer = z / batch_inner, inner = z % batch_inner */
+    int32_t split_k;            /* >= 1; > 1 needs out_f32 (atomic accumulation into pre-zeroed C) */
+    int32_t tile;               /* 0 = auto, 64 or 128 */
+    int32_t flags;              /* bit0: build K-strided fragments with ds_write_b16 instead of
+                                   ds_read_b64_tr_b16 (validation fallback) */
+    toist_epilogue epi;
+} toist_gemm;
+
+int toist_gemm_bf16(const toist_gemm* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row kernels (bf16 data, f32 statistics).
+ *  layernorm: nn.LayerNorm call sites transformer.py:279-280,341-345,481 and HF RoBERTa.
+ *    bwd accumulates dgamma/dbeta with f32 atomics (caller zeroes them) and can also emit
+ *    dx_drop = dropout-masked dx (mask regenerated from (seed, row*D+col), see toist_dropout_bf16).
+ *  softmax:  the masked softmax inside nn.MultiheadAttention (transformer.py:273,337-338):
+ *    scores/probs are [nbatch*H, Sq, ld] with ld >= roundup8(Sk); key_pad [nbatch,Sk] u8 (1 = pad).
+ *    p_drop (optional) receives dropout(p) for the PV product.
+ */
+int toist_layernorm_fwd(const void* x, const float* gamma, const float* beta, float eps, int rows, int D,
+                        void* y, float* mean, float* rstd, void* stream);
+int toist_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                        int rows, int D, void* dx, float* dgamma, float* dbeta, void* dx_drop, float drop_p,
+                        uint64_t seed, void* stream);
+int toist_softmax_fwd(const void* scores, const uint8_t* key_pad, int nbatch, int H, int Sq, int Sk, int ld,
+                      void* p, void* p_drop, float drop_p, uint64_t seed, void* stream);
+int toist_softmax_bwd(const void* p, const void* dp, int rows, int Sk, int ld, void* ds, float drop_p,
+                      uint64_t seed, void* stream);
+/* out[n] += sum_m g[m][n]  (bias gradient; out is f32, caller zeroes it) */
+int toist_colsum(const void* g, int M, int N, int ld, float* out, void* stream);
+/* out = a + b, b broadcast with period b_period elements (with_pos_embed, transformer.py:287-288) */
+int toist_add_bf16(const void* a, const void* b, int64_t n, int64_t b_period, void* out, void* stream);
+/* out = dropout(x): keep iff hash(seed, flat index) >= p*2^32, kept values scaled by 1/(1-p) */
+int toist_dropout_bf16(const void* x, int64_t n, float p, uint64_t seed, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOIST_HIP_H */

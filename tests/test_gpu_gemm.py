@@ -1,0 +1,200 @@
+"""GPU parity of the bf16 MFMA GEMM / implicit-conv family against fp32 CPU math on the same
+bf16-rounded inputs.  Tolerance: the output is bf16 (rel 2^-8) with fp32 accumulation, so
+|err| <= 1e-2 * |ref| + 2e-2 * sqrt(K)-scaled absolute slack (stated per test)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _rand(shape, gen, scale=1.0):
+    return (torch.randn(*shape, generator=gen) * scale).to(BF)
+
+
+def _close(got, ref, K, name, rtol=1.5e-2, atol_unit=4e-3):
+    got = got.float().cpu()
+    atol = atol_unit * math.sqrt(K)
+    err = (got - ref).abs()
+    bad = err > (atol + rtol * ref.abs())
+    assert not bool(bad.any()), f"{name}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.4g} (atol {atol:.3g})"
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(128, 128, 32, 128), (200, 72, 96, 64), (333, 256, 256, 0), (100, 4, 256, 64), (1024, 512, 2048, 128)])
+def test_linear_fwd(dev, M, N, K, tile):
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = _rand((M, K), g), _rand((N, K), g, 0.1)
+    bias = torch.randn(N, generator=g)
+    ref = x.float() @ w.float().t() + bias
+    out = ops.linear(x.to(dev), w.to(dev), bias.to(dev), tile=tile)
+    _close(out, ref, K, "linear")
+    out32 = ops.linear(x.to(dev), w.to(dev), bias.to(dev), out_dtype=torch.float32, tile=tile)
+    _close(out32, ref, K, "linear f32 out", rtol=2e-3, atol_unit=1e-4)
+
+
+def test_linear_epilogues(dev):
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 300, 264, 128
+    x, w = _rand((M, K), g), _rand((N, K), g, 0.1)
+    bias, scale = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
+    res = _rand((M, N), g)
+    base = (x.float() @ w.float().t()) * scale + bias + res.float()
+    xd, wd, bd, sd, rd = x.to(dev), w.to(dev), bias.to(dev), scale.to(dev), res.to(dev)
+    pre = torch.empty(M, N, dtype=BF, device=dev)
+    out = ops.linear(xd, wd, bd, scale=sd, res=rd, act=k.ACT_RELU, pre_out=pre)
+    _close(out, base.clamp(min=0), K, "relu")
+    _close(pre, base, K, "pre_out")
+    out = ops.linear(xd, wd, bd, scale=sd, res=rd, act=k.ACT_GELU)
+    _close(out, F.gelu(base), K, "gelu")
+    out = ops.linear(xd, wd, bd, scale=sd, res=rd, act=k.ACT_SIGMOID)
+    _close(out, torch.sigmoid(base), K, "sigmoid")
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_linear_dgrad_wgrad(dev, flags):
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 416, 264, 136
+    dy, w, x = _rand((M, N), g), _rand((N, K), g, 0.1), _rand((M, K), g)
+    aux = _rand((M, K), g)
+    dx_ref = dy.float() @ w.float()
+    dx = ops.linear_dgrad(dy.to(dev), w.to(dev), flags=flags)
+    _close(dx, dx_ref, N, f"dgrad flags={flags}")
+    dxm = ops.linear_dgrad(dy.to(dev), w.to(dev), act=k.ACT_MASK_POS, aux=aux.to(dev), alpha=2.0, flags=flags)
+    _close(dxm, torch.where(aux.float() > 0, 2.0 * dx_ref, torch.zeros_like(dx_ref)), N, "dgrad mask")
+    dw_ref = dy.float().t() @ x.float()
+    for sk in (1, 4):
+        dw = ops.linear_wgrad(dy.to(dev), x.to(dev), flags=flags, split_k=sk)
+        _close(dw, dw_ref, M, f"wgrad flags={flags} split={sk}", rtol=3e-3, atol_unit=1e-4)
+    db = ops.bias_grad(dy.to(dev))
+    _close(db, dy.float().sum(0), M, "bias grad", rtol=3e-3, atol_unit=1e-4)
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("C,Co,R,stride,pad,H,W", [(64, 64, 3, 1, 1, 20, 24), (64, 128, 3, 2, 1, 21, 20), (256, 512, 1, 2, 0, 16, 16),
+                                                   (128, 256, 1, 1, 0, 10, 12), (8, 64, 7, 2, 3, 40, 40)])
+def test_conv_fwd_bwd(dev, C, Co, R, stride, pad, H, W):
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(C + Co + R)
+    Nb = 3
+    x = torch.randn(Nb, C, H, W, generator=g).to(BF)
+    w = (torch.randn(Co, C, R, R, generator=g) * (1.0 / math.sqrt(C * R * R))).to(BF)
+    scale, shift = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+    xr = x.float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    y = F.conv2d(xr, wr, stride=stride, padding=pad)
+    OH, OW = y.shape[-2:]
+    res = torch.randn(Nb, Co, OH, OW, generator=g).to(BF)
+    ref = F.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res.float())
+    x_d, w_d = _nhwc(x).to(dev), _nhwc(w).to(dev)  # NHWC / KRSC
+    out = ops.conv2d(x_d, w_d, stride=stride, pad=pad, scale=scale.to(dev), shift=shift.to(dev), res=_nhwc(res).to(dev), act=k.ACT_RELU)
+    _close(out, _nhwc(ref.detach()), C * R * R, "conv fwd")
+    if C == 8:
+        return  # stem is frozen: no backward needed
+    dy = torch.randn(Nb, Co, OH, OW, generator=g).to(BF)
+    y.backward(dy.float())
+    for flags in (0, 1):
+        dx = ops.conv2d_dgrad(_nhwc(dy).to(dev), w_d, (H, W), stride=stride, pad=pad, flags=flags)
+        if R == 1 and stride > 1:
+            # scatter form: untouched rows keep their previous content -> compare only written rows
+            full = torch.zeros(Nb, H, W, C, dtype=BF, device=dev)
+            dx = ops.conv2d_dgrad(_nhwc(dy).to(dev), w_d, (H, W), stride=stride, pad=pad, out=full, flags=flags)
+        _close(dx, _nhwc(xr.grad), Co * R * R, f"conv dgrad flags={flags}")
+        dw = ops.conv2d_wgrad(_nhwc(dy).to(dev), x_d, (Co, R, R, C), stride=stride, pad=pad, flags=flags)
+        _close(dw, _nhwc(wr.grad), Nb * OH * OW, f"conv wgrad flags={flags}", rtol=3e-3, atol_unit=2e-4)
+
+
+def test_attention_products(dev):
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(5)
+    B, H, Sq, Sk, dh = 2, 8, 100, 52, 32
+    d = H * dh
+    q, kk, v = _rand((B * Sq, d), g), _rand((B * Sk, d), g), _rand((B * Sk, d), g)
+    scale = 1.0 / math.sqrt(dh)
+    qf = q.float().view(B, Sq, H, dh).permute(0, 2, 1, 3)
+    kf = kk.float().view(B, Sk, H, dh).permute(0, 2, 1, 3)
+    vf = v.float().view(B, Sk, H, dh).permute(0, 2, 1, 3)
+    s_ref = (qf @ kf.transpose(-1, -2)) * scale
+    qd, kd, vd = q.to(dev), kk.to(dev), v.to(dev)
+    s = ops.attn_scores(qd, kd, B, H, Sq, Sk, dh, scale)
+    ld = s.shape[-1]
+    _close(s.view(B, H, Sq, ld)[..., :Sk], s_ref, dh, "scores")
+    key_pad = torch.zeros(B, Sk, dtype=torch.uint8)
+    key_pad[1, -7:] = 1
+    p = torch.empty_like(s)
+    k.softmax_fwd(s, key_pad.to(dev), B, H, Sq, Sk, ld, p)
+    s_used = s.float().cpu().view(B, H, Sq, ld)[..., :Sk].masked_fill(key_pad.bool()[:, None, None, :], float("-inf"))
+    p_ref = torch.softmax(s_used, -1)
+    pc = p.float().cpu().view(B, H, Sq, ld)
+    assert float(pc[..., Sk:].abs().max()) == 0.0 if ld > Sk else True
+    _close(pc[..., :Sk], p_ref, 1, "softmax", rtol=1e-2, atol_unit=2e-3)
+    ctx = torch.empty(B * Sq, d, dtype=BF, device=dev)
+    ops.attn_context(p, vd, B, H, Sq, Sk, dh, ctx)
+    p_b = pc[..., :Sk]
+    ctx_ref = (p_b @ vf).permute(0, 2, 1, 3).reshape(B * Sq, d)
+    _close(ctx, ctx_ref, Sk, "context")
+    # backward
+    dctx = _rand((B * Sq, d), g)
+    dq, dk, dv = (torch.empty(B * Sq, d, dtype=BF, device=dev), torch.empty(B * Sk, d, dtype=BF, device=dev),
+                  torch.empty(B * Sk, d, dtype=BF, device=dev))
+
+    def sm_bwd(dp):
+        ds = torch.empty_like(dp)
+        k.softmax_bwd(p, dp, B * H * Sq, Sk, ld, ds)
+        return ds
+
+    ops.attn_backward(p, scale, qd, kd, vd, dctx.to(dev), B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
+    qa, ka, va = (qf.clone().requires_grad_(True), kf.clone().requires_grad_(True), vf.clone().requires_grad_(True))
+    sa = ((qa @ ka.transpose(-1, -2)) * scale).masked_fill(key_pad.bool()[:, None, None, :], float("-inf"))
+    oa = torch.softmax(sa, -1) @ va
+    oa.backward(dctx.float().view(B, Sq, H, dh).permute(0, 2, 1, 3))
+    back = lambda t, S: t.permute(0, 2, 1, 3).reshape(B * S, d)
+    _close(dv, back(va.grad, Sk), Sq, "dV", rtol=3e-2, atol_unit=6e-3)
+    _close(dq, back(qa.grad, Sq), Sk, "dQ", rtol=3e-2, atol_unit=6e-3)
+    _close(dk, back(ka.grad, Sk), Sq, "dK", rtol=3e-2, atol_unit=6e-3)
+
+
+def test_rows(dev):
+    from toist_amd import kernels as k
+    g = torch.Generator().manual_seed(3)
+    for rows, D, eps in [(37, 256, 1e-5), (130, 768, 1e-12)]:
+        x = _rand((rows, D), g, 2.0)
+        gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+        xr = x.float().requires_grad_(True)
+        gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        y_ref = F.layer_norm(xr, (D,), gr, br, eps)
+        xd = x.to(dev)
+        y = torch.empty_like(xd)
+        mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+        k.layernorm_fwd(xd, gamma.to(dev), beta.to(dev), eps, y, mean, rstd)
+        _close(y, y_ref.detach(), 1, "ln fwd", rtol=1e-2, atol_unit=1e-2)
+        dy = _rand((rows, D), g)
+        y_ref.backward(dy.float())
+        dx = torch.empty_like(xd)
+        dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        k.layernorm_bwd(dy.to(dev), xd, mean, rstd, gamma.to(dev), dx, dg, db)
+        _close(dx, xr.grad, 1, "ln dx", rtol=2e-2, atol_unit=2e-2)
+        _close(dg, gr.grad, rows, "ln dgamma", rtol=1e-2, atol_unit=1e-2)
+        _close(db, br.grad, rows, "ln dbeta", rtol=1e-2, atol_unit=1e-2)
+    a, b = _rand((64, 256), g), _rand((8, 256), g)
+    out = torch.empty(64, 256, dtype=BF, device=dev)
+    k.add(a.to(dev), b.to(dev), out, b_period=8 * 256)
+    _close(out, a.float() + b.float().repeat(8, 1), 1, "add", rtol=1e-2, atol_unit=1e-2)
+    # dropout: deterministic in (seed, index), keep-rate ~ 1-p, kept values scaled
+    x = torch.ones(1 << 16, dtype=BF, device=dev)
+    o1, o2 = torch.empty_like(x), torch.empty_like(x)
+    k.dropout(x, 0.1, 1234, o1)
+    k.dropout(x, 0.1, 1234, o2)
+    assert torch.equal(o1, o2)
+    keep = (o1 != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01, keep
+    assert abs(float(o1.float().max()) - 1.0 / 0.9) < 1e-2

@@ -1,0 +1,87 @@
+"""GPU parity of the one-wavefront Hungarian matcher against the oracle (oracle/matcher_ref.py +
+oracle/lsap.c, themselves pinned to the reference / SciPy on the CPU).  Indices must be bit-identical."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed, B, Q, K, sizes, L=1, dup=False, same_pm=True):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(L, B, Q, K, generator=g) * 2.0
+    cxcy = torch.rand(L, B, Q, 2, generator=g) * 0.6 + 0.2
+    wh = torch.rand(L, B, Q, 2, generator=g) * 0.35 + 0.05
+    boxes = torch.cat([cxcy, wh], -1)
+    tgt = []
+    for t in sizes:
+        c = torch.rand(t, 2, generator=g) * 0.6 + 0.2
+        s = torch.rand(t, 2, generator=g) * 0.35 + 0.05
+        bx = torch.cat([c, s], -1)
+        if dup and t >= 2:
+            bx[1] = bx[0]
+        tgt.append(bx)
+    T = sum(sizes)
+    if same_pm:
+        pm = torch.zeros(T, K)
+        pm[:, 1:15] = 1.0 / 14.0
+    else:
+        pm = torch.rand(T, K, generator=g)
+        pm = pm / pm.sum(-1, keepdim=True)
+    return logits, boxes, tgt, pm
+
+
+def _run_gpu(dev, logits, boxes, tgt, pm, w=(1.0, 5.0, 2.0), want_cost=False):
+    from toist_amd import kernels as k
+    L, B, Q, K = logits.shape
+    sizes = [int(t.shape[0]) for t in tgt]
+    off = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32) if sizes else torch.zeros(1, dtype=torch.int32)
+    moff = torch.tensor([0] + list(torch.tensor([min(Q, s) for s in sizes]).cumsum(0)), dtype=torch.int32)
+    Mtot, Ttot = int(moff[-1]), int(off[-1])
+    tb = torch.cat(tgt) if Ttot else torch.zeros(1, 4)
+    src = torch.full((L, max(Mtot, 1)), -1, dtype=torch.int64, device=dev)
+    dst = torch.full((L, max(Mtot, 1)), -1, dtype=torch.int64, device=dev)
+    status = torch.full((L * B,), -7, dtype=torch.int32, device=dev)
+    cost = torch.zeros(L, B * Q, max(Ttot, 1), device=dev) if want_cost else None
+    pmd = pm.to(dev) if Ttot else torch.zeros(1, K, device=dev)
+    k.matcher(logits.to(dev), boxes.to(dev), tb.to(dev), pmd, off.to(dev), moff.to(dev), max(sizes) if sizes else 0, w[0], w[1], w[2],
+              src, dst, status, cost)
+    torch.cuda.synchronize()
+    return src.cpu(), dst.cpu(), status.cpu(), moff, (cost.cpu() if want_cost else None)
+
+
+@pytest.mark.parametrize("seed,B,Q,K,sizes,dup,same_pm", [
+    (0, 8, 100, 256, [0, 1, 4, 10, 30, 2, 7, 3], False, True),
+    (1, 8, 100, 256, [4, 4, 4, 4, 4, 4, 4, 4], True, True),
+    (2, 4, 100, 256, [10, 0, 0, 9], True, False),
+    (3, 2, 20, 64, [30, 20], False, False),      # T > Q and T == Q
+    (4, 3, 97, 256, [97, 96, 98], False, False),  # near-square (softkd-sized)
+    (5, 1, 100, 256, [0], False, True),
+])
+def test_indices_bit_exact(dev, seed, B, Q, K, sizes, dup, same_pm):
+    from oracle import matcher_ref
+    L = 3
+    logits, boxes, tgt, pm = _case(seed, B, Q, K, sizes, L=L, dup=dup, same_pm=same_pm)
+    src, dst, status, moff, cost = _run_gpu(dev, logits, boxes, tgt, pm, want_cost=True)
+    assert int(status.abs().sum()) == 0, status
+    mism = 0
+    for l in range(L):
+        ref = matcher_ref.hungarian_match(logits[l], boxes[l], tgt, pm)
+        if sum(sizes):
+            cref = matcher_ref.cost_matrix(logits[l], boxes[l], torch.cat(tgt), pm)
+        for b, (ri, rj) in enumerate(ref):
+            lo, hi = int(moff[b]), int(moff[b + 1])
+            if not (torch.equal(src[l, lo:hi], ri) and torch.equal(dst[l, lo:hi], rj)):
+                mism += 1
+            if sizes[b]:
+                t0 = sum(sizes[:b])
+                got = cost[l, b * Q:(b + 1) * Q, t0:t0 + sizes[b]]
+                want = cref[b, :, t0:t0 + sizes[b]]
+                assert torch.allclose(got, want, rtol=1e-5, atol=2e-6), float((got - want).abs().max())
+    assert mism == 0, f"{mism} images with different assignment"
+
+
+def test_invalid_cost_flagged(dev):
+    logits, boxes, tgt, pm = _case(9, 2, 100, 256, [3, 2])
+    logits[0, 1, 5, 7] = float("nan")
+    _, _, status, _, _ = _run_gpu(dev, logits, boxes, tgt, pm)
+    assert status.tolist() == [0, 1]

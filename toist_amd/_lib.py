@@ -1,0 +1,93 @@
+"""ctypes binding of libtoist_hip.so (include/toist_hip.h).
+
+The product path has exactly one backend: the hand-written HIP library.  If it is missing or fails
+to load, importing a kernel raises -- there is no CPU or eager-PyTorch fallback.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtoist_hip.so")
+
+TOIST_OK = 0
+# operand kinds / activations (mirrors include/toist_hip.h)
+A_ROWK, A_KROW, A_CONV, A_CONVT = 0, 1, 2, 3
+B_ROWK, B_KROW, B_CONVX = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_MASK_POS, ACT_GELU_BWD, ACT_SIGMOID_BWD = range(7)
+
+
+class Operand(Structure):
+    _fields_ = [
+        ("ptr", c_void_p), ("bs_outer", c_int64), ("bs_inner", c_int64), ("ld", c_int32), ("kin", c_int32),
+        ("tap_stride", c_int64), ("SH", c_int32), ("SW", c_int32), ("SC", c_int32), ("PH", c_int32),
+        ("PW", c_int32), ("R", c_int32), ("S", c_int32), ("stride", c_int32), ("pad", c_int32), ("dil", c_int32),
+    ]
+
+
+class Epilogue(Structure):
+    _fields_ = [
+        ("alpha", c_float), ("scale", c_void_p), ("shift", c_void_p), ("res", c_void_p), ("ldr", c_int32),
+        ("aux", c_void_p), ("ldaux", c_int32), ("act", c_int32), ("pre_out", c_void_p), ("out_f32", c_int32),
+        ("accumulate", c_int32), ("cmap", c_int32), ("cH", c_int32), ("cW", c_int32), ("cOH", c_int32),
+        ("cOW", c_int32), ("cst", c_int32), ("drop_where", c_int32), ("drop_p", c_float), ("drop_seed", c_uint64),
+    ]
+
+
+class Gemm(Structure):
+    _fields_ = [
+        ("M", c_int32), ("N", c_int32), ("K", c_int32), ("a_kind", c_int32), ("b_kind", c_int32),
+        ("a", Operand), ("b", Operand), ("c", c_void_p), ("ldc", c_int32), ("cs_outer", c_int64),
+        ("cs_inner", c_int64), ("batch", c_int32), ("batch_inner", c_int32), ("split_k", c_int32),
+        ("tile", c_int32), ("flags", c_int32), ("epi", Epilogue),
+    ]
+
+
+_SIGNATURES = {
+    "toist_version": ([], ctypes.c_int),
+    "toist_last_error": ([c_char_p, c_size_t], ctypes.c_int),
+    "toist_matcher": ([c_void_p] * 6 + [c_int32] * 5 + [c_float] * 3 + [c_void_p] * 5, ctypes.c_int),
+    "toist_gemm_bf16": ([POINTER(Gemm), c_void_p], ctypes.c_int),
+    "toist_layernorm_fwd": ([c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_layernorm_bwd": ([c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 4 + [c_float, c_uint64, c_void_p], ctypes.c_int),
+    "toist_softmax_fwd": ([c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p, c_float, c_uint64, c_void_p], ctypes.c_int),
+    "toist_softmax_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_float, c_uint64, c_void_p], ctypes.c_int),
+    "toist_colsum": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "toist_add_bf16": ([c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p], ctypes.c_int),
+    "toist_dropout_bf16": ([c_void_p, c_int64, c_float, c_uint64, c_void_p, c_void_p], ctypes.c_int),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names every include/toist_hip.h entry point must be exported under."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(toist_amd has no CPU / eager fallback)"
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = handle
+    return _lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    lib().toist_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != TOIST_OK:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")

@@ -1,0 +1,68 @@
+// Shared device/host helpers for the TOIST hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/toist_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+namespace toist {
+
+// ---- error plumbing (host) -------------------------------------------------
+void set_last_error(const char* fmt, ...);
+int check_launch(const char* what);  // hipGetLastError -> TOIST_EHIP / TOIST_OK
+
+#define TOIST_REQUIRE(cond, ...)                  \
+    do {                                          \
+        if (!(cond)) {                            \
+            ::toist::set_last_error(__VA_ARGS__); \
+            return TOIST_EINVAL;                  \
+        }                                         \
+    } while (0)
+
+// ---- bf16 <-> f32 ------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// round-to-nearest-even, NaN preserved (matches torch's float->bfloat16 cast)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+// ---- wave (64-lane) reductions -------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// counter-based RNG for dropout: one 32-bit hash per (seed, element index).
+// Forward and backward regenerate the same keep-mask from (seed, index).
+__device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (unsigned)(z >> 32);
+}
+// keep with probability 1-p ; thresh = (unsigned)(p * 2^32)
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, unsigned thresh) {
+    return hash_u32(seed, idx) >= thresh;
+}
+
+}  // namespace toist

@@ -1,0 +1,287 @@
+// Hungarian matcher for the TOIST/MDETR set criterion -- one workgroup per (decoder layer, image).
+//
+// Replaces /root/reference/models/matcher.py:60-87 (cost build on device, `.cpu()` sync, per-image
+// scipy.optimize.linear_sum_assignment on the host).  Here the [Q, T_i] cost block is built in
+// fp32 in the reference's evaluation order (compiled with -ffp-contract=off so no FMA fusion
+// changes a rounding), kept in LDS, and solved in fp64 by ONE wavefront with the same
+// shortest-augmenting-path traversal and tie rules as SciPy's rectangular LSAP (restated in
+// oracle/lsap.c).  All decoder layers x images go in one launch; indices stay on the device.
+//
+// LDS-resident, latency-bound: neither the HBM nor the MFMA roofline applies.
+#include "common.h"
+
+namespace toist {
+
+struct PickKey {
+    double val;
+    int it;   // position in the `remaining` list
+    int una;  // candidate column is unassigned
+};
+
+// Combine rule equivalent to SciPy's sequential scan over `remaining`:
+// lower value wins; on equal value an unassigned column wins, the LAST such one in scan order;
+// with no unassigned column among the ties, the FIRST one in scan order.
+__device__ __forceinline__ PickKey pick_combine(PickKey a, PickKey b) {
+    if (a.val < b.val) return a;
+    if (b.val < a.val) return b;
+    if (a.val != b.val) return (a.val != a.val) ? b : a;  // NaN guard (never expected)
+    if (a.una && b.una) return (a.it > b.it) ? a : b;
+    if (a.una) return a;
+    if (b.una) return b;
+    return (a.it < b.it) ? a : b;
+}
+
+__device__ __forceinline__ PickKey wave_pick(PickKey k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        PickKey other;
+        other.val = __shfl_xor(k.val, o, 64);
+        other.it = __shfl_xor(k.it, o, 64);
+        other.una = __shfl_xor(k.una, o, 64);
+        k = pick_combine(k, other);
+    }
+    return k;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// status codes written per (layer,image)
+enum { ST_OK = 0, ST_INVALID = 1, ST_INFEASIBLE = 2 };
+
+__global__ __launch_bounds__(256) void matcher_kernel(
+    const float* __restrict__ logits,   // [L,B,Q,K]
+    const float* __restrict__ boxes,    // [L,B,Q,4] cxcywh
+    const float* __restrict__ tgt_box,  // [Ttot,4] cxcywh
+    const float* __restrict__ pos_map,  // [Ttot,K]
+    const int* __restrict__ tgt_off,    // [B+1]
+    const int* __restrict__ match_off,  // [B+1] prefix sums of min(Q,T_b)
+    int L, int B, int Q, int K, float w_class, float w_bbox, float w_giou,
+    long long* __restrict__ src_idx,    // [L, Mtot]
+    long long* __restrict__ tgt_idx,    // [L, Mtot]
+    int* __restrict__ status,           // [L*B]
+    float* __restrict__ cost_out)       // optional [L, B*Q, Ttot]
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lb = blockIdx.x;
+    const int l = lb / B, b = lb % B;
+    const int t0 = tgt_off[b];
+    const int T = tgt_off[b + 1] - t0;
+    const int Ttot = tgt_off[B];
+    const int Mtot = match_off[B];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (T == 0) {
+        if (tid == 0) status[lb] = ST_OK;
+        return;
+    }
+    const bool flip = T < Q;          // SciPy solves the transpose when rows > cols
+    const int R = flip ? T : Q;       // rows of the oriented problem
+    const int C = flip ? Q : T;       // columns
+
+    // ---- LDS carve -------------------------------------------------------------
+    double* du = reinterpret_cast<double*>(smem);            // [R]
+    double* dv = du + R;                                      // [C]
+    double* spc = dv + C;                                     // [C]
+    int* path = reinterpret_cast<int*>(spc + C);              // [C]
+    int* row4col = path + C;                                  // [C]
+    int* remaining = row4col + C;                             // [C]
+    int* col4row = remaining + C;                             // [R]
+    int* in_sr = col4row + R;                                 // [R]
+    int* in_sc = in_sr + R;                                   // [C]
+    int* bad = in_sc + C;                                     // [1]
+    float* cw = reinterpret_cast<float*>(bad + 1);            // [R*C] oriented cost
+
+    if (tid == 0) *bad = 0;
+    __syncthreads();
+
+    // ---- cost block (matcher.py:63-81) --------------------------------------------
+    const float* lg = logits + ((size_t)(l * B + b) * Q) * K;
+    const float* bx = boxes + ((size_t)(l * B + b) * Q) * 4;
+    int my_bad = 0;
+    for (int q = wave; q < Q; q += 4) {
+        // softmax over K (exp(x - max) / sum)
+        const float* row = lg + (size_t)q * K;
+        float mx = -INFINITY;
+        for (int k = lane; k < K; k += 64) mx = fmaxf(mx, row[k]);
+        mx = wave_max(mx);
+        float pr[8];  // K <= 512
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int k = lane + 64 * m;
+            pr[m] = (k < K) ? expf(row[k] - mx) : 0.f;
+            sum += pr[m];
+        }
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) pr[m] = pr[m] / sum;
+
+        const float cx = bx[q * 4 + 0], cy = bx[q * 4 + 1], w = bx[q * 4 + 2], h = bx[q * 4 + 3];
+        const float ax0 = cx - 0.5f * w, ay0 = cy - 0.5f * h, ax1 = cx + 0.5f * w, ay1 = cy + 0.5f * h;
+        const float area_a = (ax1 - ax0) * (ay1 - ay0);
+
+        for (int t = 0; t < T; ++t) {
+            const float* pm = pos_map + (size_t)(t0 + t) * K;
+            float dot = 0.f;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int k = lane + 64 * m;
+                if (k < K) dot += pr[m] * pm[k];
+            }
+            dot = wave_sum(dot);
+            if (lane == 0) {
+                const float cost_class = -dot;
+                const float* tb = tgt_box + (size_t)(t0 + t) * 4;
+                const float tcx = tb[0], tcy = tb[1], tw = tb[2], th = tb[3];
+                const float cost_bbox = ((fabsf(cx - tcx) + fabsf(cy - tcy)) + fabsf(w - tw)) + fabsf(h - th);
+                const float bx0 = tcx - 0.5f * tw, by0 = tcy - 0.5f * th, bx1 = tcx + 0.5f * tw, by1 = tcy + 0.5f * th;
+                const float area_b = (bx1 - bx0) * (by1 - by0);
+                const float iw = fmaxf(fminf(ax1, bx1) - fmaxf(ax0, bx0), 0.f);
+                const float ih = fmaxf(fminf(ay1, by1) - fmaxf(ay0, by0), 0.f);
+                const float inter = iw * ih;
+                const float uni = (area_a + area_b) - inter;
+                const float iou = inter / uni;
+                const float ew = fmaxf(fmaxf(ax1, bx1) - fminf(ax0, bx0), 0.f);
+                const float eh = fmaxf(fmaxf(ay1, by1) - fminf(ay0, by0), 0.f);
+                const float earea = ew * eh;
+                const float giou = iou - (earea - uni) / earea;
+                const float cost_giou = -giou;
+                const float c = (w_bbox * cost_bbox + w_class * cost_class) + w_giou * cost_giou;
+                if (c != c || c == -INFINITY) my_bad = 1;
+                cw[flip ? (t * Q + q) : (q * T + t)] = c;
+                if (cost_out) cost_out[((size_t)l * B * Q + (size_t)b * Q + q) * Ttot + t0 + t] = c;
+            }
+        }
+    }
+    if (my_bad) atomicOr(bad, 1);
+    __syncthreads();
+    if (*bad) {
+        if (tid == 0) status[lb] = ST_INVALID;
+        return;
+    }
+    if (wave != 0) return;
+
+    // ---- rectangular LSAP, one wavefront (oracle/lsap.c restates the same traversal) --
+    for (int j = lane; j < C; j += 64) { dv[j] = 0.0; path[j] = -1; row4col[j] = -1; }
+    for (int i = lane; i < R; i += 64) { du[i] = 0.0; col4row[i] = -1; }
+    wave_lds_fence();
+
+    int st = ST_OK;
+    for (int cur = 0; cur < R; ++cur) {
+        for (int t = lane; t < C; t += 64) { remaining[t] = C - 1 - t; spc[t] = INFINITY; in_sc[t] = 0; }
+        for (int i = lane; i < R; i += 64) in_sr[i] = 0;
+        wave_lds_fence();
+
+        int live = C, sink = -1, i = cur;
+        double floor_val = 0.0;
+        while (sink < 0) {
+            if (lane == 0) in_sr[i] = 1;
+            const double ui = du[i];
+            const float* crow = cw + (size_t)i * C;
+            PickKey best;  // per-lane replay of the reference scan, starting from lowest = +inf
+            best.val = INFINITY; best.it = 0x7fffffff; best.una = 0;
+            for (int t = lane; t < live; t += 64) {
+                const int j = remaining[t];
+                const double r = ((floor_val + (double)crow[j]) - ui) - dv[j];
+                double s = spc[j];
+                if (r < s) { path[j] = i; spc[j] = r; s = r; }
+                const int una = row4col[j] < 0;
+                if (s < best.val || (s == best.val && una)) { best.val = s; best.it = t; best.una = una; }
+            }
+            best = wave_pick(best);
+            floor_val = best.val;
+            if (!(floor_val < INFINITY)) { st = ST_INFEASIBLE; break; }
+            const int pick = best.it;
+            const int j = remaining[pick];
+            const int owner = row4col[j];
+            if (owner < 0) sink = j; else i = owner;
+            wave_lds_fence();
+            if (lane == 0) {
+                in_sc[j] = 1;
+                remaining[pick] = remaining[live - 1];
+            }
+            --live;
+            wave_lds_fence();
+        }
+        if (st != ST_OK) break;
+
+        // dual variables
+        if (lane == 0) du[cur] += floor_val;
+        for (int r = lane; r < R; r += 64)
+            if (in_sr[r] && r != cur) du[r] += floor_val - spc[col4row[r]];
+        for (int j = lane; j < C; j += 64)
+            if (in_sc[j]) dv[j] -= floor_val - spc[j];
+        wave_lds_fence();
+        // augment along the path (serial, short)
+        if (lane == 0) {
+            int j = sink;
+            for (;;) {
+                const int pi = path[j];
+                row4col[j] = pi;
+                const int prev = col4row[pi];
+                col4row[pi] = j;
+                j = prev;
+                if (pi == cur) break;
+            }
+        }
+        wave_lds_fence();
+    }
+
+    if (lane == 0) status[lb] = st;
+    if (st != ST_OK) return;
+
+    long long* so = src_idx + (size_t)l * Mtot + match_off[b];
+    long long* to = tgt_idx + (size_t)l * Mtot + match_off[b];
+    if (flip) {
+        // rows = targets; result ordered by query index (argsort of col4row)
+        for (int t = lane; t < R; t += 64) {
+            const int q = col4row[t];
+            int rank = 0;
+            for (int o = 0; o < R; ++o) rank += (col4row[o] < q);
+            so[rank] = q;
+            to[rank] = t;
+        }
+    } else {
+        for (int q = lane; q < R; q += 64) { so[q] = q; to[q] = col4row[q]; }
+    }
+}
+
+static size_t matcher_lds_bytes(int Q, int maxT) {
+    const int R = maxT < Q ? maxT : Q;
+    const int C = maxT < Q ? Q : maxT;
+    // R,C of any image are bounded by (min(Q,maxT), max(Q,maxT)); size for the worst image
+    const size_t Rm = (size_t)(Q < maxT ? Q : maxT), Cm = (size_t)(Q > maxT ? Q : maxT);
+    (void)R; (void)C;
+    size_t bytes = sizeof(double) * (Rm + 2 * Cm) + sizeof(int) * (4 * Cm + 2 * Rm + 2) + sizeof(float) * (size_t)Q * (size_t)maxT;
+    return (bytes + 15) & ~(size_t)15;
+}
+
+}  // namespace toist
+
+extern "C" int toist_matcher(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
+                             const int32_t* tgt_off_dev, const int32_t* match_off_dev, int L, int B, int Q, int K,
+                             int max_T, float w_class, float w_bbox, float w_giou, int64_t* src_idx,
+                             int64_t* tgt_idx, int32_t* status, float* cost_out, void* stream) {
+    using namespace toist;
+    TOIST_REQUIRE(L > 0 && B > 0 && Q > 0 && K > 0 && K <= 512, "toist_matcher: bad shape L=%d B=%d Q=%d K=%d (K<=512)", L, B, Q, K);
+    TOIST_REQUIRE(max_T >= 0, "toist_matcher: max_T < 0");
+    TOIST_REQUIRE(w_class != 0.f || w_bbox != 0.f || w_giou != 0.f, "toist_matcher: all costs cant be 0");
+    if (max_T == 0) {
+        hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t) * (size_t)L * B, (hipStream_t)stream);
+        if (e != hipSuccess) { set_last_error("toist_matcher: memset: %s", hipGetErrorString(e)); return TOIST_EHIP; }
+        return TOIST_OK;
+    }
+    const size_t lds = matcher_lds_bytes(Q, max_T);
+    TOIST_REQUIRE(lds <= 160 * 1024, "toist_matcher: Q=%d max_T=%d needs %zu B of LDS (> 160 KiB)", Q, max_T, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)matcher_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_last_error("toist_matcher: set LDS size: %s", hipGetErrorString(e)); return TOIST_EHIP; }
+    }
+    hipLaunchKernelGGL(matcher_kernel, dim3(L * B), dim3(256), lds, (hipStream_t)stream, logits, boxes, tgt_boxes,
+                       pos_map, tgt_off_dev, match_off_dev, L, B, Q, K, w_class, w_bbox, w_giou,
+                       (long long*)src_idx, (long long*)tgt_idx, status, cost_out);
+    return check_launch("toist_matcher");
+}

@@ -1,0 +1,138 @@
+"""Tensor-level launchers for the C-ABI kernels of libtoist_hip.so.
+
+Every function takes torch tensors that already live on the HIP device, passes raw pointers + sizes
+through ctypes on torch's current stream, and returns immediately (no host sync).  torch is used for
+memory and streams only.  There is no fallback: a CPU tensor or a missing library raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (A_CONV, A_CONVT, A_KROW, A_ROWK, ACT_GELU, ACT_GELU_BWD, ACT_MASK_POS, ACT_NONE, ACT_RELU,
+                   ACT_SIGMOID, ACT_SIGMOID_BWD, B_CONVX, B_KROW, B_ROWK, Epilogue, Gemm, Operand)
+
+__all__ = [
+    "A_ROWK", "A_KROW", "A_CONV", "A_CONVT", "B_ROWK", "B_KROW", "B_CONVX", "ACT_NONE", "ACT_RELU", "ACT_GELU",
+    "ACT_SIGMOID", "ACT_MASK_POS", "ACT_GELU_BWD", "ACT_SIGMOID_BWD", "ConvGeom", "operand", "gemm", "matcher",
+    "layernorm_fwd", "layernorm_bwd", "softmax_fwd", "softmax_bwd", "colsum", "add", "dropout",
+]
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=None):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: no CPU path exists."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("toist_amd kernels need device tensors (got a CPU tensor); there is no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+class ConvGeom:
+    """Gather geometry of an implicit-GEMM operand: source [N,SH,SW,SC] NHWC, pixel space [N,PH,PW]."""
+
+    __slots__ = ("SH", "SW", "SC", "PH", "PW", "R", "S", "stride", "pad", "dil")
+
+    def __init__(self, SH, SW, SC, PH, PW, R, S, stride, pad, dil=1):
+        self.SH, self.SW, self.SC, self.PH, self.PW = SH, SW, SC, PH, PW
+        self.R, self.S, self.stride, self.pad, self.dil = R, S, stride, pad, dil
+
+
+def operand(t, ld=0, bs_outer=0, bs_inner=0, kin=0, tap_stride=0, geom=None):
+    o = Operand()
+    o.ptr = _p(t, torch.bfloat16)
+    o.ld, o.bs_outer, o.bs_inner, o.kin, o.tap_stride = ld, bs_outer, bs_inner, kin, tap_stride
+    if geom is not None:
+        o.SH, o.SW, o.SC, o.PH, o.PW = geom.SH, geom.SW, geom.SC, geom.PH, geom.PW
+        o.R, o.S, o.stride, o.pad, o.dil = geom.R, geom.S, geom.stride, geom.pad, geom.dil
+    return o
+
+
+def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_outer=0, cs_inner=0, split_k=1, tile=0,
+         flags=0, alpha=1.0, scale=None, shift=None, res=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, pre_out=None,
+         accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0):
+    """C = epilogue(A @ B^T); see include/toist_hip.h.  `a`/`b` are Operand structs from operand()."""
+    d = Gemm()
+    d.M, d.N, d.K, d.a_kind, d.b_kind, d.a, d.b = M, N, K, a_kind, b_kind, a, b
+    if c.dtype == torch.float32:
+        d.epi.out_f32 = 1
+    elif c.dtype != torch.bfloat16:
+        raise TypeError("gemm output must be bf16 or f32")
+    d.c, d.ldc = _p(c), ldc
+    d.cs_outer, d.cs_inner, d.batch, d.batch_inner = cs_outer, cs_inner, batch, batch_inner
+    d.split_k, d.tile, d.flags = split_k, tile, flags
+    e = d.epi
+    e.alpha = alpha
+    e.scale, e.shift = _p(scale, torch.float32), _p(shift, torch.float32)
+    e.res, e.ldr = _p(res, torch.bfloat16), ldr
+    e.aux, e.ldaux = _p(aux, torch.bfloat16), ldaux
+    e.act = act
+    e.pre_out = _p(pre_out, torch.bfloat16)
+    e.accumulate = 1 if accumulate else 0
+    if cmap is not None:
+        e.cmap = 1
+        e.cH, e.cW, e.cOH, e.cOW, e.cst = cmap
+    e.drop_where, e.drop_p, e.drop_seed = drop_where, drop_p, drop_seed
+    _lib.check(_lib.lib().toist_gemm_bf16(ctypes.byref(d), _stream()), "toist_gemm_bf16")
+
+
+def matcher(logits, boxes, tgt_boxes, pos_map, tgt_off, match_off, max_T, w_class, w_bbox, w_giou, src_idx, tgt_idx,
+            status, cost_out=None):
+    L, B, Q, K = logits.shape
+    _lib.check(
+        _lib.lib().toist_matcher(_p(logits, torch.float32), _p(boxes, torch.float32), _p(tgt_boxes, torch.float32),
+                                 _p(pos_map, torch.float32), _p(tgt_off, torch.int32), _p(match_off, torch.int32), L, B, Q,
+                                 K, max_T, w_class, w_bbox, w_giou, _p(src_idx, torch.int64), _p(tgt_idx, torch.int64),
+                                 _p(status, torch.int32), _p(cost_out, torch.float32), _stream()), "toist_matcher")
+
+
+def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None):
+    rows, D = x.shape
+    _lib.check(
+        _lib.lib().toist_layernorm_fwd(_p(x, torch.bfloat16), _p(gamma, torch.float32), _p(beta, torch.float32), eps, rows, D,
+                                       _p(y, torch.bfloat16), _p(mean, torch.float32), _p(rstd, torch.float32), _stream()),
+        "toist_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma=None, dbeta=None, dx_drop=None, drop_p=0.0, seed=0):
+    rows, D = x.shape
+    _lib.check(
+        _lib.lib().toist_layernorm_bwd(_p(dy, torch.bfloat16), _p(x, torch.bfloat16), _p(mean, torch.float32),
+                                       _p(rstd, torch.float32), _p(gamma, torch.float32), rows, D, _p(dx, torch.bfloat16),
+                                       _p(dgamma, torch.float32), _p(dbeta, torch.float32), _p(dx_drop, torch.bfloat16),
+                                       drop_p, seed, _stream()), "toist_layernorm_bwd")
+
+
+def softmax_fwd(scores, key_pad, nbatch, H, Sq, Sk, ld, p, p_drop=None, drop_p=0.0, seed=0):
+    _lib.check(
+        _lib.lib().toist_softmax_fwd(_p(scores, torch.bfloat16), _p(key_pad, torch.uint8), nbatch, H, Sq, Sk, ld,
+                                     _p(p, torch.bfloat16), _p(p_drop, torch.bfloat16), drop_p, seed, _stream()),
+        "toist_softmax_fwd")
+
+
+def softmax_bwd(p, dp, rows, Sk, ld, ds, drop_p=0.0, seed=0):
+    _lib.check(
+        _lib.lib().toist_softmax_bwd(_p(p, torch.bfloat16), _p(dp, torch.bfloat16), rows, Sk, ld, _p(ds, torch.bfloat16),
+                                     drop_p, seed, _stream()), "toist_softmax_bwd")
+
+
+def colsum(g, M, N, ld, out):
+    _lib.check(_lib.lib().toist_colsum(_p(g, torch.bfloat16), M, N, ld, _p(out, torch.float32), _stream()), "toist_colsum")
+
+
+def add(a, b, out, b_period=None):
+    n = a.numel()
+    _lib.check(
+        _lib.lib().toist_add_bf16(_p(a, torch.bfloat16), _p(b, torch.bfloat16), n, n if b_period is None else b_period,
+                                  _p(out, torch.bfloat16), _stream()), "toist_add_bf16")
+
+
+def dropout(x, p, seed, out):
+    _lib.check(_lib.lib().toist_dropout_bf16(_p(x, torch.bfloat16), x.numel(), p, seed, _p(out, torch.bfloat16), _stream()),
+               "toist_dropout_bf16")

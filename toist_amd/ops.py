@@ -1,0 +1,206 @@
+"""Functional layer over the HIP kernels: linear / convolution / attention building blocks.
+
+Shapes follow the kernels' native layouts (bf16, feature axis innermost): token matrices are
+[rows, features], feature maps are NHWC, convolution weights are [Cout, R, S, Cin] ("KRSC", the
+physical layout of a channels_last OIHW parameter).  Nothing here touches autograd; the modules in
+toist_amd build their forward/backward passes out of these calls.
+"""
+import torch
+
+from . import kernels as k
+
+BF16 = torch.bfloat16
+
+
+def _ld(t):
+    """Leading dimension of a 2-D (possibly column-sliced) row-major view."""
+    assert t.dim() == 2 and t.stride(1) == 1, "need a row-major 2-D view"
+    return t.stride(0)
+
+
+def _split_k_for(tiles, ktiles, target=512, max_split=64):
+    if tiles >= target or ktiles <= 8:
+        return 1
+    s = min(max_split, max(1, target // max(tiles, 1)), max(1, ktiles // 4))
+    return max(1, s)
+
+
+# ------------------------------------------------------------------------------------------ linear
+def linear(x, w, bias=None, *, out=None, out_dtype=BF16, act=k.ACT_NONE, res=None, alpha=1.0, pre_out=None, scale=None,
+           drop_where=0, drop_p=0.0, drop_seed=0, tile=0):
+    """out[M,N] = act(alpha * x[M,K] @ w[N,K]^T * scale + bias (+dropout) + res)   (nn.Linear forward)."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    k.gemm(M, N, K, k.A_ROWK, k.operand(x, _ld(x)), k.B_ROWK, k.operand(w, _ld(w)), out, _ld(out), alpha=alpha, scale=scale,
+           shift=bias, res=res, ldr=_ld(res) if res is not None else 0, act=act, pre_out=pre_out, drop_where=drop_where,
+           drop_p=drop_p, drop_seed=drop_seed, tile=tile)
+    return out
+
+
+def linear_dgrad(dy, w, *, out=None, res=None, act=k.ACT_NONE, aux=None, alpha=1.0, scale=None, flags=0):
+    """dx[M,K] = (dy[M,N] @ w[N,K]) (+res) ; w is read k-major (no transposed copy)."""
+    M, N = dy.shape
+    K = w.shape[1]
+    assert w.shape[0] == N
+    if out is None:
+        out = torch.empty(M, K, dtype=BF16, device=dy.device)
+    k.gemm(M, K, N, k.A_ROWK, k.operand(dy, _ld(dy)), k.B_KROW, k.operand(w, _ld(w)), out, _ld(out), alpha=alpha, scale=scale,
+           res=res, ldr=_ld(res) if res is not None else 0, act=act, aux=aux, ldaux=_ld(aux) if aux is not None else 0,
+           flags=flags)
+    return out
+
+
+def linear_wgrad(dy, x, *, out=None, alpha=1.0, flags=0, split_k=None):
+    """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]; `out` must be zero-initialised or hold a running sum."""
+    M, N = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == M
+    if out is None:
+        out = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
+    if split_k is None:
+        tiles = ((N + 63) // 64) * ((K + 63) // 64)
+        split_k = _split_k_for(tiles, (M + 31) // 32)
+    k.gemm(N, K, M, k.A_KROW, k.operand(dy, _ld(dy)), k.B_KROW, k.operand(x, _ld(x)), out, _ld(out), alpha=alpha,
+           accumulate=True, split_k=split_k, flags=flags)
+    return out
+
+
+def bias_grad(dy, out=None):
+    M, N = dy.shape
+    if out is None:
+        out = torch.zeros(N, dtype=torch.float32, device=dy.device)
+    k.colsum(dy, M, N, _ld(dy), out)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ convolution
+def conv_out_hw(H, W, R, S, stride, pad, dil=1):
+    return (H + 2 * pad - dil * (R - 1) - 1) // stride + 1, (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+
+
+def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, res=None, act=k.ACT_NONE, out=None, tile=0):
+    """NHWC implicit-GEMM convolution: x [N,H,W,C], w [Co,R,S,C] -> [N,OH,OW,Co] with the
+    FrozenBatchNorm scale/shift (+residual, +ReLU) fused into the epilogue."""
+    Nb, H, W, C = x.shape
+    Co, R, S, Cw = w.shape
+    assert Cw == C and x.is_contiguous() and w.is_contiguous()
+    OH, OW = conv_out_hw(H, W, R, S, stride, pad, dil)
+    if out is None:
+        out = torch.empty(Nb, OH, OW, Co, dtype=BF16, device=x.device)
+    M = Nb * OH * OW
+    Kred = R * S * C
+    if R == 1 and S == 1 and stride == 1 and pad == 0:
+        a_kind, a = k.A_ROWK, k.operand(x, C)
+    else:
+        a_kind = k.A_CONV
+        a = k.operand(x, 0, geom=k.ConvGeom(H, W, C, OH, OW, R, S, stride, pad, dil))
+        Kred = ((Kred + 31) // 32) * 32  # taps beyond R*S are zero-filled by the gather
+    wk = w.view(Co, R * S * C)
+    if Kred != R * S * C:  # stem only (C = 8): pad the reduction axis of the weights with zeros
+        wk = torch.nn.functional.pad(wk, (0, Kred - R * S * C))
+    k.gemm(M, Co, Kred, a_kind, a, k.B_ROWK, k.operand(wk, Kred), out, Co, scale=scale, shift=shift, res=res,
+           ldr=Co if res is not None else 0, act=act, tile=tile)
+    return out
+
+
+def conv2d_dgrad(dy, w, in_hw, *, stride=1, pad=0, dil=1, scale=None, res=None, act=k.ACT_NONE, aux=None, out=None, flags=0):
+    """dx [N,H,W,C] = transposed-gather of dy [N,OH,OW,Co] with w [Co,R,S,C] read in place (k-major)."""
+    Nb, OH, OW, Co = dy.shape
+    Cw, R, S, C = w.shape
+    H, W = in_hw
+    assert Cw == Co and dy.is_contiguous() and w.is_contiguous()
+    if out is None:
+        out = torch.empty(Nb, H, W, C, dtype=BF16, device=dy.device)
+    M = Nb * H * W
+    ldr = C if res is not None else 0
+    ldaux = C if aux is not None else 0
+    if R == 1 and S == 1 and stride == 1 and pad == 0:
+        k.gemm(M, C, Co, k.A_ROWK, k.operand(dy, Co), k.B_KROW, k.operand(w.view(Co, C), C), out, C, scale=scale, res=res, ldr=ldr,
+               act=act, aux=aux, ldaux=ldaux, flags=flags)
+    elif R == 1 and S == 1 and pad == 0:
+        # strided 1x1 (downsample): only rows (n, oy*stride, ox*stride) of dx receive a value
+        k.gemm(Nb * OH * OW, C, Co, k.A_ROWK, k.operand(dy, Co), k.B_KROW, k.operand(w.view(Co, C), C), out, C, scale=scale,
+               res=res, ldr=ldr, act=act, aux=aux, ldaux=ldaux, cmap=(H, W, OH, OW, stride), flags=flags)
+    else:
+        a = k.operand(dy, 0, geom=k.ConvGeom(OH, OW, Co, H, W, R, S, stride, pad, dil))
+        b = k.operand(w, R * S * C, kin=Co, tap_stride=C)
+        k.gemm(M, C, R * S * Co, k.A_CONVT, a, k.B_KROW, b, out, C, scale=scale, res=res, ldr=ldr, act=act, aux=aux,
+               ldaux=ldaux, flags=flags)
+    return out
+
+
+def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, split_k=None):
+    """dw [Co,R,S,C] (f32, accumulated) = sum over output pixels of dy (x) gathered x."""
+    Nb, OH, OW, Co = dy.shape
+    _, H, W, C = x.shape
+    Cw, R, S, Cc = w_shape
+    assert Cw == Co and Cc == C and dy.is_contiguous() and x.is_contiguous()
+    if out is None:
+        out = torch.zeros(Co, R, S, C, dtype=torch.float32, device=dy.device)
+    P = Nb * OH * OW
+    Nn = R * S * C
+    if split_k is None:
+        tiles = ((Co + 63) // 64) * ((Nn + 63) // 64)
+        split_k = _split_k_for(tiles, (P + 31) // 32)
+    a = k.operand(dy, Co)
+    if R == 1 and S == 1 and stride == 1 and pad == 0:
+        b_kind, b = k.B_KROW, k.operand(x, C)
+    else:
+        b_kind, b = k.B_CONVX, k.operand(x, 0, geom=k.ConvGeom(H, W, C, OH, OW, R, S, stride, pad, dil))
+    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out, Nn, accumulate=True, split_k=split_k, flags=flags)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ attention
+def round8(n):
+    return (n + 7) // 8 * 8
+
+
+def attn_scores(q, kmat, B, H, Sq, Sk, dh, scale, out=None):
+    """scores[b,h,i,j] = scale * q[b,i,h,:] . k[b,j,h,:]; q/k are column slices of packed projection
+    buffers: row (b*S + s), feature (h*dh + e).  Output [B*H, Sq, round8(Sk)] bf16."""
+    ld = round8(Sk)
+    if out is None:
+        out = torch.empty(B * H, Sq, ld, dtype=BF16, device=q.device)
+    k.gemm(Sq, Sk, dh, k.A_ROWK, k.operand(q, _ld(q), bs_outer=Sq * _ld(q), bs_inner=dh), k.B_ROWK,
+           k.operand(kmat, _ld(kmat), bs_outer=Sk * _ld(kmat), bs_inner=dh), out, ld, batch=B * H, batch_inner=H,
+           cs_outer=H * Sq * ld, cs_inner=Sq * ld, alpha=scale, tile=64)
+    return out
+
+
+def attn_context(p, v, B, H, Sq, Sk, dh, out):
+    """ctx[b,i,h,:] = sum_j p[b,h,i,j] * v[b,j,h,:]; `out` is a [B*Sq, H*dh] (slice of a) buffer."""
+    ld = p.shape[-1]
+    k.gemm(Sq, dh, Sk, k.A_ROWK, k.operand(p, ld, bs_outer=H * Sq * ld, bs_inner=Sq * ld), k.B_KROW,
+           k.operand(v, _ld(v), bs_outer=Sk * _ld(v), bs_inner=dh), out, _ld(out), batch=B * H, batch_inner=H,
+           cs_outer=Sq * _ld(out), cs_inner=dh, tile=64)
+    return out
+
+
+def attn_backward(p_used, ds_scale, q, kmat, v, dctx, B, H, Sq, Sk, dh, dq, dk, dv, softmax_bwd_fn):
+    """Backward of softmax(scale*q.k^T).v for packed per-head slices.
+
+    p_used: probabilities that multiplied v in the forward pass (after dropout when training).
+    softmax_bwd_fn(dp) -> ds maps dP (wrt p_used) to dS (wrt the scaled scores)."""
+    ld = p_used.shape[-1]
+    dev = q.device
+    # dV[b,j,h,:] = sum_i p[b,h,i,j] * dctx[b,i,h,:]
+    k.gemm(Sk, dh, Sq, k.A_KROW, k.operand(p_used, ld, bs_outer=H * Sq * ld, bs_inner=Sq * ld), k.B_KROW,
+           k.operand(dctx, _ld(dctx), bs_outer=Sq * _ld(dctx), bs_inner=dh), dv, _ld(dv), batch=B * H, batch_inner=H,
+           cs_outer=Sk * _ld(dv), cs_inner=dh, tile=64)
+    # dP[b,h,i,j] = dctx[b,i,h,:] . v[b,j,h,:]
+    dp = torch.empty(B * H, Sq, ld, dtype=BF16, device=dev)
+    k.gemm(Sq, Sk, dh, k.A_ROWK, k.operand(dctx, _ld(dctx), bs_outer=Sq * _ld(dctx), bs_inner=dh), k.B_ROWK,
+           k.operand(v, _ld(v), bs_outer=Sk * _ld(v), bs_inner=dh), dp, ld, batch=B * H, batch_inner=H, cs_outer=H * Sq * ld,
+           cs_inner=Sq * ld, tile=64)
+    ds = softmax_bwd_fn(dp)
+    # dQ = scale * dS @ K ; dK = scale * dS^T @ Q
+    k.gemm(Sq, dh, Sk, k.A_ROWK, k.operand(ds, ld, bs_outer=H * Sq * ld, bs_inner=Sq * ld), k.B_KROW,
+           k.operand(kmat, _ld(kmat), bs_outer=Sk * _ld(kmat), bs_inner=dh), dq, _ld(dq), batch=B * H, batch_inner=H,
+           cs_outer=Sq * _ld(dq), cs_inner=dh, alpha=ds_scale, tile=64)
+    k.gemm(Sk, dh, Sq, k.A_KROW, k.operand(ds, ld, bs_outer=H * Sq * ld, bs_inner=Sq * ld), k.B_KROW,
+           k.operand(q, _ld(q), bs_outer=Sq * _ld(q), bs_inner=dh), dk, _ld(dk), batch=B * H, batch_inner=H,
+           cs_outer=Sk * _ld(dk), cs_inner=dh, alpha=ds_scale, tile=64)
