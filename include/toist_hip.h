@@ -101,6 +101,7 @@ typedef struct toist_epilogue {
     float alpha;          /* v = acc * alpha */
     const float* scale;   /* [N] f32 or NULL: v = v * scale[n] */
     const float* shift;   /* [N] f32 or NULL: v = v + shift[n] */
+    const float* rscale;  /* [M] f32 or NULL: v = v * rscale[m] (FrozenBN scale of a conv wgrad row) */
     const void* res;      /* bf16 residual, same row map as C, or NULL */
     int32_t ldr;
     const void* aux;      /* bf16 operand of the *_BWD / MASK_POS activations */
@@ -158,6 +159,30 @@ int toist_colsum(const void* g, int M, int N, int ld, float* out, void* stream);
 int toist_add_bf16(const void* a, const void* b, int64_t n, int64_t b_period, void* out, void* stream);
 /* out = dropout(x): keep iff hash(seed, flat index) >= p*2^32, kept values scaled by 1/(1-p) */
 int toist_dropout_bf16(const void* x, int64_t n, float p, uint64_t seed, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backbone-side layout / pooling kernels (NHWC bf16).
+ *  pack_image : f32 NCHW [N,C<=8,H,W] -> bf16 NHWC [N,H,W,8] (zero padded channels): the stem operand
+ *  maxpool    : 3x3 / stride 2 / pad 1 (ResNet stem, reached through backbone.py:87-89)
+ *  unpack     : bf16 NHWC [N,HW,C] -> f32 NCHW [N,C,HW] for API-edge feature maps
+ */
+int toist_pack_image(const float* nchw, int N, int C, int H, int W, void* nhwc8, void* stream);
+int toist_maxpool3x3s2(const void* in, int N, int H, int W, int C, void* out, void* stream);
+int toist_unpack_nhwc(const void* nhwc, int N, int HW, int C, float* nchw, void* stream);
+
+/* PositionEmbeddingSine.forward (position_encoding.py:30-49; normalize=True, scale=2*pi):
+ * mask [B,H,W] u8 (1 = padded pixel) -> bf16 [B, H*W, 2*num_pos_feats] tokens and/or f32
+ * [B, 2*num_pos_feats, H, W] (either output may be NULL). */
+int toist_sine_position(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, void* out_tok,
+                        float* out_nchw, void* stream);
+
+/* RoBERTa input embeddings (HF RobertaEmbeddings, called at transformer.py:130):
+ * out[t] = word[ids[t]] + type0 + pos[pos_ids[t]] (f32 tables -> bf16 [n,D]); bwd scatter-adds the
+ * bf16 gradient rows into the dense f32 table gradients with atomics (any of them may be NULL). */
+int toist_embed_fwd(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
+                    int n, int D, void* out, void* stream);
+int toist_embed_bwd(const void* g, const int64_t* ids, const int64_t* pos_ids, int n, int D, int64_t pad_id, float* dword,
+                    float* dpos, float* dtype0, void* stream); /* rows whose id == pad_id get no gradient (padding_idx) */
 
 #ifdef __cplusplus
 }

@@ -257,13 +257,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
             const int oy = rem / e.cOW, ox = rem - oy * e.cOW;
             crow = ((long long)n_img * e.cH + (long long)oy * e.cst) * e.cW + (long long)ox * e.cst;
         }
+        const float rs = e.rscale ? e.alpha * e.rscale[m] : e.alpha;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int n = n0 + wn * WN + j * 16 + g * 4;
             if (n >= N) continue;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * e.alpha;
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * rs;
             const int nv = (N - n < 4) ? (N - n) : 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -306,6 +306,42 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------- embeddings
+// RoBERTa input embedding (HF RobertaEmbeddings, reached from transformer.py:130):
+// out[t] = word[ids[t]] + type[0] + pos[pos_ids[t]]  (fp32 tables -> bf16 activation).
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ ids, const long long* __restrict__ pos_ids,
+                                                         const float* __restrict__ word, const float* __restrict__ pos,
+                                                         const float* __restrict__ type0, int n, int D, bf16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n) return;
+    const float* w = word + ids[t] * (long long)D;
+    const float* p = pos + pos_ids[t] * (long long)D;
+    for (int c = lane * 2; c < D; c += 128) {
+        const float a = (w[c] + type0[c]) + p[c];
+        const float b = (w[c + 1] + type0[c + 1]) + p[c + 1];
+        *reinterpret_cast<unsigned*>(out + (size_t)t * D + c) = pack2bf(a, b);
+    }
+}
+// scatter-add of the embedding gradient into the (dense, fp32) table gradients
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const bf16_t* __restrict__ g, const long long* __restrict__ ids,
+                                                         const long long* __restrict__ pos_ids, int n, int D, long long pad_id,
+                                                         float* __restrict__ dword, float* __restrict__ dpos, float* __restrict__ dtype0) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n) return;
+    // nn.Embedding(padding_idx=pad_id) never accumulates a gradient into the padding row
+    float* dw = (dword && ids[t] != pad_id) ? dword + ids[t] * (long long)D : nullptr;
+    float* dp = (dpos && pos_ids[t] != pad_id) ? dpos + pos_ids[t] * (long long)D : nullptr;
+    for (int c = lane; c < D; c += 64) {
+        const float v = bf2f(g[(size_t)t * D + c]);
+        if (dw) atomicAdd(dw + c, v);
+        if (dp) atomicAdd(dp + c, v);
+        if (dtype0) atomicAdd(dtype0 + c, v);
+    }
+}
+
 static inline int grid_for(long long n, int cap = 2048) {
     long long g = (n + 255) / 256;
     if (g < 1) g = 1;
@@ -375,4 +411,20 @@ extern "C" int toist_dropout_bf16(const void* x, int64_t n, float p, uint64_t se
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long long)(n / 8),
                        p, (unsigned long long)seed, (bf16_t*)out);
     return check_launch("toist_dropout_bf16");
+}
+
+extern "C" int toist_embed_fwd(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
+                               int n, int D, void* out, void* stream) {
+    TOIST_REQUIRE(n > 0 && D > 0 && (D % 2) == 0, "toist_embed_fwd: bad shape");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const long long*)ids,
+                       (const long long*)pos_ids, word, pos, type0, n, D, (bf16_t*)out);
+    return check_launch("toist_embed_fwd");
+}
+
+extern "C" int toist_embed_bwd(const void* g, const int64_t* ids, const int64_t* pos_ids, int n, int D, int64_t pad_id, float* dword,
+                               float* dpos, float* dtype0, void* stream) {
+    TOIST_REQUIRE(n > 0 && D > 0, "toist_embed_bwd: bad shape");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, (const long long*)ids,
+                       (const long long*)pos_ids, n, D, (long long)pad_id, dword, dpos, dtype0);
+    return check_launch("toist_embed_bwd");
 }

@@ -1,0 +1,434 @@
+"""Explicit forward/backward programs for the TOIST hot path, built from the HIP kernel calls of
+toist_amd.ops / toist_amd.kernels.
+
+There is no tracing compiler and no per-op torch autograd here: a forward pass appends its backward
+closures to a Tape, and the enclosing torch.autograd.Function (see toist_amd/functions.py) replays
+them in reverse.  Activations are bf16, statistics / parameter gradients fp32.  Activation-function
+and FrozenBN backward steps are folded into the epilogue of the GEMM that produces the gradient.
+"""
+import math
+
+import torch
+
+from . import kernels as k
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+class Var:
+    """An activation (bf16, [rows, features] or NHWC) and its gradient slot."""
+
+    __slots__ = ("data", "grad", "needs_grad")
+
+    def __init__(self, data, needs_grad=True):
+        self.data = data
+        self.grad = None
+        self.needs_grad = needs_grad
+
+    def take_grad(self):
+        g, self.grad = self.grad, None
+        return g
+
+
+class Tape:
+    def __init__(self, training, drop_p=0.0, seed=0):
+        self.steps = []
+        self.training = training
+        self.drop_p = drop_p if training else 0.0
+        self._seed = seed * 1000003 + 12345
+        self.keep = []  # tensors that must outlive the forward (API outputs etc.)
+
+    def next_seed(self):
+        self._seed += 7919
+        return self._seed & 0x7FFFFFFFFFFF
+
+    def record(self, fn):
+        self.steps.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.steps):
+            fn()
+        self.steps = []
+
+
+class ParamView:
+    """bf16 compute copy + fp32 gradient slot of one nn.Parameter (or a row slice of one)."""
+
+    __slots__ = ("w", "g", "f32")
+
+    def __init__(self, w_bf16, grad_f32, f32=None):
+        self.w = w_bf16    # bf16 tensor used by the kernels (None for fp32-only params)
+        self.g = grad_f32  # fp32 gradient accumulator (zero-initialised) or None when frozen
+        self.f32 = f32     # fp32 master values for params consumed in fp32 (biases, LN affine)
+
+    def rows(self, a, b):
+        """Row slice [a:b) of a packed parameter (e.g. the q / k / v blocks of in_proj_weight)."""
+        return ParamView(None if self.w is None else self.w[a:b], None if self.g is None else self.g[a:b],
+                         None if self.f32 is None else self.f32[a:b])
+
+
+class ParamSet:
+    """Per-call view of a module's parameters: bf16 weight copies and one flat fp32 gradient buffer.
+
+    `named` is an ordered {name: tensor(fp32 master)}; weights (dim >= 2) get a bf16 copy, vectors
+    are used in fp32 directly.  grads() returns gradients in the same order (None for frozen)."""
+
+    def __init__(self, named, trainable, need_grads, bf16_cache=None, transforms=None):
+        self.names = list(named.keys())
+        self.views = {}
+        total = 0
+        if need_grads:
+            for n in self.names:
+                if trainable.get(n, False):
+                    total += (named[n].numel() + 63) // 64 * 64
+        dev = next(iter(named.values())).device if named else None
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev) if total else None
+        off = 0
+        for n in self.names:
+            t = named[n]
+            g = None
+            if need_grads and trainable.get(n, False):
+                g = self.flat[off:off + t.numel()].view(t.shape)
+                if t.dim() == 4:  # conv weights are channels_last (physically KRSC); keep that layout
+                    O, I, R, S = t.shape
+                    g = self.flat[off:off + t.numel()].view(O, R, S, I).permute(0, 3, 1, 2)
+                off += (t.numel() + 63) // 64 * 64
+            wb = None
+            if t.dim() >= 2:
+                make = (transforms or {}).get(n) or (lambda m: m.detach().to(BF16))
+                if bf16_cache is not None:
+                    ent = bf16_cache.get(n)
+                    if ent is None or ent[0] != t._version or ent[2] != t.data_ptr():
+                        ent = (t._version, make(t), t.data_ptr())
+                        bf16_cache[n] = ent
+                    wb = ent[1]
+                else:
+                    wb = make(t)
+            self.views[n] = ParamView(wb, g, t.detach())
+
+    def __getitem__(self, name):
+        return self.views[name]
+
+    def grads(self):
+        return [self.views[n].g for n in self.names]
+
+
+def krsc(w):
+    """[Co,Cin,R,S] channels_last tensor -> its physical [Co,R,S,Cin] contiguous view."""
+    v = w.permute(0, 2, 3, 1)
+    assert v.is_contiguous(), "conv weights must be channels_last"
+    return v
+
+
+def accumulate(var, g):
+    """var.grad += g (g becomes the slot when empty)."""
+    if var.grad is None:
+        var.grad = g
+    else:
+        k.add(var.grad, g, var.grad)
+
+
+# ------------------------------------------------------------------------------------------ dense ops
+def linear_chain(tape, x, layers, res=None, final_drop=False, out_dtype=BF16, last_act_external=False):
+    """y = L_n(...L_1(x)), layer = (W, b, act[, dropout_after_act]); optional `+ res` after an
+    optional dropout on the last layer's output (the transformer's `x + dropout(sublayer(x))`).
+    Returns Var.  Activation backward of layer i is fused into the dgrad GEMM of layer i+1."""
+    acts = []
+    cur = x.data
+    p = tape.drop_p
+    seeds = []
+    n = len(layers)
+    for i, (W, b, act, drop_after) in enumerate(layers):
+        last = i == n - 1
+        kw = {}
+        seed = 0
+        if drop_after and p > 0:
+            seed = tape.next_seed()
+            kw = dict(drop_where=2, drop_p=p, drop_seed=seed)
+        if last and final_drop and p > 0:
+            seed = tape.next_seed()
+            kw = dict(drop_where=1, drop_p=p, drop_seed=seed)
+        pre = None
+        if act == k.ACT_GELU:
+            pre = torch.empty(cur.shape[0], W.w.shape[0], dtype=BF16, device=cur.device)
+        y = ops.linear(cur, W.w, b.f32 if b is not None else None, act=act, res=res.data if (last and res is not None) else None,
+                       pre_out=pre, out_dtype=out_dtype if last else BF16, **kw)
+        acts.append((cur, y, pre))
+        seeds.append(seed)
+        cur = y
+    out = Var(cur)
+
+    def bwd():
+        g = out.take_grad()
+        if g is None:
+            return
+        if res is not None and res.needs_grad:
+            accumulate(res, g)
+            if res.grad is g:  # keep our own copy if we are about to modify g
+                pass
+        for i in range(n - 1, -1, -1):
+            W, b, act, drop_after = layers[i]
+            xin, y, pre = acts[i]
+            last = i == n - 1
+            if last:
+                # g is the gradient w.r.t. the layer output after residual; undo dropout / activation
+                if final_drop and p > 0:
+                    gd = torch.empty_like(g)
+                    k.dropout(g, p, seeds[i], gd)
+                    g = gd
+                if act != k.ACT_NONE and not last_act_external:
+                    raise NotImplementedError("activation on the last layer of a chain needs last_act_external")
+            # g is now the gradient w.r.t. the pre-activation output of layer i
+            if W.g is not None:
+                ops.linear_wgrad(g, xin, out=W.g)
+                if b is not None and b.g is not None:
+                    ops.bias_grad(g, out=b.g)
+            if i == 0:
+                if x.needs_grad:
+                    x.grad = ops.linear_dgrad(g, W.w, res=x.grad)
+            else:
+                pW, pb, pact, pdrop = layers[i - 1]
+                _, py, ppre = acts[i - 1]
+                alpha = 1.0 / (1.0 - p) if (pdrop and p > 0) else 1.0
+                if pact == k.ACT_RELU:
+                    g = ops.linear_dgrad(g, W.w, act=k.ACT_MASK_POS, aux=py, alpha=alpha)
+                elif pact == k.ACT_GELU:
+                    if pdrop and p > 0:
+                        raise NotImplementedError("dropout after GELU")
+                    g = ops.linear_dgrad(g, W.w, act=k.ACT_GELU_BWD, aux=ppre)
+                elif pact == k.ACT_NONE:
+                    g = ops.linear_dgrad(g, W.w)
+                else:
+                    raise NotImplementedError
+
+    tape.record(bwd)
+    return out
+
+
+def layernorm(tape, x, gamma, beta, eps, y=None):
+    rows, D = x.data.shape
+    if y is None:
+        y = torch.empty_like(x.data)
+    mean = torch.empty(rows, dtype=torch.float32, device=y.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=y.device)
+    k.layernorm_fwd(x.data, gamma.f32, beta.f32, eps, y, mean, rstd)
+    out = Var(y)
+
+    def bwd():
+        g = out.take_grad()
+        if g is None:
+            return
+        dx = torch.empty_like(g)
+        k.layernorm_bwd(g, x.data, mean, rstd, gamma.f32, dx, gamma.g, beta.g if gamma.g is not None else None)
+        if x.needs_grad:
+            accumulate(x, dx)
+
+    tape.record(bwd)
+    return out
+
+
+def add_const(tape, x, c):
+    """x + c with c a constant bf16 tensor (positional encoding); c may be broadcast over rows."""
+    y = torch.empty_like(x.data)
+    k.add(x.data, c, y, b_period=c.numel())
+    out = Var(y)
+
+    def bwd():
+        g = out.take_grad()
+        if g is not None and x.needs_grad:
+            accumulate(x, g)
+
+    tape.record(bwd)
+    return out
+
+
+def add_vars(tape, a, b):
+    y = torch.empty_like(a.data)
+    k.add(a.data, b.data, y, b_period=b.data.numel())
+    out = Var(y)
+    rep = a.data.numel() // b.data.numel()
+
+    def bwd():
+        g = out.take_grad()
+        if g is None:
+            return
+        if b.needs_grad:
+            if rep == 1:
+                accumulate(b, g)
+            else:
+                # b was broadcast over `rep` leading blocks: reduce (rare: query_pos over the batch)
+                gb = g.view(rep, -1).float().sum(0).to(BF16).view(b.data.shape)
+                accumulate(b, gb)
+        if a.needs_grad:
+            accumulate(a, g)
+
+    tape.record(bwd)
+    return out
+
+
+def dropout(tape, x):
+    p = tape.drop_p
+    if p <= 0:
+        return x
+    seed = tape.next_seed()
+    y = torch.empty_like(x.data)
+    k.dropout(x.data, p, seed, y)
+    out = Var(y)
+
+    def bwd():
+        g = out.take_grad()
+        if g is None or not x.needs_grad:
+            return
+        gd = torch.empty_like(g)
+        k.dropout(g, p, seed, gd)
+        accumulate(x, gd)
+
+    tape.record(bwd)
+    return out
+
+
+def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq, Sk, H, packed_qk=None):
+    """resid + dropout(out_proj(softmax(q k^T / sqrt(dh) + mask) v)) -- nn.MultiheadAttention plus the
+    residual/dropout that follows it (transformer.py:297-299, 370-400), also HF RobertaSelfAttention +
+    RobertaSelfOutput.dense.  Pq/Pk/Pv = (weight ParamView, bias ParamView); packed_qk = the same for
+    the stacked [2d, d] q/k block when q_in is k_in (one GEMM).  Returns Var [B*Sq, d]."""
+    d = Wo.w.shape[0]
+    dh = d // H
+    scale = 1.0 / math.sqrt(dh)
+    dev = q_in.data.device
+    p = tape.drop_p
+    fused = packed_qk is not None and q_in is k_in
+    if fused:
+        qk = ops.linear(q_in.data, packed_qk[0].w, packed_qk[1].f32)
+        qb, kb = qk[:, :d], qk[:, d:]
+    else:
+        qb = ops.linear(q_in.data, Pq[0].w, Pq[1].f32)
+        kb = ops.linear(k_in.data, Pk[0].w, Pk[1].f32)
+    vb = ops.linear(v_in.data, Pv[0].w, Pv[1].f32)
+    s = ops.attn_scores(qb, kb, B, H, Sq, Sk, dh, scale)
+    ld = s.shape[-1]
+    prob = torch.empty_like(s)
+    seed_p = tape.next_seed() if p > 0 else 0
+    prob_used = torch.empty_like(s) if p > 0 else None
+    k.softmax_fwd(s, key_pad, B, H, Sq, Sk, ld, prob, prob_used, p, seed_p)
+    del s
+    if prob_used is None:
+        prob_used = prob
+    ctx = torch.empty(B * Sq, d, dtype=BF16, device=dev)
+    ops.attn_context(prob_used, vb, B, H, Sq, Sk, dh, ctx)
+    seed_o = tape.next_seed() if p > 0 else 0
+    z = ops.linear(ctx, Wo.w, bo.f32, res=resid.data, drop_where=1 if p > 0 else 0, drop_p=p, drop_seed=seed_o)
+    out = Var(z)
+
+    def bwd():
+        g = out.take_grad()
+        if g is None:
+            return
+        if resid.needs_grad:
+            accumulate(resid, g)
+        if p > 0:
+            go = torch.empty_like(g)
+            k.dropout(g, p, seed_o, go)
+        else:
+            go = g
+        if Wo.g is not None:
+            ops.linear_wgrad(go, ctx, out=Wo.g)
+            ops.bias_grad(go, out=bo.g)
+        dctx = ops.linear_dgrad(go, Wo.w)
+        if fused:
+            dqk = torch.empty(B * Sq, 2 * d, dtype=BF16, device=dev)
+            dq, dk = dqk[:, :d], dqk[:, d:]
+        else:
+            dq = torch.empty(B * Sq, d, dtype=BF16, device=dev)
+            dk = torch.empty(B * Sk, d, dtype=BF16, device=dev)
+        dv = torch.empty(B * Sk, d, dtype=BF16, device=dev)
+
+        def sm_bwd(dp):
+            ds = torch.empty_like(dp)
+            k.softmax_bwd(prob, dp, B * H * Sq, Sk, ld, ds, p, seed_p)
+            return ds
+
+        ops.attn_backward(prob_used, scale, qb, kb, vb, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
+        if fused:
+            if packed_qk[0].g is not None:
+                ops.linear_wgrad(dqk, q_in.data, out=packed_qk[0].g)
+                ops.bias_grad(dqk, out=packed_qk[1].g)
+            if q_in.needs_grad:
+                q_in.grad = ops.linear_dgrad(dqk, packed_qk[0].w, res=q_in.grad)
+        else:
+            if Pq[0].g is not None:
+                ops.linear_wgrad(dq, q_in.data, out=Pq[0].g)
+                ops.bias_grad(dq, out=Pq[1].g)
+            if Pk[0].g is not None:
+                ops.linear_wgrad(dk, k_in.data, out=Pk[0].g)
+                ops.bias_grad(dk, out=Pk[1].g)
+            if q_in.needs_grad:
+                q_in.grad = ops.linear_dgrad(dq, Pq[0].w, res=q_in.grad)
+            if k_in.needs_grad:
+                k_in.grad = ops.linear_dgrad(dk, Pk[0].w, res=k_in.grad)
+        if Pv[0].g is not None:
+            ops.linear_wgrad(dv, v_in.data, out=Pv[0].g)
+            ops.bias_grad(dv, out=Pv[1].g)
+        if v_in.needs_grad:
+            v_in.grad = ops.linear_dgrad(dv, Pv[0].w, res=v_in.grad)
+
+    tape.record(bwd)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ ResNet blocks
+def bottleneck(tape, x, W, bn, stride, has_down, train):
+    """torchvision Bottleneck (v1.5) on NHWC bf16 with FrozenBatchNorm folded: conv weights `W[name].w`
+    are already multiplied by the BN scale, `bn[name]` = (scale, shift) fp32.  The gradient this block
+    leaves in x.grad is already masked by (x > 0), i.e. it is the gradient w.r.t. the pre-ReLU sum of
+    the producing block (every block input is a ReLU output)."""
+    w1, w2, w3 = krsc(W["conv1"].w), krsc(W["conv2"].w), krsc(W["conv3"].w)
+    s1, t1 = bn["bn1"]
+    s2, t2 = bn["bn2"]
+    s3, t3 = bn["bn3"]
+    a1 = ops.conv2d(x.data, w1, shift=t1, act=k.ACT_RELU)
+    a2 = ops.conv2d(a1, w2, stride=stride, pad=1, shift=t2, act=k.ACT_RELU)
+    if has_down:
+        wd = krsc(W["down"].w)
+        sd, td = bn["down"]
+        idn = ops.conv2d(x.data, wd, stride=stride, shift=td)
+    else:
+        idn = x.data
+    y = ops.conv2d(a2, w3, shift=t3, res=idn, act=k.ACT_RELU)
+    if has_down:
+        del idn
+    out = Var(y)
+    if not train:
+        return out
+    H, Wd = x.data.shape[1], x.data.shape[2]
+
+    def bwd():
+        g3 = out.take_grad()  # w.r.t. the pre-ReLU sum (masked by the consumer)
+        if g3 is None:
+            return
+        ops.conv2d_wgrad(g3, a2, w3.shape, out=krsc(W["conv3"].g), rscale=s3)
+        g2 = ops.conv2d_dgrad(g3, w3, a2.shape[1:3], act=k.ACT_MASK_POS, aux=a2)
+        ops.conv2d_wgrad(g2, a1, w2.shape, stride=stride, pad=1, out=krsc(W["conv2"].g), rscale=s2)
+        g1 = ops.conv2d_dgrad(g2, w2, (H, Wd), stride=stride, pad=1, act=k.ACT_MASK_POS, aux=a1)
+        ops.conv2d_wgrad(g1, x.data, w1.shape, out=krsc(W["conv1"].g), rscale=s1)
+        if has_down:
+            ops.conv2d_wgrad(g3, x.data, wd.shape, stride=stride, out=krsc(W["down"].g), rscale=sd)
+        if not x.needs_grad:
+            return
+        prev = x.take_grad()
+        if has_down:
+            if stride == 1:
+                gx = ops.conv2d_dgrad(g3, wd, (H, Wd), res=prev)
+            else:
+                gx = prev if prev is not None else torch.zeros_like(x.data)
+                ops.conv2d_dgrad(g3, wd, (H, Wd), stride=stride, out=gx, res=gx if prev is not None else None)
+        else:
+            gx = g3
+            if prev is not None:
+                k.add(prev, g3, prev)
+                gx = prev
+        x.grad = ops.conv2d_dgrad(g1, w1, (H, Wd), res=gx, act=k.ACT_MASK_POS, aux=x.data)
+
+    tape.record(bwd)
+    return out

@@ -1,0 +1,66 @@
+"""Bridge between torch.autograd and the explicit forward/backward programs of toist_amd.engine.
+
+`run_program` executes a forward program on the HIP kernels and registers ONE autograd node whose
+backward replays the program's tape.  torch.autograd only carries tensors between these coarse nodes
+(backbone, text encoder, encoder, decoder, heads) and delivers parameter gradients to the optimizer /
+DistributedDataParallel hooks; it never differentiates through individual ops.
+"""
+import torch
+
+from . import engine
+
+
+class _TapeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, body, names, cache, n_in, tape_kw, *tensors):
+        inputs = tensors[:n_in]
+        params = tensors[n_in:]
+        tape_kw = dict(tape_kw)
+        need = tape_kw.pop('need_grads')  # grad mode is off inside Function.forward: decided by the caller
+        transforms = tape_kw.pop('transforms')
+        named = dict(zip(names, params))
+        trainable = {n: p.requires_grad for n, p in named.items()}
+        ps = engine.ParamSet(named, trainable, need_grads=need, bf16_cache=cache, transforms=transforms)
+        tape = engine.Tape(**tape_kw)
+        in_vars = [None if t is None else engine.Var(t, needs_grad=(need and t.requires_grad and t.is_floating_point()))
+                   for t in inputs]
+        out_vars, extra = body(tape, ps, *in_vars)
+        if need:
+            ctx.tape, ctx.ps, ctx.in_vars, ctx.out_vars = tape, ps, in_vars, out_vars
+        else:
+            tape.steps = []
+        ctx.n_in = n_in
+        ctx.n_par = len(params)
+        ctx.extra = extra
+        non_diff = [v.data for v in out_vars if not v.needs_grad]
+        if non_diff:
+            ctx.mark_non_differentiable(*non_diff)
+        return tuple(v.data for v in out_vars)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        tape, ps = ctx.tape, ctx.ps
+        for v, g in zip(ctx.out_vars, grads):
+            if g is not None and v.needs_grad:
+                if g.dtype != v.data.dtype:
+                    g = g.to(v.data.dtype)
+                v.grad = g.contiguous()
+        tape.backward()
+        in_grads = []
+        for v in ctx.in_vars:
+            if v is None or not v.needs_grad:
+                in_grads.append(None)
+            else:
+                in_grads.append(v.take_grad())
+        par_grads = ps.grads()
+        ctx.tape = ctx.ps = ctx.in_vars = ctx.out_vars = None
+        return (None, None, None, None, None, *in_grads, *par_grads)
+
+
+def run_program(body, named_params, inputs, cache=None, training=False, drop_p=0.0, seed=0, transforms=None):
+    """body(tape, ps, *input_vars) -> (list_of_output_vars, extra).  Returns (outputs_tuple)."""
+    names = tuple(named_params.keys())
+    params = tuple(named_params.values())
+    need = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (*inputs, *params))
+    tape_kw = dict(training=training, drop_p=drop_p, seed=seed, need_grads=need, transforms=transforms)
+    return _TapeFn.apply(body, names, cache, len(inputs), tape_kw, *inputs, *params)

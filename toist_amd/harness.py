@@ -1,0 +1,62 @@
+"""Synthetic-input harness shared by bench.py, __graft_entry__.smoke() and the tests: default args
+(the flag defaults of /root/reference/main.py:32-274) and the synthetic batch of SURVEY.md 8(d)."""
+from types import SimpleNamespace
+
+import torch
+
+from .transformer import TokenizedText
+
+
+def default_args(**over):
+    a = dict(
+        device="cuda", masks=False, mask_model="none", frozen_weights=None, num_queries=100, aux_loss=True,
+        contrastive_loss_hdim=64, contrastive_align_loss=False, contrastive_loss=False, cluster_num=3, dec_layers=6, enc_layers=6,
+        eos_coef=0.1, temperature_NCE=0.07, hidden_dim=256, nheads=8, dim_feedforward=2048, dropout=0.1, pre_norm=False,
+        pass_pos_and_query=True, text_encoder_type="roberta-base", freeze_text_encoder=False, without_pretrain=True,
+        ce_loss_coef=1.0, bbox_loss_coef=5.0, giou_loss_coef=2.0, mask_loss_coef=1.0, dice_loss_coef=1.0,
+        contrastive_align_loss_coef=1.0, set_loss="hungarian", set_cost_class=1.0, set_cost_bbox=5.0, set_cost_giou=2.0,
+        lr_backbone=1e-5, backbone="resnet101", dilation=False, position_embedding="sine", nsthl2_loss=False, softkd_loss=False,
+        cluster=False, distillation=False, lr=1e-4, text_encoder_lr=5e-5, weight_decay=1e-4, clip_max_norm=0.1,
+    )
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+def synthetic_batch(batch, height=640, width=640, tokens=16, seed=1000, device="cpu", max_targets=10, with_masks=False):
+    """Images ~ N(0,1) (already normalised), all-False padding mask; captions = <s> + ids + </s>;
+    T_i ~ U{0..max_targets} boxes with cx,cy~U(.2,.8), w,h~U(.05,.4); positive_map rows = 1/(tokens-2)
+    on the caption tokens."""
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(batch, 3, height, width, generator=g)
+    mask = torch.zeros(batch, height, width, dtype=torch.bool)
+    ids = torch.randint(3, 50265, (batch, tokens), generator=g)
+    ids[:, 0], ids[:, -1] = 0, 2
+    tokenized = TokenizedText({"input_ids": ids, "attention_mask": torch.ones(batch, tokens, dtype=torch.int64)})
+    targets, rows = [], []
+    for i in range(batch):
+        t = int(torch.randint(0, max_targets + 1, (1,), generator=g))
+        c = torch.rand(t, 2, generator=g) * 0.6 + 0.2
+        s = torch.rand(t, 2, generator=g) * 0.35 + 0.05
+        boxes = torch.cat([c, s], -1)
+        pm = torch.zeros(t, 256)
+        pm[:, 1:tokens - 1] = 1.0 / (tokens - 2)
+        tgt = {"boxes": boxes, "labels": torch.ones(t, dtype=torch.int64), "positive_map": pm,
+               "token_spans": [[(1, tokens - 2)] for _ in range(t)]}
+        if with_masks:
+            m = torch.zeros(t, height, width, dtype=torch.bool)
+            for j in range(t):
+                x0, y0 = int((boxes[j, 0] - boxes[j, 2] / 2) * width), int((boxes[j, 1] - boxes[j, 3] / 2) * height)
+                x1, y1 = int((boxes[j, 0] + boxes[j, 2] / 2) * width), int((boxes[j, 1] + boxes[j, 3] / 2) * height)
+                m[j, max(y0, 0):max(y1, 1), max(x0, 0):max(x1, 1)] = True
+            tgt["masks"] = m
+        targets.append(tgt)
+        rows.append(pm)
+    positive_map = torch.cat(rows) if rows else torch.zeros(0, 256)
+
+    def to(x):
+        return x.to(device) if torch.is_tensor(x) else x
+
+    from .misc import NestedTensor
+    samples = NestedTensor(images.to(device), mask.to(device))
+    targets = [{k: (to(v) if k != "token_spans" else v) for k, v in t.items()} for t in targets]
+    return samples, tokenized.to(device), targets, positive_map.to(device)

@@ -15,7 +15,8 @@ from ._lib import (A_CONV, A_CONVT, A_KROW, A_ROWK, ACT_GELU, ACT_GELU_BWD, ACT_
 __all__ = [
     "A_ROWK", "A_KROW", "A_CONV", "A_CONVT", "B_ROWK", "B_KROW", "B_CONVX", "ACT_NONE", "ACT_RELU", "ACT_GELU",
     "ACT_SIGMOID", "ACT_MASK_POS", "ACT_GELU_BWD", "ACT_SIGMOID_BWD", "ConvGeom", "operand", "gemm", "matcher",
-    "layernorm_fwd", "layernorm_bwd", "softmax_fwd", "softmax_bwd", "colsum", "add", "dropout",
+    "layernorm_fwd", "layernorm_bwd", "softmax_fwd", "softmax_bwd", "colsum", "add", "dropout", "pack_image", "maxpool3x3s2",
+    "unpack_nhwc", "sine_position", "embed_fwd", "embed_bwd",
 ]
 
 
@@ -55,7 +56,7 @@ def operand(t, ld=0, bs_outer=0, bs_inner=0, kin=0, tap_stride=0, geom=None):
 
 
 def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_outer=0, cs_inner=0, split_k=1, tile=0,
-         flags=0, alpha=1.0, scale=None, shift=None, res=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, pre_out=None,
+         flags=0, alpha=1.0, scale=None, shift=None, rscale=None, res=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, pre_out=None,
          accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0):
     """C = epilogue(A @ B^T); see include/toist_hip.h.  `a`/`b` are Operand structs from operand()."""
     d = Gemm()
@@ -70,6 +71,7 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
     e = d.epi
     e.alpha = alpha
     e.scale, e.shift = _p(scale, torch.float32), _p(shift, torch.float32)
+    e.rscale = _p(rscale, torch.float32)
     e.res, e.ldr = _p(res, torch.bfloat16), ldr
     e.aux, e.ldaux = _p(aux, torch.bfloat16), ldaux
     e.act = act
@@ -136,3 +138,38 @@ def add(a, b, out, b_period=None):
 def dropout(x, p, seed, out):
     _lib.check(_lib.lib().toist_dropout_bf16(_p(x, torch.bfloat16), x.numel(), p, seed, _p(out, torch.bfloat16), _stream()),
                "toist_dropout_bf16")
+
+
+def pack_image(nchw, out):
+    N, C, H, W = nchw.shape
+    _lib.check(_lib.lib().toist_pack_image(_p(nchw, torch.float32), N, C, H, W, _p(out, torch.bfloat16), _stream()), "toist_pack_image")
+
+
+def maxpool3x3s2(x, out):
+    N, H, W, C = x.shape
+    _lib.check(_lib.lib().toist_maxpool3x3s2(_p(x, torch.bfloat16), N, H, W, C, _p(out, torch.bfloat16), _stream()), "toist_maxpool3x3s2")
+
+
+def unpack_nhwc(x, out):
+    """bf16 [N, HW, C] -> f32 [N, C, HW]"""
+    N, HW, C = x.shape
+    _lib.check(_lib.lib().toist_unpack_nhwc(_p(x, torch.bfloat16), N, HW, C, _p(out, torch.float32), _stream()), "toist_unpack_nhwc")
+
+
+def sine_position(mask_u8, num_pos_feats, temperature, out_tok=None, out_nchw=None):
+    B, H, W = mask_u8.shape
+    _lib.check(_lib.lib().toist_sine_position(_p(mask_u8, torch.uint8), B, H, W, num_pos_feats, temperature, _p(out_tok, torch.bfloat16),
+                                              _p(out_nchw, torch.float32), _stream()), "toist_sine_position")
+
+
+def embed_fwd(ids, pos_ids, word, pos, type0, out):
+    n, D = out.shape
+    _lib.check(_lib.lib().toist_embed_fwd(_p(ids, torch.int64), _p(pos_ids, torch.int64), _p(word, torch.float32), _p(pos, torch.float32),
+                                          _p(type0, torch.float32), n, D, _p(out, torch.bfloat16), _stream()), "toist_embed_fwd")
+
+
+def embed_bwd(g, ids, pos_ids, pad_id, dword, dpos, dtype0):
+    n, D = g.shape
+    _lib.check(_lib.lib().toist_embed_bwd(_p(g, torch.bfloat16), _p(ids, torch.int64), _p(pos_ids, torch.int64), n, D, pad_id,
+                                          _p(dword, torch.float32), _p(dpos, torch.float32), _p(dtype0, torch.float32), _stream()),
+               "toist_embed_bwd")

@@ -1,0 +1,77 @@
+"""HungarianMatcher on the MI355X (reference: /root/reference/models/matcher.py:16-99).
+
+The cost block and the assignment of every (decoder layer, image) pair are computed by ONE launch of
+the wavefront kernel toist_matcher; indices stay on the device for the set criterion.  The public
+`forward` keeps the reference contract (list of CPU int64 index pairs) and pays the single host sync
+there, on demand.
+"""
+import torch
+from torch import nn
+
+from . import kernels as k
+
+
+class MatchResult:
+    """Device-resident assignment for L layers: src/tgt [L, Mtot] int64, per-image slices by `match_off`."""
+
+    def __init__(self, src, tgt, status, sizes, num_queries):
+        self.src, self.tgt, self.status = src, tgt, status
+        self.sizes = list(sizes)
+        self.counts = [min(num_queries, s) for s in self.sizes]
+        self.match_off = [0]
+        for c in self.counts:
+            self.match_off.append(self.match_off[-1] + c)
+
+    def check(self):
+        """Raise like SciPy does for an invalid cost matrix (host sync)."""
+        st = self.status.cpu()
+        if bool((st == 1).any()):
+            raise ValueError("matrix contains invalid numeric entries")
+        if bool((st == 2).any()):
+            raise ValueError("cost matrix is infeasible")
+
+    def to_list(self, layer=0):
+        self.check()
+        s, t = self.src[layer].cpu(), self.tgt[layer].cpu()
+        return [(s[a:b].clone(), t[a:b].clone()) for a, b in zip(self.match_off[:-1], self.match_off[1:])]
+
+
+class HungarianMatcher(nn.Module):
+    def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1):
+        super().__init__()
+        self.cost_class, self.cost_bbox, self.cost_giou = cost_class, cost_bbox, cost_giou
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
+
+    @torch.no_grad()
+    def match_layers(self, logits, boxes, targets, positive_map):
+        """logits [L,B,Q,K], boxes [L,B,Q,4] (any float dtype) -> MatchResult; no host sync."""
+        L, B, Q, K = logits.shape
+        dev = logits.device
+        sizes = [int(t["boxes"].shape[0]) for t in targets]
+        assert sum(sizes) == len(positive_map)
+        res_counts = [min(Q, s) for s in sizes]
+        tgt_off = torch.tensor([0] + [sum(sizes[:i + 1]) for i in range(B)], dtype=torch.int32)
+        m_off = torch.tensor([0] + [sum(res_counts[:i + 1]) for i in range(B)], dtype=torch.int32)
+        mtot, ttot = int(m_off[-1]), int(tgt_off[-1])
+        src = torch.zeros(L, max(mtot, 1), dtype=torch.int64, device=dev)[:, :mtot]
+        tgt = torch.zeros(L, max(mtot, 1), dtype=torch.int64, device=dev)[:, :mtot]
+        status = torch.zeros(L * B, dtype=torch.int32, device=dev)
+        if ttot > 0:
+            tb = torch.cat([t["boxes"] for t in targets]).float().contiguous()
+            k.matcher(logits.float().contiguous(), boxes.float().contiguous(), tb, positive_map.float().contiguous(),
+                      tgt_off.to(dev, non_blocking=True), m_off.to(dev, non_blocking=True), max(sizes), float(self.cost_class),
+                      float(self.cost_bbox), float(self.cost_giou), src if mtot else torch.zeros(L, 1, dtype=torch.int64, device=dev),
+                      tgt if mtot else torch.zeros(L, 1, dtype=torch.int64, device=dev), status)
+        return MatchResult(src, tgt, status, sizes, Q)
+
+    @torch.no_grad()
+    def forward(self, outputs, targets, positive_map):
+        """Reference contract (matcher.py:40-87): list over images of (query idx, target idx) CPU int64."""
+        res = self.match_layers(outputs["pred_logits"][None], outputs["pred_boxes"][None], targets, positive_map)
+        return res.to_list(0)
+
+
+def build_matcher(args):
+    if args.set_loss != "hungarian":
+        raise ValueError(f"Only hungarian accepted, got {args.set_loss}")
+    return HungarianMatcher(cost_class=args.set_cost_class, cost_bbox=args.set_cost_bbox, cost_giou=args.set_cost_giou)

@@ -1,0 +1,385 @@
+"""MDETR model, set criterion and builder on the MI355X kernels.
+
+Mirrors /root/reference/models/mdetr.py: MDETR (:315-462), SetCriterion (:465-1021; the non-list
+branch used by configs 1-4), MLP (:1024-1036), build (:1039-1141) -- same constructor arguments,
+forward signatures, output / loss dict keys and state_dict names, so engine.py / main.py style
+drivers run unchanged.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import dist, engine, functions
+from . import kernels as k
+from .backbone import build_backbone, nearest_mask
+from .matcher import build_matcher
+from .misc import NestedTensor
+from .transformer import build_transformer
+
+BF16 = torch.bfloat16
+
+
+class MLP(nn.Module):
+    """Parameter holder of the 3-layer box head (mdetr.py:1024-1036)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, o) for n, o in zip([input_dim] + h, h + [output_dim]))
+
+
+class MDETR(nn.Module):
+    def __init__(self, backbone, transformer, num_classes, num_queries, aux_loss=False, contrastive_hdim=64,
+                 contrastive_align_loss=False, cluster_num=16, args=None):
+        super().__init__()
+        self.args = args
+        self.num_queries = num_queries
+        self.transformer = transformer
+        hidden_dim = transformer.d_model
+        self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
+        self.bbox_embed = MLP(hidden_dim, hidden_dim, 4, 3)
+        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        self.input_proj = nn.Conv2d(backbone.num_channels, hidden_dim, kernel_size=1)
+        self.backbone = backbone
+        self.aux_loss = aux_loss
+        self.contrastive_align_loss = contrastive_align_loss
+        if contrastive_align_loss:
+            self.contrastive_align_projection_image = nn.Linear(hidden_dim, contrastive_hdim)
+            self.contrastive_align_projection_text = nn.Linear(hidden_dim, contrastive_hdim)
+        self._cache_proj, self._cache_heads = {}, {}
+
+    # ---- native pieces ------------------------------------------------------------------------------
+    def _project(self, c5):
+        """input_proj (1x1 conv 2048 -> d, mdetr.py:351,383) on NHWC bf16 C5 -> tokens [B*hw, d] bf16."""
+        B, h, w, C = c5.shape
+        named = OrderedDict(self.input_proj.named_parameters())
+
+        def prog(tape, ps, x):
+            W, b = ps["weight"], ps["bias"]
+            d = W.w.shape[0]
+            Wv = engine.ParamView(W.w.reshape(d, C), None if W.g is None else engine.krsc(W.g).reshape(d, C), None)
+            xin = engine.Var(x.data.view(B * h * w, C), needs_grad=x.needs_grad)
+
+            def bwd():  # recorded first -> runs after the chain's backward
+                g = xin.take_grad()
+                if g is not None:
+                    x.grad = g.view(B, h, w, C)
+
+            tape.record(bwd)
+            y = engine.linear_chain(tape, xin, [(Wv, b, k.ACT_NONE, False)])
+            return [y], None
+
+        (tok,) = functions.run_program(prog, named, [c5], cache=self._cache_proj, training=self.training)
+        return tok
+
+    def _heads(self, stack, B):
+        """class_embed / bbox_embed (+ contrastive image projection) on all decoder layers at once
+        (mdetr.py:420-433).  stack: [L, B*Q, d] bf16 -> logits [L,B,Q,K+1] f32, boxes [L,B,Q,4] f32."""
+        L, BQ, d = stack.shape
+        Q = BQ // B
+        named = OrderedDict()
+        named.update(("class_embed." + n, p) for n, p in self.class_embed.named_parameters())
+        named.update(("bbox_embed." + n, p) for n, p in self.bbox_embed.named_parameters())
+        if self.contrastive_align_loss:
+            named.update(("cimg." + n, p) for n, p in self.contrastive_align_projection_image.named_parameters())
+        want_proj = self.contrastive_align_loss
+
+        def prog(tape, ps, hs):
+            x = engine.Var(hs.data.view(L * BQ, d), needs_grad=hs.needs_grad)
+
+            def x_bwd():
+                g = x.take_grad()
+                if g is not None:
+                    hs.grad = g.view(L, BQ, d)
+
+            tape.record(x_bwd)
+            outs = []
+            # --- class logits (f32 out) ---
+            logits = engine.linear_chain(tape, x, [(ps["class_embed.weight"], ps["class_embed.bias"], k.ACT_NONE, False)],
+                                         out_dtype=torch.float32)
+
+            def logits_bwd():
+                if logits.grad is not None:
+                    logits.grad = logits.grad.to(BF16)
+
+            tape.record(logits_bwd)
+            outs.append(logits)
+            # --- box head: last layer padded from 4 to 8 outputs (16-byte rows), sigmoid in the epilogue ---
+            W2, b2 = ps["bbox_embed.layers.2.weight"], ps["bbox_embed.layers.2.bias"]
+            w2p = torch.zeros(8, d, dtype=BF16, device=hs.data.device)
+            w2p[:4] = W2.w
+            b2p = torch.zeros(8, dtype=torch.float32, device=hs.data.device)
+            b2p[:4] = b2.f32
+            need = W2.g is not None
+            g2w = torch.zeros(8, d, dtype=torch.float32, device=hs.data.device) if need else None
+            g2b = torch.zeros(8, dtype=torch.float32, device=hs.data.device) if need else None
+
+            def pad_bwd():
+                if need:
+                    W2.g.add_(g2w[:4])
+                    b2.g.add_(g2b[:4])
+
+            tape.record(pad_bwd)
+            boxes = engine.linear_chain(
+                tape, x, [(ps["bbox_embed.layers.0.weight"], ps["bbox_embed.layers.0.bias"], k.ACT_RELU, False),
+                          (ps["bbox_embed.layers.1.weight"], ps["bbox_embed.layers.1.bias"], k.ACT_RELU, False),
+                          (engine.ParamView(w2p, g2w), engine.ParamView(None, g2b, b2p), k.ACT_SIGMOID, False)],
+                out_dtype=torch.float32, last_act_external=True)
+
+            def boxes_bwd():
+                if boxes.grad is not None:
+                    y = boxes.data
+                    boxes.grad = (boxes.grad * y * (1 - y)).to(BF16)
+
+            tape.record(boxes_bwd)
+            outs.append(boxes)
+            if want_proj:
+                proj = engine.linear_chain(tape, x, [(ps["cimg.weight"], ps["cimg.bias"], k.ACT_NONE, False)], out_dtype=torch.float32)
+
+                def proj_bwd():
+                    if proj.grad is not None:
+                        proj.grad = proj.grad.to(BF16)
+
+                tape.record(proj_bwd)
+                outs.append(proj)
+            return outs, None
+
+        res = functions.run_program(prog, named, [stack], cache=self._cache_heads, training=self.training)
+        K = res[0].shape[-1]
+        logits = res[0].view(L, B, Q, K)
+        boxes = res[1][:, :4].reshape(L, B, Q, 4)
+        proj = res[2].view(L, B, Q, -1) if want_proj else None
+        return logits, boxes, proj
+
+    # ---- reference-compatible forward -------------------------------------------------------------------
+    def forward(self, samples: NestedTensor, captions, encode_and_save=True, memory_cache=None):
+        """Two-phase call of the reference (mdetr.py:359-462): encode -> memory_cache dict; decode -> outputs."""
+        if encode_and_save:
+            assert memory_cache is None
+            if not isinstance(samples, NestedTensor):
+                samples = NestedTensor.from_tensor_list(samples)
+            return self.encode(samples, captions)
+        assert memory_cache is not None
+        return self.decode(memory_cache)
+
+    def encode(self, samples, captions, levels=(4,)):
+        body = self.backbone[0]
+        feats = body.forward_native(samples.tensors, levels)
+        c5 = feats[-1]
+        B, h, w, _ = c5.shape
+        mask = nearest_mask(samples.mask, (h, w))
+        pos_tok = self.backbone[1].tokens(mask) if hasattr(self.backbone[1], "tokens") else \
+            self.backbone[1](NestedTensor(c5.permute(0, 3, 1, 2), mask)).flatten(2).permute(0, 2, 1).to(BF16).contiguous()
+        tok = self._project(c5).view(B, h * w, -1)
+        mc = self.transformer.encode_native(tok, pos_tok, mask.flatten(1), self.query_embed.weight, captions)
+        mc["_native"]["features"] = feats
+        mc["_native"]["feat_mask"] = mask
+        mc["_native"]["src_proj"] = tok
+        return mc
+
+    def decode(self, memory_cache):
+        native = memory_cache.get("_native")
+        key = "img_memory_mod" if (self.args is not None and getattr(self.args, "cluster", False)) else "img_memory"
+        stack = self.transformer.decode_native(memory_cache[key], memory_cache["pos_embed"], memory_cache["mask"],
+                                               memory_cache["query_embed"], native=native)
+        B = memory_cache["mask"].shape[0]
+        logits, boxes, proj = self._heads(stack, B)
+        out = {"pred_logits": logits[-1], "pred_boxes": boxes[-1]}
+        proj_tokens = None
+        if self.contrastive_align_loss:
+            proj_q = F.normalize(proj, p=2, dim=-1)
+            tm = memory_cache["text_memory"]
+            proj_tokens = F.normalize(F.linear(tm, self.contrastive_align_projection_text.weight, self.contrastive_align_projection_text.bias)
+                                      .transpose(0, 1), p=2, dim=-1)
+            out.update({"proj_queries": proj_q[-1], "proj_tokens": proj_tokens, "tokenized": memory_cache["tokenized"]})
+        if self.aux_loss:
+            aux = []
+            for i in range(logits.shape[0] - 1):
+                a = {"pred_logits": logits[i], "pred_boxes": boxes[i]}
+                if self.contrastive_align_loss:
+                    a.update({"proj_queries": proj_q[i], "proj_tokens": proj_tokens, "tokenized": memory_cache["tokenized"]})
+                aux.append(a)
+            out["aux_outputs"] = aux
+        out["_stacked"] = {"pred_logits": logits, "pred_boxes": boxes, "hs": stack}
+        return out
+
+
+class SetCriterion(nn.Module):
+    """Set-prediction loss (mdetr.py:465-1021, non-list branch): Hungarian matching of every decoder
+    layer in one device launch, then labels / boxes / cardinality (+ contrastive_align, + masks)."""
+
+    def __init__(self, args, num_classes, matcher, eos_coef, losses, temperature, contrastive_hdim=64, task_count=14):
+        super().__init__()
+        self.args = args
+        self.num_classes = num_classes
+        self.matcher = matcher
+        self.eos_coef = eos_coef
+        self.losses = losses
+        self.temperature = temperature
+        self.last_match = None
+
+    # -- helpers ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _slot_maps(match, device):
+        """Per matched slot: image index and offset of the image's first target (host arithmetic on shapes)."""
+        b_idx, t_base, acc = [], [], 0
+        for b, (cnt, size) in enumerate(zip(match.counts, match.sizes)):
+            b_idx += [b] * cnt
+            t_base += [acc] * cnt
+            acc += size
+        return (torch.tensor(b_idx, dtype=torch.int64, device=device), torch.tensor(t_base, dtype=torch.int64, device=device))
+
+    def _num_boxes(self, targets, device):
+        n = torch.as_tensor([float(sum(len(t["labels"]) for t in targets))], dtype=torch.float, device=device)
+        if dist.is_dist_avail_and_initialized():
+            torch.distributed.all_reduce(n)
+        return torch.clamp(n / dist.get_world_size(), min=1)[0]
+
+    def _stack(self, outputs):
+        st = outputs.get("_stacked")
+        if st is not None:
+            return st["pred_logits"], st["pred_boxes"]
+        layers = list(outputs.get("aux_outputs", [])) + [outputs]
+        return torch.stack([o["pred_logits"] for o in layers]), torch.stack([o["pred_boxes"] for o in layers])
+
+    # -- losses over all layers at once -------------------------------------------------------------------
+    def _detection_losses(self, logits, boxes, match, targets, positive_map, num_boxes):
+        L, B, Q, K = logits.shape
+        dev = logits.device
+        out = {}
+        logp = logits.float().log_softmax(-1)
+        ce_row = -logp[..., -1] * self.eos_coef  # [L,B,Q]: unmatched rows (one-hot on the no-object slot)
+        ce = ce_row.sum((1, 2))
+        sizes = torch.tensor(match.sizes, dtype=torch.float32, device=dev)
+        if match.src.shape[1] > 0:
+            b_idx, t_base = self._slot_maps(match, dev)
+            lidx = torch.arange(L, device=dev)[:, None]
+            src, tgt = match.src, match.tgt + t_base[None]
+            lp_m = logp[lidx, b_idx[None], src]                      # [L, M, K]
+            ce_m = -(lp_m * positive_map.float()[tgt]).sum(-1)       # matched rows use the soft token target
+            ce = ce - ce_row[lidx, b_idx[None], src].sum(1) + ce_m.sum(1)
+            pred = boxes.float()[lidx, b_idx[None], src]             # [L, M, 4]
+            tbox = torch.cat([t["boxes"] for t in targets]).float()[tgt]
+            l1 = (pred - tbox).abs().sum((1, 2))
+            giou = _paired_giou(pred, tbox)
+            lg = (1 - giou).sum(1)
+        else:
+            l1 = torch.zeros(L, device=dev) + boxes.sum() * 0
+            lg = torch.zeros(L, device=dev) + boxes.sum() * 0
+        with torch.no_grad():
+            card_pred = (logits.argmax(-1) != K - 1).sum(2).float()  # [L,B]
+            card = (card_pred - sizes[None]).abs().mean(1)
+        for l in range(L):
+            sfx = "" if l == L - 1 else f"_{l}"
+            if "labels" in self.losses:
+                out["loss_ce" + sfx] = ce[l] / num_boxes
+            if "boxes" in self.losses:
+                out["loss_bbox" + sfx] = l1[l] / num_boxes
+                out["loss_giou" + sfx] = lg[l] / num_boxes
+            if "cardinality" in self.losses:
+                out["cardinality_error" + sfx] = card[l]
+        return out
+
+    def _contrastive_align(self, outputs, match, targets, num_boxes, layer, L):
+        """mdetr.py:601-666; token spans come from `tokens_positive` through tokenized.char_to_token on
+        the host exactly like the reference, or from target['token_spans'] (already token indices)."""
+        pq, pt = outputs["proj_queries"], outputs["proj_tokens"]
+        logits = torch.matmul(pq, pt.transpose(-1, -2)) / self.temperature
+        pm = torch.zeros(logits.shape, dtype=torch.bool)
+        pairs = match.to_list(layer)
+        tokenized = outputs.get("tokenized")
+        for i, ((si, ti), tgt) in enumerate(zip(pairs, targets)):
+            for q, t in zip(si.tolist(), ti.tolist()):
+                if "token_spans" in tgt:
+                    spans = tgt["token_spans"][t]
+                else:
+                    spans = []
+                    for beg, end in tgt["tokens_positive"][t]:
+                        bp, ep = tokenized.char_to_token(i, beg), tokenized.char_to_token(i, end - 1)
+                        if bp is None or ep is None:
+                            continue
+                        spans.append((bp, ep))
+                for bp, ep in spans:
+                    pm[i, q, bp:ep + 1] = True
+        pm = pm.to(logits.device)
+        pos = -logits.masked_fill(~pm, 0)
+        b2t = ((pos.sum(2) / (pm.sum(2) + 1e-6) + logits.logsumexp(2))).masked_fill(~pm.any(2), 0).sum()
+        t2b = ((pos.sum(1) / (pm.sum(1) + 1e-6) + logits.logsumexp(1))).masked_fill(~pm.any(1), 0).sum()
+        return (b2t + t2b) / 2 / num_boxes
+
+    def forward(self, memory_cache, outputs, targets, positive_map, example_rel=None):
+        if isinstance(outputs, list):
+            raise NotImplementedError("distillation (teacher, student) criterion branch is SURVEY 8(f) 'next'")
+        logits, boxes = self._stack(outputs)
+        L = logits.shape[0]
+        match = self.matcher.match_layers(logits.detach(), boxes.detach(), targets, positive_map)
+        self.last_match = match
+        num_boxes = self._num_boxes(targets, logits.device)
+        losses = self._detection_losses(logits, boxes, match, targets, positive_map, num_boxes)
+        if "contrastive_align" in self.losses:
+            layers = list(outputs.get("aux_outputs", [])) + [outputs]
+            for l, o in enumerate(layers):
+                sfx = "" if l == L - 1 else f"_{l}"
+                losses["loss_contrastive_align" + sfx] = self._contrastive_align(o, match, targets, num_boxes, l, L)
+        if "masks" in self.losses:
+            from .segmentation import mask_losses
+            losses.update(mask_losses(outputs, targets, match, L - 1, num_boxes))
+        return losses
+
+
+def _paired_giou(a, b):
+    """GIoU of matching rows (the diagonal the reference takes at mdetr.py:820-822); cxcywh inputs."""
+    ax0, ay0, ax1, ay1 = a[..., 0] - 0.5 * a[..., 2], a[..., 1] - 0.5 * a[..., 3], a[..., 0] + 0.5 * a[..., 2], a[..., 1] + 0.5 * a[..., 3]
+    bx0, by0, bx1, by1 = b[..., 0] - 0.5 * b[..., 2], b[..., 1] - 0.5 * b[..., 3], b[..., 0] + 0.5 * b[..., 2], b[..., 1] + 0.5 * b[..., 3]
+    area_a, area_b = (ax1 - ax0) * (ay1 - ay0), (bx1 - bx0) * (by1 - by0)
+    iw = (torch.min(ax1, bx1) - torch.max(ax0, bx0)).clamp(min=0)
+    ih = (torch.min(ay1, by1) - torch.max(ay0, by0)).clamp(min=0)
+    inter = iw * ih
+    union = area_a + area_b - inter
+    ew = (torch.max(ax1, bx1) - torch.min(ax0, bx0)).clamp(min=0)
+    eh = (torch.max(ay1, by1) - torch.min(ay0, by0)).clamp(min=0)
+    hull = ew * eh
+    return inter / union - (hull - union) / hull
+
+
+def build(args):
+    """Reference build(), mdetr.py:1039-1141: (model, criterion, cluster_criterion, weight_dict)."""
+    num_classes = 255
+    device = torch.device(args.device)
+    assert not args.masks or args.mask_model != "none"
+    backbone = build_backbone(args)
+    transformer = build_transformer(args)
+    model = MDETR(backbone, transformer, num_classes=num_classes, num_queries=args.num_queries, aux_loss=args.aux_loss,
+                  contrastive_hdim=args.contrastive_loss_hdim, contrastive_align_loss=args.contrastive_align_loss,
+                  cluster_num=getattr(args, "cluster_num", 16), args=args)
+    if args.mask_model != "none":
+        from .segmentation import DETRsegm
+        model = DETRsegm(model, mask_head=args.mask_model, freeze_detr=(args.frozen_weights is not None))
+    matcher = build_matcher(args)
+    weight_dict = {"loss_ce": args.ce_loss_coef, "loss_bbox": args.bbox_loss_coef}
+    if args.contrastive_align_loss:
+        weight_dict["loss_contrastive_align"] = args.contrastive_align_loss_coef
+    if getattr(args, "nsthl2_loss", False) or getattr(args, "softkd_loss", False) or getattr(args, "cluster", False) \
+            or getattr(args, "distillation", False):
+        raise NotImplementedError("noun-pronoun distillation (config 5) is SURVEY 8(f) 'next', not built yet")
+    weight_dict["loss_giou"] = args.giou_loss_coef
+    if args.masks:
+        weight_dict["loss_mask"] = args.mask_loss_coef
+        weight_dict["loss_dice"] = args.dice_loss_coef
+    if args.aux_loss:
+        aux = {}
+        for i in range(args.dec_layers - 1):
+            aux.update({kk + f"_{i}": v for kk, v in weight_dict.items()})
+        weight_dict.update(aux)
+    losses = ["labels", "boxes", "cardinality"]
+    if args.masks:
+        losses += ["masks"]
+    if args.contrastive_align_loss:
+        losses += ["contrastive_align"]
+    criterion = SetCriterion(args, num_classes, matcher=matcher, eos_coef=args.eos_coef, losses=losses,
+                             temperature=args.temperature_NCE, contrastive_hdim=args.contrastive_loss_hdim)
+    criterion.to(device)
+    return model, criterion, None, weight_dict

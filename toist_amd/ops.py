@@ -132,7 +132,7 @@ def conv2d_dgrad(dy, w, in_hw, *, stride=1, pad=0, dil=1, scale=None, res=None, 
     return out
 
 
-def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, split_k=None):
+def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, split_k=None, rscale=None):
     """dw [Co,R,S,C] (f32, accumulated) = sum over output pixels of dy (x) gathered x."""
     Nb, OH, OW, Co = dy.shape
     _, H, W, C = x.shape
@@ -150,7 +150,7 @@ def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, s
         b_kind, b = k.B_KROW, k.operand(x, C)
     else:
         b_kind, b = k.B_CONVX, k.operand(x, 0, geom=k.ConvGeom(H, W, C, OH, OW, R, S, stride, pad, dil))
-    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out, Nn, accumulate=True, split_k=split_k, flags=flags)
+    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out, Nn, accumulate=True, split_k=split_k, flags=flags, rscale=rscale)
     return out
 
 

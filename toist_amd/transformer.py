@@ -1,0 +1,440 @@
+"""Cross-modal transformer of TOIST/MDETR on the MI355X kernels.
+
+Same constructor arguments, attributes (`d_model`, `nhead`, `text_encoder`, `resizer`, `encoder`,
+`decoder`, `tokenizer`) and state_dict keys as /root/reference/models/transformer.py (Transformer
+:22-188, TransformerEncoder/Decoder(+Layer) :191-470, FeatureResizer :473-492).  The nn.Modules
+below only own parameters; the arithmetic is the explicit forward/backward programs of
+toist_amd.engine.  Only the post-norm path exists (the reference's decoder forward_pre is
+`assert False`, :423).
+"""
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import engine, functions
+from . import kernels as k
+
+BF16 = torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------ parameter holders
+class MHAParams(nn.Module):
+    """Parameters of nn.MultiheadAttention (packed in_proj + out_proj), reference names."""
+
+    def __init__(self, d_model, nhead, dropout=0.0):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.dropout = d_model, nhead, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = nn.Linear(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+        super().__init__()
+        self.self_attn = MHAParams(d_model, nhead, dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+        super().__init__()
+        self.self_attn = MHAParams(d_model, nhead, dropout)
+        self.cross_attn_image = MHAParams(d_model, nhead, dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.norm4 = nn.LayerNorm(d_model)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+        self.num_layers = len(layers)
+        self.norm = None
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, layers, d_model):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+        self.num_layers = len(layers)
+        self.norm = nn.LayerNorm(d_model)
+        self.return_intermediate = True
+
+
+class FeatureResizer(nn.Module):
+    """Linear + LayerNorm(eps=1e-12) + dropout (transformer.py:473-492)."""
+
+    def __init__(self, input_feat_size, output_feat_size, dropout):
+        super().__init__()
+        self.fc = nn.Linear(input_feat_size, output_feat_size, bias=True)
+        self.layer_norm = nn.LayerNorm(output_feat_size, eps=1e-12)
+        self.dropout_p = dropout
+
+
+class _RobertaLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        att = nn.Module()
+        att.self = nn.Module()
+        att.self.query = nn.Linear(c.hidden_size, c.hidden_size)
+        att.self.key = nn.Linear(c.hidden_size, c.hidden_size)
+        att.self.value = nn.Linear(c.hidden_size, c.hidden_size)
+        att.output = nn.Module()
+        att.output.dense = nn.Linear(c.hidden_size, c.hidden_size)
+        att.output.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.attention = att
+        self.intermediate = nn.Module()
+        self.intermediate.dense = nn.Linear(c.hidden_size, c.intermediate_size)
+        self.output = nn.Module()
+        self.output.dense = nn.Linear(c.intermediate_size, c.hidden_size)
+        self.output.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+
+def roberta_config(**kw):
+    """Defaults of transformers.RobertaConfig(type_vocab_size=1, vocab_size=50265) (transformer.py:61)."""
+    c = dict(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+             max_position_embeddings=512, type_vocab_size=1, layer_norm_eps=1e-12, pad_token_id=1, hidden_dropout_prob=0.1,
+             attention_probs_dropout_prob=0.1, initializer_range=0.02)
+    c.update(kw)
+    return SimpleNamespace(**c)
+
+
+class RobertaTextEncoder(nn.Module):
+    """Parameter tree with the key names of transformers.RobertaModel (embeddings.*, encoder.layer.N.*,
+    pooler.dense.*); the pooler is kept for checkpoint compatibility but is frozen and unused
+    (CLS is None on the hot path, transformer.py:55,159)."""
+
+    def __init__(self, config):
+        super().__init__()
+        c = self.config = config
+        emb = nn.Module()
+        emb.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size, padding_idx=c.pad_token_id)
+        emb.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size, padding_idx=c.pad_token_id)
+        emb.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
+        emb.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.embeddings = emb
+        self.encoder = nn.Module()
+        self.encoder.layer = nn.ModuleList([_RobertaLayer(c) for _ in range(c.num_hidden_layers)])
+        self.pooler = nn.Module()
+        self.pooler.dense = nn.Linear(c.hidden_size, c.hidden_size)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, std=c.initializer_range)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Embedding):
+                nn.init.normal_(m.weight, std=c.initializer_range)
+                if m.padding_idx is not None:
+                    with torch.no_grad():
+                        m.weight[m.padding_idx].zero_()
+        for p in self.pooler.parameters():
+            p.requires_grad_(False)
+
+
+class TokenizedText(dict):
+    """Minimal stand-in for a HF BatchEncoding: dict with attribute access and .to()."""
+
+    def __getattr__(self, key):
+        try:
+            return self[key]
+        except KeyError as e:
+            raise AttributeError(key) from e
+
+    def to(self, device):
+        return TokenizedText({k_: (v.to(device) if torch.is_tensor(v) else v) for k_, v in self.items()})
+
+
+# ------------------------------------------------------------------------------------------ the module
+class Transformer(nn.Module):
+    def __init__(self, args=None, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                 dropout=0.1, activation="relu", normalize_before=False, return_intermediate_dec=False, pass_pos_and_query=True,
+                 text_encoder_type="roberta-base", freeze_text_encoder=False, contrastive_loss=False):
+        super().__init__()
+        if normalize_before:
+            raise NotImplementedError("pre-norm is not on the hot path (the reference decoder asserts False)")
+        if activation != "relu":
+            raise NotImplementedError("only relu FFNs are on the hot path")
+        if not pass_pos_and_query:
+            raise NotImplementedError("pass_pos_and_query=False is not on the hot path")
+        self.args = args
+        self.pass_pos_and_query = True
+        self.encoder = TransformerEncoder([TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout) for _ in range(num_encoder_layers)])
+        self.decoder = TransformerDecoder([TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout) for _ in range(num_decoder_layers)], d_model)
+        self.CLS = nn.Embedding(1, d_model) if contrastive_loss else None
+        if contrastive_loss:
+            raise NotImplementedError("--contrastive_loss (CLS token) is off in every TOIST recipe; not on the hot path")
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self._tokenizer = None
+        self.text_encoder_type = text_encoder_type
+        without_pretrain = bool(getattr(args, "without_pretrain", False)) if args is not None else True
+        if without_pretrain:
+            self.text_encoder = RobertaTextEncoder(roberta_config())
+        else:
+            self.text_encoder = self._from_pretrained(text_encoder_type)
+        if freeze_text_encoder:
+            for p in self.text_encoder.parameters():
+                p.requires_grad_(False)
+        self.expander_dropout = 0.1
+        self.resizer = FeatureResizer(self.text_encoder.config.hidden_size, d_model, self.expander_dropout)
+        self.d_model, self.nhead, self.dropout = d_model, nhead, dropout
+        self._cache_text, self._cache_enc, self._cache_dec = {}, {}, {}
+        self._step = 0
+
+    @staticmethod
+    def _from_pretrained(name):
+        """Load HF weights when a local copy exists (no network here); keys map 1:1."""
+        try:
+            from transformers import RobertaModel
+            hf = RobertaModel.from_pretrained(name)
+        except Exception as e:  # no cache / offline
+            raise RuntimeError(f"pretrained text encoder {name!r} is unavailable offline; pass args.without_pretrain=True "
+                               f"or load a TOIST checkpoint ({e})")
+        c = hf.config
+        enc = RobertaTextEncoder(roberta_config(vocab_size=c.vocab_size, hidden_size=c.hidden_size, num_hidden_layers=c.num_hidden_layers,
+                                                num_attention_heads=c.num_attention_heads, intermediate_size=c.intermediate_size,
+                                                max_position_embeddings=c.max_position_embeddings, type_vocab_size=c.type_vocab_size,
+                                                layer_norm_eps=c.layer_norm_eps, pad_token_id=c.pad_token_id))
+        enc.load_state_dict(hf.state_dict(), strict=False)
+        return enc
+
+    @property
+    def tokenizer(self):
+        if self._tokenizer is None:
+            try:
+                from transformers import RobertaTokenizerFast
+                self._tokenizer = RobertaTokenizerFast.from_pretrained(self.text_encoder_type)
+            except Exception as e:
+                raise RuntimeError("RobertaTokenizerFast files are unavailable offline: pass pre-tokenised captions "
+                                   f"(dict with input_ids / attention_mask) instead of strings ({e})")
+        return self._tokenizer
+
+    def _next_seed(self):
+        self._step += 1
+        return self._step
+
+    # ---- text -------------------------------------------------------------------------------------
+    def encode_text(self, tokenized):
+        """RoBERTa + FeatureResizer -> bf16 tokens [B*L, d] (batch-major)."""
+        ids = tokenized["input_ids"]
+        att = tokenized["attention_mask"]
+        B, L = ids.shape
+        te, cfg = self.text_encoder, self.text_encoder.config
+        H = cfg.num_attention_heads
+        keep = ids.ne(cfg.pad_token_id).to(torch.int64)
+        pos_ids = (torch.cumsum(keep, dim=1) * keep + cfg.pad_token_id).contiguous()
+        ids_flat = ids.contiguous().view(-1)
+        key_pad = att.ne(1).to(torch.uint8).contiguous()
+        named = OrderedDict(("text_encoder." + n, p) for n, p in te.named_parameters())
+        named.update(("resizer." + n, p) for n, p in self.resizer.named_parameters())
+
+        def prog(tape, ps):
+            P = lambda n: ps["text_encoder." + n]
+            D = cfg.hidden_size
+            x0 = torch.empty(B * L, D, dtype=BF16, device=ids.device)
+            wv, pv, tv = P("embeddings.word_embeddings.weight"), P("embeddings.position_embeddings.weight"), P("embeddings.token_type_embeddings.weight")
+            k.embed_fwd(ids_flat, pos_ids.view(-1), wv.f32, pv.f32, tv.f32[0], x0)
+            emb = engine.Var(x0)
+
+            def emb_bwd():
+                g = emb.take_grad()
+                if g is None or wv.g is None:
+                    return
+                k.embed_bwd(g, ids_flat, pos_ids.view(-1), cfg.pad_token_id, wv.g, pv.g, tv.g[0] if tv.g is not None else None)
+
+            tape.record(emb_bwd)
+            x = engine.layernorm(tape, emb, P("embeddings.LayerNorm.weight"), P("embeddings.LayerNorm.bias"), cfg.layer_norm_eps)
+            x = engine.dropout(tape, x)
+            for i in range(cfg.num_hidden_layers):
+                lp = f"encoder.layer.{i}."
+                z = engine.attention(
+                    tape, x, x, x, (P(lp + "attention.self.query.weight"), P(lp + "attention.self.query.bias")),
+                    (P(lp + "attention.self.key.weight"), P(lp + "attention.self.key.bias")),
+                    (P(lp + "attention.self.value.weight"), P(lp + "attention.self.value.bias")), P(lp + "attention.output.dense.weight"),
+                    P(lp + "attention.output.dense.bias"), x, key_pad, B, L, L, H)
+                x1 = engine.layernorm(tape, z, P(lp + "attention.output.LayerNorm.weight"), P(lp + "attention.output.LayerNorm.bias"), cfg.layer_norm_eps)
+                z2 = engine.linear_chain(tape, x1, [(P(lp + "intermediate.dense.weight"), P(lp + "intermediate.dense.bias"), k.ACT_GELU, False),
+                                                    (P(lp + "output.dense.weight"), P(lp + "output.dense.bias"), k.ACT_NONE, False)],
+                                         res=x1, final_drop=True)
+                x = engine.layernorm(tape, z2, P(lp + "output.LayerNorm.weight"), P(lp + "output.LayerNorm.bias"), cfg.layer_norm_eps)
+            r = engine.linear_chain(tape, x, [(ps["resizer.fc.weight"], ps["resizer.fc.bias"], k.ACT_NONE, False)])
+            r = engine.layernorm(tape, r, ps["resizer.layer_norm.weight"], ps["resizer.layer_norm.bias"], 1e-12)
+            r = engine.dropout(tape, r)
+            return [r], None
+
+        (out,) = functions.run_program(prog, named, [], cache=self._cache_text, training=self.training, drop_p=cfg.hidden_dropout_prob,
+                                       seed=self._next_seed())
+        return out, key_pad
+
+    # ---- encoder ----------------------------------------------------------------------------------
+    def encode_tokens(self, tokens, pos, key_pad, B, S):
+        """6 post-norm encoder layers over batch-major tokens [B*S, d]; pos is a bf16 constant."""
+        d, H = self.d_model, self.nhead
+        named = OrderedDict(self.encoder.named_parameters())
+        n_layers = self.encoder.num_layers
+
+        def prog(tape, ps, x):
+            for i in range(n_layers):
+                lp = f"layers.{i}."
+                Wi, bi = ps[lp + "self_attn.in_proj_weight"], ps[lp + "self_attn.in_proj_bias"]
+                qk = engine.add_const(tape, x, pos)
+                z = engine.attention(tape, qk, qk, x, None, None, (Wi.rows(2 * d, 3 * d), bi.rows(2 * d, 3 * d)),
+                                     ps[lp + "self_attn.out_proj.weight"], ps[lp + "self_attn.out_proj.bias"], x, key_pad, B, S, S, H,
+                                     packed_qk=(Wi.rows(0, 2 * d), bi.rows(0, 2 * d)))
+                x1 = engine.layernorm(tape, z, ps[lp + "norm1.weight"], ps[lp + "norm1.bias"], 1e-5)
+                z2 = engine.linear_chain(tape, x1, [(ps[lp + "linear1.weight"], ps[lp + "linear1.bias"], k.ACT_RELU, True),
+                                                    (ps[lp + "linear2.weight"], ps[lp + "linear2.bias"], k.ACT_NONE, False)],
+                                         res=x1, final_drop=True)
+                x = engine.layernorm(tape, z2, ps[lp + "norm2.weight"], ps[lp + "norm2.bias"], 1e-5)
+            return [x], None
+
+        (out,) = functions.run_program(prog, named, [tokens], cache=self._cache_enc, training=self.training, drop_p=self.dropout,
+                                       seed=self._next_seed())
+        return out
+
+    # ---- decoder ----------------------------------------------------------------------------------
+    def decode_tokens(self, memory, pos, key_pad, query_embed, B, S):
+        """6 decoder layers; returns the stack of shared-LayerNorm'ed layer outputs [L, B*Q, d] bf16."""
+        d, H = self.d_model, self.nhead
+        Q = query_embed.shape[0]
+        named = OrderedDict(self.decoder.named_parameters())
+        n_layers = self.decoder.num_layers
+        dev = memory.device
+
+        def prog(tape, ps, mem, qe):
+            qpos_data = qe.data.to(BF16).unsqueeze(0).expand(B, Q, d).reshape(B * Q, d).contiguous()
+            qpos = engine.Var(qpos_data, needs_grad=qe.needs_grad)
+
+            def qpos_bwd():
+                g = qpos.take_grad()
+                if g is not None and qe.needs_grad:
+                    gq = g.view(B, Q, d).float().sum(0)
+                    qe.grad = gq if qe.grad is None else qe.grad + gq
+
+            tape.record(qpos_bwd)
+            mem_pos = engine.add_const(tape, mem, pos)
+            tgt = engine.Var(torch.zeros(B * Q, d, dtype=BF16, device=dev), needs_grad=False)
+            stack = torch.empty(n_layers, B * Q, d, dtype=BF16, device=dev)
+            inter = []
+            for i in range(n_layers):
+                lp = f"layers.{i}."
+                Ws, bs = ps[lp + "self_attn.in_proj_weight"], ps[lp + "self_attn.in_proj_bias"]
+                Wc, bc = ps[lp + "cross_attn_image.in_proj_weight"], ps[lp + "cross_attn_image.in_proj_bias"]
+                qk = engine.add_vars(tape, tgt, qpos)
+                z1 = engine.attention(tape, qk, qk, tgt, None, None, (Ws.rows(2 * d, 3 * d), bs.rows(2 * d, 3 * d)),
+                                      ps[lp + "self_attn.out_proj.weight"], ps[lp + "self_attn.out_proj.bias"], tgt, None, B, Q, Q, H,
+                                      packed_qk=(Ws.rows(0, 2 * d), bs.rows(0, 2 * d)))
+                t1 = engine.layernorm(tape, z1, ps[lp + "norm1.weight"], ps[lp + "norm1.bias"], 1e-5)
+                q2 = engine.add_vars(tape, t1, qpos)
+                z3 = engine.attention(tape, q2, mem_pos, mem, (Wc.rows(0, d), bc.rows(0, d)), (Wc.rows(d, 2 * d), bc.rows(d, 2 * d)),
+                                      (Wc.rows(2 * d, 3 * d), bc.rows(2 * d, 3 * d)), ps[lp + "cross_attn_image.out_proj.weight"],
+                                      ps[lp + "cross_attn_image.out_proj.bias"], t1, key_pad, B, Q, S, H)
+                t3 = engine.layernorm(tape, z3, ps[lp + "norm3.weight"], ps[lp + "norm3.bias"], 1e-5)
+                z4 = engine.linear_chain(tape, t3, [(ps[lp + "linear1.weight"], ps[lp + "linear1.bias"], k.ACT_RELU, True),
+                                                    (ps[lp + "linear2.weight"], ps[lp + "linear2.bias"], k.ACT_NONE, False)],
+                                         res=t3, final_drop=True)
+                tgt = engine.layernorm(tape, z4, ps[lp + "norm4.weight"], ps[lp + "norm4.bias"], 1e-5)
+                inter.append(engine.layernorm(tape, tgt, ps["norm.weight"], ps["norm.bias"], 1e-5, y=stack[i]))
+            hs = engine.Var(stack)
+
+            def split_bwd():
+                g = hs.take_grad()
+                if g is None:
+                    return
+                for i, v in enumerate(inter):
+                    v.grad = g[i]
+
+            tape.record(split_bwd)
+            return [hs], None
+
+        (out,) = functions.run_program(prog, named, [memory, query_embed], cache=self._cache_dec, training=self.training,
+                                       drop_p=self.dropout, seed=self._next_seed())
+        return out
+
+    # ---- reference-compatible API -------------------------------------------------------------------
+    def forward(self, src=None, mask=None, query_embed=None, pos_embed=None, text=None, encode_and_save=True, text_memory=None,
+                img_memory=None, text_attention_mask=None):
+        """Same contract as the reference Transformer.forward (transformer.py:86-188): fp32, sequence
+        first.  `text` may be list[str] (needs tokenizer files), a dict/BatchEncoding with input_ids and
+        attention_mask, or the pre-encoded tuple (text_attention_mask, text_memory_resized, tokenized)."""
+        if encode_and_save:
+            bs, c, h, w = src.shape
+            tokens_img = src.flatten(2).permute(0, 2, 1).to(BF16)  # [B, HW, d]
+            pos_img = pos_embed.flatten(2).permute(0, 2, 1).to(BF16)
+            return self.encode_native(tokens_img, pos_img, mask.flatten(1), query_embed, text)
+        stack = self.decode_native(img_memory, pos_embed, mask, query_embed)
+        L, B = stack.shape[0], img_memory.shape[1]
+        return stack.view(L, B, -1, stack.shape[-1]).float()
+
+    def _tokenize(self, text, device):
+        if isinstance(text, (list, tuple)) and len(text) and isinstance(text[0], str):
+            tok = self.tokenizer.batch_encode_plus(list(text), padding="longest", return_tensors="pt").to(device)
+            return tok
+        if isinstance(text, dict) or hasattr(text, "input_ids"):
+            tok = text if isinstance(text, TokenizedText) else TokenizedText({"input_ids": text["input_ids"], "attention_mask": text["attention_mask"]})
+            return tok.to(device)
+        raise TypeError("captions must be list[str] or a dict with input_ids / attention_mask")
+
+    def encode_native(self, tokens_img, pos_img, mask_img, query_embed, text):
+        """tokens_img / pos_img: bf16 [B, HW, d]; mask_img bool [B, HW]; returns the memory_cache dict
+        of the reference (fp32, sequence first) plus the native bf16 tensors under '_native'."""
+        B, HW, d = tokens_img.shape
+        dev = tokens_img.device
+        pre_encoded = isinstance(text, tuple) and len(text) == 3 and torch.is_tensor(text[0])
+        if pre_encoded:
+            text_attention_mask, text_memory_resized, tokenized = text
+            text_tok = text_memory_resized.permute(1, 0, 2).to(BF16)
+            L = text_tok.shape[1]
+        else:
+            tokenized = self._tokenize(text, dev)
+            flat, key_pad_text = self.encode_text(tokenized)
+            L = tokenized["input_ids"].shape[1]
+            text_tok = flat.view(B, L, d)
+            text_attention_mask = tokenized["attention_mask"].ne(1).bool()
+            text_memory_resized = text_tok.permute(1, 0, 2).float()
+        S = HW + L
+        tokens = torch.cat([tokens_img, text_tok], dim=1).reshape(B * S, d)
+        pos = torch.cat([pos_img, torch.zeros(B, L, d, dtype=BF16, device=dev)], dim=1).reshape(B * S, d).contiguous()
+        mask = torch.cat([mask_img, text_attention_mask], dim=1)
+        key_pad = mask.to(torch.uint8).contiguous()
+        mem = self.encode_tokens(tokens, pos, key_pad, B, S)
+        mem3 = mem.view(B, S, d)
+        img_memory = mem3.permute(1, 0, 2).float()
+        q = query_embed.unsqueeze(1).repeat(1, B, 1)
+        return {
+            "text_memory_resized": text_memory_resized, "text_memory": img_memory[-L:], "img_memory": img_memory,
+            "text_pooled_op": None, "img_pooled_op": None, "mask": mask, "text_attention_mask": text_attention_mask,
+            "pos_embed": pos.view(B, S, d).permute(1, 0, 2).float(), "query_embed": q, "tokenized": tokenized,
+            "_native": {"memory": mem, "pos": pos, "key_pad": key_pad, "B": B, "S": S, "img_memory_ref": img_memory},
+        }
+
+    def decode_native(self, img_memory, pos_embed, mask, query_embed, native=None):
+        """-> hs fp32 [L, B, Q, d] (the reference returns hs.transpose(1, 2))."""
+        if native is not None and native.get("img_memory_ref") is img_memory:
+            mem, pos, key_pad, B, S = native["memory"], native["pos"], native["key_pad"], native["B"], native["S"]
+        else:
+            S, B, d = img_memory.shape
+            mem = img_memory.permute(1, 0, 2).reshape(B * S, d).to(BF16)
+            pos = pos_embed.permute(1, 0, 2).reshape(B * S, d).to(BF16).contiguous()
+            key_pad = mask.to(torch.uint8).contiguous()
+        qe = query_embed[:, 0, :] if query_embed.dim() == 3 else query_embed
+        stack = self.decode_tokens(mem, pos, key_pad, qe, B, S)
+        return stack
+
+
+def build_transformer(args):
+    return Transformer(args=args, d_model=args.hidden_dim, dropout=args.dropout, nhead=args.nheads, dim_feedforward=args.dim_feedforward,
+                       num_encoder_layers=args.enc_layers, num_decoder_layers=args.dec_layers, normalize_before=args.pre_norm,
+                       return_intermediate_dec=True, pass_pos_and_query=args.pass_pos_and_query, text_encoder_type=args.text_encoder_type,
+                       freeze_text_encoder=args.freeze_text_encoder, contrastive_loss=args.contrastive_loss)
