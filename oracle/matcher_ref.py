@@ -56,7 +56,9 @@ def hungarian_match(pred_logits, pred_boxes, tgt_boxes_list, positive_map, w_cla
     sizes = [int(t.shape[0]) for t in tgt_boxes_list]
     tgt = torch.cat(list(tgt_boxes_list)) if len(tgt_boxes_list) else torch.zeros(0, 4)
     assert tgt.shape[0] == positive_map.shape[0]
-    C = cost_matrix(pred_logits.cpu(), pred_boxes.cpu(), tgt.cpu(), positive_map.cpu(), w_class, w_bbox, w_giou)
+    with torch.no_grad():  # matcher.py:38 (@torch.no_grad)
+        C = cost_matrix(pred_logits.detach().cpu(), pred_boxes.detach().cpu(), tgt.detach().cpu(), positive_map.detach().cpu(),
+                        w_class, w_bbox, w_giou)
     out = []
     for i, blk in enumerate(C.split(sizes, -1)):
         r, c = lsap.linear_sum_assignment(blk[i].numpy())

@@ -1,0 +1,245 @@
+"""Generate the golden vectors under tests/golden/ by running the REAL reference (/root/reference)
+on closed-form inputs.  Runs only in the build container (the reference never travels); commit the
+resulting fixtures.  Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Throw-away import stubs (IPython / torchvision.ops.boxes.box_area / timm) are created under
+/tmp/toist_ref_stubs, outside the repo.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import formula  # noqa: E402
+
+from transformers import RobertaConfig, RobertaModel, RobertaTokenizerFast  # noqa: E402,F401  (before the stubs)
+
+STUBS = "/tmp/toist_ref_stubs"
+
+
+def make_stubs():
+    files = {
+        "IPython/__init__.py": "def embed(*a, **k):\n    pass\n",
+        "torchvision/__init__.py": "from . import ops, models\n",
+        "torchvision/ops/__init__.py": "from . import boxes\n",
+        "torchvision/ops/boxes.py": "def box_area(b):\n    return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])\n",
+        "torchvision/models/__init__.py": "from . import _utils\n",
+        "torchvision/models/_utils.py": "class IntermediateLayerGetter:\n    pass\n",
+        "timm/__init__.py": "from . import models\n",
+        "timm/models/__init__.py": "def create_model(*a, **k):\n    raise RuntimeError('stub')\n",
+    }
+    for rel, text in files.items():
+        path = os.path.join(STUBS, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text)
+
+
+make_stubs()
+sys.path[:0] = [STUBS, "/root/reference"]
+sys.dont_write_bytecode = True
+
+import models.transformer as ref_transformer  # noqa: E402
+from models.backbone import FrozenBatchNorm2d  # noqa: E402
+from models.matcher import HungarianMatcher  # noqa: E402
+from models.mdetr import MDETR, SetCriterion  # noqa: E402
+from models.position_encoding import PositionEmbeddingSine  # noqa: E402
+from models.postprocessors import PostProcess  # noqa: E402
+from util import box_ops  # noqa: E402
+from util.misc import NestedTensor  # noqa: E402
+
+
+class FakeTokenizer:
+    @classmethod
+    def from_pretrained(cls, name):
+        return cls()
+
+
+ref_transformer.RobertaTokenizerFast = FakeTokenizer
+
+
+def save(name, **arrays):
+    np.savez_compressed(os.path.join(HERE, name), **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
+    print("wrote", name, {k: tuple(np.asarray(v).shape) for k, v in arrays.items()})
+
+
+def sampled(t):
+    flat = t.detach().reshape(-1)
+    idx = formula.sample_indices(flat.numel())
+    return flat[torch.from_numpy(idx)].numpy(), np.array([float(flat.sum()), float(flat.abs().sum())])
+
+
+# ------------------------------------------------------------------------------------------ matcher
+def matcher_cases():
+    cases = []
+    specs = [("rand", 4, 100, [0, 1, 4, 10]), ("dup", 4, 100, [4, 4, 2, 6]), ("big", 2, 100, [30, 17]), ("wide", 2, 20, [30, 20]),
+             ("samepm", 8, 100, [3, 0, 5, 1, 2, 10, 7, 4])]
+    for name, B, Q, sizes in specs:
+        K = 256
+        logits = formula.tensor(f"m.{name}.logits", (B, Q, K), 6.0)
+        cxcy = formula.tensor(f"m.{name}.c", (B, Q, 2), 0.6, 0.5)
+        wh = formula.tensor(f"m.{name}.s", (B, Q, 2), 0.35, 0.225)
+        boxes = torch.cat([cxcy, wh], -1)
+        tgts = []
+        for i, t in enumerate(sizes):
+            c = formula.tensor(f"m.{name}.tc{i}", (t, 2), 0.6, 0.5)
+            s = formula.tensor(f"m.{name}.ts{i}", (t, 2), 0.35, 0.225)
+            bx = torch.cat([c, s], -1)
+            if name == "dup" and t >= 2:
+                bx[1] = bx[0]
+            tgts.append(bx)
+        T = sum(sizes)
+        if name in ("dup", "samepm"):
+            pm = torch.zeros(T, K)
+            pm[:, 1:15] = 1.0 / 14.0
+        else:
+            pm = formula.tensor(f"m.{name}.pm", (T, K), 1.0, 0.5)
+            pm = pm / pm.sum(-1, keepdim=True)
+        matcher = HungarianMatcher(cost_class=1.0, cost_bbox=5.0, cost_giou=2.0)
+        out = matcher({"pred_logits": logits, "pred_boxes": boxes}, [{"boxes": b} for b in tgts], pm)
+        rec = {"logits": logits, "boxes": boxes, "pm": pm, "sizes": np.array(sizes)}
+        for i, b in enumerate(tgts):
+            rec[f"tgt{i}"] = b
+        for i, (a, b) in enumerate(out):
+            rec[f"src{i}"], rec[f"dst{i}"] = a, b
+        cases.append((name, rec))
+    for name, rec in cases:
+        save(f"matcher_{name}.npz", **rec)
+
+
+# ------------------------------------------------------------------------------------------ small ops
+def small_ops():
+    a = torch.cat([formula.tensor("b.a.c", (7, 2), 0.6, 0.5), formula.tensor("b.a.s", (7, 2), 0.3, 0.2)], -1)
+    b = torch.cat([formula.tensor("b.b.c", (5, 2), 0.6, 0.5), formula.tensor("b.b.s", (5, 2), 0.3, 0.2)], -1)
+    axy, bxy = box_ops.box_cxcywh_to_xyxy(a), box_ops.box_cxcywh_to_xyxy(b)
+    iou, union = box_ops.box_iou(axy, bxy)
+    giou = box_ops.generalized_box_iou(axy, bxy)
+    save("box_ops.npz", a=a, b=b, axy=axy, iou=iou, union=union, giou=giou, back=box_ops.box_xyxy_to_cxcywh(axy))
+
+    mask = torch.zeros(3, 9, 11, dtype=torch.bool)
+    mask[1, 6:, :] = True
+    mask[1, :, 8:] = True
+    mask[2, :, 10:] = True
+    pe = PositionEmbeddingSine(128, normalize=True)
+    pos = pe(NestedTensor(torch.zeros(3, 4, 9, 11), mask))
+    save("position_sine.npz", mask=mask, pos=pos)
+
+    bn = FrozenBatchNorm2d(6)
+    sd = formula.fill_state_dict({"bn.weight": bn.weight, "bn.bias": bn.bias, "bn.running_mean": bn.running_mean, "bn.running_var": bn.running_var})
+    bn.load_state_dict({k[3:]: v for k, v in sd.items()})
+    x = formula.tensor("bn.x", (2, 6, 3, 5), 2.0)
+    save("frozen_bn.npz", x=x, y=bn(x))
+
+    logits = formula.tensor("pp.logits", (2, 10, 256), 6.0)
+    boxes = torch.cat([formula.tensor("pp.c", (2, 10, 2), 0.6, 0.5), formula.tensor("pp.s", (2, 10, 2), 0.3, 0.2)], -1)
+    sizes = torch.tensor([[480.0, 640.0], [600.0, 333.0]])
+    res = PostProcess()({"pred_logits": logits, "pred_boxes": boxes}, sizes)
+    save("postprocess.npz", logits=logits, boxes=boxes, sizes=sizes, scores=torch.stack([r["scores"] for r in res]),
+         labels=torch.stack([r["labels"] for r in res]), out_boxes=torch.stack([r["boxes"] for r in res]))
+
+
+# ------------------------------------------------------------------------------------------ whole model (fake backbone)
+class FakeBackbone(torch.nn.Sequential):
+    """Contract of Joiner.forward (backbone.py:169-178): returns ([NestedTensor], [pos])."""
+
+    def __init__(self, feat, mask):
+        super().__init__()
+        self.num_channels = feat.shape[1]
+        self.feat, self.mask = feat, mask
+        self.pe = PositionEmbeddingSine(128, normalize=True)
+
+    def forward(self, tensor_list):
+        nt = NestedTensor(self.feat, self.mask)
+        return [nt], [self.pe(nt).to(self.feat.dtype)]
+
+
+class FakeTokenized(dict):
+    def __getattr__(self, k):
+        return self[k]
+
+    def to(self, device):
+        return self
+
+    def char_to_token(self, i, c=None):
+        # deterministic fake: character index -> token index, 3 characters per token
+        if c is None:
+            return None
+        t = c // 3 + 1
+        return t if t < self["input_ids"].shape[1] - 1 else None
+
+
+def whole_model():
+    args = types.SimpleNamespace(without_pretrain=True, cluster=False, num_queries=100, nsthl2_loss=False, softkd_loss=False)
+    torch.manual_seed(0)
+    tr = ref_transformer.Transformer(args=args, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                                     dropout=0.1, return_intermediate_dec=True, pass_pos_and_query=True, text_encoder_type="roberta-base",
+                                     contrastive_loss=False)
+    B, h, w, Ltok = 2, 5, 6, 7
+    feat = formula.tensor("wm.feat", (B, 2048, h, w), 2.0).clamp(min=0)
+    fmask = torch.zeros(B, h, w, dtype=torch.bool)
+    fmask[1, :, 4:] = True
+    bb = FakeBackbone(feat, fmask)
+    model = MDETR(bb, tr, num_classes=255, num_queries=100, aux_loss=True, contrastive_align_loss=True, args=args)
+    model.eval()
+    sd = model.state_dict()
+    shapes = {k: list(v.shape) for k, v in sd.items() if not k.startswith("backbone.")}
+    with open(os.path.join(HERE, "reference_state_dict_shapes.json"), "w") as f:
+        json.dump(shapes, f, indent=0, sort_keys=True)
+    filled = formula.fill_state_dict({k: v for k, v in sd.items()})
+    model.load_state_dict(filled)
+
+    ids = torch.tensor([[0, 713, 16, 10, 1296, 4, 2], [0, 31414, 232, 2, 1, 1, 1]])
+    att = ids.ne(1).long()
+    tok = FakeTokenized(input_ids=ids, attention_mask=att)
+    tr.tokenizer = types.SimpleNamespace(batch_encode_plus=lambda text, padding, return_tensors: tok)
+    images = NestedTensor(torch.zeros(B, 3, h * 32, w * 32), torch.zeros(B, h * 32, w * 32, dtype=torch.bool))
+    with torch.no_grad():
+        mc = model(images, ["a", "b"], encode_and_save=True)
+        out = model(images, ["a", "b"], encode_and_save=False, memory_cache=mc)
+    rec = {"ids": ids, "att": att, "feat_shape": np.array(feat.shape), "fmask": fmask}
+    for k in ("text_memory_resized", "text_memory", "img_memory", "pos_embed", "query_embed"):
+        rec["mc_" + k], rec["mc_" + k + "_sum"] = sampled(mc[k])
+    rec["mc_mask"], rec["mc_text_attention_mask"] = mc["mask"], mc["text_attention_mask"]
+    for k in ("pred_logits", "pred_boxes", "proj_queries", "proj_tokens"):
+        rec["out_" + k], rec["out_" + k + "_sum"] = sampled(out[k])
+    for i, a in enumerate(out["aux_outputs"]):
+        rec[f"aux{i}_pred_logits"], _ = sampled(a["pred_logits"])
+        rec[f"aux{i}_pred_boxes"], _ = sampled(a["pred_boxes"])
+    save("whole_model.npz", **rec)
+
+    # ---- criterion on these outputs (labels, boxes, cardinality, contrastive_align; aux layers) ----
+    sizes = [3, 2]
+    targets = []
+    for i, t in enumerate(sizes):
+        bx = torch.cat([formula.tensor(f"cr.c{i}", (t, 2), 0.6, 0.5), formula.tensor(f"cr.s{i}", (t, 2), 0.3, 0.2)], -1)
+        targets.append({"boxes": bx, "labels": torch.ones(t, dtype=torch.int64), "tokens_positive": [[(0, 6)], [(3, 9)], [(0, 3), (9, 12)]][:t]})
+    pm = torch.zeros(sum(sizes), 256)
+    pm[:, 1:6] = 0.2
+    matcher = HungarianMatcher(1.0, 5.0, 2.0)
+    crit = SetCriterion(args, 255, matcher=matcher, eos_coef=0.1, losses=["labels", "boxes", "cardinality", "contrastive_align"],
+                        temperature=0.07, contrastive_hdim=64)
+    with torch.no_grad():
+        losses = crit(mc, out, targets, pm, None)
+    crec = {"pm": pm, "sizes": np.array(sizes)}
+    for i, t in enumerate(targets):
+        crec[f"boxes{i}"] = t["boxes"]
+    names = sorted(losses)
+    crec["names"] = np.array(names)
+    crec["values"] = np.array([float(losses[k]) for k in names], dtype=np.float64)
+    # full outputs are needed to re-run the oracle criterion on identical inputs
+    crec["pred_logits"] = torch.stack([a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]])
+    crec["pred_boxes"] = torch.stack([a["pred_boxes"] for a in out["aux_outputs"]] + [out["pred_boxes"]])
+    crec["proj_queries"] = torch.stack([a["proj_queries"] for a in out["aux_outputs"]] + [out["proj_queries"]])
+    crec["proj_tokens"] = out["proj_tokens"]
+    save("criterion.npz", **crec)
+
+
+if __name__ == "__main__":
+    matcher_cases()
+    small_ops()
+    whole_model()

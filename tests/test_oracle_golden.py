@@ -1,0 +1,140 @@
+"""Pins the oracle (oracle/*.py, oracle/lsap.c) against golden vectors produced by the REAL reference
+(tests/golden/make_golden.py imported /root/reference in the build container).  CPU only.
+Tolerance: fp32 vs fp32 with different op fusion/order -> atol 2e-5 / rtol 2e-5 on activations
+(1e-4 after the 6+6+12-layer stack), exact for indices and masks."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import matcher_ref, model_ref
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+import sys
+sys.path.insert(0, G)
+import formula  # noqa: E402
+
+
+def load(name):
+    return {k: v for k, v in np.load(os.path.join(G, name), allow_pickle=False).items()}
+
+
+@pytest.mark.parametrize("name", ["rand", "dup", "big", "wide", "samepm"])
+def test_matcher_indices_match_reference(name):
+    d = load(f"matcher_{name}.npz")
+    sizes = d["sizes"].tolist()
+    tgts = [torch.from_numpy(d[f"tgt{i}"]) for i in range(len(sizes))]
+    out = matcher_ref.hungarian_match(torch.from_numpy(d["logits"]), torch.from_numpy(d["boxes"]), tgts, torch.from_numpy(d["pm"]))
+    for i, (r, c) in enumerate(out):
+        assert r.dtype == torch.int64 and c.dtype == torch.int64
+        assert np.array_equal(r.numpy(), d[f"src{i}"]) and np.array_equal(c.numpy(), d[f"dst{i}"]), f"image {i}"
+
+
+def test_box_ops():
+    d = load("box_ops.npz")
+    a, b = torch.from_numpy(d["a"]), torch.from_numpy(d["b"])
+    axy, bxy = matcher_ref.cxcywh_to_xyxy(a), matcher_ref.cxcywh_to_xyxy(b)
+    assert np.allclose(axy.numpy(), d["axy"], atol=1e-7)
+    iou, union = matcher_ref.pairwise_iou(axy, bxy)
+    assert np.allclose(iou.numpy(), d["iou"], atol=1e-6) and np.allclose(union.numpy(), d["union"], atol=1e-6)
+    assert np.allclose(matcher_ref.pairwise_giou(axy, bxy).numpy(), d["giou"], atol=1e-6)
+    g = matcher_ref.pairwise_giou(axy, axy)
+    assert np.allclose(np.diag(g.numpy()), 1.0, atol=1e-6) and float(g.min()) >= -1.0 - 1e-6
+
+
+def test_sine_position_and_frozen_bn():
+    d = load("position_sine.npz")
+    pos = model_ref.sine_position(torch.from_numpy(d["mask"]), 128)
+    assert np.allclose(pos.numpy(), d["pos"], atol=1e-6)
+    d = load("frozen_bn.npz")
+    sd = formula.fill_state_dict({f"bn.{k}": torch.zeros(6) for k in ("weight", "bias", "running_mean", "running_var")})
+    y = model_ref.frozen_bn(torch.from_numpy(d["x"]), sd, "bn.")
+    assert np.allclose(y.numpy(), d["y"], atol=1e-6)
+
+
+def test_postprocess():
+    d = load("postprocess.npz")
+    res = model_ref.post_process({"pred_logits": torch.from_numpy(d["logits"]), "pred_boxes": torch.from_numpy(d["boxes"])},
+                                 torch.from_numpy(d["sizes"]))
+    assert np.allclose(torch.stack([r["scores"] for r in res]).numpy(), d["scores"], atol=1e-6)
+    assert np.array_equal(torch.stack([r["labels"] for r in res]).numpy(), d["labels"])
+    assert np.allclose(torch.stack([r["boxes"] for r in res]).numpy(), d["out_boxes"], atol=1e-4)
+
+
+@pytest.fixture(scope="module")
+def whole():
+    d = load("whole_model.npz")
+    with open(os.path.join(G, "reference_state_dict_shapes.json")) as f:
+        shapes = json.load(f)
+    sd = formula.fill_state_dict({k: torch.zeros(s) for k, s in shapes.items() if not k.endswith("position_ids")})
+    feat = formula.tensor("wm.feat", tuple(d["feat_shape"].tolist()), 2.0).clamp(min=0)
+    ids, att = torch.from_numpy(d["ids"]), torch.from_numpy(d["att"])
+    with torch.no_grad():
+        # pixel mask whose nearest downsample reproduces the feature-level mask of the fixture
+        fmask = torch.from_numpy(d["fmask"])
+        pix = fmask.repeat_interleave(32, 1).repeat_interleave(32, 2)
+        mc = model_ref.mdetr_encode(sd, None, pix, ids, att, features=feat)
+        out = model_ref.mdetr_decode(sd, mc, contrastive_align=True)
+    return d, mc, out
+
+
+def _cmp(t, d, key, atol, rtol):
+    flat = t.reshape(-1)
+    got = flat[torch.from_numpy(formula.sample_indices(flat.numel()))].numpy()
+    assert np.allclose(got, d[key], atol=atol, rtol=rtol), f"{key}: max abs err {np.abs(got - d[key]).max()}"
+    if key + "_sum" in d:
+        s = d[key + "_sum"]
+        assert abs(float(flat.sum()) - s[0]) <= 1e-3 * max(1.0, s[1]) * 1e-1 + 1e-2
+        assert abs(float(flat.abs().sum()) - s[1]) <= 1e-4 * s[1] + 1e-3
+
+
+def test_whole_model_matches_reference(whole):
+    d, mc, out = whole
+    assert np.array_equal(mc["mask"].numpy(), d["mc_mask"])
+    assert np.array_equal(mc["text_attention_mask"].numpy(), d["mc_text_attention_mask"])
+    for k in ("text_memory_resized", "pos_embed", "query_embed"):
+        _cmp(mc[k], d, "mc_" + k, 2e-5, 2e-5)
+    for k in ("text_memory", "img_memory"):
+        _cmp(mc[k], d, "mc_" + k, 1e-4, 1e-4)
+    for k in ("pred_logits", "pred_boxes", "proj_queries", "proj_tokens"):
+        _cmp(out[k], d, "out_" + k, 2e-4, 2e-4)
+    for i, a in enumerate(out["aux_outputs"]):
+        _cmp(a["pred_logits"], d, f"aux{i}_pred_logits", 2e-4, 2e-4)
+        _cmp(a["pred_boxes"], d, f"aux{i}_pred_boxes", 2e-4, 2e-4)
+
+
+def test_criterion_matches_reference():
+    d = load("criterion.npz")
+    sizes = d["sizes"].tolist()
+    targets = [{"boxes": torch.from_numpy(d[f"boxes{i}"]), "labels": torch.ones(s, dtype=torch.int64)} for i, s in enumerate(sizes)]
+    logits, boxes, pq = torch.from_numpy(d["pred_logits"]), torch.from_numpy(d["pred_boxes"]), torch.from_numpy(d["proj_queries"])
+    pt = torch.from_numpy(d["proj_tokens"])
+    L = logits.shape[0]
+    out = {"pred_logits": logits[-1], "pred_boxes": boxes[-1], "proj_queries": pq[-1], "proj_tokens": pt,
+           "aux_outputs": [{"pred_logits": logits[i], "pred_boxes": boxes[i], "proj_queries": pq[i], "proj_tokens": pt} for i in range(L - 1)]}
+    # the generator's fake tokenizer maps character c -> token c // 3 + 1 (None past the last real token)
+    ntok = pt.shape[1]
+
+    def c2t(c):
+        t = c // 3 + 1
+        return t if t < ntok - 1 else None
+
+    chars = [[(0, 6)], [(3, 9)], [(0, 3), (9, 12)]]
+    spans = []
+    for s in sizes:
+        per = []
+        for t in range(s):
+            lst = []
+            for beg, end in chars[t]:
+                b, e = c2t(beg), c2t(end - 1)
+                if b is not None and e is not None:
+                    lst.append((b, e))
+            per.append(lst)
+        spans.append(per)
+    losses = model_ref.set_criterion(out, targets, torch.from_numpy(d["pm"]), token_spans=spans)
+    names = [str(n) for n in d["names"]]
+    assert sorted(losses) == names
+    for n, v in zip(names, d["values"]):
+        assert abs(float(losses[n]) - v) <= 1e-5 + 1e-5 * abs(v), f"{n}: {float(losses[n])} vs {v}"
