@@ -9,6 +9,10 @@ import torch
 
 from . import engine
 
+# Optional callable(flat_grad_buffer) invoked when a program's backward has produced all of its
+# parameter gradients (set by toist_amd.parallel.GradSync).
+GRAD_SYNC = None
+
 
 class _TapeFn(torch.autograd.Function):
     @staticmethod
@@ -27,6 +31,7 @@ class _TapeFn(torch.autograd.Function):
         out_vars, extra = body(tape, ps, *in_vars)
         if need:
             ctx.tape, ctx.ps, ctx.in_vars, ctx.out_vars = tape, ps, in_vars, out_vars
+            ctx.params = params
         else:
             tape.steps = []
         ctx.n_in = n_in
@@ -52,9 +57,22 @@ class _TapeFn(torch.autograd.Function):
                 in_grads.append(None)
             else:
                 in_grads.append(v.take_grad())
-        par_grads = ps.grads()
-        ctx.tape = ctx.ps = ctx.in_vars = ctx.out_vars = None
-        return (None, None, None, None, None, *in_grads, *par_grads)
+        # Parameter gradients live in ONE flat fp32 buffer per program; they are attached to .grad
+        # directly (no autograd accumulation copies), so a data-parallel all-reduce can run in place
+        # on the flat buffer while the rest of the backward pass proceeds (toist_amd/parallel.py).
+        for p, g in zip(ctx.params, ps.grads()):
+            if g is None:
+                continue
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+                ps.flat = None  # accumulated into an older buffer: nothing to reduce in place
+        if GRAD_SYNC is not None and ps.flat is not None:
+            GRAD_SYNC(ps.flat)
+        n_par = len(ctx.params)
+        ctx.tape = ctx.ps = ctx.in_vars = ctx.out_vars = ctx.params = None
+        return (None, None, None, None, None, *in_grads, *([None] * n_par))
 
 
 def run_program(body, named_params, inputs, cache=None, training=False, drop_p=0.0, seed=0, transforms=None):

@@ -20,6 +20,11 @@ __all__ = [
 ]
 
 
+# bench.py sets this to {"key": (tile, a_kind, b_kind) | None, "records": [], "other": {}} to time GEMM
+# launches with HIP events on the launch stream (roofline accounting); None = no instrumentation.
+PROFILE = None
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -57,8 +62,9 @@ def operand(t, ld=0, bs_outer=0, bs_inner=0, kin=0, tap_stride=0, geom=None):
 
 def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_outer=0, cs_inner=0, split_k=1, tile=0,
          flags=0, alpha=1.0, scale=None, shift=None, rscale=None, res=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, pre_out=None,
-         accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0):
-    """C = epilogue(A @ B^T); see include/toist_hip.h.  `a`/`b` are Operand structs from operand()."""
+         accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0, flops=0):
+    """C = epilogue(A @ B^T); see include/toist_hip.h.  `a`/`b` are Operand structs from operand().
+    `flops` = algorithmic FLOPs of the call (bench.py's roofline accounting only)."""
     d = Gemm()
     d.M, d.N, d.K, d.a_kind, d.b_kind, d.a, d.b = M, N, K, a_kind, b_kind, a, b
     if c.dtype == torch.float32:
@@ -81,7 +87,24 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
         e.cmap = 1
         e.cH, e.cW, e.cOH, e.cOW, e.cst = cmap
     e.drop_where, e.drop_p, e.drop_seed = drop_where, drop_p, drop_seed
+    prof = PROFILE
+    if prof is None:
+        _lib.check(_lib.lib().toist_gemm_bf16(ctypes.byref(d), _stream()), "toist_gemm_bf16")
+        return
+    t = tile
+    if t == 0:
+        t128 = ((M + 127) // 128) * ((N + 127) // 128) * max(batch, 1) * max(split_k, 1)
+        t = 128 if (t128 >= 192 and M >= 128 and N >= 128) else 64
+    key = (t, a_kind, b_kind)
+    if prof["key"] is not None and prof["key"] != key:
+        _lib.check(_lib.lib().toist_gemm_bf16(ctypes.byref(d), _stream()), "toist_gemm_bf16")
+        prof["other"][key] = prof["other"].get(key, 0) + flops
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _lib.check(_lib.lib().toist_gemm_bf16(ctypes.byref(d), _stream()), "toist_gemm_bf16")
+    e1.record()
+    prof["records"].append((e0, e1, flops, key))
 
 
 def matcher(logits, boxes, tgt_boxes, pos_map, tgt_off, match_off, max_T, w_class, w_bbox, w_giou, src_idx, tgt_idx,

@@ -36,7 +36,7 @@ def linear(x, w, bias=None, *, out=None, out_dtype=BF16, act=k.ACT_NONE, res=Non
         out = torch.empty(M, N, dtype=out_dtype, device=x.device)
     k.gemm(M, N, K, k.A_ROWK, k.operand(x, _ld(x)), k.B_ROWK, k.operand(w, _ld(w)), out, _ld(out), alpha=alpha, scale=scale,
            shift=bias, res=res, ldr=_ld(res) if res is not None else 0, act=act, pre_out=pre_out, drop_where=drop_where,
-           drop_p=drop_p, drop_seed=drop_seed, tile=tile)
+           drop_p=drop_p, drop_seed=drop_seed, tile=tile, flops=2 * M * N * K)
     return out
 
 
@@ -49,7 +49,7 @@ def linear_dgrad(dy, w, *, out=None, res=None, act=k.ACT_NONE, aux=None, alpha=1
         out = torch.empty(M, K, dtype=BF16, device=dy.device)
     k.gemm(M, K, N, k.A_ROWK, k.operand(dy, _ld(dy)), k.B_KROW, k.operand(w, _ld(w)), out, _ld(out), alpha=alpha, scale=scale,
            res=res, ldr=_ld(res) if res is not None else 0, act=act, aux=aux, ldaux=_ld(aux) if aux is not None else 0,
-           flags=flags)
+           flags=flags, flops=2 * M * N * K)
     return out
 
 
@@ -64,7 +64,7 @@ def linear_wgrad(dy, x, *, out=None, alpha=1.0, flags=0, split_k=None):
         tiles = ((N + 63) // 64) * ((K + 63) // 64)
         split_k = _split_k_for(tiles, (M + 31) // 32)
     k.gemm(N, K, M, k.A_KROW, k.operand(dy, _ld(dy)), k.B_KROW, k.operand(x, _ld(x)), out, _ld(out), alpha=alpha,
-           accumulate=True, split_k=split_k, flags=flags)
+           accumulate=True, split_k=split_k, flags=flags, flops=2 * M * N * K)
     return out
 
 
@@ -102,7 +102,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, res=None, ac
     if Kred != R * S * C:  # stem only (C = 8): pad the reduction axis of the weights with zeros
         wk = torch.nn.functional.pad(wk, (0, Kred - R * S * C))
     k.gemm(M, Co, Kred, a_kind, a, k.B_ROWK, k.operand(wk, Kred), out, Co, scale=scale, shift=shift, res=res,
-           ldr=Co if res is not None else 0, act=act, tile=tile)
+           ldr=Co if res is not None else 0, act=act, tile=tile, flops=2 * M * Co * R * S * (3 if C == 8 else C))
     return out
 
 
@@ -117,18 +117,19 @@ def conv2d_dgrad(dy, w, in_hw, *, stride=1, pad=0, dil=1, scale=None, res=None, 
     M = Nb * H * W
     ldr = C if res is not None else 0
     ldaux = C if aux is not None else 0
+    fl = 2 * Nb * OH * OW * Co * R * S * C  # algorithmic: the forward conv's MACs
     if R == 1 and S == 1 and stride == 1 and pad == 0:
         k.gemm(M, C, Co, k.A_ROWK, k.operand(dy, Co), k.B_KROW, k.operand(w.view(Co, C), C), out, C, scale=scale, res=res, ldr=ldr,
-               act=act, aux=aux, ldaux=ldaux, flags=flags)
+               act=act, aux=aux, ldaux=ldaux, flags=flags, flops=fl)
     elif R == 1 and S == 1 and pad == 0:
         # strided 1x1 (downsample): only rows (n, oy*stride, ox*stride) of dx receive a value
         k.gemm(Nb * OH * OW, C, Co, k.A_ROWK, k.operand(dy, Co), k.B_KROW, k.operand(w.view(Co, C), C), out, C, scale=scale,
-               res=res, ldr=ldr, act=act, aux=aux, ldaux=ldaux, cmap=(H, W, OH, OW, stride), flags=flags)
+               res=res, ldr=ldr, act=act, aux=aux, ldaux=ldaux, cmap=(H, W, OH, OW, stride), flags=flags, flops=fl)
     else:
         a = k.operand(dy, 0, geom=k.ConvGeom(OH, OW, Co, H, W, R, S, stride, pad, dil))
         b = k.operand(w, R * S * C, kin=Co, tap_stride=C)
         k.gemm(M, C, R * S * Co, k.A_CONVT, a, k.B_KROW, b, out, C, scale=scale, res=res, ldr=ldr, act=act, aux=aux,
-               ldaux=ldaux, flags=flags)
+               ldaux=ldaux, flags=flags, flops=fl)
     return out
 
 
@@ -150,7 +151,8 @@ def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, s
         b_kind, b = k.B_KROW, k.operand(x, C)
     else:
         b_kind, b = k.B_CONVX, k.operand(x, 0, geom=k.ConvGeom(H, W, C, OH, OW, R, S, stride, pad, dil))
-    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out, Nn, accumulate=True, split_k=split_k, flags=flags, rscale=rscale)
+    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out, Nn, accumulate=True, split_k=split_k, flags=flags, rscale=rscale,
+           flops=2 * P * Co * Nn)
     return out
 
 
@@ -167,7 +169,7 @@ def attn_scores(q, kmat, B, H, Sq, Sk, dh, scale, out=None):
         out = torch.empty(B * H, Sq, ld, dtype=BF16, device=q.device)
     k.gemm(Sq, Sk, dh, k.A_ROWK, k.operand(q, _ld(q), bs_outer=Sq * _ld(q), bs_inner=dh), k.B_ROWK,
            k.operand(kmat, _ld(kmat), bs_outer=Sk * _ld(kmat), bs_inner=dh), out, ld, batch=B * H, batch_inner=H,
-           cs_outer=H * Sq * ld, cs_inner=Sq * ld, alpha=scale, tile=64)
+           cs_outer=H * Sq * ld, cs_inner=Sq * ld, alpha=scale, tile=64, flops=2 * B * H * Sq * Sk * dh)
     return out
 
 
@@ -176,7 +178,7 @@ def attn_context(p, v, B, H, Sq, Sk, dh, out):
     ld = p.shape[-1]
     k.gemm(Sq, dh, Sk, k.A_ROWK, k.operand(p, ld, bs_outer=H * Sq * ld, bs_inner=Sq * ld), k.B_KROW,
            k.operand(v, _ld(v), bs_outer=Sk * _ld(v), bs_inner=dh), out, _ld(out), batch=B * H, batch_inner=H,
-           cs_outer=Sq * _ld(out), cs_inner=dh, tile=64)
+           cs_outer=Sq * _ld(out), cs_inner=dh, tile=64, flops=2 * B * H * Sq * Sk * dh)
     return out
 
 
@@ -190,17 +192,17 @@ def attn_backward(p_used, ds_scale, q, kmat, v, dctx, B, H, Sq, Sk, dh, dq, dk, 
     # dV[b,j,h,:] = sum_i p[b,h,i,j] * dctx[b,i,h,:]
     k.gemm(Sk, dh, Sq, k.A_KROW, k.operand(p_used, ld, bs_outer=H * Sq * ld, bs_inner=Sq * ld), k.B_KROW,
            k.operand(dctx, _ld(dctx), bs_outer=Sq * _ld(dctx), bs_inner=dh), dv, _ld(dv), batch=B * H, batch_inner=H,
-           cs_outer=Sk * _ld(dv), cs_inner=dh, tile=64)
+           cs_outer=Sk * _ld(dv), cs_inner=dh, tile=64, flops=2 * B * H * Sq * Sk * dh)
     # dP[b,h,i,j] = dctx[b,i,h,:] . v[b,j,h,:]
     dp = torch.empty(B * H, Sq, ld, dtype=BF16, device=dev)
     k.gemm(Sq, Sk, dh, k.A_ROWK, k.operand(dctx, _ld(dctx), bs_outer=Sq * _ld(dctx), bs_inner=dh), k.B_ROWK,
            k.operand(v, _ld(v), bs_outer=Sk * _ld(v), bs_inner=dh), dp, ld, batch=B * H, batch_inner=H, cs_outer=H * Sq * ld,
-           cs_inner=Sq * ld, tile=64)
+           cs_inner=Sq * ld, tile=64, flops=2 * B * H * Sq * Sk * dh)
     ds = softmax_bwd_fn(dp)
     # dQ = scale * dS @ K ; dK = scale * dS^T @ Q
     k.gemm(Sq, dh, Sk, k.A_ROWK, k.operand(ds, ld, bs_outer=H * Sq * ld, bs_inner=Sq * ld), k.B_KROW,
            k.operand(kmat, _ld(kmat), bs_outer=Sk * _ld(kmat), bs_inner=dh), dq, _ld(dq), batch=B * H, batch_inner=H,
-           cs_outer=Sq * _ld(dq), cs_inner=dh, alpha=ds_scale, tile=64)
+           cs_outer=Sq * _ld(dq), cs_inner=dh, alpha=ds_scale, tile=64, flops=2 * B * H * Sq * Sk * dh)
     k.gemm(Sk, dh, Sq, k.A_KROW, k.operand(ds, ld, bs_outer=H * Sq * ld, bs_inner=Sq * ld), k.B_KROW,
            k.operand(q, _ld(q), bs_outer=Sq * _ld(q), bs_inner=dh), dk, _ld(dk), batch=B * H, batch_inner=H,
-           cs_outer=Sk * _ld(dk), cs_inner=dh, alpha=ds_scale, tile=64)
+           cs_outer=Sk * _ld(dk), cs_inner=dh, alpha=ds_scale, tile=64, flops=2 * B * H * Sq * Sk * dh)
