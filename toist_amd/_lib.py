@@ -74,6 +74,9 @@ def exported_symbols():
 def lib():
     global _lib
     if _lib is None:
+        # torch ships its own HIP runtime (libamdhip64); it must be the one already loaded when our
+        # library binds, otherwise two runtimes coexist and launches fail with "no ROCm-capable device".
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -13,6 +13,8 @@
 // NOT the contiguous one (wgrad, PV, dgrad from the forward weight layout) are staged k-major and
 // turned into MFMA fragments by the LDS transpose read ds_read_b64_tr_b16.  The MFMA is issued as
 // D^T = B * A^T so each lane owns 4 consecutive output columns -> 8-byte packed bf16 stores.
+#include <type_traits>
+
 #include "common.h"
 
 namespace toist {
@@ -25,44 +27,243 @@ __device__ __forceinline__ float gelu_grad_f(float a) {
     return 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * __expf(-0.5f * a * a);
 }
 
-struct PixRow {      // per-thread gather state of one staged row (conv kinds)
-    long long base;  // element offset of image n in the source tensor
-    int y0, x0;      // CONV: py*stride-pad ; CONVT: py+pad
+// One 1x4 output fragment: v = acc*alpha*rscale[m] -> *scale[n] + shift[n] -> dropout -> + res -> act -> dropout -> store.
+// Written with compile-time element indices only (no break/continue) so accumulators stay in registers.
+__device__ __forceinline__ void epilogue_frag(const toist_gemm& p, const f32x4_t a, const int m, const int n, const int bz,
+                                              const long long coff) {
+    const toist_epilogue& e = p.epi;
+    const int N = p.N, M = p.M;
+    const int nv = (N - n < 4) ? (N - n) : 4;
+    long long crow = m;
+    if (e.cmap) {
+        const int plane = e.cOH * e.cOW;
+        const int n_img = m / plane, rem = m - n_img * plane;
+        const int oy = rem / e.cOW, ox = rem - oy * e.cOW;
+        crow = ((long long)n_img * e.cH + (long long)oy * e.cst) * e.cW + (long long)ox * e.cst;
+    }
+    const float rs = e.rscale ? e.alpha * e.rscale[m] : e.alpha;
+    float v0 = a[0] * rs, v1 = a[1] * rs, v2 = a[2] * rs, v3 = a[3] * rs;
+    if (e.scale) {
+        v0 *= e.scale[n];
+        if (nv > 1) v1 *= e.scale[n + 1];
+        if (nv > 2) v2 *= e.scale[n + 2];
+        if (nv > 3) v3 *= e.scale[n + 3];
+    }
+    if (e.shift) {
+        v0 += e.shift[n];
+        if (nv > 1) v1 += e.shift[n + 1];
+        if (nv > 2) v2 += e.shift[n + 2];
+        if (nv > 3) v3 += e.shift[n + 3];
+    }
+    const unsigned long long didx = ((unsigned long long)bz * M + m) * N + n;
+    if (e.drop_where == 1) {
+        const unsigned th = (unsigned)(e.drop_p * 4294967296.0);
+        const float sc = 1.f / (1.f - e.drop_p);
+        v0 = dropout_keep(e.drop_seed, didx, th) ? v0 * sc : 0.f;
+        v1 = dropout_keep(e.drop_seed, didx + 1, th) ? v1 * sc : 0.f;
+        v2 = dropout_keep(e.drop_seed, didx + 2, th) ? v2 * sc : 0.f;
+        v3 = dropout_keep(e.drop_seed, didx + 3, th) ? v3 * sc : 0.f;
+    }
+    if (e.res) {
+        const bf16_t* rp = (const bf16_t*)e.res + coff + crow * e.ldr + n;
+        if (nv == 4 && ((((size_t)rp) & 7) == 0)) {
+            const uint2 u = *reinterpret_cast<const uint2*>(rp);
+            v0 += __uint_as_float(u.x << 16); v1 += __uint_as_float(u.x & 0xffff0000u);
+            v2 += __uint_as_float(u.y << 16); v3 += __uint_as_float(u.y & 0xffff0000u);
+        } else {
+            v0 += bf2f(rp[0]);
+            if (nv > 1) v1 += bf2f(rp[1]);
+            if (nv > 2) v2 += bf2f(rp[2]);
+            if (nv > 3) v3 += bf2f(rp[3]);
+        }
+    }
+    if (e.pre_out) {
+        bf16_t* pp = (bf16_t*)e.pre_out + coff + crow * p.ldc + n;
+        pp[0] = f2bf(v0);
+        if (nv > 1) pp[1] = f2bf(v1);
+        if (nv > 2) pp[2] = f2bf(v2);
+        if (nv > 3) pp[3] = f2bf(v3);
+    }
+    if (e.act != TOIST_ACT_NONE) {
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+        if (e.act >= TOIST_ACT_MASK_POS) {
+            const bf16_t* ap = (const bf16_t*)e.aux + coff + crow * e.ldaux + n;
+            if (nv == 4 && ((((size_t)ap) & 7) == 0)) {
+                const uint2 u = *reinterpret_cast<const uint2*>(ap);
+                x0 = __uint_as_float(u.x << 16); x1 = __uint_as_float(u.x & 0xffff0000u);
+                x2 = __uint_as_float(u.y << 16); x3 = __uint_as_float(u.y & 0xffff0000u);
+            } else {
+                x0 = bf2f(ap[0]);
+                if (nv > 1) x1 = bf2f(ap[1]);
+                if (nv > 2) x2 = bf2f(ap[2]);
+                if (nv > 3) x3 = bf2f(ap[3]);
+            }
+        }
+        switch (e.act) {
+            case TOIST_ACT_RELU: v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); break;
+            case TOIST_ACT_GELU: v0 = gelu_f(v0); v1 = gelu_f(v1); v2 = gelu_f(v2); v3 = gelu_f(v3); break;
+            case TOIST_ACT_SIGMOID:
+                v0 = 1.f / (1.f + __expf(-v0)); v1 = 1.f / (1.f + __expf(-v1));
+                v2 = 1.f / (1.f + __expf(-v2)); v3 = 1.f / (1.f + __expf(-v3)); break;
+            case TOIST_ACT_MASK_POS:
+                v0 = x0 > 0.f ? v0 : 0.f; v1 = x1 > 0.f ? v1 : 0.f; v2 = x2 > 0.f ? v2 : 0.f; v3 = x3 > 0.f ? v3 : 0.f; break;
+            case TOIST_ACT_GELU_BWD:
+                v0 *= gelu_grad_f(x0); v1 *= gelu_grad_f(x1); v2 *= gelu_grad_f(x2); v3 *= gelu_grad_f(x3); break;
+            case TOIST_ACT_SIGMOID_BWD:
+                v0 *= x0 * (1.f - x0); v1 *= x1 * (1.f - x1); v2 *= x2 * (1.f - x2); v3 *= x3 * (1.f - x3); break;
+            default: break;
+        }
+    }
+    if (e.drop_where == 2) {
+        const unsigned th = (unsigned)(e.drop_p * 4294967296.0);
+        const float sc = 1.f / (1.f - e.drop_p);
+        v0 = dropout_keep(e.drop_seed, didx, th) ? v0 * sc : 0.f;
+        v1 = dropout_keep(e.drop_seed, didx + 1, th) ? v1 * sc : 0.f;
+        v2 = dropout_keep(e.drop_seed, didx + 2, th) ? v2 * sc : 0.f;
+        v3 = dropout_keep(e.drop_seed, didx + 3, th) ? v3 * sc : 0.f;
+    }
+    if (e.out_f32) {
+        float* cp = (float*)p.c + coff + crow * p.ldc + n;
+        if (e.accumulate || p.split_k > 1) {
+            atomicAdd(cp, v0);
+            if (nv > 1) atomicAdd(cp + 1, v1);
+            if (nv > 2) atomicAdd(cp + 2, v2);
+            if (nv > 3) atomicAdd(cp + 3, v3);
+        } else if (nv == 4 && ((((size_t)cp) & 15) == 0)) {
+            *reinterpret_cast<float4*>(cp) = make_float4(v0, v1, v2, v3);
+        } else {
+            cp[0] = v0;
+            if (nv > 1) cp[1] = v1;
+            if (nv > 2) cp[2] = v2;
+            if (nv > 3) cp[3] = v3;
+        }
+    } else {
+        bf16_t* cp = (bf16_t*)p.c + coff + crow * p.ldc + n;
+        if (nv == 4 && ((((size_t)cp) & 7) == 0)) {
+            *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+        } else {
+            cp[0] = f2bf(v0);
+            if (nv > 1) cp[1] = f2bf(v1);
+            if (nv > 2) cp[2] = f2bf(v2);
+            if (nv > 3) cp[3] = f2bf(v3);
+        }
+    }
+}
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// ---- one 16-byte chunk of a staged tile ------------------------------------------------------------
+struct ChunkA {            // per-thread, per-chunk invariants of the A tile
+    const bf16_t* base;    // ROWK: &A[m][kc*8] ; KROW: &A[0][m0 + rc*8] ; conv: image base + channel offset
+    int row, kc;           // tile-local coordinates (row/k-row, chunk index)
+    int y0, x0;            // conv gather origin
     bool ok;
 };
 
-template <int KIND>
-__device__ __forceinline__ PixRow make_pixrow(const toist_operand& o, long long pix, long long npix) {
-    PixRow r;
-    r.ok = pix < npix;
-    const int plane = o.PH * o.PW;
-    const int n = (int)(pix / plane);
-    const int rem = (int)(pix - (long long)n * plane);
-    const int py = rem / o.PW, px = rem - py * o.PW;
-    r.base = (long long)n * o.SH * o.SW * o.SC;
-    if (KIND == TOIST_A_CONVT) { r.y0 = py + o.pad; r.x0 = px + o.pad; }
-    else { r.y0 = py * o.stride - o.pad; r.x0 = px * o.stride - o.pad; }
-    return r;
+template <int AK>
+__device__ __forceinline__ uint4 load_a(const ChunkA& c, const toist_operand& o, int k0, int K, long long lda) {
+    const bf16_t* src = nullptr;
+    if (AK == TOIST_A_ROWK) {
+        if (c.ok && k0 + c.kc * 8 < K) src = c.base + k0;
+    } else if (AK == TOIST_A_KROW) {
+        const int k = k0 + c.row;
+        if (c.ok && k < K) src = c.base + (long long)k * lda;
+    } else {
+        int tap, c0;
+        if (o.SC % BK == 0) { tap = k0 / o.SC; c0 = k0 - tap * o.SC + c.kc * 8; }
+        else { const int kk = k0 + c.kc * 8; tap = kk / o.SC; c0 = kk - tap * o.SC; }
+        if (c.ok && tap < o.R * o.S) {
+            const int r = tap / o.S, s = tap - r * o.S;
+            int iy, ix;
+            bool in = true;
+            if (AK == TOIST_A_CONVT) {
+                const int ty = c.y0 - r * o.dil, tx = c.x0 - s * o.dil;
+                in = (ty >= 0) & (tx >= 0);
+                if (o.stride > 1) {
+                    in = in && ((ty % o.stride) == 0) && ((tx % o.stride) == 0);
+                    iy = ty / o.stride; ix = tx / o.stride;
+                } else { iy = ty; ix = tx; }
+            } else {
+                iy = c.y0 + r * o.dil; ix = c.x0 + s * o.dil;
+                in = (iy >= 0) & (ix >= 0);
+            }
+            if (in && iy < o.SH && ix < o.SW) src = c.base + ((long long)iy * o.SW + ix) * o.SC + c0;
+        }
+    }
+    return src ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
 }
 
-// source element offset for (pixel row, tap (r,s)); returns false when the tap falls outside
-template <int KIND>
-__device__ __forceinline__ bool pix_src(const toist_operand& o, const PixRow& pr, int r, int s, long long& off) {
-    int iy, ix;
-    if (KIND == TOIST_A_CONVT) {
-        const int ty = pr.y0 - r * o.dil, tx = pr.x0 - s * o.dil;
-        if (ty < 0 || tx < 0) return false;
-        if (o.stride > 1) {
-            if ((ty % o.stride) | (tx % o.stride)) return false;
-            iy = ty / o.stride; ix = tx / o.stride;
-        } else { iy = ty; ix = tx; }
-    } else {
-        iy = pr.y0 + r * o.dil; ix = pr.x0 + s * o.dil;
-        if (iy < 0 || ix < 0) return false;
+struct ChunkB {
+    const bf16_t* base;    // ROWK: &B[n][kc*8] ; KROW: &B[0][n0 + rc*8] ; CONVX: source + channel offset
+    int row, kc;
+    int r, s;              // CONVX: tap of this chunk's columns
+    bool ok;
+};
+
+template <int BKD>
+__device__ __forceinline__ uint4 load_b(const ChunkB& c, const toist_operand& o, int k0, int K, long long ldb) {
+    const bf16_t* src = nullptr;
+    if (BKD == TOIST_B_ROWK) {
+        if (c.ok && k0 + c.kc * 8 < K) src = c.base + k0;
+    } else if (BKD == TOIST_B_KROW) {
+        const int k = k0 + c.row;
+        if (c.ok && k < K) {
+            if (o.kin > 0) {
+                const int tap = k0 / o.kin;
+                src = c.base + (long long)(k - tap * o.kin) * ldb + (long long)tap * o.tap_stride;
+            } else src = c.base + (long long)k * ldb;
+        }
+    } else {  // CONVX: k = output pixel, columns = (tap, c)
+        const long long pix = (long long)k0 + c.row;
+        if (c.ok && pix < K) {
+            const int plane = o.PH * o.PW;
+            const int n = (int)(pix / plane);
+            const int rem = (int)(pix - (long long)n * plane);
+            const int py = rem / o.PW, px = rem - py * o.PW;
+            const int iy = py * o.stride - o.pad + c.r * o.dil, ix = px * o.stride - o.pad + c.s * o.dil;
+            if (iy >= 0 && ix >= 0 && iy < o.SH && ix < o.SW)
+                src = c.base + (((long long)n * o.SH + iy) * o.SW + ix) * o.SC;
+        }
     }
-    if (iy >= o.SH || ix >= o.SW) return false;
-    off = pr.base + ((long long)iy * o.SW + ix) * o.SC;
-    return true;
+    return src ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+}
+
+// k-contiguous LDS tile [rows][BKP]; k-major LDS tile [BK][rows + 8]
+template <bool KM, bool TR, int ROWS>
+__device__ __forceinline__ void stage(bf16_t* s, int row, int kc, const uint4& v) {
+    if (!KM) *reinterpret_cast<uint4*>(&s[row * BKP + kc * 8]) = v;
+    else if (TR) *reinterpret_cast<uint4*>(&s[row * (ROWS + 8) + kc * 8]) = v;
+    else {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[(kc * 8 + 2 * j) * BKP + row] = (bf16_t)(w[j] & 0xffffu);
+            s[(kc * 8 + 2 * j + 1) * BKP + row] = (bf16_t)(w[j] >> 16);
+        }
+    }
+}
+
+// MFMA operand fragment: 8 consecutive k (k = 8*g + j) of tile row (r0 + c16)
+template <bool KM, bool TR, int ROWS>
+__device__ __forceinline__ bf16x8_t fragment(const bf16_t* s, int r0, int g, int c16) {
+    if (KM && TR) {
+        // 16-lane group g transposes the [4 k][16 rows] blocks at k = 8g and k = 8g + 4 (ds_read_b64_tr_b16)
+        constexpr int LD = ROWS + 8;
+        const bf16_t* q = &s[(8 * g + (c16 >> 2)) * LD + r0 + (c16 & 3) * 4];
+        typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q + 4 * LD));
+        union { struct { s16x4_t a, b; } h; bf16x8_t v; } u;
+        u.h.a = lo; u.h.b = hi;
+        return u.v;
+    }
+    return *reinterpret_cast<const bf16x8_t*>(&s[(r0 + c16) * BKP + g * 8]);
 }
 
 template <int BM, int BN, int AK, int BKD, bool TR>
@@ -71,149 +272,82 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     constexpr int ACH = BM * BK / 8 / 256, BCH = BN * BK / 8 / 256;  // 16-byte chunks per thread
     constexpr bool A_KM = (AK == TOIST_A_KROW);    // A staged k-major
     constexpr bool B_KM = (BKD != TOIST_B_ROWK);   // B staged k-major
-    constexpr int LDA_T = BM + 8, LDB_T = BN + 8;  // k-major LDS pitches
-    constexpr int SA_ELEMS = (A_KM && TR) ? BK * LDA_T : BM * BKP;
-    constexpr int SB_ELEMS = (B_KM && TR) ? BK * LDB_T : BN * BKP;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[SA_ELEMS + SB_ELEMS];
-    bf16_t* sA = smem;
-    bf16_t* sB = smem + SA_ELEMS;
+    constexpr int SA_ELEMS = (A_KM && TR) ? BK * (BM + 8) : BM * BKP;
+    constexpr int SB_ELEMS = (B_KM && TR) ? BK * (BN + 8) : BN * BKP;
+    constexpr int STAGE = SA_ELEMS + SB_ELEMS;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];  // double buffered: one barrier per k-tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, c16 = lane & 15;
 
+    const int M = p.M, N = p.N, K = p.K;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int z = blockIdx.z;
     const int bz = z / p.split_k, ksl = z - bz * p.split_k;
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
-    const bf16_t* Ab = (const bf16_t*)p.a.ptr + bo * p.a.bs_outer + bi * p.a.bs_inner;
-    const bf16_t* Bb = (const bf16_t*)p.b.ptr + bo * p.b.bs_outer + bi * p.b.bs_inner;
+    const toist_operand oa = p.a, ob = p.b;
+    const bf16_t* Ab = (const bf16_t*)oa.ptr + bo * oa.bs_outer + bi * oa.bs_inner;
+    const bf16_t* Bb = (const bf16_t*)ob.ptr + bo * ob.bs_outer + bi * ob.bs_inner;
     const long long coff = bo * p.cs_outer + bi * p.cs_inner;
+    const long long lda = oa.ld, ldb = ob.ld;
 
-    const int M = p.M, N = p.N, K = p.K;
     const int ktiles = (K + BK - 1) / BK;
     const int kper = (ktiles + p.split_k - 1) / p.split_k;
     const int kt_beg = ksl * kper;
     const int kt_end = (kt_beg + kper < ktiles) ? kt_beg + kper : ktiles;
     if (kt_beg >= kt_end) return;
 
-    // ---- per-thread staging coordinates --------------------------------------------------
-    int a_row[ACH], a_kc[ACH];
-    PixRow a_pix[ACH];
+    // ---- per-thread chunk invariants ---------------------------------------------------------
+    ChunkA ca[ACH];
 #pragma unroll
     for (int it = 0; it < ACH; ++it) {
         const int ch = tid + 256 * it;
-        if (A_KM) { a_row[it] = ch / (BM / 8); a_kc[it] = ch % (BM / 8); }   // (k row, m chunk)
-        else { a_row[it] = ch >> 2; a_kc[it] = ch & 3; }                       // (m row, k chunk)
-        if (AK == TOIST_A_CONV || AK == TOIST_A_CONVT) a_pix[it] = make_pixrow<AK>(p.a, (long long)m0 + a_row[it], M);
+        ChunkA c;
+        c.y0 = c.x0 = 0;
+        if (A_KM) {
+            c.row = ch / (BM / 8); c.kc = ch % (BM / 8);
+            c.ok = (m0 + c.kc * 8) < M;
+            c.base = Ab + m0 + c.kc * 8;
+        } else {
+            c.row = ch >> 2; c.kc = ch & 3;
+            const int m = m0 + c.row;
+            c.ok = m < M;
+            if (AK == TOIST_A_ROWK) c.base = Ab + (long long)m * lda + c.kc * 8;
+            else {
+                const int plane = oa.PH * oa.PW;
+                const int n = m / plane, rem = m - n * plane;
+                const int py = rem / oa.PW, px = rem - py * oa.PW;
+                c.base = Ab + (long long)n * oa.SH * oa.SW * oa.SC;
+                if (AK == TOIST_A_CONVT) { c.y0 = py + oa.pad; c.x0 = px + oa.pad; }
+                else { c.y0 = py * oa.stride - oa.pad; c.x0 = px * oa.stride - oa.pad; }
+            }
+        }
+        ca[it] = c;
     }
-    int b_row[BCH], b_kc[BCH], b_r[BCH], b_s[BCH], b_c[BCH];
+    ChunkB cb[BCH];
 #pragma unroll
     for (int it = 0; it < BCH; ++it) {
         const int ch = tid + 256 * it;
-        if (B_KM) { b_row[it] = ch / (BN / 8); b_kc[it] = ch % (BN / 8); }
-        else { b_row[it] = ch >> 2; b_kc[it] = ch & 3; }
-        if (BKD == TOIST_B_CONVX) {
-            const int nn = n0 + b_kc[it] * 8;
-            const int tap = nn / p.b.SC;
-            b_c[it] = nn - tap * p.b.SC;
-            b_r[it] = tap / p.b.S;
-            b_s[it] = tap - b_r[it] * p.b.S;
+        ChunkB c;
+        c.r = c.s = 0;
+        if (B_KM) {
+            c.row = ch / (BN / 8); c.kc = ch % (BN / 8);
+            const int nn = n0 + c.kc * 8;
+            c.ok = nn < N;
+            if (BKD == TOIST_B_CONVX) {
+                const int tap = nn / ob.SC;
+                c.r = tap / ob.S; c.s = tap - c.r * ob.S;
+                c.base = Bb + (nn - tap * ob.SC);
+            } else c.base = Bb + nn;
+        } else {
+            c.row = ch >> 2; c.kc = ch & 3;
+            const int n = n0 + c.row;
+            c.ok = n < N;
+            c.base = Bb + (long long)n * ldb + c.kc * 8;
         }
+        cb[it] = c;
     }
-
-    uint4 ra[ACH], rb[BCH];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-    auto load_tiles = [&](int kt) {
-        const int k0 = kt * BK;
-        // ---- A ----
-#pragma unroll
-        for (int it = 0; it < ACH; ++it) {
-            const bf16_t* src = nullptr;
-            if (AK == TOIST_A_ROWK) {
-                const int m = m0 + a_row[it], kk = k0 + a_kc[it] * 8;
-                if (m < M && kk < K) src = Ab + (long long)m * p.a.ld + kk;
-            } else if (AK == TOIST_A_KROW) {
-                const int k = k0 + a_row[it], m = m0 + a_kc[it] * 8;
-                if (k < K && m < M) src = Ab + (long long)k * p.a.ld + m;
-            } else {
-                int tap, c0;
-                if (p.a.SC % BK == 0) { tap = k0 / p.a.SC; c0 = k0 - tap * p.a.SC + a_kc[it] * 8; }
-                else { const int kk = k0 + a_kc[it] * 8; tap = kk / p.a.SC; c0 = kk - tap * p.a.SC; }
-                if (a_pix[it].ok && tap < p.a.R * p.a.S) {
-                    const int r = tap / p.a.S, s = tap - r * p.a.S;
-                    long long off;
-                    if (pix_src<AK>(p.a, a_pix[it], r, s, off)) src = Ab + off + c0;
-                }
-            }
-            ra[it] = src ? *reinterpret_cast<const uint4*>(src) : zero4;
-        }
-        // ---- B ----
-#pragma unroll
-        for (int it = 0; it < BCH; ++it) {
-            const bf16_t* src = nullptr;
-            if (BKD == TOIST_B_ROWK) {
-                const int n = n0 + b_row[it], kk = k0 + b_kc[it] * 8;
-                if (n < N && kk < K) src = Bb + (long long)n * p.b.ld + kk;
-            } else if (BKD == TOIST_B_KROW) {
-                const int k = k0 + b_row[it], n = n0 + b_kc[it] * 8;
-                if (k < K && n < N) {
-                    if (p.b.kin > 0) {
-                        const int tap = k0 / p.b.kin;
-                        src = Bb + (long long)(k - tap * p.b.kin) * p.b.ld + (long long)tap * p.b.tap_stride + n;
-                    } else src = Bb + (long long)k * p.b.ld + n;
-                }
-            } else {  // CONVX: k = output pixel, n = (tap, c)
-                const long long pix = (long long)k0 + b_row[it];
-                const int nn = n0 + b_kc[it] * 8;
-                if (nn < N) {
-                    const PixRow pr = make_pixrow<TOIST_A_CONV>(p.b, pix, K);
-                    long long off;
-                    if (pr.ok && pix_src<TOIST_A_CONV>(p.b, pr, b_r[it], b_s[it], off)) src = Bb + off + b_c[it];
-                }
-            }
-            rb[it] = src ? *reinterpret_cast<const uint4*>(src) : zero4;
-        }
-    };
-
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int it = 0; it < ACH; ++it) {
-            if (!A_KM) *reinterpret_cast<uint4*>(&sA[a_row[it] * BKP + a_kc[it] * 8]) = ra[it];
-            else if (TR) *reinterpret_cast<uint4*>(&sA[a_row[it] * LDA_T + a_kc[it] * 8]) = ra[it];
-            else {
-                const bf16_t* e = reinterpret_cast<const bf16_t*>(&ra[it]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sA[(a_kc[it] * 8 + j) * BKP + a_row[it]] = e[j];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < BCH; ++it) {
-            if (!B_KM) *reinterpret_cast<uint4*>(&sB[b_row[it] * BKP + b_kc[it] * 8]) = rb[it];
-            else if (TR) *reinterpret_cast<uint4*>(&sB[b_row[it] * LDB_T + b_kc[it] * 8]) = rb[it];
-            else {
-                const bf16_t* e = reinterpret_cast<const bf16_t*>(&rb[it]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sB[(b_kc[it] * 8 + j) * BKP + b_row[it]] = e[j];
-            }
-        }
-    };
-
-    // fragment = 8 consecutive k (k = 8*g + j) of tile row (r0 + c16)
-    auto frag_rowk = [&](const bf16_t* s, int r0) -> bf16x8_t {
-        return *reinterpret_cast<const bf16x8_t*>(&s[(r0 + c16) * BKP + g * 8]);
-    };
-    auto frag_tr = [&](const bf16_t* s, int ld, int r0) -> bf16x8_t {
-        // 16-lane group g transposes the [4 k][16 rows] blocks at k = 8g and k = 8g+4
-        const bf16_t* q = &s[(8 * g + (c16 >> 2)) * ld + r0 + (c16 & 3) * 4];
-        typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q + 4 * ld));
-        union { struct { s16x4_t a, b; } h; bf16x8_t v; } u;
-        u.h.a = lo; u.h.b = hi;
-        return u.v;
-    };
 
     f32x4_t acc[FM][FN];
 #pragma unroll
@@ -221,123 +355,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    load_tiles(kt_beg);
+    uint4 ra[ACH], rb[BCH];
+#pragma unroll
+    for (int it = 0; it < ACH; ++it) ra[it] = load_a<AK>(ca[it], oa, kt_beg * BK, K, lda);
+#pragma unroll
+    for (int it = 0; it < BCH; ++it) rb[it] = load_b<BKD>(cb[it], ob, kt_beg * BK, K, ldb);
+#pragma unroll
+    for (int it = 0; it < ACH; ++it) stage<A_KM, TR, BM>(smem, ca[it].row, ca[it].kc, ra[it]);
+#pragma unroll
+    for (int it = 0; it < BCH; ++it) stage<B_KM, TR, BN>(smem + SA_ELEMS, cb[it].row, cb[it].kc, rb[it]);
+    __syncthreads();
+
+    int cur = 0;
     for (int kt = kt_beg; kt < kt_end; ++kt) {
-        store_tiles();
-        __syncthreads();
-        if (kt + 1 < kt_end) load_tiles(kt + 1);
+        const bool more = kt + 1 < kt_end;
+        if (more) {  // next tile's global loads fly under this tile's MFMAs
+#pragma unroll
+            for (int it = 0; it < ACH; ++it) ra[it] = load_a<AK>(ca[it], oa, (kt + 1) * BK, K, lda);
+#pragma unroll
+            for (int it = 0; it < BCH; ++it) rb[it] = load_b<BKD>(cb[it], ob, (kt + 1) * BK, K, ldb);
+        }
+        const bf16_t* sA = smem + cur * STAGE;
+        const bf16_t* sB = sA + SA_ELEMS;
         bf16x8_t af[FM], bfr[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
-            af[i] = (A_KM && TR) ? frag_tr(sA, LDA_T, wm * WM + i * 16) : frag_rowk(sA, wm * WM + i * 16);
+        for (int i = 0; i < FM; ++i) af[i] = fragment<A_KM, TR, BM>(sA, wm * WM + i * 16, g, c16);
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-            bfr[j] = (B_KM && TR) ? frag_tr(sB, LDB_T, wn * WN + j * 16) : frag_rowk(sB, wn * WN + j * 16);
+        for (int j = 0; j < FN; ++j) bfr[j] = fragment<B_KM, TR, BN>(sB, wn * WN + j * 16, g, c16);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        if (more) {
+            bf16_t* dA = smem + (cur ^ 1) * STAGE;
+#pragma unroll
+            for (int it = 0; it < ACH; ++it) stage<A_KM, TR, BM>(dA, ca[it].row, ca[it].kc, ra[it]);
+#pragma unroll
+            for (int it = 0; it < BCH; ++it) stage<B_KM, TR, BN>(dA + SA_ELEMS, cb[it].row, cb[it].kc, rb[it]);
+        }
         __syncthreads();
+        cur ^= 1;
     }
 
     // ---- epilogue: lane owns output row m (c16) and 4 consecutive columns n (4*g .. 4*g+3) ----
-    const toist_epilogue& e = p.epi;
-    const bool atomic = e.accumulate || p.split_k > 1;
-    const unsigned drop_thresh = (e.drop_where != 0) ? (unsigned)(e.drop_p * 4294967296.0) : 0u;
-    const float drop_scale = (e.drop_where != 0) ? 1.f / (1.f - e.drop_p) : 1.f;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
+    static_for<FM * FN>([&](auto idx) {
+        constexpr int i = decltype(idx)::value / FN, j = decltype(idx)::value % FN;
         const int m = m0 + wm * WM + i * 16 + c16;
-        if (m >= M) continue;
-        long long crow = m;
-        if (e.cmap) {
-            const int plane = e.cOH * e.cOW;
-            const int n_img = m / plane, rem = m - n_img * plane;
-            const int oy = rem / e.cOW, ox = rem - oy * e.cOW;
-            crow = ((long long)n_img * e.cH + (long long)oy * e.cst) * e.cW + (long long)ox * e.cst;
-        }
-        const float rs = e.rscale ? e.alpha * e.rscale[m] : e.alpha;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * WN + j * 16 + g * 4;
-            if (n >= N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * rs;
-            const int nv = (N - n < 4) ? (N - n) : 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r >= nv) break;
-                if (e.scale) v[r] *= e.scale[n + r];
-                if (e.shift) v[r] += e.shift[n + r];
-            }
-            if (e.drop_where == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned long long idx = ((unsigned long long)bz * M + m) * N + n + r;
-                    v[r] = dropout_keep(e.drop_seed, idx, drop_thresh) ? v[r] * drop_scale : 0.f;
-                }
-            }
-            if (e.res) {
-                const bf16_t* rp = (const bf16_t*)e.res + coff + crow * e.ldr + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (r < nv) v[r] += bf2f(rp[r]);
-            }
-            if (e.pre_out) {
-                bf16_t* pp = (bf16_t*)e.pre_out + coff + crow * p.ldc + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (r < nv) pp[r] = f2bf(v[r]);
-            }
-            if (e.act != TOIST_ACT_NONE) {
-                float ax[4] = {0.f, 0.f, 0.f, 0.f};
-                if (e.act >= TOIST_ACT_MASK_POS) {
-                    const bf16_t* ap = (const bf16_t*)e.aux + coff + crow * e.ldaux + n;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (r < nv) ax[r] = bf2f(ap[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    switch (e.act) {
-                        case TOIST_ACT_RELU: v[r] = fmaxf(v[r], 0.f); break;
-                        case TOIST_ACT_GELU: v[r] = gelu_f(v[r]); break;
-                        case TOIST_ACT_SIGMOID: v[r] = 1.f / (1.f + __expf(-v[r])); break;
-                        case TOIST_ACT_MASK_POS: v[r] = ax[r] > 0.f ? v[r] : 0.f; break;
-                        case TOIST_ACT_GELU_BWD: v[r] *= gelu_grad_f(ax[r]); break;
-                        case TOIST_ACT_SIGMOID_BWD: v[r] *= ax[r] * (1.f - ax[r]); break;
-                        default: break;
-                    }
-                }
-            }
-            if (e.drop_where == 2) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned long long idx = ((unsigned long long)bz * M + m) * N + n + r;
-                    v[r] = dropout_keep(e.drop_seed, idx, drop_thresh) ? v[r] * drop_scale : 0.f;
-                }
-            }
-            if (e.out_f32) {
-                float* cp = (float*)p.c + coff + crow * p.ldc + n;
-                if (atomic) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (r < nv) atomicAdd(cp + r, v[r]);
-                } else if (nv == 4 && ((((size_t)cp) & 15) == 0)) {
-                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (r < nv) cp[r] = v[r];
-                }
-            } else {
-                bf16_t* cp = (bf16_t*)p.c + coff + crow * p.ldc + n;
-                if (nv == 4 && ((((size_t)cp) & 7) == 0)) {
-                    *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (r < nv) cp[r] = f2bf(v[r]);
-                }
-            }
-        }
-    }
+        const int n = n0 + wn * WN + j * 16 + g * 4;
+        if (m < M && n < N) epilogue_frag(p, acc[i][j], m, n, bz, coff);
+    });
 }
 
 template <int BM, int BN, int AK, int BKD>
