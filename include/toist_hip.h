@@ -109,7 +109,7 @@ typedef struct toist_epilogue {
     int32_t act;          /* TOIST_ACT_* */
     void* pre_out;        /* optional bf16 copy of v before the activation (ld = ldc) */
     int32_t out_f32;      /* C is f32 instead of bf16 */
-    int32_t accumulate;   /* C += v with f32 atomics (requires out_f32); implied by split_k > 1 */
+    int32_t accumulate;   /* C += v (requires out_f32); read-modify-write by the owning thread, no atomics */
     /* optional row scatter of C/res/aux: m = (n,oy,ox) in [*,cOH,cOW] -> ((n*cH + oy*cst)*cW + ox*cst) */
     int32_t cmap, cH, cW, cOH, cOW, cst;
     /* dropout: where = 0 none, 1 = before the residual add, 2 = after the activation */
@@ -126,11 +126,16 @@ typedef struct toist_gemm {
     int32_t ldc;
     int64_t cs_outer, cs_inner; /* batch strides of C (and res/aux/pre_out) */
     int32_t batch, batch_inner; /* z in [0,batch): outer = z / batch_inner, inner = z % batch_inner */
-    int32_t split_k;            /* >= 1; > 1 needs out_f32 (atomic accumulation into pre-zeroed C) */
-    int32_t tile;               /* 0 = auto, 64 or 128 */
+    int32_t split_k;            /* >= 1; > 1 needs out_f32 and `workspace`: every k-slice stores its raw f32
+                                   partial tile there and a second kernel reduces them into C */
+    int32_t tile;               /* 0 = auto; 64 = 64x64x32, 65 = 64x64x64, 128 = 128x128x32, 129 = 128x128x64,
+                                   130 = 128x64x64 (BM x BN x BK) */
     int32_t flags;              /* bit0: build K-strided fragments with ds_write_b16 instead of
                                    ds_read_b64_tr_b16 (validation fallback) */
     toist_epilogue epi;
+    float* workspace;           /* split_k > 1: f32 scratch of >= split_k * M * N elements (caller-owned) */
+    float* a_colsum;            /* optional, A_KROW only: a_colsum[m] += sum_k A[m][k]  (f32 atomics) --
+                                   the bias gradient of nn.Linear falls out of the wgrad GEMM's A tiles */
 } toist_gemm;
 
 int toist_gemm_bf16(const toist_gemm* desc, void* stream);

@@ -39,7 +39,7 @@ class Gemm(Structure):
         ("M", c_int32), ("N", c_int32), ("K", c_int32), ("a_kind", c_int32), ("b_kind", c_int32),
         ("a", Operand), ("b", Operand), ("c", c_void_p), ("ldc", c_int32), ("cs_outer", c_int64),
         ("cs_inner", c_int64), ("batch", c_int32), ("batch_inner", c_int32), ("split_k", c_int32),
-        ("tile", c_int32), ("flags", c_int32), ("epi", Epilogue),
+        ("tile", c_int32), ("flags", c_int32), ("epi", Epilogue), ("workspace", c_void_p), ("a_colsum", c_void_p),
     ]
 
 

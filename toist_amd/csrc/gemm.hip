@@ -19,8 +19,8 @@
 
 namespace toist {
 
-constexpr int BK = 32;        // k extent of one staged tile (one MFMA k-step)
-constexpr int BKP = BK + 8;   // row pitch (elements) of a k-contiguous LDS tile: 80 B, keeps b128 reads spread
+// BK (template parameter) = k extent of one staged tile; k-contiguous LDS tiles use a row pitch of
+// BK + 8 elements (80 / 144 B) so the 16-lane groups of a ds_read_b128 spread over the banks.
 
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float a) {
@@ -124,11 +124,11 @@ __device__ __forceinline__ void epilogue_frag(const toist_gemm& p, const f32x4_t
     }
     if (e.out_f32) {
         float* cp = (float*)p.c + coff + crow * p.ldc + n;
-        if (e.accumulate || p.split_k > 1) {
-            atomicAdd(cp, v0);
-            if (nv > 1) atomicAdd(cp + 1, v1);
-            if (nv > 2) atomicAdd(cp + 2, v2);
-            if (nv > 3) atomicAdd(cp + 3, v3);
+        if (e.accumulate) {  // the element is owned by this thread: plain read-modify-write
+            cp[0] += v0;
+            if (nv > 1) cp[1] += v1;
+            if (nv > 2) cp[2] += v2;
+            if (nv > 3) cp[3] += v3;
         } else if (nv == 4 && ((((size_t)cp) & 15) == 0)) {
             *reinterpret_cast<float4*>(cp) = make_float4(v0, v1, v2, v3);
         } else {
@@ -150,6 +150,13 @@ __device__ __forceinline__ void epilogue_frag(const toist_gemm& p, const f32x4_t
     }
 }
 
+__device__ __forceinline__ void add8(float* acc, const uint4& v) {
+    acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
+    acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
+    acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xffff0000u);
+    acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xffff0000u);
+}
+
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (N > 0) {
@@ -166,7 +173,7 @@ struct ChunkA {            // per-thread, per-chunk invariants of the A tile
     bool ok;
 };
 
-template <int AK>
+template <int AK, int BK>
 __device__ __forceinline__ uint4 load_a(const ChunkA& c, const toist_operand& o, int k0, int K, long long lda) {
     const bf16_t* src = nullptr;
     if (AK == TOIST_A_ROWK) {
@@ -206,7 +213,7 @@ struct ChunkB {
     bool ok;
 };
 
-template <int BKD>
+template <int BKD, int BK>
 __device__ __forceinline__ uint4 load_b(const ChunkB& c, const toist_operand& o, int k0, int K, long long ldb) {
     const bf16_t* src = nullptr;
     if (BKD == TOIST_B_ROWK) {
@@ -235,8 +242,9 @@ __device__ __forceinline__ uint4 load_b(const ChunkB& c, const toist_operand& o,
 }
 
 // k-contiguous LDS tile [rows][BKP]; k-major LDS tile [BK][rows + 8]
-template <bool KM, bool TR, int ROWS>
+template <bool KM, bool TR, int ROWS, int BK>
 __device__ __forceinline__ void stage(bf16_t* s, int row, int kc, const uint4& v) {
+    constexpr int BKP = BK + 8;
     if (!KM) *reinterpret_cast<uint4*>(&s[row * BKP + kc * 8]) = v;
     else if (TR) *reinterpret_cast<uint4*>(&s[row * (ROWS + 8) + kc * 8]) = v;
     else {
@@ -250,12 +258,13 @@ __device__ __forceinline__ void stage(bf16_t* s, int row, int kc, const uint4& v
 }
 
 // MFMA operand fragment: 8 consecutive k (k = 8*g + j) of tile row (r0 + c16)
-template <bool KM, bool TR, int ROWS>
-__device__ __forceinline__ bf16x8_t fragment(const bf16_t* s, int r0, int g, int c16) {
+template <bool KM, bool TR, int ROWS, int BK>
+__device__ __forceinline__ bf16x8_t fragment(const bf16_t* s, int r0, int ks, int g, int c16) {
+    constexpr int BKP = BK + 8;
     if (KM && TR) {
         // 16-lane group g transposes the [4 k][16 rows] blocks at k = 8g and k = 8g + 4 (ds_read_b64_tr_b16)
         constexpr int LD = ROWS + 8;
-        const bf16_t* q = &s[(8 * g + (c16 >> 2)) * LD + r0 + (c16 & 3) * 4];
+        const bf16_t* q = &s[(ks * 32 + 8 * g + (c16 >> 2)) * LD + r0 + (c16 & 3) * 4];
         typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q));
         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q + 4 * LD));
@@ -263,11 +272,12 @@ __device__ __forceinline__ bf16x8_t fragment(const bf16_t* s, int r0, int g, int
         u.h.a = lo; u.h.b = hi;
         return u.v;
     }
-    return *reinterpret_cast<const bf16x8_t*>(&s[(r0 + c16) * BKP + g * 8]);
+    return *reinterpret_cast<const bf16x8_t*>(&s[(r0 + c16) * BKP + ks * 32 + g * 8]);
 }
 
-template <int BM, int BN, int AK, int BKD, bool TR>
+template <int BM, int BN, int BK, int AK, int BKD, bool TR>
 __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
+    constexpr int BKP = BK + 8, KC = BK / 8;  // 16-byte chunks per k-contiguous row
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int ACH = BM * BK / 8 / 256, BCH = BN * BK / 8 / 256;  // 16-byte chunks per thread
     constexpr bool A_KM = (AK == TOIST_A_KROW);    // A staged k-major
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
             c.ok = (m0 + c.kc * 8) < M;
             c.base = Ab + m0 + c.kc * 8;
         } else {
-            c.row = ch >> 2; c.kc = ch & 3;
+            c.row = ch / KC; c.kc = ch % KC;
             const int m = m0 + c.row;
             c.ok = m < M;
             if (AK == TOIST_A_ROWK) c.base = Ab + (long long)m * lda + c.kc * 8;
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
                 c.base = Bb + (nn - tap * ob.SC);
             } else c.base = Bb + nn;
         } else {
-            c.row = ch >> 2; c.kc = ch & 3;
+            c.row = ch / KC; c.kc = ch % KC;
             const int n = n0 + c.row;
             c.ok = n < N;
             c.base = Bb + (long long)n * ldb + c.kc * 8;
@@ -355,15 +365,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    float csum[ACH][8];
+    const bool want_csum = A_KM && p.a_colsum != nullptr && blockIdx.y == 0;
+#pragma unroll
+    for (int it = 0; it < ACH; ++it)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csum[it][j] = 0.f;
+
     uint4 ra[ACH], rb[BCH];
 #pragma unroll
-    for (int it = 0; it < ACH; ++it) ra[it] = load_a<AK>(ca[it], oa, kt_beg * BK, K, lda);
+    for (int it = 0; it < ACH; ++it) ra[it] = load_a<AK, BK>(ca[it], oa, kt_beg * BK, K, lda);
 #pragma unroll
-    for (int it = 0; it < BCH; ++it) rb[it] = load_b<BKD>(cb[it], ob, kt_beg * BK, K, ldb);
+    for (int it = 0; it < BCH; ++it) rb[it] = load_b<BKD, BK>(cb[it], ob, kt_beg * BK, K, ldb);
 #pragma unroll
-    for (int it = 0; it < ACH; ++it) stage<A_KM, TR, BM>(smem, ca[it].row, ca[it].kc, ra[it]);
+    for (int it = 0; it < ACH; ++it) stage<A_KM, TR, BM, BK>(smem, ca[it].row, ca[it].kc, ra[it]);
 #pragma unroll
-    for (int it = 0; it < BCH; ++it) stage<B_KM, TR, BN>(smem + SA_ELEMS, cb[it].row, cb[it].kc, rb[it]);
+    for (int it = 0; it < BCH; ++it) stage<B_KM, TR, BN, BK>(smem + SA_ELEMS, cb[it].row, cb[it].kc, rb[it]);
+    if (want_csum) {
+#pragma unroll
+        for (int it = 0; it < ACH; ++it) add8(csum[it], ra[it]);
+    }
     __syncthreads();
 
     int cur = 0;
@@ -371,34 +392,78 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
         const bool more = kt + 1 < kt_end;
         if (more) {  // next tile's global loads fly under this tile's MFMAs
 #pragma unroll
-            for (int it = 0; it < ACH; ++it) ra[it] = load_a<AK>(ca[it], oa, (kt + 1) * BK, K, lda);
+            for (int it = 0; it < ACH; ++it) ra[it] = load_a<AK, BK>(ca[it], oa, (kt + 1) * BK, K, lda);
 #pragma unroll
-            for (int it = 0; it < BCH; ++it) rb[it] = load_b<BKD>(cb[it], ob, (kt + 1) * BK, K, ldb);
+            for (int it = 0; it < BCH; ++it) rb[it] = load_b<BKD, BK>(cb[it], ob, (kt + 1) * BK, K, ldb);
         }
         const bf16_t* sA = smem + cur * STAGE;
         const bf16_t* sB = sA + SA_ELEMS;
-        bf16x8_t af[FM], bfr[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = fragment<A_KM, TR, BM>(sA, wm * WM + i * 16, g, c16);
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8_t af[FM], bfr[FN];
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bfr[j] = fragment<B_KM, TR, BN>(sB, wn * WN + j * 16, g, c16);
+            for (int i = 0; i < FM; ++i) af[i] = fragment<A_KM, TR, BM, BK>(sA, wm * WM + i * 16, ks, g, c16);
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+            for (int j = 0; j < FN; ++j) bfr[j] = fragment<B_KM, TR, BN, BK>(sB, wn * WN + j * 16, ks, g, c16);
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
         if (more) {
             bf16_t* dA = smem + (cur ^ 1) * STAGE;
 #pragma unroll
-            for (int it = 0; it < ACH; ++it) stage<A_KM, TR, BM>(dA, ca[it].row, ca[it].kc, ra[it]);
+            for (int it = 0; it < ACH; ++it) stage<A_KM, TR, BM, BK>(dA, ca[it].row, ca[it].kc, ra[it]);
 #pragma unroll
-            for (int it = 0; it < BCH; ++it) stage<B_KM, TR, BN>(dA + SA_ELEMS, cb[it].row, cb[it].kc, rb[it]);
+            for (int it = 0; it < BCH; ++it) stage<B_KM, TR, BN, BK>(dA + SA_ELEMS, cb[it].row, cb[it].kc, rb[it]);
+            if (want_csum) {
+#pragma unroll
+                for (int it = 0; it < ACH; ++it) add8(csum[it], ra[it]);
+            }
         }
         __syncthreads();
         cur ^= 1;
     }
 
+    if (A_KM && p.a_colsum != nullptr && blockIdx.y == 0) {
+        // bias gradient: column sums of the staged A tiles, reduced over the k rows held by other threads
+        float* red = reinterpret_cast<float*>(smem);  // main loop is done: LDS is free
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ACH; ++it)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[(ca[it].row * (BM / 8) + ca[it].kc) * 8 + j] = csum[it][j];
+        __syncthreads();
+        for (int col = tid; col < BM; col += 256) {
+            float t = 0.f;
+            for (int r = 0; r < BK; ++r) t += red[r * BM + col];
+            if (m0 + col < M) atomicAdd(p.a_colsum + m0 + col, t);
+        }
+    }
+
     // ---- epilogue: lane owns output row m (c16) and 4 consecutive columns n (4*g .. 4*g+3) ----
+    if (p.split_k > 1) {
+        // k-slice partial: raw f32 tile into the workspace; splitk_reduce_kernel applies the epilogue
+        float* ws = p.workspace + (size_t)ksl * M * N;
+        static_for<FM * FN>([&](auto idx) {
+            constexpr int i = decltype(idx)::value / FN, j = decltype(idx)::value % FN;
+            const int m = m0 + wm * WM + i * 16 + c16;
+            const int n = n0 + wn * WN + j * 16 + g * 4;
+            if (m < M && n < N) {
+                float* cp = ws + (size_t)m * N + n;
+                const f32x4_t a = acc[i][j];
+                if (N - n >= 4 && ((((size_t)cp) & 15) == 0)) *reinterpret_cast<float4*>(cp) = make_float4(a[0], a[1], a[2], a[3]);
+                else {
+                    cp[0] = a[0];
+                    if (N - n > 1) cp[1] = a[1];
+                    if (N - n > 2) cp[2] = a[2];
+                    if (N - n > 3) cp[3] = a[3];
+                }
+            }
+        });
+        return;
+    }
     static_for<FM * FN>([&](auto idx) {
         constexpr int i = decltype(idx)::value / FN, j = decltype(idx)::value % FN;
         const int m = m0 + wm * WM + i * 16 + c16;
@@ -407,25 +472,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     });
 }
 
-template <int BM, int BN, int AK, int BKD>
+// C[m][n] (+)= alpha * rscale[m] * sum_s ws[s][m][n]   (second half of a split-K GEMM)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float alpha,
+                                                             const float* __restrict__ rscale, int accumulate, float* __restrict__ c,
+                                                             int ldc) {
+    const long long total4 = ((long long)M * N) >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        float4 s = reinterpret_cast<const float4*>(ws)[i];
+        for (int k = 1; k < splits; ++k) {
+            const float4 t = reinterpret_cast<const float4*>(ws + (size_t)k * M * N)[i];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        const long long e = i << 2;
+        const int m = (int)(e / N), n = (int)(e - (long long)m * N);
+        const float f = rscale ? alpha * rscale[m] : alpha;
+        float* cp = c + (long long)m * ldc + n;
+        if (accumulate) { cp[0] += s.x * f; cp[1] += s.y * f; cp[2] += s.z * f; cp[3] += s.w * f; }
+        else { cp[0] = s.x * f; cp[1] = s.y * f; cp[2] = s.z * f; cp[3] = s.w * f; }
+    }
+}
+
+template <int BM, int BN, int BK, int AK, int BKD>
 static void launch_variant(const toist_gemm& d, hipStream_t st) {
     dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, d.batch * d.split_k);
     if (d.flags & 1)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BKD, false>), grid, dim3(256), 0, st, d);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, false>), grid, dim3(256), 0, st, d);
     else
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BKD, true>), grid, dim3(256), 0, st, d);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, true>), grid, dim3(256), 0, st, d);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 static int launch_tile(const toist_gemm& d, hipStream_t st) {
     const int ak = d.a_kind, bk = d.b_kind;
-    if (ak == TOIST_A_ROWK && bk == TOIST_B_ROWK) launch_variant<BM, BN, TOIST_A_ROWK, TOIST_B_ROWK>(d, st);
-    else if (ak == TOIST_A_ROWK && bk == TOIST_B_KROW) launch_variant<BM, BN, TOIST_A_ROWK, TOIST_B_KROW>(d, st);
-    else if (ak == TOIST_A_CONV && bk == TOIST_B_ROWK) launch_variant<BM, BN, TOIST_A_CONV, TOIST_B_ROWK>(d, st);
-    else if (ak == TOIST_A_CONVT && bk == TOIST_B_KROW) launch_variant<BM, BN, TOIST_A_CONVT, TOIST_B_KROW>(d, st);
-    else if (ak == TOIST_A_CONVT && bk == TOIST_B_ROWK) launch_variant<BM, BN, TOIST_A_CONVT, TOIST_B_ROWK>(d, st);
-    else if (ak == TOIST_A_KROW && bk == TOIST_B_KROW) launch_variant<BM, BN, TOIST_A_KROW, TOIST_B_KROW>(d, st);
-    else if (ak == TOIST_A_KROW && bk == TOIST_B_CONVX) launch_variant<BM, BN, TOIST_A_KROW, TOIST_B_CONVX>(d, st);
+    if (ak == TOIST_A_ROWK && bk == TOIST_B_ROWK) launch_variant<BM, BN, BK, TOIST_A_ROWK, TOIST_B_ROWK>(d, st);
+    else if (ak == TOIST_A_ROWK && bk == TOIST_B_KROW) launch_variant<BM, BN, BK, TOIST_A_ROWK, TOIST_B_KROW>(d, st);
+    else if (ak == TOIST_A_CONV && bk == TOIST_B_ROWK) launch_variant<BM, BN, BK, TOIST_A_CONV, TOIST_B_ROWK>(d, st);
+    else if (ak == TOIST_A_CONVT && bk == TOIST_B_KROW) launch_variant<BM, BN, BK, TOIST_A_CONVT, TOIST_B_KROW>(d, st);
+    else if (ak == TOIST_A_KROW && bk == TOIST_B_KROW) launch_variant<BM, BN, BK, TOIST_A_KROW, TOIST_B_KROW>(d, st);
+    else if (ak == TOIST_A_KROW && bk == TOIST_B_CONVX) launch_variant<BM, BN, BK, TOIST_A_KROW, TOIST_B_CONVX>(d, st);
     else {
         set_last_error("toist_gemm_bf16: unsupported operand kinds a=%d b=%d", ak, bk);
         return TOIST_EINVAL;
@@ -460,8 +544,6 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
             TOIST_REQUIRE(o.ld > 0 && (o.ld % 8) == 0, "toist_gemm_bf16: leading dimension must be a multiple of 8 (got %d)", o.ld);
         }
     }
-    if (d.a_kind == TOIST_A_CONVT) TOIST_REQUIRE((d.a.SC % 32) == 0, "toist_gemm_bf16: CONVT needs source channels %% 32 == 0");
-    if (d.b_kind == TOIST_B_KROW && d.b.kin > 0) TOIST_REQUIRE((d.b.kin % 32) == 0, "toist_gemm_bf16: kin %% 32 != 0");
     if (d.b_kind == TOIST_B_CONVX) TOIST_REQUIRE((d.N % 8) == 0, "toist_gemm_bf16: CONVX needs N %% 8 == 0");
     // k-major operands are read in 8-row chunks: rows beyond M/N inside the last chunk are read
     // (and discarded), so ld must cover the rounded-up extent.
@@ -469,19 +551,52 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     if (d.b_kind == TOIST_B_KROW) TOIST_REQUIRE(d.b.ld >= ((d.N + 7) & ~7), "toist_gemm_bf16: B_KROW needs ldb >= roundup8(N)");
     if (d.split_k > 1 || d.epi.accumulate)
         TOIST_REQUIRE(d.epi.out_f32, "toist_gemm_bf16: split_k/accumulate needs an f32 output");
-    if (d.split_k > 1)
-        TOIST_REQUIRE(!d.epi.shift && !d.epi.res && d.epi.act == TOIST_ACT_NONE && !d.epi.pre_out && d.epi.drop_where == 0,
-                      "toist_gemm_bf16: split_k only supports alpha/scale epilogues");
+    if (d.a_colsum) TOIST_REQUIRE(d.a_kind == TOIST_A_KROW, "toist_gemm_bf16: a_colsum needs a k-major A operand");
+    if (d.split_k > 1) {
+        TOIST_REQUIRE(!d.epi.scale && !d.epi.shift && !d.epi.res && d.epi.act == TOIST_ACT_NONE && !d.epi.pre_out && d.epi.drop_where == 0 &&
+                          !d.epi.cmap && d.batch == 1,
+                      "toist_gemm_bf16: split_k only supports alpha/rscale/accumulate epilogues on a single batch");
+        TOIST_REQUIRE(d.workspace != nullptr && (d.N % 4) == 0 && (d.ldc % 4) == 0, "toist_gemm_bf16: split_k needs a workspace and N, ldc %% 4 == 0");
+    }
     if (d.epi.act >= TOIST_ACT_MASK_POS) TOIST_REQUIRE(d.epi.aux != nullptr, "toist_gemm_bf16: activation %d needs aux", d.epi.act);
     if (d.epi.drop_where) TOIST_REQUIRE(d.epi.drop_p >= 0.f && d.epi.drop_p < 1.f, "toist_gemm_bf16: bad dropout p");
 
     int tile = d.tile;
     if (tile == 0) {
+        // measured on MI355X (tools/sweep_gemm.py): 128x128x64 only pays once >= ~3 tiles per CU exist;
+        // below that 64x64 tiles keep more workgroups (and loads) in flight; BK = 64 needs K > 128.
         const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.split_k;
-        tile = (t128 >= 192 && d.M >= 128 && d.N >= 128) ? 128 : 64;
+        if (t128 >= 768 && d.K >= 2048) tile = 129;
+        else tile = (d.K > 128) ? 65 : 64;
     }
-    TOIST_REQUIRE(tile == 64 || tile == 128, "toist_gemm_bf16: tile must be 0, 64 or 128");
-    int rc = (tile == 128) ? launch_tile<128, 128>(d, (hipStream_t)stream) : launch_tile<64, 64>(d, (hipStream_t)stream);
+    {
+        // drop k-slices that would own no k-tile
+        const int bk0 = (tile == 64 || tile == 128) ? 32 : 64;
+        const int ktiles = (d.K + bk0 - 1) / bk0;
+        if (d.split_k > ktiles) d.split_k = ktiles;
+        const int kper = (ktiles + d.split_k - 1) / d.split_k;
+        d.split_k = (ktiles + kper - 1) / kper;
+    }
+    // tile codes: 64 = 64x64x32, 65 = 64x64x64, 128 = 128x128x32, 129 = 128x128x64, 130 = 128x64x64
+    const int bkt = (tile == 64 || tile == 128) ? 32 : 64;
+    if (d.a_kind == TOIST_A_CONVT) TOIST_REQUIRE((d.a.SC % bkt) == 0, "toist_gemm_bf16: CONVT needs source channels %% BK == 0");
+    if (d.b_kind == TOIST_B_KROW && d.b.kin > 0) TOIST_REQUIRE((d.b.kin % bkt) == 0, "toist_gemm_bf16: kin %% BK != 0");
+    int rc;
+    hipStream_t st = (hipStream_t)stream;
+    switch (tile) {
+        case 64: rc = launch_tile<64, 64, 32>(d, st); break;
+        case 65: rc = launch_tile<64, 64, 64>(d, st); break;
+        case 128: rc = launch_tile<128, 128, 32>(d, st); break;
+        case 129: rc = launch_tile<128, 128, 64>(d, st); break;
+        case 130: rc = launch_tile<128, 64, 64>(d, st); break;
+        default: set_last_error("toist_gemm_bf16: bad tile code %d", tile); return TOIST_EINVAL;
+    }
     if (rc != TOIST_OK) return rc;
-    return check_launch("toist_gemm_bf16");
+    rc = check_launch("toist_gemm_bf16");
+    if (rc != TOIST_OK || d.split_k <= 1) return rc;
+    const long long total4 = ((long long)d.M * d.N) / 4;
+    int grid = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)d.workspace, d.split_k, d.M, d.N, d.epi.alpha,
+                       d.epi.rscale, d.epi.accumulate, (float*)d.c, d.ldc);
+    return check_launch("toist_gemm_bf16(splitk reduce)");
 }

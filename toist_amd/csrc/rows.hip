@@ -133,16 +133,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
         }
     }
     if (dgamma) {
+        // reduce the 4 waves of the block in LDS, then one atomic per column per block
+        __shared__ float red[2][4][LN_MAXCH * 64 * 8];
+        const int w = threadIdx.x >> 6;
 #pragma unroll
         for (int i = 0; i < LN_MAXCH; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    atomicAdd(dgamma + ch * 8 + j, ag[i][j]);
-                    atomicAdd(dbeta + ch * 8 + j, ab[i][j]);
+                    red[0][w][ch * 8 + j] = ag[i][j];
+                    red[1][w][ch * 8 + j] = ab[i][j];
                 }
             }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) {
+            atomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+            atomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
         }
     }
 }
@@ -256,26 +264,39 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restri
 }
 
 // ---------------------------------------------------------------------------------- column sum
-// out[n] += sum_m g[m][n]  (bias gradient).  Block = 256 threads x 2 columns, 64-row slabs.
+// out[n] += sum_m g[m][n]  (bias gradient).  Block = 32 column-chunks (8 columns, 16-byte loads) x 8 row
+// lanes over a 256-row slab; LDS reduction over the row lanes, one atomic per column per block.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ g, int M, int N, int ld, float* __restrict__ out) {
-    const int n = (blockIdx.x * 256 + threadIdx.x) * 2;
-    if (n >= N) return;
-    const int m_beg = blockIdx.y * 64;
-    const int m_end = (m_beg + 64 < M) ? m_beg + 64 : M;
-    float a0 = 0.f, a1 = 0.f;
-    const bool pair = (n + 1 < N) && ((ld & 1) == 0);
-    for (int m = m_beg; m < m_end; ++m) {
-        if (pair) {
-            const unsigned u = *reinterpret_cast<const unsigned*>(g + (size_t)m * ld + n);
-            a0 += __uint_as_float(u << 16);
-            a1 += __uint_as_float(u & 0xffff0000u);
-        } else {
-            a0 += bf2f(g[(size_t)m * ld + n]);
-            if (n + 1 < N) a1 += bf2f(g[(size_t)m * ld + n + 1]);
+    __shared__ float red[8][256];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int n = blockIdx.x * 256 + cx * 8;
+    const int m_beg = blockIdx.y * 256;
+    const int m_end = (m_beg + 256 < M) ? m_beg + 256 : M;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        const bool vec = (n + 8 <= N) && ((ld & 7) == 0) && ((((size_t)g) & 15) == 0);
+        for (int m = m_beg + ry; m < m_end; m += 8) {
+            if (vec) {
+                float v[8];
+                unpack8(*reinterpret_cast<const uint4*>(g + (size_t)m * ld + n), v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (n + j < N) a[j] += bf2f(g[(size_t)m * ld + n + j]);
+            }
         }
     }
-    atomicAdd(out + n, a0);
-    if (n + 1 < N) atomicAdd(out + n + 1, a1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[ry][cx * 8 + j] = a[j];
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (blockIdx.x * 256 + c < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][c];
+        atomicAdd(out + blockIdx.x * 256 + c, t);
+    }
 }
 
 // ---------------------------------------------------------------------------------- elementwise
@@ -365,8 +386,9 @@ extern "C" int toist_layernorm_bwd(const void* dy, const void* x, const float* m
                                    uint64_t seed, void* stream) {
     TOIST_REQUIRE(rows > 0 && D > 0 && (D % 8) == 0 && D <= 1024, "toist_layernorm_bwd: rows=%d D=%d", rows, D);
     TOIST_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "toist_layernorm_bwd: dgamma/dbeta must both be set or null");
-    int blocks = (rows + 3) / 4;
-    if (blocks > 256) blocks = 256;
+    int blocks = (rows + 15) / 16;  // >= 4 rows per wave so the parameter-gradient atomics stay few
+    if (blocks > 128) blocks = 128;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, mean, rstd, gamma, rows, D, (bf16_t*)dx, dgamma, dbeta, (bf16_t*)dx_drop, drop_p,
                        (unsigned long long)seed);
@@ -393,7 +415,7 @@ extern "C" int toist_softmax_bwd(const void* p, const void* dp, int rows, int Sk
 
 extern "C" int toist_colsum(const void* g, int M, int N, int ld, float* out, void* stream) {
     TOIST_REQUIRE(M > 0 && N > 0 && ld >= N, "toist_colsum: bad shape");
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, M,
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, M,
                        N, ld, out);
     return check_launch("toist_colsum");
 }

@@ -181,9 +181,7 @@ def linear_chain(tape, x, layers, res=None, final_drop=False, out_dtype=BF16, la
                     raise NotImplementedError("activation on the last layer of a chain needs last_act_external")
             # g is now the gradient w.r.t. the pre-activation output of layer i
             if W.g is not None:
-                ops.linear_wgrad(g, xin, out=W.g)
-                if b is not None and b.g is not None:
-                    ops.bias_grad(g, out=b.g)
+                ops.linear_wgrad(g, xin, out=W.g, bias_out=b.g if b is not None else None)
             if i == 0:
                 if x.needs_grad:
                     x.grad = ops.linear_dgrad(g, W.w, res=x.grad)
@@ -333,8 +331,7 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
         else:
             go = g
         if Wo.g is not None:
-            ops.linear_wgrad(go, ctx, out=Wo.g)
-            ops.bias_grad(go, out=bo.g)
+            ops.linear_wgrad(go, ctx, out=Wo.g, bias_out=bo.g)
         dctx = ops.linear_dgrad(go, Wo.w)
         if fused:
             dqk = torch.empty(B * Sq, 2 * d, dtype=BF16, device=dev)
@@ -352,24 +349,20 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
         ops.attn_backward(prob_used, scale, qb, kb, vb, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
         if fused:
             if packed_qk[0].g is not None:
-                ops.linear_wgrad(dqk, q_in.data, out=packed_qk[0].g)
-                ops.bias_grad(dqk, out=packed_qk[1].g)
+                ops.linear_wgrad(dqk, q_in.data, out=packed_qk[0].g, bias_out=packed_qk[1].g)
             if q_in.needs_grad:
                 q_in.grad = ops.linear_dgrad(dqk, packed_qk[0].w, res=q_in.grad)
         else:
             if Pq[0].g is not None:
-                ops.linear_wgrad(dq, q_in.data, out=Pq[0].g)
-                ops.bias_grad(dq, out=Pq[1].g)
+                ops.linear_wgrad(dq, q_in.data, out=Pq[0].g, bias_out=Pq[1].g)
             if Pk[0].g is not None:
-                ops.linear_wgrad(dk, k_in.data, out=Pk[0].g)
-                ops.bias_grad(dk, out=Pk[1].g)
+                ops.linear_wgrad(dk, k_in.data, out=Pk[0].g, bias_out=Pk[1].g)
             if q_in.needs_grad:
                 q_in.grad = ops.linear_dgrad(dq, Pq[0].w, res=q_in.grad)
             if k_in.needs_grad:
                 k_in.grad = ops.linear_dgrad(dk, Pk[0].w, res=k_in.grad)
         if Pv[0].g is not None:
-            ops.linear_wgrad(dv, v_in.data, out=Pv[0].g)
-            ops.bias_grad(dv, out=Pv[1].g)
+            ops.linear_wgrad(dv, v_in.data, out=Pv[0].g, bias_out=Pv[1].g)
         if v_in.needs_grad:
             v_in.grad = ops.linear_dgrad(dv, Pv[0].w, res=v_in.grad)
 

@@ -23,6 +23,20 @@ __all__ = [
 # bench.py sets this to {"key": (tile, a_kind, b_kind) | None, "records": [], "other": {}} to time GEMM
 # launches with HIP events on the launch stream (roofline accounting); None = no instrumentation.
 PROFILE = None
+FORCE_TILE = 0    # experiments: overrides tile == 0 (auto) in every gemm() call
+FORCE_SPLIT = 0   # experiments: overrides split_k when > 0 and the call accumulates
+
+
+_WS = {}
+
+
+def _workspace(elems, device):
+    """Caller-owned split-K scratch handed to the library (grown on demand, reused across calls)."""
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < elems:
+        ws = torch.empty(max(elems, 1 << 22), dtype=torch.float32, device=device)
+        _WS[device] = ws
+    return ws
 
 
 def _stream():
@@ -62,9 +76,13 @@ def operand(t, ld=0, bs_outer=0, bs_inner=0, kin=0, tap_stride=0, geom=None):
 
 def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_outer=0, cs_inner=0, split_k=1, tile=0,
          flags=0, alpha=1.0, scale=None, shift=None, rscale=None, res=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, pre_out=None,
-         accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0, flops=0):
+         accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0, flops=0, a_colsum=None):
     """C = epilogue(A @ B^T); see include/toist_hip.h.  `a`/`b` are Operand structs from operand().
     `flops` = algorithmic FLOPs of the call (bench.py's roofline accounting only)."""
+    if tile == 0 and FORCE_TILE:
+        tile = FORCE_TILE
+    if FORCE_SPLIT and accumulate:
+        split_k = FORCE_SPLIT
     d = Gemm()
     d.M, d.N, d.K, d.a_kind, d.b_kind, d.a, d.b = M, N, K, a_kind, b_kind, a, b
     if c.dtype == torch.float32:
@@ -87,6 +105,9 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
         e.cmap = 1
         e.cH, e.cW, e.cOH, e.cOW, e.cst = cmap
     e.drop_where, e.drop_p, e.drop_seed = drop_where, drop_p, drop_seed
+    d.a_colsum = _p(a_colsum, torch.float32)
+    if split_k > 1:
+        d.workspace = _p(_workspace(split_k * M * N, c.device), torch.float32)
     prof = PROFILE
     if prof is None:
         _lib.check(_lib.lib().toist_gemm_bf16(ctypes.byref(d), _stream()), "toist_gemm_bf16")
@@ -94,7 +115,7 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
     t = tile
     if t == 0:
         t128 = ((M + 127) // 128) * ((N + 127) // 128) * max(batch, 1) * max(split_k, 1)
-        t = 128 if (t128 >= 192 and M >= 128 and N >= 128) else 64
+        t = 129 if (t128 >= 768 and K >= 2048) else (65 if K > 128 else 64)
     key = (t, a_kind, b_kind)
     if prof["key"] is not None and prof["key"] != key:
         _lib.check(_lib.lib().toist_gemm_bf16(ctypes.byref(d), _stream()), "toist_gemm_bf16")

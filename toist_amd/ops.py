@@ -18,7 +18,9 @@ def _ld(t):
     return t.stride(0)
 
 
-def _split_k_for(tiles, ktiles, target=512, max_split=64):
+def _split_k_for(tiles, ktiles, target=768, max_split=256):
+    """k-slices for a reduction-heavy GEMM with few output tiles (wgrad): fill ~3 workgroups per CU
+    while leaving every slice at least 4 k-tiles."""
     if tiles >= target or ktiles <= 8:
         return 1
     s = min(max_split, max(1, target // max(tiles, 1)), max(1, ktiles // 4))
@@ -53,8 +55,9 @@ def linear_dgrad(dy, w, *, out=None, res=None, act=k.ACT_NONE, aux=None, alpha=1
     return out
 
 
-def linear_wgrad(dy, x, *, out=None, alpha=1.0, flags=0, split_k=None):
-    """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]; `out` must be zero-initialised or hold a running sum."""
+def linear_wgrad(dy, x, *, out=None, alpha=1.0, flags=0, split_k=None, bias_out=None):
+    """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]; `out` must be zero-initialised or hold a running sum.
+    bias_out (f32 [N]) additionally receives += sum_m dy[m, :] from the same kernel."""
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M
@@ -62,9 +65,9 @@ def linear_wgrad(dy, x, *, out=None, alpha=1.0, flags=0, split_k=None):
         out = torch.zeros(N, K, dtype=torch.float32, device=dy.device)
     if split_k is None:
         tiles = ((N + 63) // 64) * ((K + 63) // 64)
-        split_k = _split_k_for(tiles, (M + 31) // 32)
+        split_k = _split_k_for(tiles, (M + 63) // 64)
     k.gemm(N, K, M, k.A_KROW, k.operand(dy, _ld(dy)), k.B_KROW, k.operand(x, _ld(x)), out, _ld(out), alpha=alpha,
-           accumulate=True, split_k=split_k, flags=flags, flops=2 * M * N * K)
+           accumulate=True, split_k=split_k, flags=flags, flops=2 * M * N * K, a_colsum=bias_out)
     return out
 
 
@@ -145,7 +148,7 @@ def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, s
     Nn = R * S * C
     if split_k is None:
         tiles = ((Co + 63) // 64) * ((Nn + 63) // 64)
-        split_k = _split_k_for(tiles, (P + 31) // 32)
+        split_k = _split_k_for(tiles, (P + 63) // 64)
     a = k.operand(dy, Co)
     if R == 1 and S == 1 and stride == 1 and pad == 0:
         b_kind, b = k.B_KROW, k.operand(x, C)
