@@ -150,12 +150,45 @@ __device__ __forceinline__ void epilogue_frag(const toist_gemm& p, const f32x4_t
     }
 }
 
-__device__ __forceinline__ void add8(float* acc, const uint4& v) {
-    acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
-    acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
-    acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xffff0000u);
-    acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xffff0000u);
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+__device__ __forceinline__ void add8(float* acc, const u32x4_t& v) {
+    acc[0] += __uint_as_float(v[0] << 16); acc[1] += __uint_as_float(v[0] & 0xffff0000u);
+    acc[2] += __uint_as_float(v[1] << 16); acc[3] += __uint_as_float(v[1] & 0xffff0000u);
+    acc[4] += __uint_as_float(v[2] << 16); acc[5] += __uint_as_float(v[2] & 0xffff0000u);
+    acc[6] += __uint_as_float(v[3] << 16); acc[7] += __uint_as_float(v[3] & 0xffff0000u);
 }
+
+// Operand tiles go global -> LDS directly (LDS-DMA, `buffer_load_dwordx4 ... lds`): each wave
+// instruction lands 64 x 16 B = 1 KiB at M0 + lane*16, so an LDS tile is "lane linear" and any
+// bank-conflict swizzle is applied to WHICH global chunk a lane fetches, with the matching XOR on the
+// fragment read.  The buffer descriptor spans 2 GiB from the (per-batch) base pointer; an out-of-tile
+// or padding chunk uses an offset beyond it and the hardware writes zeros -- no branches, no VGPR
+// staging, no ds_write pass.  Loads are counted by hand (`s_waitcnt vmcnt(N)` + raw `s_barrier`):
+// hipcc neither sees the DMA nor may it drain it (cdna_hip_programming.md 5, 5.7).  Rules kept here:
+// no compiler-visible VMEM access between the first DMA and the final vmcnt(0); a tile is read only
+// after (own vmcnt wait) -> s_barrier; a ring slot is re-filled only after the barrier that follows
+// its last read.  tools/probe/dma_probe.hip pins the DMA semantics on the hardware.
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+constexpr int OOB = (int)0x80000000u;  // unsigned 2^31 >= num_records -> out of range for every dword
+__device__ __forceinline__ i32x4_t make_rsrc(const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+    r[2] = 0x7ffffff0;   // num_records (bytes): an offset at or above it reads as zero
+    r[3] = 0x00020000;
+    return r;
+}
+// one 1 KiB piece: lane l copies 16 B from (descriptor base + voff) to LDS byte address lds_dst + 16*l
+__device__ __forceinline__ void dma16(unsigned lds_dst, const i32x4_t& r, int elem_off, bool valid) {
+    const int voff = valid ? elem_off * 2 : OOB;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(r) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -165,129 +198,129 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// ---- LDS tile layouts ------------------------------------------------------------------------------
+// k-contiguous tile: [ROWS][BK], 16-byte chunk (row, kc) lives in slot kc ^ ((row / RPL) % CPR) of its row
+// (CPR = BK/8 chunks per row, RPL = 16/CPR rows per 256-byte LDS line): the 16 lanes of a ds_read_b128
+// group (16 consecutive rows, same kc) hit 16 distinct 16-byte slots.
+template <int BK>
+__device__ __forceinline__ int swz_k(int row, int kc) {
+    constexpr int CPR = BK / 8, RPL = 16 / CPR;
+    return kc ^ ((row / RPL) % CPR);
+}
+// k-major tile: [BK][ROWS], chunk (krow, rc) lives in slot rc ^ 2*h(krow) (32-byte pairs stay together
+// for ds_read_b64_tr_b16), h = (krow & 3) | ((krow >> 3) & 1) << 2, limited to the pairs a row has.
+template <int ROWS>
+__device__ __forceinline__ int swz_m(int krow, int rc) {
+    constexpr int PAIRS = ROWS / 16;
+    const int h = ((krow & 3) | (((krow >> 3) & 1) << 2)) & (PAIRS - 1);
+    return rc ^ (h << 1);
+}
+
 // ---- one 16-byte chunk of a staged tile ------------------------------------------------------------
-struct ChunkA {            // per-thread, per-chunk invariants of the A tile
-    const bf16_t* base;    // ROWK: &A[m][kc*8] ; KROW: &A[0][m0 + rc*8] ; conv: image base + channel offset
-    int row, kc;           // tile-local coordinates (row/k-row, chunk index)
+struct ChunkA {            // per-thread, per-piece invariants of the A tile
+    int base;              // element offset: ROWK m*lda + kc*8 ; KROW m0 + rc*8 ; conv: image n base
+    int row, kc;           // tile-local (row, k-chunk) for k-contiguous tiles, (k-row, m-chunk) for k-major
     int y0, x0;            // conv gather origin
     bool ok;
 };
 
 template <int AK, int BK>
-__device__ __forceinline__ uint4 load_a(const ChunkA& c, const toist_operand& o, int k0, int K, long long lda) {
-    const bf16_t* src = nullptr;
-    if (AK == TOIST_A_ROWK) {
-        if (c.ok && k0 + c.kc * 8 < K) src = c.base + k0;
-    } else if (AK == TOIST_A_KROW) {
+__device__ __forceinline__ void load_a(unsigned lds, const i32x4_t& rs, const ChunkA& c, const toist_operand& o, int k0, int K, int lda) {
+    if (AK == TOIST_A_ROWK) { dma16(lds, rs, c.base + k0, c.ok && (k0 + c.kc * 8 < K)); return; }
+    if (AK == TOIST_A_KROW) {
         const int k = k0 + c.row;
-        if (c.ok && k < K) src = c.base + (long long)k * lda;
-    } else {
-        int tap, c0;
-        if (o.SC % BK == 0) { tap = k0 / o.SC; c0 = k0 - tap * o.SC + c.kc * 8; }
-        else { const int kk = k0 + c.kc * 8; tap = kk / o.SC; c0 = kk - tap * o.SC; }
-        if (c.ok && tap < o.R * o.S) {
-            const int r = tap / o.S, s = tap - r * o.S;
-            int iy, ix;
-            bool in = true;
-            if (AK == TOIST_A_CONVT) {
-                const int ty = c.y0 - r * o.dil, tx = c.x0 - s * o.dil;
-                in = (ty >= 0) & (tx >= 0);
-                if (o.stride > 1) {
-                    in = in && ((ty % o.stride) == 0) && ((tx % o.stride) == 0);
-                    iy = ty / o.stride; ix = tx / o.stride;
-                } else { iy = ty; ix = tx; }
-            } else {
-                iy = c.y0 + r * o.dil; ix = c.x0 + s * o.dil;
-                in = (iy >= 0) & (ix >= 0);
-            }
-            if (in && iy < o.SH && ix < o.SW) src = c.base + ((long long)iy * o.SW + ix) * o.SC + c0;
-        }
+        dma16(lds, rs, c.base + k * lda, c.ok && k < K);
+        return;
     }
-    return src ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+    int tap, c0;
+    if (o.SC % BK == 0) { tap = k0 / o.SC; c0 = k0 - tap * o.SC + c.kc * 8; }
+    else { const int kk = k0 + c.kc * 8; tap = kk / o.SC; c0 = kk - tap * o.SC; }
+    const int r = tap / o.S, s = tap - r * o.S;
+    int iy, ix;
+    bool in = c.ok && tap < o.R * o.S;
+    if (AK == TOIST_A_CONVT) {
+        const int ty = c.y0 - r * o.dil, tx = c.x0 - s * o.dil;
+        in = in && (ty >= 0) && (tx >= 0);
+        if (o.stride > 1) {
+            in = in && ((ty % o.stride) == 0) && ((tx % o.stride) == 0);
+            iy = ty / o.stride; ix = tx / o.stride;
+        } else { iy = ty; ix = tx; }
+    } else {
+        iy = c.y0 + r * o.dil; ix = c.x0 + s * o.dil;
+        in = in && (iy >= 0) && (ix >= 0);
+    }
+    in = in && iy < o.SH && ix < o.SW;
+    dma16(lds, rs, c.base + (iy * o.SW + ix) * o.SC + c0, in);
 }
 
 struct ChunkB {
-    const bf16_t* base;    // ROWK: &B[n][kc*8] ; KROW: &B[0][n0 + rc*8] ; CONVX: source + channel offset
+    int base;              // element offset: ROWK n*ldb + kc*8 ; KROW n0 + rc*8 ; CONVX channel offset
     int row, kc;
     int r, s;              // CONVX: tap of this chunk's columns
     bool ok;
 };
 
 template <int BKD, int BK>
-__device__ __forceinline__ uint4 load_b(const ChunkB& c, const toist_operand& o, int k0, int K, long long ldb) {
-    const bf16_t* src = nullptr;
-    if (BKD == TOIST_B_ROWK) {
-        if (c.ok && k0 + c.kc * 8 < K) src = c.base + k0;
-    } else if (BKD == TOIST_B_KROW) {
+__device__ __forceinline__ void load_b(unsigned lds, const i32x4_t& rs, const ChunkB& c, const toist_operand& o, int k0, int K, int ldb) {
+    if (BKD == TOIST_B_ROWK) { dma16(lds, rs, c.base + k0, c.ok && (k0 + c.kc * 8 < K)); return; }
+    if (BKD == TOIST_B_KROW) {
         const int k = k0 + c.row;
-        if (c.ok && k < K) {
-            if (o.kin > 0) {
-                const int tap = k0 / o.kin;
-                src = c.base + (long long)(k - tap * o.kin) * ldb + (long long)tap * o.tap_stride;
-            } else src = c.base + (long long)k * ldb;
-        }
-    } else {  // CONVX: k = output pixel, columns = (tap, c)
-        const long long pix = (long long)k0 + c.row;
-        if (c.ok && pix < K) {
-            const int plane = o.PH * o.PW;
-            const int n = (int)(pix / plane);
-            const int rem = (int)(pix - (long long)n * plane);
-            const int py = rem / o.PW, px = rem - py * o.PW;
-            const int iy = py * o.stride - o.pad + c.r * o.dil, ix = px * o.stride - o.pad + c.s * o.dil;
-            if (iy >= 0 && ix >= 0 && iy < o.SH && ix < o.SW)
-                src = c.base + (((long long)n * o.SH + iy) * o.SW + ix) * o.SC;
-        }
+        int off;
+        if (o.kin > 0) {
+            const int tap = k0 / o.kin;
+            off = c.base + (k - tap * o.kin) * ldb + tap * (int)o.tap_stride;
+        } else off = c.base + k * ldb;
+        dma16(lds, rs, off, c.ok && k < K);
+        return;
     }
-    return src ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+    // CONVX: k = output pixel, columns = (tap, c)
+    const int pix = k0 + c.row;
+    const int plane = o.PH * o.PW;
+    const int n = pix / plane;
+    const int rem = pix - n * plane;
+    const int py = rem / o.PW, px = rem - py * o.PW;
+    const int iy = py * o.stride - o.pad + c.r * o.dil, ix = px * o.stride - o.pad + c.s * o.dil;
+    const bool in = c.ok && pix < K && iy >= 0 && ix >= 0 && iy < o.SH && ix < o.SW;
+    dma16(lds, rs, c.base + ((n * o.SH + iy) * o.SW + ix) * o.SC, in);
 }
 
-// k-contiguous LDS tile [rows][BKP]; k-major LDS tile [BK][rows + 8]
-template <bool KM, bool TR, int ROWS, int BK>
-__device__ __forceinline__ void stage(bf16_t* s, int row, int kc, const uint4& v) {
-    constexpr int BKP = BK + 8;
-    if (!KM) *reinterpret_cast<uint4*>(&s[row * BKP + kc * 8]) = v;
-    else if (TR) *reinterpret_cast<uint4*>(&s[row * (ROWS + 8) + kc * 8]) = v;
-    else {
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[(kc * 8 + 2 * j) * BKP + row] = (bf16_t)(w[j] & 0xffffu);
-            s[(kc * 8 + 2 * j + 1) * BKP + row] = (bf16_t)(w[j] >> 16);
-        }
-    }
-}
-
-// MFMA operand fragment: 8 consecutive k (k = 8*g + j) of tile row (r0 + c16)
-template <bool KM, bool TR, int ROWS, int BK>
+// MFMA operand fragment: 8 consecutive k (k = 32*ks + 8*g + j) of tile row (r0 + c16)
+template <bool KM, int ROWS, int BK>
 __device__ __forceinline__ bf16x8_t fragment(const bf16_t* s, int r0, int ks, int g, int c16) {
-    constexpr int BKP = BK + 8;
-    if (KM && TR) {
+    if (KM) {
         // 16-lane group g transposes the [4 k][16 rows] blocks at k = 8g and k = 8g + 4 (ds_read_b64_tr_b16)
-        constexpr int LD = ROWS + 8;
-        const bf16_t* q = &s[(ks * 32 + 8 * g + (c16 >> 2)) * LD + r0 + (c16 & 3) * 4];
+        const int k = ks * 32 + 8 * g + (c16 >> 2);
+        const int rc = (r0 >> 3) + ((c16 & 3) >> 1);          // 16-byte chunk holding this lane's 4 rows
+        const int sub = (c16 & 1) * 4;                         // element offset inside the chunk
         typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
-        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q));
-        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q + 4 * LD));
+        const bf16_t* q0 = &s[k * ROWS + swz_m<ROWS>(k, rc) * 8 + sub];
+        const bf16_t* q1 = &s[(k + 4) * ROWS + swz_m<ROWS>(k + 4, rc) * 8 + sub];
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q0));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q1));
         union { struct { s16x4_t a, b; } h; bf16x8_t v; } u;
         u.h.a = lo; u.h.b = hi;
         return u.v;
     }
-    return *reinterpret_cast<const bf16x8_t*>(&s[(r0 + c16) * BKP + ks * 32 + g * 8]);
+    const int row = r0 + c16;
+    return *reinterpret_cast<const bf16x8_t*>(&s[row * BK + swz_k<BK>(row, ks * 4 + g) * 8]);
 }
 
-template <int BM, int BN, int BK, int AK, int BKD, bool TR>
+template <int BM, int BN, int BK, int AK, int BKD>
 __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
-    constexpr int BKP = BK + 8, KC = BK / 8;  // 16-byte chunks per k-contiguous row
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
-    constexpr int ACH = BM * BK / 8 / 256, BCH = BN * BK / 8 / 256;  // 16-byte chunks per thread
+    constexpr int ACH = BM * BK / 8 / 256, BCH = BN * BK / 8 / 256;  // 1 KiB DMA pieces per wave per tile
     constexpr bool A_KM = (AK == TOIST_A_KROW);    // A staged k-major
     constexpr bool B_KM = (BKD != TOIST_B_ROWK);   // B staged k-major
-    constexpr int SA_ELEMS = (A_KM && TR) ? BK * (BM + 8) : BM * BKP;
-    constexpr int SB_ELEMS = (B_KM && TR) ? BK * (BN + 8) : BN * BKP;
-    constexpr int STAGE = SA_ELEMS + SB_ELEMS;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];  // double buffered: one barrier per k-tile
+    constexpr int SA_ELEMS = BM * BK, SB_ELEMS = BN * BK;
+    constexpr int STAGE = SA_ELEMS + SB_ELEMS;                       // elements per ring slot
+    // ring depth: measured on MI355X, occupancy beats depth -- 2 slots (5 workgroups/CU for 64x64x64) run
+    // 15-30 % faster than 3 slots (3 workgroups/CU) on the K = 256..2048 hot-path shapes
+    constexpr int NS = (STAGE * 2 <= 8192) ? 4 : 2;
+    constexpr int CNT = ACH + BCH;
+    static_assert(NS >= 2 && NS <= 4, "wait ladder below covers up to 2 younger tiles");
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, c16 = lane & 15;
 
@@ -297,10 +330,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     const int bz = z / p.split_k, ksl = z - bz * p.split_k;
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
     const toist_operand oa = p.a, ob = p.b;
-    const bf16_t* Ab = (const bf16_t*)oa.ptr + bo * oa.bs_outer + bi * oa.bs_inner;
-    const bf16_t* Bb = (const bf16_t*)ob.ptr + bo * ob.bs_outer + bi * ob.bs_inner;
+    const i32x4_t rsA = make_rsrc((const bf16_t*)oa.ptr + bo * oa.bs_outer + bi * oa.bs_inner);
+    const i32x4_t rsB = make_rsrc((const bf16_t*)ob.ptr + bo * ob.bs_outer + bi * ob.bs_inner);
     const long long coff = bo * p.cs_outer + bi * p.cs_inner;
-    const long long lda = oa.ld, ldb = ob.ld;
+    const int lda = oa.ld, ldb = ob.ld;
 
     const int ktiles = (K + BK - 1) / BK;
     const int kper = (ktiles + p.split_k - 1) / p.split_k;
@@ -308,27 +341,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     const int kt_end = (kt_beg + kper < ktiles) ? kt_beg + kper : ktiles;
     if (kt_beg >= kt_end) return;
 
-    // ---- per-thread chunk invariants ---------------------------------------------------------
+    // ---- per-thread piece invariants: piece i of wave w covers LDS chunks (i*4 + w)*64 + lane ----------
     ChunkA ca[ACH];
 #pragma unroll
     for (int it = 0; it < ACH; ++it) {
-        const int ch = tid + 256 * it;
+        const int pch = (it * 4 + wave) * 64 + lane;
         ChunkA c;
         c.y0 = c.x0 = 0;
         if (A_KM) {
-            c.row = ch / (BM / 8); c.kc = ch % (BM / 8);
+            c.row = pch / (BM / 8);                                   // k-row
+            c.kc = swz_m<BM>(c.row, pch % (BM / 8));                  // m-chunk stored in this slot
             c.ok = (m0 + c.kc * 8) < M;
-            c.base = Ab + m0 + c.kc * 8;
+            c.base = m0 + c.kc * 8;
         } else {
-            c.row = ch / KC; c.kc = ch % KC;
+            c.row = pch / (BK / 8);
+            c.kc = swz_k<BK>(c.row, pch % (BK / 8));                  // k-chunk stored in this slot
             const int m = m0 + c.row;
             c.ok = m < M;
-            if (AK == TOIST_A_ROWK) c.base = Ab + (long long)m * lda + c.kc * 8;
+            if (AK == TOIST_A_ROWK) c.base = m * lda + c.kc * 8;
             else {
                 const int plane = oa.PH * oa.PW;
                 const int n = m / plane, rem = m - n * plane;
                 const int py = rem / oa.PW, px = rem - py * oa.PW;
-                c.base = Ab + (long long)n * oa.SH * oa.SW * oa.SC;
+                c.base = n * oa.SH * oa.SW * oa.SC;
                 if (AK == TOIST_A_CONVT) { c.y0 = py + oa.pad; c.x0 = px + oa.pad; }
                 else { c.y0 = py * oa.stride - oa.pad; c.x0 = px * oa.stride - oa.pad; }
             }
@@ -338,23 +373,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     ChunkB cb[BCH];
 #pragma unroll
     for (int it = 0; it < BCH; ++it) {
-        const int ch = tid + 256 * it;
+        const int pch = (it * 4 + wave) * 64 + lane;
         ChunkB c;
         c.r = c.s = 0;
         if (B_KM) {
-            c.row = ch / (BN / 8); c.kc = ch % (BN / 8);
+            c.row = pch / (BN / 8);
+            c.kc = swz_m<BN>(c.row, pch % (BN / 8));
             const int nn = n0 + c.kc * 8;
             c.ok = nn < N;
             if (BKD == TOIST_B_CONVX) {
                 const int tap = nn / ob.SC;
                 c.r = tap / ob.S; c.s = tap - c.r * ob.S;
-                c.base = Bb + (nn - tap * ob.SC);
-            } else c.base = Bb + nn;
+                c.base = nn - tap * ob.SC;
+            } else c.base = nn;
         } else {
-            c.row = ch / KC; c.kc = ch % KC;
+            c.row = pch / (BK / 8);
+            c.kc = swz_k<BK>(c.row, pch % (BK / 8));
             const int n = n0 + c.row;
             c.ok = n < N;
-            c.base = Bb + (long long)n * ldb + c.kc * 8;
+            c.base = n * ldb + c.kc * 8;
         }
         cb[it] = c;
     }
@@ -372,59 +409,59 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) csum[it][j] = 0.f;
 
-    uint4 ra[ACH], rb[BCH];
+    const unsigned lds0 = (unsigned)(size_t)smem;  // LDS byte address of the ring
+    auto issue = [&](int kt, int slot) {
+        const unsigned sbase = lds0 + (unsigned)slot * (STAGE * 2) + (unsigned)wave * 1024u;
 #pragma unroll
-    for (int it = 0; it < ACH; ++it) ra[it] = load_a<AK, BK>(ca[it], oa, kt_beg * BK, K, lda);
+        for (int it = 0; it < ACH; ++it) load_a<AK, BK>(sbase + it * 4096u, rsA, ca[it], oa, kt * BK, K, lda);
 #pragma unroll
-    for (int it = 0; it < BCH; ++it) rb[it] = load_b<BKD, BK>(cb[it], ob, kt_beg * BK, K, ldb);
-#pragma unroll
-    for (int it = 0; it < ACH; ++it) stage<A_KM, TR, BM, BK>(smem, ca[it].row, ca[it].kc, ra[it]);
-#pragma unroll
-    for (int it = 0; it < BCH; ++it) stage<B_KM, TR, BN, BK>(smem + SA_ELEMS, cb[it].row, cb[it].kc, rb[it]);
-    if (want_csum) {
-#pragma unroll
-        for (int it = 0; it < ACH; ++it) add8(csum[it], ra[it]);
-    }
-    __syncthreads();
+        for (int it = 0; it < BCH; ++it) load_b<BKD, BK>(sbase + SA_ELEMS * 2 + it * 4096u, rsB, cb[it], ob, kt * BK, K, ldb);
+    };
 
-    int cur = 0;
-    for (int kt = kt_beg; kt < kt_end; ++kt) {
-        const bool more = kt + 1 < kt_end;
-        if (more) {  // next tile's global loads fly under this tile's MFMAs
+    const int ntiles = kt_end - kt_beg;
 #pragma unroll
-            for (int it = 0; it < ACH; ++it) ra[it] = load_a<AK, BK>(ca[it], oa, (kt + 1) * BK, K, lda);
-#pragma unroll
-            for (int it = 0; it < BCH; ++it) rb[it] = load_b<BKD, BK>(cb[it], ob, (kt + 1) * BK, K, ldb);
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < ntiles) issue(kt_beg + t, t);
+
+    int slot = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        // tiles issued after tile t that may stay in flight: t+1 .. min(t+NS-2, ntiles-1)
+        int younger = ntiles - 1 - t;
+        if (younger > NS - 2) younger = NS - 2;
+        if (younger <= 0) wait_vm<0>();
+        else if (younger == 1) wait_vm<CNT>();
+        else wait_vm<2 * CNT>();
+        __builtin_amdgcn_s_barrier();   // every wave's pieces of tile t landed; everyone is done with tile t-1
+        if (t + NS - 1 < ntiles) {
+            int ns = slot + NS - 1;
+            if (ns >= NS) ns -= NS;
+            issue(kt_beg + t + NS - 1, ns);  // refills the slot tile t-1 was read from
         }
-        const bf16_t* sA = smem + cur * STAGE;
+        const bf16_t* sA = smem + slot * STAGE;
         const bf16_t* sB = sA + SA_ELEMS;
+        if (want_csum) {
+#pragma unroll
+            for (int it = 0; it < ACH; ++it) {
+                const int pch = (it * 4 + wave) * 64 + lane;
+                add8(csum[it], *reinterpret_cast<const u32x4_t*>(sA + pch * 8));
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8_t af[FM], bfr[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = fragment<A_KM, TR, BM, BK>(sA, wm * WM + i * 16, ks, g, c16);
+            for (int i = 0; i < FM; ++i) af[i] = fragment<A_KM, BM, BK>(sA, wm * WM + i * 16, ks, g, c16);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j] = fragment<B_KM, TR, BN, BK>(sB, wn * WN + j * 16, ks, g, c16);
+            for (int j = 0; j < FN; ++j) bfr[j] = fragment<B_KM, BN, BK>(sB, wn * WN + j * 16, ks, g, c16);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            bf16_t* dA = smem + (cur ^ 1) * STAGE;
-#pragma unroll
-            for (int it = 0; it < ACH; ++it) stage<A_KM, TR, BM, BK>(dA, ca[it].row, ca[it].kc, ra[it]);
-#pragma unroll
-            for (int it = 0; it < BCH; ++it) stage<B_KM, TR, BN, BK>(dA + SA_ELEMS, cb[it].row, cb[it].kc, rb[it]);
-            if (want_csum) {
-#pragma unroll
-                for (int it = 0; it < ACH; ++it) add8(csum[it], ra[it]);
-            }
-        }
-        __syncthreads();
-        cur ^= 1;
+        if (++slot == NS) slot = 0;
     }
+    wait_vm<0>();
 
     if (A_KM && p.a_colsum != nullptr && blockIdx.y == 0) {
         // bias gradient: column sums of the staged A tiles, reduced over the k rows held by other threads
@@ -433,7 +470,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
 #pragma unroll
         for (int it = 0; it < ACH; ++it)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) red[(ca[it].row * (BM / 8) + ca[it].kc) * 8 + j] = csum[it][j];
+            for (int j = 0; j < 8; ++j) red[ca[it].row * BM + ca[it].kc * 8 + j] = csum[it][j];
         __syncthreads();
         for (int col = tid; col < BM; col += 256) {
             float t = 0.f;
@@ -495,10 +532,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <int BM, int BN, int BK, int AK, int BKD>
 static void launch_variant(const toist_gemm& d, hipStream_t st) {
     dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, d.batch * d.split_k);
-    if (d.flags & 1)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, false>), grid, dim3(256), 0, st, d);
-    else
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, true>), grid, dim3(256), 0, st, d);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD>), grid, dim3(256), 0, st, d);
 }
 
 template <int BM, int BN, int BK>
@@ -563,11 +597,11 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
 
     int tile = d.tile;
     if (tile == 0) {
-        // measured on MI355X (tools/sweep_gemm.py): 128x128x64 only pays once >= ~3 tiles per CU exist;
-        // below that 64x64 tiles keep more workgroups (and loads) in flight; BK = 64 needs K > 128.
+        // measured on MI355X (tools/sweep_gemm.py): 128x128x64 only pays once >= ~4 tiles per CU exist and K
+        // is deep; below that 64x64x64 tiles keep more workgroups (and DMA) in flight.
         const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.split_k;
-        if (t128 >= 768 && d.K >= 2048) tile = 129;
-        else tile = (d.K > 128) ? 65 : 64;
+        if (t128 >= 1024 && d.K >= 1024) tile = 129;
+        else tile = (d.K > 64) ? 65 : 64;
     }
     {
         // drop k-slices that would own no k-tile

@@ -13,13 +13,25 @@ BF = torch.bfloat16
 
 
 def timeit(fn, iters):
-    for _ in range(3):
+    """GPU time per call: the launches are captured into a hipGraph and replayed, so the Python /
+    ctypes launch cost (~10-20 us per call, larger than most hot-path kernels) is not measured."""
+    for _ in range(2):
         fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        fn()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(iters):
+                fn()
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn()
+    graph.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
