@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="time every GEMM launch (diagnostic; adds host overhead)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
     return ap.parse_args()
 
 
@@ -103,7 +104,9 @@ def main():
         {"params": [p for n, p in named if "backbone" in n], "lr": args.lr_backbone},
         {"params": [p for n, p in named if "text_encoder" in n], "lr": args.text_encoder_lr},
     ]
-    opt = torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay, fused=True)
+    use_graph = (world == 1) and not a.no_graph and not a.profile_all
+    opt = torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay, fused=True, capturable=use_graph)
+    kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)  # bumped every step: fresh dropout masks per replay
     ema_src = [v for v in model.state_dict().values() if v.is_floating_point()]
     ema = [v.detach().clone() for v in ema_src]
     all_params = [p for _, p in named]
@@ -111,8 +114,10 @@ def main():
     samples, tok, targets, pmap = harness.synthetic_batch(a.batch, a.size, a.size, tokens=16, seed=1000 + rank, device=dev)
     sync = parallel.GradSync()
 
-    def step():
-        opt.zero_grad(set_to_none=True)
+    def step(zero=True):
+        if zero:
+            opt.zero_grad(set_to_none=True)
+        kernels.SEED_DEV.add_(1000003)
         with sync:
             mc = model(samples, tok, encode_and_save=True)
             out = model(samples, tok, encode_and_save=False, memory_cache=mc)
@@ -132,20 +137,52 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    graph = None
+    if use_graph:
+        # The whole step (forward, criterion, backward, clip, AdamW, EMA: ~1500 kernel launches) is captured
+        # once into a hipGraph and replayed: the Python/ctypes launch path (~10-20 us per launch) would
+        # otherwise bound the step.  Inputs are static device tensors; dropout masks change per replay
+        # through the device-side seed word.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(a.warmup, 2)):
+                step()
+            opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                static_loss = step(zero=False)
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()
+
+        def run_step():
+            graph.replay()
+            return static_loss
+    else:
+        for _ in range(a.warmup):
+            step()
+        run_step = step
     prof = None
-    if rank == 0 and not a.no_roofline:
-        prof = {"key": None if a.profile_all else (128, kernels.A_CONV, kernels.B_ROWK), "records": [], "other": {}}
+    if rank == 0 and not a.no_roofline and not use_graph:
+        prof = {"key": None if a.profile_all else (65, kernels.A_CONV, kernels.B_ROWK), "records": [], "other": {}}
     barrier()
     kernels.PROFILE = prof
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        last = step()
+        last = run_step()
     barrier()
     dt = time.perf_counter() - t0
     kernels.PROFILE = None
     loss_val = float(last)
+    if rank == 0 and not a.no_roofline and use_graph:
+        # kernel-level timing needs per-launch HIP events, which a replayed graph cannot carry: time the
+        # same K steps once more, eagerly, on the same stream right after the timed region
+        prof = {"key": (65, kernels.A_CONV, kernels.B_ROWK), "records": [], "other": {}}
+        kernels.PROFILE = prof
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        kernels.PROFILE = None
     if world > 1:
         t = torch.tensor([dt], device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -160,7 +197,7 @@ def main():
             "config": {"workload": f"configs[1]: ResNet-101 + RoBERTa-base + 6+6 transformer, 100 queries, batch {a.batch}/GPU {a.size}x{a.size}, "
                                    "16-token captions, detection loss (labels+boxes+cardinality, 5 aux layers), dropout 0.1, "
                                    "clip 0.1 + AdamW + EMA; random-init weights",
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4),
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4), "launch": "hipGraph replay" if use_graph else "eager",
                        "mfma_frac_whole_step": round(ips / world * GFLOP_PER_IMG_TRAIN / 1000.0 / PEAK_BF16_TFLOPS, 5)},
         }
         if prof is not None and prof["records"]:
@@ -177,7 +214,8 @@ def main():
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16_TFLOPS, 5), "traffic": None,
-                               "kernel": "gemm_kernel<128,128,A_CONV,B_ROWK> (implicit-GEMM conv forward)" if prof["key"] else "all gemm_kernel launches",
+                               "kernel": "gemm_kernel<64,64,64,A_CONV,B_ROWK> (implicit-GEMM conv forward)" if prof["key"] else "all gemm_kernel launches",
+                               "timed": "HIP events around each launch, %d eager steps %s" % (a.steps, "after the graph-replayed timed region" if use_graph else "inside the timed region"),
                                "launches": n, "avg_launch_us": round(1000 * tot_ms / n, 2), "avg_gflop_per_launch": round(tot_fl / n / 1e9, 3)}
             if a.profile_all:
                 res["roofline"]["per_variant"] = {k_: {"ms_per_step": round(v[0] / a.steps, 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1),

@@ -116,6 +116,8 @@ typedef struct toist_epilogue {
     int32_t drop_where;
     float drop_p;
     uint64_t drop_seed;
+    const uint64_t* drop_seed_dev; /* optional device word added to drop_seed at run time, so a captured
+                                      hipGraph draws a fresh mask on every replay */
 } toist_epilogue;
 
 typedef struct toist_gemm {
@@ -153,17 +155,18 @@ int toist_layernorm_fwd(const void* x, const float* gamma, const float* beta, fl
                         void* y, float* mean, float* rstd, void* stream);
 int toist_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         int rows, int D, void* dx, float* dgamma, float* dbeta, void* dx_drop, float drop_p,
-                        uint64_t seed, void* stream);
+                        uint64_t seed, const uint64_t* seed_dev, void* stream);
 int toist_softmax_fwd(const void* scores, const uint8_t* key_pad, int nbatch, int H, int Sq, int Sk, int ld,
-                      void* p, void* p_drop, float drop_p, uint64_t seed, void* stream);
+                      void* p, void* p_drop, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 int toist_softmax_bwd(const void* p, const void* dp, int rows, int Sk, int ld, void* ds, float drop_p,
-                      uint64_t seed, void* stream);
+                      uint64_t seed, const uint64_t* seed_dev, void* stream);
+/* every dropout seed is `seed + (seed_dev ? *seed_dev : 0)`: seed_dev is an optional device word */
 /* out[n] += sum_m g[m][n]  (bias gradient; out is f32, caller zeroes it) */
 int toist_colsum(const void* g, int M, int N, int ld, float* out, void* stream);
 /* out = a + b, b broadcast with period b_period elements (with_pos_embed, transformer.py:287-288) */
 int toist_add_bf16(const void* a, const void* b, int64_t n, int64_t b_period, void* out, void* stream);
 /* out = dropout(x): keep iff hash(seed, flat index) >= p*2^32, kept values scaled by 1/(1-p) */
-int toist_dropout_bf16(const void* x, int64_t n, float p, uint64_t seed, void* out, void* stream);
+int toist_dropout_bf16(const void* x, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backbone-side layout / pooling kernels (NHWC bf16).

@@ -30,7 +30,7 @@ class Epilogue(Structure):
         ("alpha", c_float), ("scale", c_void_p), ("shift", c_void_p), ("rscale", c_void_p), ("res", c_void_p), ("ldr", c_int32),
         ("aux", c_void_p), ("ldaux", c_int32), ("act", c_int32), ("pre_out", c_void_p), ("out_f32", c_int32),
         ("accumulate", c_int32), ("cmap", c_int32), ("cH", c_int32), ("cW", c_int32), ("cOH", c_int32),
-        ("cOW", c_int32), ("cst", c_int32), ("drop_where", c_int32), ("drop_p", c_float), ("drop_seed", c_uint64),
+        ("cOW", c_int32), ("cst", c_int32), ("drop_where", c_int32), ("drop_p", c_float), ("drop_seed", c_uint64), ("drop_seed_dev", c_void_p),
     ]
 
 
@@ -49,9 +49,9 @@ _SIGNATURES = {
     "toist_matcher": ([c_void_p] * 6 + [c_int32] * 5 + [c_float] * 3 + [c_void_p] * 5, ctypes.c_int),
     "toist_gemm_bf16": ([POINTER(Gemm), c_void_p], ctypes.c_int),
     "toist_layernorm_fwd": ([c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "toist_layernorm_bwd": ([c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 4 + [c_float, c_uint64, c_void_p], ctypes.c_int),
-    "toist_softmax_fwd": ([c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p, c_float, c_uint64, c_void_p], ctypes.c_int),
-    "toist_softmax_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_float, c_uint64, c_void_p], ctypes.c_int),
+    "toist_layernorm_bwd": ([c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 4 + [c_float, c_uint64, c_void_p, c_void_p], ctypes.c_int),
+    "toist_softmax_fwd": ([c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p, c_float, c_uint64, c_void_p, c_void_p], ctypes.c_int),
+    "toist_softmax_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_float, c_uint64, c_void_p, c_void_p], ctypes.c_int),
     "toist_colsum": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_add_bf16": ([c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p], ctypes.c_int),
     "toist_pack_image": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
@@ -60,7 +60,7 @@ _SIGNATURES = {
     "toist_sine_position": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_embed_fwd": ([c_void_p] * 5 + [c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_embed_bwd": ([c_void_p] * 3 + [c_int32, c_int32, c_int64] + [c_void_p] * 4, ctypes.c_int),
-    "toist_dropout_bf16": ([c_void_p, c_int64, c_float, c_uint64, c_void_p, c_void_p], ctypes.c_int),
+    "toist_dropout_bf16": ([c_void_p, c_int64, c_float, c_uint64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
 }
 
 _lib = None

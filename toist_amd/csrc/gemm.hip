@@ -56,13 +56,14 @@ __device__ __forceinline__ void epilogue_frag(const toist_gemm& p, const f32x4_t
         if (nv > 3) v3 += e.shift[n + 3];
     }
     const unsigned long long didx = ((unsigned long long)bz * M + m) * N + n;
+    const unsigned long long dseed = e.drop_where ? e.drop_seed + (e.drop_seed_dev ? *e.drop_seed_dev : 0ull) : 0ull;
     if (e.drop_where == 1) {
         const unsigned th = (unsigned)(e.drop_p * 4294967296.0);
         const float sc = 1.f / (1.f - e.drop_p);
-        v0 = dropout_keep(e.drop_seed, didx, th) ? v0 * sc : 0.f;
-        v1 = dropout_keep(e.drop_seed, didx + 1, th) ? v1 * sc : 0.f;
-        v2 = dropout_keep(e.drop_seed, didx + 2, th) ? v2 * sc : 0.f;
-        v3 = dropout_keep(e.drop_seed, didx + 3, th) ? v3 * sc : 0.f;
+        v0 = dropout_keep(dseed, didx, th) ? v0 * sc : 0.f;
+        v1 = dropout_keep(dseed, didx + 1, th) ? v1 * sc : 0.f;
+        v2 = dropout_keep(dseed, didx + 2, th) ? v2 * sc : 0.f;
+        v3 = dropout_keep(dseed, didx + 3, th) ? v3 * sc : 0.f;
     }
     if (e.res) {
         const bf16_t* rp = (const bf16_t*)e.res + coff + crow * e.ldr + n;
@@ -117,10 +118,10 @@ __device__ __forceinline__ void epilogue_frag(const toist_gemm& p, const f32x4_t
     if (e.drop_where == 2) {
         const unsigned th = (unsigned)(e.drop_p * 4294967296.0);
         const float sc = 1.f / (1.f - e.drop_p);
-        v0 = dropout_keep(e.drop_seed, didx, th) ? v0 * sc : 0.f;
-        v1 = dropout_keep(e.drop_seed, didx + 1, th) ? v1 * sc : 0.f;
-        v2 = dropout_keep(e.drop_seed, didx + 2, th) ? v2 * sc : 0.f;
-        v3 = dropout_keep(e.drop_seed, didx + 3, th) ? v3 * sc : 0.f;
+        v0 = dropout_keep(dseed, didx, th) ? v0 * sc : 0.f;
+        v1 = dropout_keep(dseed, didx + 1, th) ? v1 * sc : 0.f;
+        v2 = dropout_keep(dseed, didx + 2, th) ? v2 * sc : 0.f;
+        v3 = dropout_keep(dseed, didx + 3, th) ? v3 * sc : 0.f;
     }
     if (e.out_f32) {
         float* cp = (float*)p.c + coff + crow * p.ldc + n;

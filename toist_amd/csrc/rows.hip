@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
                                                              const float* __restrict__ gamma, int rows, int D,
                                                              bf16_t* __restrict__ dx, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, bf16_t* __restrict__ dx_drop,
-                                                             float drop_p, unsigned long long seed) {
+                                                             float drop_p, unsigned long long seed,
+                                                             const unsigned long long* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;
     const int lane = threadIdx.x & 63;
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
@@ -163,7 +165,9 @@ constexpr int SM_MAXCH = 4;  // Sk <= 2048
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const bf16_t* __restrict__ s, const unsigned char* __restrict__ key_pad,
                                                            int rows, int H, int Sq, int Sk, int ld,
                                                            bf16_t* __restrict__ p, bf16_t* __restrict__ p_drop,
-                                                           float drop_p, unsigned long long seed) {
+                                                           float drop_p, unsigned long long seed,
+                                                           const unsigned long long* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -222,7 +226,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const bf16_t* __restri
 // ds = p * (m*dp - sum_j p_j*m_j*dp_j), m = dropout keep-mask / (1-p_drop) (1 when no dropout)
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ p, const bf16_t* __restrict__ dp, int rows,
                                                            int Sk, int ld, bf16_t* __restrict__ ds, float drop_p,
-                                                           unsigned long long seed) {
+                                                           unsigned long long seed, const unsigned long long* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -315,7 +320,8 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, 
 
 // out = dropout(x) with the (seed, index) mask used by the GEMM epilogue / LN backward
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, long long n8, float p, unsigned long long seed,
-                                                       bf16_t* __restrict__ out) {
+                                                       const unsigned long long* __restrict__ seed_dev, bf16_t* __restrict__ out) {
+    if (seed_dev) seed += *seed_dev;
     const unsigned thresh = (unsigned)(p * 4294967296.0);
     const float sc = 1.f / (1.f - p);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -383,7 +389,7 @@ extern "C" int toist_layernorm_fwd(const void* x, const float* gamma, const floa
 
 extern "C" int toist_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                                    int rows, int D, void* dx, float* dgamma, float* dbeta, void* dx_drop, float drop_p,
-                                   uint64_t seed, void* stream) {
+                                   uint64_t seed, const uint64_t* seed_dev, void* stream) {
     TOIST_REQUIRE(rows > 0 && D > 0 && (D % 8) == 0 && D <= 1024, "toist_layernorm_bwd: rows=%d D=%d", rows, D);
     TOIST_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "toist_layernorm_bwd: dgamma/dbeta must both be set or null");
     int blocks = (rows + 15) / 16;  // >= 4 rows per wave so the parameter-gradient atomics stay few
@@ -391,25 +397,25 @@ extern "C" int toist_layernorm_bwd(const void* dy, const void* x, const float* m
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, mean, rstd, gamma, rows, D, (bf16_t*)dx, dgamma, dbeta, (bf16_t*)dx_drop, drop_p,
-                       (unsigned long long)seed);
+                       (unsigned long long)seed, (const unsigned long long*)seed_dev);
     return check_launch("toist_layernorm_bwd");
 }
 
 extern "C" int toist_softmax_fwd(const void* scores, const uint8_t* key_pad, int nbatch, int H, int Sq, int Sk, int ld,
-                                 void* p, void* p_drop, float drop_p, uint64_t seed, void* stream) {
+                                 void* p, void* p_drop, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
     TOIST_REQUIRE(nbatch > 0 && H > 0 && Sq > 0 && Sk > 0, "toist_softmax_fwd: bad shape");
     TOIST_REQUIRE((ld % 8) == 0 && ld >= Sk && ld <= 2048, "toist_softmax_fwd: ld=%d Sk=%d (ld%%8==0, Sk<=ld<=2048)", ld, Sk);
     const int rows = nbatch * H * Sq;
     hipLaunchKernelGGL(softmax_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)scores, key_pad,
-                       rows, H, Sq, Sk, ld, (bf16_t*)p, (bf16_t*)p_drop, drop_p, (unsigned long long)seed);
+                       rows, H, Sq, Sk, ld, (bf16_t*)p, (bf16_t*)p_drop, drop_p, (unsigned long long)seed, (const unsigned long long*)seed_dev);
     return check_launch("toist_softmax_fwd");
 }
 
 extern "C" int toist_softmax_bwd(const void* p, const void* dp, int rows, int Sk, int ld, void* ds, float drop_p, uint64_t seed,
-                                 void* stream) {
+                                 const uint64_t* seed_dev, void* stream) {
     TOIST_REQUIRE(rows > 0 && Sk > 0 && (ld % 8) == 0 && ld >= Sk && ld <= 2048, "toist_softmax_bwd: bad shape");
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p,
-                       (const bf16_t*)dp, rows, Sk, ld, (bf16_t*)ds, drop_p, (unsigned long long)seed);
+                       (const bf16_t*)dp, rows, Sk, ld, (bf16_t*)ds, drop_p, (unsigned long long)seed, (const unsigned long long*)seed_dev);
     return check_launch("toist_softmax_bwd");
 }
 
@@ -428,10 +434,10 @@ extern "C" int toist_add_bf16(const void* a, const void* b, int64_t n, int64_t b
     return check_launch("toist_add_bf16");
 }
 
-extern "C" int toist_dropout_bf16(const void* x, int64_t n, float p, uint64_t seed, void* out, void* stream) {
+extern "C" int toist_dropout_bf16(const void* x, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, void* out, void* stream) {
     TOIST_REQUIRE(n > 0 && (n % 8) == 0 && p >= 0.f && p < 1.f, "toist_dropout_bf16: bad args");
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long long)(n / 8),
-                       p, (unsigned long long)seed, (bf16_t*)out);
+                       p, (unsigned long long)seed, (const unsigned long long*)seed_dev, (bf16_t*)out);
     return check_launch("toist_dropout_bf16");
 }
 

@@ -23,6 +23,9 @@ __all__ = [
 # bench.py sets this to {"key": (tile, a_kind, b_kind) | None, "records": [], "other": {}} to time GEMM
 # launches with HIP events on the launch stream (roofline accounting); None = no instrumentation.
 PROFILE = None
+# Optional int64[1] device tensor added to every dropout seed inside the kernels.  A training loop that
+# replays a captured hipGraph bumps it once per step so each replay draws fresh dropout masks.
+SEED_DEV = None
 FORCE_TILE = 0    # experiments: overrides tile == 0 (auto) in every gemm() call
 FORCE_SPLIT = 0   # experiments: overrides split_k when > 0 and the call accumulates
 
@@ -105,6 +108,7 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
         e.cmap = 1
         e.cH, e.cW, e.cOH, e.cOW, e.cst = cmap
     e.drop_where, e.drop_p, e.drop_seed = drop_where, drop_p, drop_seed
+    e.drop_seed_dev = _p(SEED_DEV) if drop_where else None
     d.a_colsum = _p(a_colsum, torch.float32)
     if split_k > 1:
         d.workspace = _p(_workspace(split_k * M * N, c.device), torch.float32)
@@ -152,20 +156,20 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma=None, dbeta=None, dx_drop
         _lib.lib().toist_layernorm_bwd(_p(dy, torch.bfloat16), _p(x, torch.bfloat16), _p(mean, torch.float32),
                                        _p(rstd, torch.float32), _p(gamma, torch.float32), rows, D, _p(dx, torch.bfloat16),
                                        _p(dgamma, torch.float32), _p(dbeta, torch.float32), _p(dx_drop, torch.bfloat16),
-                                       drop_p, seed, _stream()), "toist_layernorm_bwd")
+                                       drop_p, seed, _p(SEED_DEV), _stream()), "toist_layernorm_bwd")
 
 
 def softmax_fwd(scores, key_pad, nbatch, H, Sq, Sk, ld, p, p_drop=None, drop_p=0.0, seed=0):
     _lib.check(
         _lib.lib().toist_softmax_fwd(_p(scores, torch.bfloat16), _p(key_pad, torch.uint8), nbatch, H, Sq, Sk, ld,
-                                     _p(p, torch.bfloat16), _p(p_drop, torch.bfloat16), drop_p, seed, _stream()),
+                                     _p(p, torch.bfloat16), _p(p_drop, torch.bfloat16), drop_p, seed, _p(SEED_DEV), _stream()),
         "toist_softmax_fwd")
 
 
 def softmax_bwd(p, dp, rows, Sk, ld, ds, drop_p=0.0, seed=0):
     _lib.check(
         _lib.lib().toist_softmax_bwd(_p(p, torch.bfloat16), _p(dp, torch.bfloat16), rows, Sk, ld, _p(ds, torch.bfloat16),
-                                     drop_p, seed, _stream()), "toist_softmax_bwd")
+                                     drop_p, seed, _p(SEED_DEV), _stream()), "toist_softmax_bwd")
 
 
 def colsum(g, M, N, ld, out):
@@ -180,7 +184,7 @@ def add(a, b, out, b_period=None):
 
 
 def dropout(x, p, seed, out):
-    _lib.check(_lib.lib().toist_dropout_bf16(_p(x, torch.bfloat16), x.numel(), p, seed, _p(out, torch.bfloat16), _stream()),
+    _lib.check(_lib.lib().toist_dropout_bf16(_p(x, torch.bfloat16), x.numel(), p, seed, _p(SEED_DEV), _p(out, torch.bfloat16), _stream()),
                "toist_dropout_bf16")
 
 

@@ -41,6 +41,7 @@ class HungarianMatcher(nn.Module):
         super().__init__()
         self.cost_class, self.cost_bbox, self.cost_giou = cost_class, cost_bbox, cost_giou
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
+        self._offsets = {}
 
     @torch.no_grad()
     def match_layers(self, logits, boxes, targets, positive_map):
@@ -50,16 +51,25 @@ class HungarianMatcher(nn.Module):
         sizes = [int(t["boxes"].shape[0]) for t in targets]
         assert sum(sizes) == len(positive_map)
         res_counts = [min(Q, s) for s in sizes]
-        tgt_off = torch.tensor([0] + [sum(sizes[:i + 1]) for i in range(B)], dtype=torch.int32)
-        m_off = torch.tensor([0] + [sum(res_counts[:i + 1]) for i in range(B)], dtype=torch.int32)
-        mtot, ttot = int(m_off[-1]), int(tgt_off[-1])
+        # prefix sums live on the device; cached per batch signature so a steady-state step issues no
+        # host->device copy (and stays hipGraph-capturable)
+        key = (tuple(sizes), Q, str(dev))
+        ent = self._offsets.get(key)
+        if ent is None:
+            if len(self._offsets) > 64:
+                self._offsets.clear()
+            tgt_off = torch.tensor([0] + [sum(sizes[:i + 1]) for i in range(B)], dtype=torch.int32)
+            m_off = torch.tensor([0] + [sum(res_counts[:i + 1]) for i in range(B)], dtype=torch.int32)
+            ent = (tgt_off.to(dev), m_off.to(dev), int(m_off[-1]), int(tgt_off[-1]))
+            self._offsets[key] = ent
+        tgt_off, m_off, mtot, ttot = ent
         src = torch.zeros(L, max(mtot, 1), dtype=torch.int64, device=dev)[:, :mtot]
         tgt = torch.zeros(L, max(mtot, 1), dtype=torch.int64, device=dev)[:, :mtot]
         status = torch.zeros(L * B, dtype=torch.int32, device=dev)
         if ttot > 0:
             tb = torch.cat([t["boxes"] for t in targets]).float().contiguous()
             k.matcher(logits.float().contiguous(), boxes.float().contiguous(), tb, positive_map.float().contiguous(),
-                      tgt_off.to(dev, non_blocking=True), m_off.to(dev, non_blocking=True), max(sizes), float(self.cost_class),
+                      tgt_off, m_off, max(sizes), float(self.cost_class),
                       float(self.cost_bbox), float(self.cost_giou), src if mtot else torch.zeros(L, 1, dtype=torch.int64, device=dev),
                       tgt if mtot else torch.zeros(L, 1, dtype=torch.int64, device=dev), status)
         return MatchResult(src, tgt, status, sizes, Q)

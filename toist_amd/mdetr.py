@@ -220,20 +220,35 @@ class SetCriterion(nn.Module):
         self.losses = losses
         self.temperature = temperature
         self.last_match = None
+        self._maps, self._nb = {}, {}
 
     # -- helpers ------------------------------------------------------------------------------------------
-    @staticmethod
-    def _slot_maps(match, device):
-        """Per matched slot: image index and offset of the image's first target (host arithmetic on shapes)."""
-        b_idx, t_base, acc = [], [], 0
-        for b, (cnt, size) in enumerate(zip(match.counts, match.sizes)):
-            b_idx += [b] * cnt
-            t_base += [acc] * cnt
-            acc += size
-        return (torch.tensor(b_idx, dtype=torch.int64, device=device), torch.tensor(t_base, dtype=torch.int64, device=device))
+    def _slot_maps(self, match, device):
+        """Per matched slot: image index and offset of the image's first target, plus the per-image target
+        counts -- host arithmetic on shapes, cached per batch signature (no H2D copy in steady state)."""
+        key = (tuple(match.sizes), tuple(match.counts), str(device))
+        ent = self._maps.get(key)
+        if ent is None:
+            if len(self._maps) > 64:
+                self._maps.clear()
+            b_idx, t_base, acc = [], [], 0
+            for b, (cnt, size) in enumerate(zip(match.counts, match.sizes)):
+                b_idx += [b] * cnt
+                t_base += [acc] * cnt
+                acc += size
+            ent = (torch.tensor(b_idx, dtype=torch.int64, device=device), torch.tensor(t_base, dtype=torch.int64, device=device),
+                   torch.tensor(match.sizes, dtype=torch.float32, device=device))
+            self._maps[key] = ent
+        return ent
 
     def _num_boxes(self, targets, device):
-        n = torch.as_tensor([float(sum(len(t["labels"]) for t in targets))], dtype=torch.float, device=device)
+        total = float(sum(len(t["labels"]) for t in targets))
+        key = (total, str(device))
+        n = self._nb.get(key)
+        if n is None:
+            n = torch.as_tensor([total], dtype=torch.float, device=device)
+            self._nb = {key: n}
+        n = n.clone()
         if dist.is_dist_avail_and_initialized():
             torch.distributed.all_reduce(n)
         return torch.clamp(n / dist.get_world_size(), min=1)[0]
@@ -253,9 +268,8 @@ class SetCriterion(nn.Module):
         logp = logits.float().log_softmax(-1)
         ce_row = -logp[..., -1] * self.eos_coef  # [L,B,Q]: unmatched rows (one-hot on the no-object slot)
         ce = ce_row.sum((1, 2))
-        sizes = torch.tensor(match.sizes, dtype=torch.float32, device=dev)
+        b_idx, t_base, sizes = self._slot_maps(match, dev)
         if match.src.shape[1] > 0:
-            b_idx, t_base = self._slot_maps(match, dev)
             lidx = torch.arange(L, device=dev)[:, None]
             src, tgt = match.src, match.tgt + t_base[None]
             lp_m = logp[lidx, b_idx[None], src]                      # [L, M, K]
