@@ -192,6 +192,22 @@ int toist_embed_fwd(const int64_t* ids, const int64_t* pos_ids, const float* wor
 int toist_embed_bwd(const void* g, const int64_t* ids, const int64_t* pos_ids, int n, int D, int64_t pad_id, float* dword,
                     float* dpos, float* dtype0, void* stream); /* rows whose id == pad_id get no gradient (padding_idx) */
 
+/* ------------------------------------------------------------------------------------------------
+ * Set-criterion losses for all decoder layers at once.  Replaces SetCriterion.loss_labels / loss_boxes
+ * / loss_cardinality (/root/reference/models/mdetr.py:488-518, 805-825, 783-803) given the device-
+ * resident assignment of toist_matcher (same src_idx/tgt_idx/match_off/tgt_off).
+ *   num_boxes  device f32[1] (already all-reduced / clamped, mdetr.py:997-1001)
+ *   fwd: losses [L,4] f32 += (loss_ce, loss_bbox, loss_giou, cardinality_error) -- caller zeroes it
+ *   bwd: upstream [L,4] = d(total)/d(loss); dlogits [L,B,Q,K], dboxes [L,B,Q,4] are fully written
+ */
+int toist_criterion_fwd(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
+                        const int32_t* tgt_off, const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx,
+                        const float* num_boxes, int L, int B, int Q, int K, float eos_coef, float* losses, void* stream);
+int toist_criterion_bwd(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
+                        const int32_t* tgt_off, const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx,
+                        const float* num_boxes, int L, int B, int Q, int K, float eos_coef, const float* upstream,
+                        float* dlogits, float* dboxes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ __all__ = [
     "A_ROWK", "A_KROW", "A_CONV", "A_CONVT", "B_ROWK", "B_KROW", "B_CONVX", "ACT_NONE", "ACT_RELU", "ACT_GELU",
     "ACT_SIGMOID", "ACT_MASK_POS", "ACT_GELU_BWD", "ACT_SIGMOID_BWD", "ConvGeom", "operand", "gemm", "matcher",
     "layernorm_fwd", "layernorm_bwd", "softmax_fwd", "softmax_bwd", "colsum", "add", "dropout", "pack_image", "maxpool3x3s2",
-    "unpack_nhwc", "sine_position", "embed_fwd", "embed_bwd",
+    "unpack_nhwc", "sine_position", "embed_fwd", "embed_bwd", "criterion_fwd", "criterion_bwd",
 ]
 
 
@@ -221,3 +221,20 @@ def embed_bwd(g, ids, pos_ids, pad_id, dword, dpos, dtype0):
     _lib.check(_lib.lib().toist_embed_bwd(_p(g, torch.bfloat16), _p(ids, torch.int64), _p(pos_ids, torch.int64), n, D, pad_id,
                                           _p(dword, torch.float32), _p(dpos, torch.float32), _p(dtype0, torch.float32), _stream()),
                "toist_embed_bwd")
+
+
+def criterion_fwd(logits, boxes, tgt_boxes, pos_map, tgt_off, match_off, src_idx, tgt_idx, num_boxes, eos_coef, losses):
+    L, B, Q, K = logits.shape
+    _lib.check(_lib.lib().toist_criterion_fwd(_p(logits, torch.float32), _p(boxes, torch.float32), _p(tgt_boxes, torch.float32),
+                                              _p(pos_map, torch.float32), _p(tgt_off, torch.int32), _p(match_off, torch.int32),
+                                              _p(src_idx, torch.int64), _p(tgt_idx, torch.int64), _p(num_boxes, torch.float32), L, B, Q, K,
+                                              eos_coef, _p(losses, torch.float32), _stream()), "toist_criterion_fwd")
+
+
+def criterion_bwd(logits, boxes, tgt_boxes, pos_map, tgt_off, match_off, src_idx, tgt_idx, num_boxes, eos_coef, upstream, dlogits, dboxes):
+    L, B, Q, K = logits.shape
+    _lib.check(_lib.lib().toist_criterion_bwd(_p(logits, torch.float32), _p(boxes, torch.float32), _p(tgt_boxes, torch.float32),
+                                              _p(pos_map, torch.float32), _p(tgt_off, torch.int32), _p(match_off, torch.int32),
+                                              _p(src_idx, torch.int64), _p(tgt_idx, torch.int64), _p(num_boxes, torch.float32), L, B, Q, K,
+                                              eos_coef, _p(upstream, torch.float32), _p(dlogits, torch.float32), _p(dboxes, torch.float32),
+                                              _stream()), "toist_criterion_bwd")

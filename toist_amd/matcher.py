@@ -14,8 +14,9 @@ from . import kernels as k
 class MatchResult:
     """Device-resident assignment for L layers: src/tgt [L, Mtot] int64, per-image slices by `match_off`."""
 
-    def __init__(self, src, tgt, status, sizes, num_queries):
+    def __init__(self, src, tgt, status, sizes, num_queries, tgt_off=None, match_off_dev=None, tgt_boxes=None):
         self.src, self.tgt, self.status = src, tgt, status
+        self.tgt_off_dev, self.match_off_dev, self.tgt_boxes = tgt_off, match_off_dev, tgt_boxes
         self.sizes = list(sizes)
         self.counts = [min(num_queries, s) for s in self.sizes]
         self.match_off = [0]
@@ -66,13 +67,14 @@ class HungarianMatcher(nn.Module):
         src = torch.zeros(L, max(mtot, 1), dtype=torch.int64, device=dev)[:, :mtot]
         tgt = torch.zeros(L, max(mtot, 1), dtype=torch.int64, device=dev)[:, :mtot]
         status = torch.zeros(L * B, dtype=torch.int32, device=dev)
+        tb = None
         if ttot > 0:
             tb = torch.cat([t["boxes"] for t in targets]).float().contiguous()
             k.matcher(logits.float().contiguous(), boxes.float().contiguous(), tb, positive_map.float().contiguous(),
                       tgt_off, m_off, max(sizes), float(self.cost_class),
                       float(self.cost_bbox), float(self.cost_giou), src if mtot else torch.zeros(L, 1, dtype=torch.int64, device=dev),
                       tgt if mtot else torch.zeros(L, 1, dtype=torch.int64, device=dev), status)
-        return MatchResult(src, tgt, status, sizes, Q)
+        return MatchResult(src, tgt, status, sizes, Q, tgt_off, m_off, tb)
 
     @torch.no_grad()
     def forward(self, outputs, targets, positive_map):

@@ -262,39 +262,21 @@ class SetCriterion(nn.Module):
 
     # -- losses over all layers at once -------------------------------------------------------------------
     def _detection_losses(self, logits, boxes, match, targets, positive_map, num_boxes):
-        L, B, Q, K = logits.shape
-        dev = logits.device
+        """labels / boxes / cardinality for every decoder layer: one forward launch of the fused HIP
+        criterion kernel (and one backward launch), see csrc/criterion.hip."""
+        L = logits.shape[0]
+        vals = _SetLossFn.apply(logits.float().contiguous(), boxes.float().contiguous(), match, positive_map.float().contiguous(),
+                                num_boxes.reshape(1).float().contiguous(), float(self.eos_coef))
         out = {}
-        logp = logits.float().log_softmax(-1)
-        ce_row = -logp[..., -1] * self.eos_coef  # [L,B,Q]: unmatched rows (one-hot on the no-object slot)
-        ce = ce_row.sum((1, 2))
-        b_idx, t_base, sizes = self._slot_maps(match, dev)
-        if match.src.shape[1] > 0:
-            lidx = torch.arange(L, device=dev)[:, None]
-            src, tgt = match.src, match.tgt + t_base[None]
-            lp_m = logp[lidx, b_idx[None], src]                      # [L, M, K]
-            ce_m = -(lp_m * positive_map.float()[tgt]).sum(-1)       # matched rows use the soft token target
-            ce = ce - ce_row[lidx, b_idx[None], src].sum(1) + ce_m.sum(1)
-            pred = boxes.float()[lidx, b_idx[None], src]             # [L, M, 4]
-            tbox = torch.cat([t["boxes"] for t in targets]).float()[tgt]
-            l1 = (pred - tbox).abs().sum((1, 2))
-            giou = _paired_giou(pred, tbox)
-            lg = (1 - giou).sum(1)
-        else:
-            l1 = torch.zeros(L, device=dev) + boxes.sum() * 0
-            lg = torch.zeros(L, device=dev) + boxes.sum() * 0
-        with torch.no_grad():
-            card_pred = (logits.argmax(-1) != K - 1).sum(2).float()  # [L,B]
-            card = (card_pred - sizes[None]).abs().mean(1)
         for l in range(L):
             sfx = "" if l == L - 1 else f"_{l}"
             if "labels" in self.losses:
-                out["loss_ce" + sfx] = ce[l] / num_boxes
+                out["loss_ce" + sfx] = vals[l, 0]
             if "boxes" in self.losses:
-                out["loss_bbox" + sfx] = l1[l] / num_boxes
-                out["loss_giou" + sfx] = lg[l] / num_boxes
+                out["loss_bbox" + sfx] = vals[l, 1]
+                out["loss_giou" + sfx] = vals[l, 2]
             if "cardinality" in self.losses:
-                out["cardinality_error" + sfx] = card[l]
+                out["cardinality_error" + sfx] = vals[l, 3].detach()
         return out
 
     def _contrastive_align(self, outputs, match, targets, num_boxes, layer, L):
@@ -342,6 +324,29 @@ class SetCriterion(nn.Module):
             from .segmentation import mask_losses
             losses.update(mask_losses(outputs, targets, match, L - 1, num_boxes))
         return losses
+
+
+class _SetLossFn(torch.autograd.Function):
+    """losses [L,4] = (loss_ce, loss_bbox, loss_giou, cardinality_error) per decoder layer."""
+
+    @staticmethod
+    def forward(ctx, logits, boxes, match, positive_map, num_boxes, eos_coef):
+        L = logits.shape[0]
+        losses = torch.zeros(L, 4, dtype=torch.float32, device=logits.device)
+        k.criterion_fwd(logits, boxes, match.tgt_boxes, positive_map, match.tgt_off_dev, match.match_off_dev, match.src, match.tgt,
+                        num_boxes, eos_coef, losses)
+        ctx.save_for_backward(logits, boxes, positive_map, num_boxes)
+        ctx.match, ctx.eos = match, eos_coef
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, boxes, positive_map, num_boxes = ctx.saved_tensors
+        m = ctx.match
+        dlogits, dboxes = torch.empty_like(logits), torch.empty_like(boxes)
+        k.criterion_bwd(logits, boxes, m.tgt_boxes, positive_map, m.tgt_off_dev, m.match_off_dev, m.src, m.tgt, num_boxes, ctx.eos,
+                        g.float().contiguous(), dlogits, dboxes)
+        return dlogits, dboxes, None, None, None, None
 
 
 def _paired_giou(a, b):
