@@ -338,3 +338,92 @@ def post_process(out, target_sizes):
     h, w = target_sizes.unbind(1)
     boxes = boxes * torch.stack([w, h, w, h], dim=1)[:, None, :]
     return [{"scores": s, "labels": l, "boxes": b} for s, l, b in zip(scores, labels, boxes)]
+
+
+# ------------------------------------------------------------------------------------------ segmentation (config 3)
+
+
+def attention_map(sd, p, hs, memory, mask, nhead=8):
+    """MHAttentionMap.forward, /root/reference/models/segmentation.py:262-273: softmax over heads x H x W jointly.
+    hs [B,Q,d], memory [B,d,h,w], mask [B,h,w] bool -> [B,Q,nhead,h,w]."""
+    d = hs.shape[-1]
+    q = F.linear(hs, sd[p + "q_linear.weight"], sd[p + "q_linear.bias"])
+    k = F.conv2d(memory, sd[p + "k_linear.weight"].unsqueeze(-1).unsqueeze(-1), sd[p + "k_linear.bias"])
+    qh = q.view(q.shape[0], q.shape[1], nhead, d // nhead)
+    kh = k.view(k.shape[0], nhead, d // nhead, k.shape[-2], k.shape[-1])
+    w = torch.einsum("bqnc,bnchw->bqnhw", qh * float(d / nhead) ** -0.5, kh)
+    if mask is not None:
+        w = w.masked_fill(mask.unsqueeze(1).unsqueeze(1), float("-inf"))
+    return F.softmax(w.flatten(3), dim=-1).view_as(w)
+
+
+def mask_head(sd, p, x, bbox_mask, fpns):
+    """MaskHeadSmallConv.forward, segmentation.py:203-241 (GroupNorm(8), nearest 2x upsampling + 1x1 FPN adapters).
+    x [B,d,h,w], bbox_mask [B,Q,nhead,h,w], fpns = [C4, C3, C2] -> [B*Q,1,8h,8w]."""
+    Q = bbox_mask.shape[1]
+
+    def expand(t, n):
+        return t.unsqueeze(1).repeat(1, int(n), 1, 1, 1).flatten(0, 1)
+
+    def block(y, i):
+        y = F.conv2d(y, sd[f"{p}lay{i}.weight"], sd[f"{p}lay{i}.bias"], padding=1)
+        return F.relu(F.group_norm(y, 8, sd[f"{p}gn{i}.weight"], sd[f"{p}gn{i}.bias"]))
+
+    y = torch.cat([expand(x, Q), bbox_mask.flatten(0, 1)], 1)
+    y = block(block(y, 1), 2)
+    for i, f in enumerate(fpns, start=1):
+        cur = F.conv2d(f, sd[f"{p}adapter{i}.weight"], sd[f"{p}adapter{i}.bias"])
+        if cur.shape[0] != y.shape[0]:
+            cur = expand(cur, y.shape[0] / cur.shape[0])
+        y = cur + F.interpolate(y, size=cur.shape[-2:], mode="nearest")
+        y = block(y, i + 2)
+    return F.conv2d(y, sd[p + "out_lay.weight"], sd[p + "out_lay.bias"], padding=1)
+
+
+def segm_decode(sd, mc, out, feats, src_proj, feat_mask, *, nhead=8, prefix="detr."):
+    """The mask branch of DETRsegm.forward, segmentation.py:154-167.  `out` comes from mdetr_decode (needs 'hs');
+    feats = [C2, C3, C4, C5]; src_proj [B,d,h,w]."""
+    L = mc["text_memory"].shape[0]
+    memory = mc["img_memory"][:-L].permute(1, 2, 0).reshape(src_proj.shape)
+    P = prefix[:-5] if prefix.endswith("detr.") else ""
+    bbox_mask = attention_map(sd, P + "bbox_attention.", out["hs"][-1], memory, feat_mask, nhead)
+    seg = mask_head(sd, P + "mask_head.", src_proj, bbox_mask, [feats[2], feats[1], feats[0]])
+    B, Q = bbox_mask.shape[:2]
+    return seg.view(B, Q, seg.shape[-2], seg.shape[-1])
+
+
+def dice_loss(inputs, targets, num_boxes):
+    """segmentation.py:276-291"""
+    p = inputs.sigmoid().flatten(1)
+    num = 2 * (p * targets).sum(1)
+    den = p.sum(-1) + targets.sum(-1)
+    return (1 - (num + 1) / (den + 1)).sum() / num_boxes
+
+
+def sigmoid_focal_loss(inputs, targets, num_boxes, alpha=0.25, gamma=2.0):
+    """segmentation.py:294-319"""
+    prob = inputs.sigmoid()
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = prob * targets + (1 - prob) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss.mean(1).sum() / num_boxes
+
+
+def loss_masks(pred_masks, targets, indices, num_boxes):
+    """SetCriterion.loss_masks, mdetr.py:827-853: bilinear upsample of the matched predictions to the (padded) GT
+    size, focal + dice."""
+    batch, src = _flat_indices(indices)
+    tb = torch.cat([torch.full_like(j, i) for i, (_, j) in enumerate(indices)])
+    tj = torch.cat([j for _, j in indices])
+    H = max(t["masks"].shape[-2] for t in targets)
+    W = max(t["masks"].shape[-1] for t in targets)
+    maxT = max(t["masks"].shape[0] for t in targets)
+    padded = torch.zeros(len(targets), maxT, H, W)
+    for i, t in enumerate(targets):
+        m = t["masks"]
+        padded[i, : m.shape[0], : m.shape[1], : m.shape[2]] = m.float()
+    sm = pred_masks[batch, src]
+    sm = F.interpolate(sm[:, None], size=(H, W), mode="bilinear", align_corners=False)[:, 0].flatten(1)
+    tm = padded[tb, tj].flatten(1)
+    return {"loss_mask": sigmoid_focal_loss(sm, tm, num_boxes), "loss_dice": dice_loss(sm, tm, num_boxes)}

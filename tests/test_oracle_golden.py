@@ -138,3 +138,32 @@ def test_criterion_matches_reference():
     assert sorted(losses) == names
     for n, v in zip(names, d["values"]):
         assert abs(float(losses[n]) - v) <= 1e-5 + 1e-5 * abs(v), f"{n}: {float(losses[n])} vs {v}"
+
+
+def test_segmentation_branch_matches_reference():
+    """MHAttentionMap + MaskHeadSmallConv + loss_masks (focal, dice) vs the reference (tests/golden/segm.npz)."""
+    d = load("segm.npz")
+    with open(os.path.join(G, "reference_segm_state_dict_shapes.json")) as f:
+        shapes = json.load(f)
+    sd = formula.fill_state_dict({k: torch.zeros(s) for k, s in shapes.items()})
+    B, Q, dm, H, h, w = 2, 5, 256, 8, 3, 4
+    hs = formula.tensor("sg.hs", (B, Q, dm), 2.0)
+    memory = formula.tensor("sg.mem", (B, dm, h, w), 2.0)
+    src_proj = formula.tensor("sg.src", (B, dm, h, w), 2.0)
+    fmask = torch.from_numpy(d["fmask"])
+    fpns = [formula.tensor("sg.c4", (B, 1024, 2 * h, 2 * w), 2.0).clamp(min=0), formula.tensor("sg.c3", (B, 512, 4 * h, 4 * w), 2.0).clamp(min=0),
+            formula.tensor("sg.c2", (B, 256, 8 * h, 8 * w), 2.0).clamp(min=0)]
+    with torch.no_grad():
+        bm = model_ref.attention_map(sd, "bbox_attention.", hs, memory, fmask, H)
+        seg = model_ref.mask_head(sd, "mask_head.", src_proj, bm, fpns).view(B, Q, 8 * h, 8 * w)
+    assert np.allclose(bm.numpy(), d["bbox_mask"], atol=1e-6, rtol=1e-4)
+    assert np.allclose(seg.numpy(), d["pred_masks"], atol=2e-4, rtol=2e-4), np.abs(seg.numpy() - d["pred_masks"]).max()
+    sizes = d["sizes"].tolist()
+    targets = [{"boxes": torch.from_numpy(d[f"tboxes{i}"]), "labels": torch.ones(s, dtype=torch.int64), "masks": torch.from_numpy(d[f"tmasks{i}"])}
+               for i, s in enumerate(sizes)]
+    out = {"pred_logits": torch.from_numpy(d["logits"]), "pred_boxes": torch.from_numpy(d["boxes"])}
+    idx = matcher_ref.hungarian_match(out["pred_logits"], out["pred_boxes"], [t["boxes"] for t in targets], torch.from_numpy(d["pm"]))
+    ml = model_ref.loss_masks(torch.from_numpy(d["pred_masks"]), targets, idx, float(sum(sizes)))
+    ref = dict(zip([str(n) for n in d["names"]], d["values"]))
+    for k in ("loss_mask", "loss_dice"):
+        assert abs(float(ml[k]) - ref[k]) <= 1e-5 + 1e-5 * abs(ref[k]), (k, float(ml[k]), ref[k])

@@ -193,25 +193,26 @@ class BackboneBase(nn.Module):
 
         return prog
 
-    def forward_native(self, images, levels=(4,)):
+    def forward_native(self, images, levels=(4,), premasked=()):
         """images: fp32 NCHW on the device -> tuple of NHWC bf16 feature maps (post-ReLU) for `levels`.
-        Note: a gradient fed back into these outputs must be w.r.t. the post-ReLU values; the ReLU
-        mask of the last block is applied here before the tape replays."""
+        A gradient fed back into an output is taken w.r.t. the post-ReLU values and masked by (out > 0)
+        here, unless its index is listed in `premasked` (the consumer's dgrad epilogue already did it:
+        input_proj, toist_amd/mdetr.py)."""
         named = OrderedDict(self.body.named_parameters())
         prog = self._program(levels)
 
         def wrapped(tape, ps, img):
             outs, extra = prog(tape, ps, img)
             finals = []
-            for o in outs:
+            for oi, o in enumerate(outs):
                 f = engine.Var(o.data)
 
-                def bwd(o=o, f=f):
+                def bwd(o=o, f=f, oi=oi):
                     g = f.take_grad()
                     if g is None or not o.needs_grad:
                         return
-                    # mask by (out > 0): blocks expect gradients w.r.t. their pre-ReLU sum
-                    gm = torch.where(o.data > 0, g, torch.zeros_like(g))
+                    # blocks expect gradients w.r.t. their pre-ReLU sum: mask by (out > 0)
+                    gm = g if oi in premasked else torch.where(o.data > 0, g, torch.zeros_like(g))
                     engine.accumulate(o, gm)
 
                 tape.record(bwd)

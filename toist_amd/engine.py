@@ -130,7 +130,7 @@ def accumulate(var, g):
 
 
 # ------------------------------------------------------------------------------------------ dense ops
-def linear_chain(tape, x, layers, res=None, final_drop=False, out_dtype=BF16, last_act_external=False):
+def linear_chain(tape, x, layers, res=None, final_drop=False, out_dtype=BF16, last_act_external=False, in_relu_mask=False):
     """y = L_n(...L_1(x)), layer = (W, b, act[, dropout_after_act]); optional `+ res` after an
     optional dropout on the last layer's output (the transformer's `x + dropout(sublayer(x))`).
     Returns Var.  Activation backward of layer i is fused into the dgrad GEMM of layer i+1."""
@@ -184,7 +184,10 @@ def linear_chain(tape, x, layers, res=None, final_drop=False, out_dtype=BF16, la
                 ops.linear_wgrad(g, xin, out=W.g, bias_out=b.g if b is not None else None)
             if i == 0:
                 if x.needs_grad:
-                    x.grad = ops.linear_dgrad(g, W.w, res=x.grad)
+                    if in_relu_mask:  # x is a ReLU output whose producer wants d/d(pre-ReLU): mask in the epilogue
+                        x.grad = ops.linear_dgrad(g, W.w, res=x.grad, act=k.ACT_MASK_POS, aux=x.data)
+                    else:
+                        x.grad = ops.linear_dgrad(g, W.w, res=x.grad)
             else:
                 pW, pb, pact, pdrop = layers[i - 1]
                 _, py, ppre = acts[i - 1]

@@ -69,7 +69,7 @@ class MDETR(nn.Module):
                     x.grad = g.view(B, h, w, C)
 
             tape.record(bwd)
-            y = engine.linear_chain(tape, xin, [(Wv, b, k.ACT_NONE, False)])
+            y = engine.linear_chain(tape, xin, [(Wv, b, k.ACT_NONE, False)], in_relu_mask=True)
             return [y], None
 
         (tok,) = functions.run_program(prog, named, [c5], cache=self._cache_proj, training=self.training)
@@ -167,7 +167,7 @@ class MDETR(nn.Module):
 
     def encode(self, samples, captions, levels=(4,)):
         body = self.backbone[0]
-        feats = body.forward_native(samples.tensors, levels)
+        feats = body.forward_native(samples.tensors, levels, premasked=(len(levels) - 1,))
         c5 = feats[-1]
         B, h, w, _ = c5.shape
         mask = nearest_mask(samples.mask, (h, w))
