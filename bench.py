@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="time every GEMM launch (diagnostic; adds host overhead)")
+    ap.add_argument("--masks", action="store_true", help="config 3: add the segmentation head and the mask losses")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
     return ap.parse_args()
 
@@ -90,7 +91,7 @@ def main():
 
     import toist_amd
     from toist_amd import harness, kernels, parallel
-    args = harness.default_args(device="cuda")
+    args = harness.default_args(device="cuda", masks=a.masks, mask_model="smallconv" if a.masks else "none")
     torch.manual_seed(0)
     model, criterion, _, weight_dict = toist_amd.build_model(args)
     model.to(dev)
@@ -104,14 +105,14 @@ def main():
         {"params": [p for n, p in named if "backbone" in n], "lr": args.lr_backbone},
         {"params": [p for n, p in named if "text_encoder" in n], "lr": args.text_encoder_lr},
     ]
-    use_graph = (world == 1) and not a.no_graph and not a.profile_all
+    use_graph = (world == 1) and not a.no_graph and not a.profile_all and not a.masks
     opt = torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay, fused=True, capturable=use_graph)
     kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)  # bumped every step: fresh dropout masks per replay
     ema_src = [v for v in model.state_dict().values() if v.is_floating_point()]
     ema = [v.detach().clone() for v in ema_src]
     all_params = [p for _, p in named]
 
-    samples, tok, targets, pmap = harness.synthetic_batch(a.batch, a.size, a.size, tokens=16, seed=1000 + rank, device=dev)
+    samples, tok, targets, pmap = harness.synthetic_batch(a.batch, a.size, a.size, tokens=16, seed=1000 + rank, device=dev, with_masks=a.masks)
     sync = parallel.GradSync()
 
     def step(zero=True):
@@ -194,7 +195,7 @@ def main():
             "metric": "train images/sec/node (640x640, bs=8/GPU) + matcher index bit-match", "value": round(ips, 3), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"configs[1]: ResNet-101 + RoBERTa-base + 6+6 transformer, 100 queries, batch {a.batch}/GPU {a.size}x{a.size}, "
+            "config": {"workload": ("configs[2] (det + mask head + mask losses): " if a.masks else "") + f"configs[1]: ResNet-101 + RoBERTa-base + 6+6 transformer, 100 queries, batch {a.batch}/GPU {a.size}x{a.size}, "
                                    "16-token captions, detection loss (labels+boxes+cardinality, 5 aux layers), dropout 0.1, "
                                    "clip 0.1 + AdamW + EMA; random-init weights",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4), "launch": "hipGraph replay" if use_graph else "eager",

@@ -112,6 +112,9 @@ typedef struct toist_epilogue {
     int32_t accumulate;   /* C += v (requires out_f32); read-modify-write by the owning thread, no atomics */
     /* optional row scatter of C/res/aux: m = (n,oy,ox) in [*,cOH,cOW] -> ((n*cH + oy*cst)*cW + ox*cst) */
     int32_t cmap, cH, cW, cOH, cOW, cst;
+    /* optional residual broadcast: res row = (m / res_div) * res_mod + (m % res_mod) when res_div > 0
+       (one residual map shared by the res_div / res_mod consecutive row blocks, e.g. all queries of an image) */
+    int32_t res_div, res_mod;
     /* dropout: where = 0 none, 1 = before the residual add, 2 = after the activation */
     int32_t drop_where;
     float drop_p;
@@ -207,6 +210,32 @@ int toist_criterion_bwd(const float* logits, const float* boxes, const float* tg
                         const int32_t* tgt_off, const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx,
                         const float* num_boxes, int L, int B, int Q, int K, float eos_coef, const float* upstream,
                         float* dlogits, float* dboxes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Segmentation branch (config 3), /root/reference/models/segmentation.py.
+ *  attnmap_softmax: per-head softmax over HW of MHAttentionMap.forward (:262-273, `flatten(3)`).  scores [B,Q,H,ld] bf16
+ *      (+ key_pad [B,HW] u8) -> probabilities channels-last [B*Q, HW, H] bf16; bwd returns dscores [B*Q,H,ld].
+ *  groupnorm: torch.nn.GroupNorm(G, C) (+ReLU) on NHWC bf16 [N,HW,C] (:203-241); stats / bstats are f32 [N,G,2]
+ *      scratch owned by the caller; bwd accumulates dgamma/dbeta with atomics (caller zeroes them).
+ *  upsample_add: out[bq,Y,X,:] = fpn[bq/Q,Y,X,:] + in[bq,Y/2,X/2,:] (nearest 2x + shared FPN term); bwd = 2x2 sums.
+ *  sum_queries: out[b,i] = sum_q in[b,q,i] (backward of the per-query broadcasts).
+ *  mask_loss: bilinear (align_corners=False) upsample of pred[pred_row[t]] [h,w] f32 to [TH,TW], sigmoid focal
+ *      (alpha, gamma=2) + dice sums against gt[gt_row[t]] u8 [TH,TW] (mdetr.py:827-853, segmentation.py:276-319):
+ *      sums[t] += {focal, p*t, p, t}; bwd scatters coef[0]*dfocal + coef[1]*ddice into dpred (f32 atomics).
+ */
+int toist_attnmap_softmax_fwd(const void* scores, const uint8_t* key_pad, int B, int Q, int H, int HW, int ld, void* out, void* stream);
+int toist_attnmap_softmax_bwd(const void* prob, const void* dprob, int BQ, int H, int HW, int ld, void* dscores, void* stream);
+int toist_groupnorm_fwd(const void* x, const float* gamma, const float* beta, int N, int HW, int C, int G, float eps, int relu,
+                        void* y, float* stats, void* stream);
+int toist_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, int N, int HW, int C, int G,
+                        float eps, int relu, void* dx, float* dgamma, float* dbeta, float* bstats, void* stream);
+int toist_upsample_add(const void* in, const void* fpn, int BQ, int Q, int H, int W, int C, void* out, void* stream);
+int toist_upsample_add_bwd(const void* dout, int BQ, int H, int W, int C, void* din, void* stream);
+int toist_sum_queries(const void* in, int B, int Q, int64_t per, void* out, void* stream);
+int toist_mask_loss_fwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
+                        int TH, int TW, float alpha, float* sums, void* stream);
+int toist_mask_loss_bwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
+                        int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred, void* stream);
 
 #ifdef __cplusplus
 }

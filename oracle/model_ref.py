@@ -344,7 +344,7 @@ def post_process(out, target_sizes):
 
 
 def attention_map(sd, p, hs, memory, mask, nhead=8):
-    """MHAttentionMap.forward, /root/reference/models/segmentation.py:262-273: softmax over heads x H x W jointly.
+    """MHAttentionMap.forward, /root/reference/models/segmentation.py:262-273: `flatten(3)` = softmax over H x W per head.
     hs [B,Q,d], memory [B,d,h,w], mask [B,h,w] bool -> [B,Q,nhead,h,w]."""
     d = hs.shape[-1]
     q = F.linear(hs, sd[p + "q_linear.weight"], sd[p + "q_linear.bias"])

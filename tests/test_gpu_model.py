@@ -131,3 +131,51 @@ def test_criterion_and_gradients(dev, setup):
     assert not bad, f"gradient mismatch (cos, norm ratio): {bad}\nall: {worst}"
     frozen = params["backbone.0.body.layer1.0.conv1.weight"]
     assert frozen.grad is None and not frozen.requires_grad
+
+
+def test_segmentation_model_end_to_end(dev):
+    """Config 3: build_model(masks=True) -> DETRsegm; pred_masks vs the oracle, mask losses, a backward pass."""
+    import toist_amd
+    from oracle import model_ref
+    from toist_amd import harness
+    torch.manual_seed(0)
+    args = harness.default_args(device="cuda", masks=True, mask_model="smallconv")
+    model, criterion, _, weight_dict = toist_amd.build_model(args)
+    assert type(model).__name__ == "DETRsegm" and hasattr(model, "detr") and "loss_dice" in weight_dict
+    for n, b in model.named_buffers():
+        if n.endswith("bn3.weight"):
+            b.mul_(0.3)
+    sd = {k_: v.detach().clone().float() for k_, v in model.state_dict().items()}
+    assert "mask_head.adapter3.bias" in sd and "detr.transformer.encoder.layers.0.linear1.weight" in sd
+    model.to(dev).eval()
+    samples, tok, targets, pmap = harness.synthetic_batch(2, 128, 160, tokens=12, seed=9, max_targets=4, with_masks=True)
+    t_dev = [{k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in t.items()} for t in targets]
+    mc = model(samples.to(dev), tok.to(dev), encode_and_save=True)
+    out = model(samples.to(dev), tok.to(dev), encode_and_save=False, memory_cache=mc)
+    assert out["pred_masks"].shape == (2, 100, 32, 40)
+    assert len(mc["features_4_mask"]) == 4 and mc["src_proj_4_mask"].shape == (2, 256, 4, 5)
+    losses = criterion(mc, out, t_dev, pmap.to(dev), None)
+    assert {"loss_mask", "loss_dice"} <= set(losses)
+    total = sum(losses[k_] * weight_dict[k_] for k_ in losses if k_ in weight_dict)
+    total.backward()
+    torch.cuda.synchronize()
+    # oracle forward on the same weights / inputs
+    dsd = {k_[5:]: v for k_, v in sd.items() if k_.startswith("detr.")}
+    feats = model_ref.resnet_body(samples.tensors, dsd, "backbone.0.body.")
+    rmc = model_ref.mdetr_encode(dsd, samples.tensors, samples.mask, tok["input_ids"], tok["attention_mask"], features=feats[-1])
+    rout = model_ref.mdetr_decode(dsd, rmc)
+    src_proj = torch.nn.functional.conv2d(feats[-1], dsd["input_proj.weight"], dsd["input_proj.bias"])
+    fmask = model_ref.downsample_mask(samples.mask, feats[-1].shape[-2:])
+    rmasks = model_ref.segm_decode(sd, rmc, rout, feats, src_proj, fmask, prefix="detr.")
+    e = rel_err(out["pred_masks"], rmasks)
+    assert e < 6e-2, f"pred_masks rel err {e}"
+    # mask losses on the GPU model's own predictions vs the oracle formulas (same assignment)
+    L = out["_stacked"]["pred_logits"].shape[0]
+    idx = criterion.last_match.to_list(L - 1)
+    nb = max(float(sum(len(t["boxes"]) for t in targets)), 1.0)
+    ref = model_ref.loss_masks(out["pred_masks"].detach().float().cpu(), targets, idx, nb)
+    for k_ in ("loss_mask", "loss_dice"):
+        assert abs(float(losses[k_]) - float(ref[k_])) <= 2e-3 * abs(float(ref[k_])) + 1e-5, (k_, float(losses[k_]), float(ref[k_]))
+    g = model.mask_head.lay3.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    assert model.detr.backbone[0].body.layer2[0].conv1.weight.grad is not None

@@ -1,0 +1,99 @@
+"""GPU parity of the segmentation branch (config 3) against the oracle (pinned to the reference by
+tests/golden/segm.npz): attention map + mask head forward (rel err <= 4e-2, bf16 vs fp32), parameter and
+input gradients (cosine >= 0.97), and the fused mask losses (focal + dice) forward / backward (rtol 1e-3)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def cos(a, b):
+    return float(torch.nn.functional.cosine_similarity(a.float().cpu().flatten(), b.float().cpu().flatten(), dim=0))
+
+
+def test_mask_head_forward_backward(dev):
+    from oracle import model_ref
+    from toist_amd.segmentation import DETRsegm, MaskHeadSmallConv, MHAttentionMap
+    torch.manual_seed(0)
+    B, Q, d, H, h, w = 2, 6, 256, 8, 5, 6
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.transformer = type("T", (), {"d_model": d, "nhead": H})()
+    seg = DETRsegm(Stub(), "smallconv", freeze_detr=False)
+    g = torch.Generator().manual_seed(1)
+    for n, p in seg.named_parameters():
+        if n.endswith("bias") or "gn" in n:
+            p.data.add_(torch.randn(p.shape, generator=g) * 0.05)
+    sd = {k_: v.detach().clone().float().requires_grad_(True) for k_, v in seg.state_dict().items()}
+    seg.to(dev)
+    hs = (torch.randn(B, Q, d, generator=g)).to(BF)
+    mem = (torch.randn(B, h * w, d, generator=g)).to(BF)
+    src = (torch.randn(B, h * w, d, generator=g)).to(BF)
+    c4 = torch.randn(B, 2 * h, 2 * w, 1024, generator=g).clamp(min=0).to(BF)
+    c3 = torch.randn(B, 4 * h, 4 * w, 512, generator=g).clamp(min=0).to(BF)
+    c2 = torch.randn(B, 8 * h, 8 * w, 256, generator=g).clamp(min=0).to(BF)
+    fmask = torch.zeros(B, h, w, dtype=torch.bool)
+    fmask[1, :, 4:] = True
+    ins = [t.to(dev).requires_grad_(True) for t in (hs.view(B * Q, d), mem.view(B * h * w, d), src.view(B * h * w, d), c4, c3, c2)]
+    masks = seg._masks(*ins, fmask.to(dev), B, Q, h, w)
+    gout = torch.randn(masks.shape, generator=g) * 0.1
+    masks.backward(gout.to(dev))
+    torch.cuda.synchronize()
+    # oracle (fp32 on the same bf16-rounded inputs)
+    r = [t.float().requires_grad_(True) for t in (hs, mem, src, c4, c3, c2)]
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    bm = model_ref.attention_map(sd, "bbox_attention.", r[0], r[1].transpose(1, 2).reshape(B, d, h, w), fmask, H)
+    ref = model_ref.mask_head(sd, "mask_head.", r[2].transpose(1, 2).reshape(B, d, h, w), bm, [nchw(r[3]), nchw(r[4]), nchw(r[5])])
+    ref = ref.view(B, Q, 8 * h, 8 * w)
+    ref.backward(gout)
+    assert rel(masks, ref) < 4e-2, rel(masks, ref)
+    bad = {}
+    top = max(float(v.grad.norm()) for v in sd.values())
+    for n, p in seg.named_parameters():
+        rn = float(sd[n].grad.norm())
+        if rn < 1e-5 * top:
+            # analytically zero gradient (k_linear.bias: a constant key shift leaves every softmax unchanged):
+            # only bf16 round-off may remain
+            assert float(p.grad.float().norm()) < 1e-2 * top, n
+            continue
+        c, ratio = cos(p.grad, sd[n].grad), float(p.grad.float().norm().cpu() / (rn + 1e-20))
+        if c < 0.97 or not (0.8 < ratio < 1.25):
+            bad[n] = (round(c, 4), round(ratio, 3))
+    assert not bad, bad
+    names = ["hs", "memory", "src_proj", "c4", "c3", "c2"]
+    for n, a, b in zip(names, ins, r):
+        got = a.grad.float().cpu().reshape(b.grad.shape)
+        assert cos(got, b.grad) > 0.97, (n, cos(got, b.grad))
+
+
+def test_mask_losses(dev):
+    from oracle import model_ref
+    from toist_amd.matcher import MatchResult
+    from toist_amd.segmentation import mask_losses
+    g = torch.Generator().manual_seed(3)
+    B, Q, hm, wm = 2, 7, 24, 32
+    pred = (torch.randn(B, Q, hm, wm, generator=g) * 2).requires_grad_(True)
+    sizes = [2, 3]
+    targets = [{"masks": torch.rand(t, 96 - 8 * i, 128, generator=g) > 0.6, "boxes": torch.zeros(t, 4)} for i, t in enumerate(sizes)]
+    indices = [(torch.tensor([1, 4]), torch.tensor([1, 0])), (torch.tensor([0, 2, 6]), torch.tensor([2, 0, 1]))]
+    ref = model_ref.loss_masks(pred, targets, indices, 5.0)
+    (ref["loss_mask"] * 1.5 + ref["loss_dice"] * 0.7).backward()
+    src = torch.cat([i for i, _ in indices])[None].to(dev)
+    tgt = torch.cat([j for _, j in indices])[None].to(dev)
+    match = MatchResult(src, tgt, torch.zeros(B, dtype=torch.int32), sizes, Q)
+    p2 = pred.detach().to(dev).requires_grad_(True)
+    t_dev = [{k_: v.to(dev) for k_, v in t.items()} for t in targets]
+    got = mask_losses({"pred_masks": p2}, t_dev, match, 0, torch.tensor(5.0, device=dev))
+    (got["loss_mask"] * 1.5 + got["loss_dice"] * 0.7).backward()
+    for k_ in ("loss_mask", "loss_dice"):
+        assert abs(float(got[k_]) - float(ref[k_])) <= 1e-4 * abs(float(ref[k_])) + 1e-6, (k_, float(got[k_]), float(ref[k_]))
+    err = float((p2.grad.cpu() - pred.grad).abs().max())
+    assert err <= 1e-3 * float(pred.grad.abs().max()) + 1e-8, err

@@ -30,7 +30,7 @@ class Epilogue(Structure):
         ("alpha", c_float), ("scale", c_void_p), ("shift", c_void_p), ("rscale", c_void_p), ("res", c_void_p), ("ldr", c_int32),
         ("aux", c_void_p), ("ldaux", c_int32), ("act", c_int32), ("pre_out", c_void_p), ("out_f32", c_int32),
         ("accumulate", c_int32), ("cmap", c_int32), ("cH", c_int32), ("cW", c_int32), ("cOH", c_int32),
-        ("cOW", c_int32), ("cst", c_int32), ("drop_where", c_int32), ("drop_p", c_float), ("drop_seed", c_uint64), ("drop_seed_dev", c_void_p),
+        ("cOW", c_int32), ("cst", c_int32), ("res_div", c_int32), ("res_mod", c_int32), ("drop_where", c_int32), ("drop_p", c_float), ("drop_seed", c_uint64), ("drop_seed_dev", c_void_p),
     ]
 
 
@@ -62,6 +62,15 @@ _SIGNATURES = {
     "toist_embed_bwd": ([c_void_p] * 3 + [c_int32, c_int32, c_int64] + [c_void_p] * 4, ctypes.c_int),
     "toist_criterion_fwd": ([c_void_p] * 9 + [c_int32] * 4 + [c_float, c_void_p, c_void_p], ctypes.c_int),
     "toist_criterion_bwd": ([c_void_p] * 9 + [c_int32] * 4 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_attnmap_softmax_fwd": ([c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p], ctypes.c_int),
+    "toist_attnmap_softmax_bwd": ([c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p, c_void_p], ctypes.c_int),
+    "toist_groupnorm_fwd": ([c_void_p] * 3 + [c_int32] * 4 + [c_float, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_groupnorm_bwd": ([c_void_p] * 5 + [c_int32] * 4 + [c_float, c_int32] + [c_void_p] * 5, ctypes.c_int),
+    "toist_upsample_add": ([c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p], ctypes.c_int),
+    "toist_upsample_add_bwd": ([c_void_p] + [c_int32] * 4 + [c_void_p, c_void_p], ctypes.c_int),
+    "toist_sum_queries": ([c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_loss_fwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_loss_bwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_dropout_bf16": ([c_void_p, c_int64, c_float, c_uint64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
 }
 

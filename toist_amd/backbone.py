@@ -164,7 +164,7 @@ class BackboneBase(nn.Module):
             xin = torch.empty(N, H, W, 8, dtype=BF16, device=x.device)
             k.pack_image(x.contiguous(), xin)
             s0, t0 = bn("bn1")
-            y = ops.conv2d(xin, engine.krsc(ps["conv1.weight"].w), stride=2, pad=3, shift=t0, act=k.ACT_RELU)
+            y = ops.conv2d(xin, engine.krsc(ps["conv1.weight"].w), stride=2, pad=3, shift=t0, act=k.ACT_RELU, cin_real=C)
             OH, OW = (y.shape[1] + 2 - 3) // 2 + 1, (y.shape[2] + 2 - 3) // 2 + 1
             pooled = torch.empty(N, OH, OW, 64, dtype=BF16, device=x.device)
             k.maxpool3x3s2(y, pooled)

@@ -66,7 +66,8 @@ __device__ __forceinline__ void epilogue_frag(const toist_gemm& p, const f32x4_t
         v3 = dropout_keep(dseed, didx + 3, th) ? v3 * sc : 0.f;
     }
     if (e.res) {
-        const bf16_t* rp = (const bf16_t*)e.res + coff + crow * e.ldr + n;
+        const long long rrow = (e.res_div > 0) ? (long long)(m / e.res_div) * e.res_mod + (m % e.res_mod) : crow;
+        const bf16_t* rp = (const bf16_t*)e.res + coff + rrow * e.ldr + n;
         if (nv == 4 && ((((size_t)rp) & 7) == 0)) {
             const uint2 u = *reinterpret_cast<const uint2*>(rp);
             v0 += __uint_as_float(u.x << 16); v1 += __uint_as_float(u.x & 0xffff0000u);
@@ -268,7 +269,7 @@ __device__ __forceinline__ void load_b(unsigned lds, const i32x4_t& rs, const Ch
         const int k = k0 + c.row;
         int off;
         if (o.kin > 0) {
-            const int tap = k0 / o.kin;
+            const int tap = (o.kin % BK == 0) ? k0 / o.kin : k / o.kin;   // tile-uniform when a k-tile never straddles taps
             off = c.base + (k - tap * o.kin) * ldb + tap * (int)o.tap_stride;
         } else off = c.base + k * ldb;
         dma16(lds, rs, off, c.ok && k < K);
@@ -614,8 +615,8 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     }
     // tile codes: 64 = 64x64x32, 65 = 64x64x64, 128 = 128x128x32, 129 = 128x128x64, 130 = 128x64x64
     const int bkt = (tile == 64 || tile == 128) ? 32 : 64;
-    if (d.a_kind == TOIST_A_CONVT) TOIST_REQUIRE((d.a.SC % bkt) == 0, "toist_gemm_bf16: CONVT needs source channels %% BK == 0");
-    if (d.b_kind == TOIST_B_KROW && d.b.kin > 0) TOIST_REQUIRE((d.b.kin % bkt) == 0, "toist_gemm_bf16: kin %% BK != 0");
+    if (d.b_kind == TOIST_B_KROW && d.b.kin > 0) TOIST_REQUIRE((d.b.kin % 8) == 0, "toist_gemm_bf16: kin %% 8 != 0");
+    (void)bkt;
     int rc;
     hipStream_t st = (hipStream_t)stream;
     switch (tile) {

@@ -1,0 +1,465 @@
+// Segmentation-branch kernels (config 3): /root/reference/models/segmentation.py
+//   attnmap_softmax  : the per-head softmax over H x W of MHAttentionMap.forward (:262-273, `flatten(3)`)
+//   groupnorm(+ReLU) : torch.nn.GroupNorm(8, C) + F.relu of MaskHeadSmallConv.forward (:203-241), NHWC
+//   upsample_add     : `cur_fpn + F.interpolate(x, size, mode="nearest")` with the FPN term shared by all queries
+//   sum_over_queries : reduction used by the backward of every "expand(...)" broadcast (:204-205)
+//   mask_loss        : bilinear upsample + sigmoid focal + dice of SetCriterion.loss_masks (mdetr.py:827-853,
+//                      segmentation.py:276-319), forward and backward
+// All of these are HBM-bound passes over bf16 activations (16-byte vector accesses, fp32 math).
+#include "common.h"
+
+namespace toist {
+
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+__device__ __forceinline__ float block_reduce_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_reduce_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ------------------------------------------------------------------------------- attention-map softmax
+// MHAttentionMap.forward normalises `weights.flatten(3)`, i.e. over the H*W positions of EACH head
+// (segmentation.py:271).  scores [B,Q,H,ld] bf16 (ld >= HW) -> probabilities channels-last [B*Q, HW, H] bf16
+// (heads innermost: the layout the mask head's first convolution gathers).  One wave per (b,q,head) row.
+__global__ __launch_bounds__(256) void attnmap_softmax_fwd_kernel(const bf16_t* __restrict__ s, const unsigned char* __restrict__ key_pad,
+                                                                   int rows, int Q, int H, int HW, int ld, bf16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // (b*Q + q)*H + h
+    if (row >= rows) return;
+    const int bq = row / H, h = row - bq * H, b = bq / Q;
+    const bf16_t* sr = s + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int p = lane; p < HW; p += 64) {
+        const float v = (key_pad && key_pad[(size_t)b * HW + p]) ? -INFINITY : bf2f(sr[p]);
+        mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int p = lane; p < HW; p += 64) {
+        const float v = (key_pad && key_pad[(size_t)b * HW + p]) ? -INFINITY : bf2f(sr[p]);
+        sum += __expf(v - mx);
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int p = lane; p < HW; p += 64) {
+        const float v = (key_pad && key_pad[(size_t)b * HW + p]) ? -INFINITY : bf2f(sr[p]);
+        out[((size_t)bq * HW + p) * H + h] = f2bf(__expf(v - mx) * inv);
+    }
+}
+// dscores[b,q,h,p] = P * (dP - sum_p(P*dP)) per head; prob / dprob are channels-last [B*Q, HW, H]
+__global__ __launch_bounds__(256) void attnmap_softmax_bwd_kernel(const bf16_t* __restrict__ prob, const bf16_t* __restrict__ dprob, int rows, int H,
+                                                                   int HW, int ld, bf16_t* __restrict__ ds) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int bq = row / H, h = row - bq * H;
+    float dot = 0.f;
+    for (int p = lane; p < HW; p += 64) {
+        const size_t j = ((size_t)bq * HW + p) * H + h;
+        dot += bf2f(prob[j]) * bf2f(dprob[j]);
+    }
+    dot = wave_sum(dot);
+    for (int p = lane; p < ld; p += 64) {
+        float v = 0.f;
+        if (p < HW) {
+            const size_t j = ((size_t)bq * HW + p) * H + h;
+            v = bf2f(prob[j]) * (bf2f(dprob[j]) - dot);
+        }
+        ds[(size_t)row * ld + p] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------- GroupNorm (+ReLU), NHWC
+// Work split shared by the reducing GroupNorm kernels: a block owns a slab of pixels of sample n; thread t always
+// handles channel chunk (t % c8) of pixel (t / c8) + k * (256 / c8), so its 8 channels -- and their groups -- are fixed
+// and every partial sum stays in registers until one LDS/global atomic per channel at the end.
+// stats[n][g] = {sum, sum of squares} over the (HW x C/G) elements of group g of sample n (f32 atomics).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, int HW, int C, int G, float* __restrict__ stats) {
+    __shared__ float acc[2][16];
+    const int n = blockIdx.y;
+    const int Cg = C / G, c8 = C >> 3;
+    if (threadIdx.x < 32) acc[threadIdx.x >> 4][threadIdx.x & 15] = 0.f;
+    __syncthreads();
+    const int ppi = 256 / c8;                      // pixels per block iteration
+    const int cc = threadIdx.x % c8, pl = threadIdx.x / c8;
+    const int per = (HW + gridDim.x - 1) / gridDim.x;
+    const int p_beg = blockIdx.x * per, p_end = (p_beg + per < HW) ? p_beg + per : HW;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (pl < ppi) {
+        for (int p = p_beg + pl; p < p_end; p += ppi) {
+            float v[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + ((size_t)n * HW + p) * C + cc * 8), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (cc * 8 + j) / Cg;
+            atomicAdd(&acc[0][g], s[j]);
+            atomicAdd(&acc[1][g], q[j]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        atomicAdd(stats + ((size_t)n * G + threadIdx.x) * 2, acc[0][threadIdx.x]);
+        atomicAdd(stats + ((size_t)n * G + threadIdx.x) * 2 + 1, acc[1][threadIdx.x]);
+    }
+}
+// y = relu((x - mean) * rstd * gamma + beta)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int HW, int C, int G, float eps, int relu,
+                                                        bf16_t* __restrict__ y) {
+    const int n = blockIdx.y;
+    const int Cg = C / G, c8 = C >> 3;
+    const float cnt = (float)HW * (float)Cg;
+    const long long total = (long long)HW * c8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cc = (int)(i % c8);
+        float v[8];
+        const size_t off = ((size_t)n * HW * C) + (size_t)i * 8;
+        unpack8(*reinterpret_cast<const uint4*>(x + off), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cc * 8 + j, g = c / Cg;
+            const float mean = stats[((size_t)n * G + g) * 2] / cnt;
+            const float var = fmaxf(stats[((size_t)n * G + g) * 2 + 1] / cnt - mean * mean, 0.f);
+            const float o = (v[j] - mean) * rsqrtf(var + eps) * gamma[c] + beta[c];
+            v[j] = relu ? fmaxf(o, 0.f) : o;
+        }
+        *reinterpret_cast<uint4*>(y + off) = pack8(v);
+    }
+}
+// backward pass 1: with g = dy * (y > 0): bstats[n][g] = {sum g*gamma, sum g*gamma*xhat}; dgamma[c] += sum g*xhat; dbeta[c] += sum g
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma, int HW, int C, int G,
+                                                            float eps, int relu, float* __restrict__ bstats, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+    extern __shared__ float sm[];  // [2][C] channel partials + [2][16] group partials
+    float* cg = sm;
+    float* cb = sm + C;
+    float* ga = sm + 2 * C;
+    const int n = blockIdx.y;
+    const int Cg = C / G, c8 = C >> 3;
+    const float cnt = (float)HW * (float)Cg;
+    for (int i = threadIdx.x; i < 2 * C + 32; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    const int ppi = 256 / c8;
+    const int cc = threadIdx.x % c8, pl = threadIdx.x / c8;
+    const int per = (HW + gridDim.x - 1) / gridDim.x;
+    const int p_beg = blockIdx.x * per, p_end = (p_beg + per < HW) ? p_beg + per : HW;
+    if (pl < ppi) {
+        float mean[8], rs[8], gm[8], a_gx[8], a_g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cc * 8 + j, g = c / Cg;
+            mean[j] = stats[((size_t)n * G + g) * 2] / cnt;
+            const float var = fmaxf(stats[((size_t)n * G + g) * 2 + 1] / cnt - mean[j] * mean[j], 0.f);
+            rs[j] = rsqrtf(var + eps);
+            gm[j] = gamma[c];
+            a_gx[j] = 0.f; a_g[j] = 0.f;
+        }
+        for (int p = p_beg + pl; p < p_end; p += ppi) {
+            float d[8], yy[8], xv[8];
+            const size_t off = ((size_t)n * HW + p) * C + cc * 8;
+            unpack8(*reinterpret_cast<const uint4*>(dy + off), d);
+            unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
+            if (relu) unpack8(*reinterpret_cast<const uint4*>(y + off), yy);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gj = (relu && !(yy[j] > 0.f)) ? 0.f : d[j];
+                a_gx[j] += gj * (xv[j] - mean[j]) * rs[j];
+                a_g[j] += gj;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cc * 8 + j, g = c / Cg;
+            atomicAdd(&cg[c], a_gx[j]);
+            atomicAdd(&cb[c], a_g[j]);
+            atomicAdd(&ga[g], a_g[j] * gm[j]);
+            atomicAdd(&ga[16 + g], a_gx[j] * gm[j]);
+        }
+    }
+    __syncthreads();
+    if (dgamma)
+        for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(dgamma + c, cg[c]); atomicAdd(dbeta + c, cb[c]); }
+    if (threadIdx.x < G) {
+        atomicAdd(bstats + ((size_t)n * G + threadIdx.x) * 2, ga[threadIdx.x]);
+        atomicAdd(bstats + ((size_t)n * G + threadIdx.x) * 2 + 1, ga[16 + threadIdx.x]);
+    }
+}
+// backward pass 2: dx = rstd * (g*gamma - mean_g(g*gamma) - xhat * mean_g(g*gamma*xhat))
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
+                                                            const float* __restrict__ stats, const float* __restrict__ bstats,
+                                                            const float* __restrict__ gamma, int HW, int C, int G, float eps, int relu,
+                                                            bf16_t* __restrict__ dx) {
+    const int n = blockIdx.y;
+    const int Cg = C / G, c8 = C >> 3;
+    const float cnt = (float)HW * (float)Cg;
+    const long long total = (long long)HW * c8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cc = (int)(i % c8);
+        float d[8], yy[8], xv[8];
+        const size_t off = ((size_t)n * HW * C) + (size_t)i * 8;
+        unpack8(*reinterpret_cast<const uint4*>(dy + off), d);
+        unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
+        if (relu) unpack8(*reinterpret_cast<const uint4*>(y + off), yy);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cc * 8 + j, g = c / Cg;
+            const float mean = stats[((size_t)n * G + g) * 2] / cnt;
+            const float var = fmaxf(stats[((size_t)n * G + g) * 2 + 1] / cnt - mean * mean, 0.f);
+            const float rs = rsqrtf(var + eps);
+            const float xh = (xv[j] - mean) * rs;
+            const float gj = (relu && !(yy[j] > 0.f)) ? 0.f : d[j];
+            const float m1 = bstats[((size_t)n * G + g) * 2] / cnt, m2 = bstats[((size_t)n * G + g) * 2 + 1] / cnt;
+            d[j] = rs * (gj * gamma[c] - m1 - xh * m2);
+        }
+        *reinterpret_cast<uint4*>(dx + off) = pack8(d);
+    }
+}
+
+// ------------------------------------------------------------------------------- nearest 2x upsample + shared FPN term
+// out[bq, Y, X, :] = fpn[bq / Q, Y, X, :] + in[bq, Y/2, X/2, :]   (in is [BQ, H, W, C], out [BQ, 2H, 2W, C])
+__global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ fpn, int BQ, int Q, int H,
+                                                            int W, int C, bf16_t* __restrict__ out) {
+    const int c8 = C >> 3, OH = 2 * H, OW = 2 * W;
+    const long long total = (long long)BQ * OH * OW * c8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cc = (int)(i % c8);
+        long long p = i / c8;
+        const int X = (int)(p % OW); p /= OW;
+        const int Y = (int)(p % OH);
+        const int bq = (int)(p / OH);
+        float a[8], f[8];
+        unpack8(*reinterpret_cast<const uint4*>(in + ((((size_t)bq * H + (Y >> 1)) * W + (X >> 1)) * C) + cc * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(fpn + ((((size_t)(bq / Q) * OH + Y) * OW + X) * C) + cc * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += f[j];
+        *reinterpret_cast<uint4*>(out + (size_t)i * 8) = pack8(a);
+    }
+}
+// din[bq, y, x, :] = sum of the 4 output pixels that read it
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const bf16_t* __restrict__ dout, int BQ, int H, int W, int C, bf16_t* __restrict__ din) {
+    const int c8 = C >> 3, OW = 2 * W;
+    const long long total = (long long)BQ * H * W * c8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cc = (int)(i % c8);
+        long long p = i / c8;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const int bq = (int)(p / H);
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float v[8];
+                unpack8(*reinterpret_cast<const uint4*>(dout + ((((size_t)bq * 2 * H + 2 * y + dy) * OW + 2 * x + dx) * C) + cc * 8), v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += v[j];
+            }
+        *reinterpret_cast<uint4*>(din + (size_t)i * 8) = pack8(a);
+    }
+}
+// out[b, i] = sum_q in[b, q, i]   (i over HW*C elements, 8 per thread)
+__global__ __launch_bounds__(256) void sum_queries_kernel(const bf16_t* __restrict__ in, int B, int Q, long long per8, bf16_t* __restrict__ out) {
+    const long long total = (long long)B * per8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / per8, r = i - b * per8;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < Q; ++q) {
+            float v[8];
+            unpack8(reinterpret_cast<const uint4*>(in)[(b * Q + q) * per8 + r], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += v[j];
+        }
+        reinterpret_cast<uint4*>(out)[i] = pack8(a);
+    }
+}
+
+// ------------------------------------------------------------------------------- mask losses
+// For matched pair t: prediction map pred[pred_row[t]] [h,w] f32 is bilinearly upsampled (align_corners=False) to
+// [TH,TW] and compared with gt[gt_row[t]] (u8 [TH,TW], zero padded like NestedTensor.from_tensor_list).  Accumulates per pair
+// sums[t] = {sum focal, sum p*t, sum p, sum t}.
+__device__ __forceinline__ void bilinear_src(int o, int in, int out, int& i0, int& i1, float& w1) {
+    float s = ((float)o + 0.5f) * ((float)in / (float)out) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    i1 = (i0 < in - 1) ? i0 + 1 : i0;
+    w1 = s - (float)i0;
+}
+__global__ __launch_bounds__(256) void mask_loss_fwd_kernel(const float* __restrict__ pred, const int* __restrict__ pred_row,
+                                                             const unsigned char* __restrict__ gt, const int* __restrict__ gt_row,
+                                                             int h, int w, int TH, int TW, float alpha, float* __restrict__ sums) {
+    __shared__ float red[4];
+    const int t = blockIdx.y;
+    const float* pm = pred + (size_t)pred_row[t] * h * w;
+    const unsigned char* gm = gt + (size_t)gt_row[t] * TH * TW;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int total = TH * TW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int Y = i / TW, X = i - Y * TW;
+        int y0, y1, x0, x1; float wy, wx;
+        bilinear_src(Y, h, TH, y0, y1, wy);
+        bilinear_src(X, w, TW, x0, x1, wx);
+        const float v = (1.f - wy) * ((1.f - wx) * pm[y0 * w + x0] + wx * pm[y0 * w + x1]) + wy * ((1.f - wx) * pm[y1 * w + x0] + wx * pm[y1 * w + x1]);
+        const float tg = gm[i] ? 1.f : 0.f;
+        const float p = 1.f / (1.f + __expf(-v));
+        const float ce = fmaxf(v, 0.f) - v * tg + log1pf(__expf(-fabsf(v)));   // BCE with logits
+        const float pt = p * tg + (1.f - p) * (1.f - tg);
+        const float at = alpha * tg + (1.f - alpha) * (1.f - tg);
+        a0 += at * ce * (1.f - pt) * (1.f - pt);
+        a1 += p * tg; a2 += p; a3 += tg;
+    }
+    a0 = block_reduce_sum(a0, red); a1 = block_reduce_sum(a1, red); a2 = block_reduce_sum(a2, red); a3 = block_reduce_sum(a3, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + t * 4 + 0, a0); atomicAdd(sums + t * 4 + 1, a1); atomicAdd(sums + t * 4 + 2, a2); atomicAdd(sums + t * 4 + 3, a3);
+    }
+}
+// d(loss_mask*g_f + loss_dice*g_d)/d pred, scattered back through the bilinear weights (f32 atomics into dpred,
+// which the caller zeroes).  scale_f = g_f / (TH*TW*num_boxes), scale_d = g_d / num_boxes are read from `coef`.
+__global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restrict__ pred, const int* __restrict__ pred_row,
+                                                             const unsigned char* __restrict__ gt, const int* __restrict__ gt_row,
+                                                             int h, int w, int TH, int TW, float alpha, const float* __restrict__ sums,
+                                                             const float* __restrict__ coef, float* __restrict__ dpred) {
+    const int t = blockIdx.y;
+    const float* pm = pred + (size_t)pred_row[t] * h * w;
+    float* dp = dpred + (size_t)pred_row[t] * h * w;
+    const unsigned char* gm = gt + (size_t)gt_row[t] * TH * TW;
+    const float sf = coef[0], sd = coef[1];
+    const float num = 2.f * sums[t * 4 + 1] + 1.f, den = sums[t * 4 + 2] + sums[t * 4 + 3] + 1.f;
+    const int total = TH * TW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int Y = i / TW, X = i - Y * TW;
+        int y0, y1, x0, x1; float wy, wx;
+        bilinear_src(Y, h, TH, y0, y1, wy);
+        bilinear_src(X, w, TW, x0, x1, wx);
+        const float v = (1.f - wy) * ((1.f - wx) * pm[y0 * w + x0] + wx * pm[y0 * w + x1]) + wy * ((1.f - wx) * pm[y1 * w + x0] + wx * pm[y1 * w + x1]);
+        const float tg = gm[i] ? 1.f : 0.f;
+        const float p = 1.f / (1.f + __expf(-v));
+        const float ce = fmaxf(v, 0.f) - v * tg + log1pf(__expf(-fabsf(v)));
+        const float pt = p * tg + (1.f - p) * (1.f - tg);
+        const float at = alpha * tg + (1.f - alpha) * (1.f - tg);
+        // focal: d/dv [at * ce * (1-pt)^2], dce/dv = p - t, dpt/dv = (2t-1) p (1-p)
+        const float dfocal = at * ((p - tg) * (1.f - pt) * (1.f - pt) - ce * 2.f * (1.f - pt) * (2.f * tg - 1.f) * p * (1.f - p));
+        // dice: loss = 1 - num/den ; d/dp = -(2 t den - num) / den^2
+        const float ddice = -(2.f * tg * den - num) / (den * den) * p * (1.f - p);
+        const float gv = sf * dfocal + sd * ddice;
+        atomicAdd(dp + y0 * w + x0, gv * (1.f - wy) * (1.f - wx));
+        atomicAdd(dp + y0 * w + x1, gv * (1.f - wy) * wx);
+        atomicAdd(dp + y1 * w + x0, gv * wy * (1.f - wx));
+        atomicAdd(dp + y1 * w + x1, gv * wy * wx);
+    }
+}
+
+static inline int grid_cap(long long n, int cap = 4096) {
+    long long g = (n + 255) / 256;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+}  // namespace toist
+
+using namespace toist;
+
+extern "C" int toist_attnmap_softmax_fwd(const void* scores, const uint8_t* key_pad, int B, int Q, int H, int HW, int ld, void* out, void* stream) {
+    TOIST_REQUIRE(B > 0 && Q > 0 && H > 0 && HW > 0 && ld >= HW, "toist_attnmap_softmax_fwd: bad shape");
+    const int rows = B * Q * H;
+    hipLaunchKernelGGL(attnmap_softmax_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)scores, key_pad, rows, Q, H,
+                       HW, ld, (bf16_t*)out);
+    return check_launch("toist_attnmap_softmax_fwd");
+}
+extern "C" int toist_attnmap_softmax_bwd(const void* prob, const void* dprob, int BQ, int H, int HW, int ld, void* dscores, void* stream) {
+    TOIST_REQUIRE(BQ > 0 && H > 0 && HW > 0 && ld >= HW, "toist_attnmap_softmax_bwd: bad shape");
+    const int rows = BQ * H;
+    hipLaunchKernelGGL(attnmap_softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)prob, (const bf16_t*)dprob, rows,
+                       H, HW, ld, (bf16_t*)dscores);
+    return check_launch("toist_attnmap_softmax_bwd");
+}
+
+extern "C" int toist_groupnorm_fwd(const void* x, const float* gamma, const float* beta, int N, int HW, int C, int G, float eps, int relu,
+                                   void* y, float* stats, void* stream) {
+    TOIST_REQUIRE(N > 0 && HW > 0 && C > 0 && (C % 8) == 0 && C / 8 <= 256 && G > 0 && G <= 16 && (C % G) == 0, "toist_groupnorm_fwd: bad shape (C%%8==0, C<=2048, G<=16)");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)N * G, st);
+    if (e != hipSuccess) { set_last_error("toist_groupnorm_fwd: memset: %s", hipGetErrorString(e)); return TOIST_EHIP; }
+    const long long total = (long long)HW * (C / 8);
+    int gx = (int)((total + 8191) / 8192);   // pixel slabs per sample
+    if (gx > 32) gx = 32;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)x, HW, C, G, stats);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_cap(total, 64), N), dim3(256), 0, st, (const bf16_t*)x, stats, gamma, beta, HW, C, G, eps, relu,
+                       (bf16_t*)y);
+    return check_launch("toist_groupnorm_fwd");
+}
+extern "C" int toist_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, int N, int HW, int C, int G,
+                                   float eps, int relu, void* dx, float* dgamma, float* dbeta, float* bstats, void* stream) {
+    TOIST_REQUIRE(N > 0 && HW > 0 && C > 0 && (C % 8) == 0 && G > 0 && G <= 16 && (C % G) == 0 && C / 8 <= 256, "toist_groupnorm_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(bstats, 0, sizeof(float) * 2 * (size_t)N * G, st);
+    if (e != hipSuccess) { set_last_error("toist_groupnorm_bwd: memset: %s", hipGetErrorString(e)); return TOIST_EHIP; }
+    const long long total = (long long)HW * (C / 8);
+    int gx = (int)((total + 8191) / 8192);
+    if (gx > 32) gx = 32;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(gx, N), dim3(256), sizeof(float) * (2 * C + 32), st, (const bf16_t*)dy, (const bf16_t*)y,
+                       (const bf16_t*)x, stats, gamma, HW, C, G, eps, relu, bstats, dgamma, dbeta);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_cap(total, 64), N), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, stats,
+                       bstats, gamma, HW, C, G, eps, relu, (bf16_t*)dx);
+    return check_launch("toist_groupnorm_bwd");
+}
+
+extern "C" int toist_upsample_add(const void* in, const void* fpn, int BQ, int Q, int H, int W, int C, void* out, void* stream) {
+    TOIST_REQUIRE(BQ > 0 && Q > 0 && (BQ % Q) == 0 && H > 0 && W > 0 && (C % 8) == 0, "toist_upsample_add: bad shape");
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_cap((long long)BQ * 4 * H * W * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, (const bf16_t*)fpn, BQ, Q, H, W, C, (bf16_t*)out);
+    return check_launch("toist_upsample_add");
+}
+extern "C" int toist_upsample_add_bwd(const void* dout, int BQ, int H, int W, int C, void* din, void* stream) {
+    TOIST_REQUIRE(BQ > 0 && H > 0 && W > 0 && (C % 8) == 0, "toist_upsample_add_bwd: bad shape");
+    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_cap((long long)BQ * H * W * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dout, BQ, H, W, C, (bf16_t*)din);
+    return check_launch("toist_upsample_add_bwd");
+}
+extern "C" int toist_sum_queries(const void* in, int B, int Q, int64_t per, void* out, void* stream) {
+    TOIST_REQUIRE(B > 0 && Q > 0 && per > 0 && (per % 8) == 0, "toist_sum_queries: bad shape");
+    hipLaunchKernelGGL(sum_queries_kernel, dim3(grid_cap((long long)B * (per / 8), 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, B, Q,
+                       (long long)(per / 8), (bf16_t*)out);
+    return check_launch("toist_sum_queries");
+}
+
+extern "C" int toist_mask_loss_fwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
+                                   int TH, int TW, float alpha, float* sums, void* stream) {
+    TOIST_REQUIRE(T > 0 && h > 0 && w > 0 && TH > 0 && TW > 0, "toist_mask_loss_fwd: bad shape");
+    hipLaunchKernelGGL(mask_loss_fwd_kernel, dim3(grid_cap((long long)TH * TW, 64), T), dim3(256), 0, (hipStream_t)stream, pred, pred_row, gt, gt_row, h, w,
+                       TH, TW, alpha, sums);
+    return check_launch("toist_mask_loss_fwd");
+}
+extern "C" int toist_mask_loss_bwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
+                                   int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred, void* stream) {
+    TOIST_REQUIRE(T > 0 && h > 0 && w > 0 && TH > 0 && TW > 0, "toist_mask_loss_bwd: bad shape");
+    hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(grid_cap((long long)TH * TW, 64), T), dim3(256), 0, (hipStream_t)stream, pred, pred_row, gt, gt_row, h, w,
+                       TH, TW, alpha, sums, coef, dpred);
+    return check_launch("toist_mask_loss_bwd");
+}

@@ -90,7 +90,8 @@ class ParamSet:
             g = None
             if need_grads and trainable.get(n, False):
                 g = self.flat[off:off + t.numel()].view(t.shape)
-                if t.dim() == 4:  # conv weights are channels_last (physically KRSC); keep that layout
+                if t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last):
+                    # channels_last conv weights (physically KRSC): the gradient keeps the parameter's layout
                     O, I, R, S = t.shape
                     g = self.flat[off:off + t.numel()].view(O, R, S, I).permute(0, 3, 1, 2)
                 off += (t.numel() + 63) // 64 * 64

@@ -16,7 +16,8 @@ __all__ = [
     "A_ROWK", "A_KROW", "A_CONV", "A_CONVT", "B_ROWK", "B_KROW", "B_CONVX", "ACT_NONE", "ACT_RELU", "ACT_GELU",
     "ACT_SIGMOID", "ACT_MASK_POS", "ACT_GELU_BWD", "ACT_SIGMOID_BWD", "ConvGeom", "operand", "gemm", "matcher",
     "layernorm_fwd", "layernorm_bwd", "softmax_fwd", "softmax_bwd", "colsum", "add", "dropout", "pack_image", "maxpool3x3s2",
-    "unpack_nhwc", "sine_position", "embed_fwd", "embed_bwd", "criterion_fwd", "criterion_bwd",
+    "unpack_nhwc", "sine_position", "embed_fwd", "embed_bwd", "criterion_fwd", "criterion_bwd", "attnmap_softmax_fwd", "attnmap_softmax_bwd",
+    "groupnorm_fwd", "groupnorm_bwd", "upsample_add", "upsample_add_bwd", "sum_queries", "mask_loss_fwd", "mask_loss_bwd",
 ]
 
 
@@ -79,7 +80,7 @@ def operand(t, ld=0, bs_outer=0, bs_inner=0, kin=0, tap_stride=0, geom=None):
 
 def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_outer=0, cs_inner=0, split_k=1, tile=0,
          flags=0, alpha=1.0, scale=None, shift=None, rscale=None, res=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, pre_out=None,
-         accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0, flops=0, a_colsum=None):
+         accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0, flops=0, a_colsum=None, res_bcast=None):
     """C = epilogue(A @ B^T); see include/toist_hip.h.  `a`/`b` are Operand structs from operand().
     `flops` = algorithmic FLOPs of the call (bench.py's roofline accounting only)."""
     if tile == 0 and FORCE_TILE:
@@ -107,6 +108,8 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
     if cmap is not None:
         e.cmap = 1
         e.cH, e.cW, e.cOH, e.cOW, e.cst = cmap
+    if res_bcast is not None:
+        e.res_div, e.res_mod = res_bcast
     e.drop_where, e.drop_p, e.drop_seed = drop_where, drop_p, drop_seed
     e.drop_seed_dev = _p(SEED_DEV) if drop_where else None
     d.a_colsum = _p(a_colsum, torch.float32)
@@ -238,3 +241,50 @@ def criterion_bwd(logits, boxes, tgt_boxes, pos_map, tgt_off, match_off, src_idx
                                               _p(src_idx, torch.int64), _p(tgt_idx, torch.int64), _p(num_boxes, torch.float32), L, B, Q, K,
                                               eos_coef, _p(upstream, torch.float32), _p(dlogits, torch.float32), _p(dboxes, torch.float32),
                                               _stream()), "toist_criterion_bwd")
+
+
+# ---- segmentation branch ---------------------------------------------------------------------------------
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def attnmap_softmax_fwd(scores, key_pad, B, Q, H, HW, ld, out):
+    _lib.check(_lib.lib().toist_attnmap_softmax_fwd(_p(scores, BF16), _p(key_pad, torch.uint8), B, Q, H, HW, ld, _p(out, BF16), _stream()),
+               "toist_attnmap_softmax_fwd")
+
+
+def attnmap_softmax_bwd(prob, dprob, BQ, H, HW, ld, dscores):
+    _lib.check(_lib.lib().toist_attnmap_softmax_bwd(_p(prob, BF16), _p(dprob, BF16), BQ, H, HW, ld, _p(dscores, BF16), _stream()),
+               "toist_attnmap_softmax_bwd")
+
+
+def groupnorm_fwd(x, gamma, beta, N, HW, C, G, eps, relu, y, stats):
+    _lib.check(_lib.lib().toist_groupnorm_fwd(_p(x, BF16), _p(gamma, F32), _p(beta, F32), N, HW, C, G, eps, 1 if relu else 0, _p(y, BF16),
+                                              _p(stats, F32), _stream()), "toist_groupnorm_fwd")
+
+
+def groupnorm_bwd(dy, y, x, stats, gamma, N, HW, C, G, eps, relu, dx, dgamma, dbeta, bstats):
+    _lib.check(_lib.lib().toist_groupnorm_bwd(_p(dy, BF16), _p(y, BF16), _p(x, BF16), _p(stats, F32), _p(gamma, F32), N, HW, C, G, eps,
+                                              1 if relu else 0, _p(dx, BF16), _p(dgamma, F32), _p(dbeta, F32), _p(bstats, F32), _stream()),
+               "toist_groupnorm_bwd")
+
+
+def upsample_add(inp, fpn, BQ, Q, H, W, C, out):
+    _lib.check(_lib.lib().toist_upsample_add(_p(inp, BF16), _p(fpn, BF16), BQ, Q, H, W, C, _p(out, BF16), _stream()), "toist_upsample_add")
+
+
+def upsample_add_bwd(dout, BQ, H, W, C, din):
+    _lib.check(_lib.lib().toist_upsample_add_bwd(_p(dout, BF16), BQ, H, W, C, _p(din, BF16), _stream()), "toist_upsample_add_bwd")
+
+
+def sum_queries(inp, B, Q, per, out):
+    _lib.check(_lib.lib().toist_sum_queries(_p(inp, BF16), B, Q, per, _p(out, BF16), _stream()), "toist_sum_queries")
+
+
+def mask_loss_fwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, alpha, sums):
+    _lib.check(_lib.lib().toist_mask_loss_fwd(_p(pred, F32), _p(pred_row, torch.int32), _p(gt, torch.uint8), _p(gt_row, torch.int32), T, h, w, TH,
+                                              TW, alpha, _p(sums, F32), _stream()), "toist_mask_loss_fwd")
+
+
+def mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, alpha, sums, coef, dpred):
+    _lib.check(_lib.lib().toist_mask_loss_bwd(_p(pred, F32), _p(pred_row, torch.int32), _p(gt, torch.uint8), _p(gt_row, torch.int32), T, h, w, TH,
+                                              TW, alpha, _p(sums, F32), _p(coef, F32), _p(dpred, F32), _stream()), "toist_mask_loss_bwd")

@@ -84,7 +84,8 @@ def conv_out_hw(H, W, R, S, stride, pad, dil=1):
     return (H + 2 * pad - dil * (R - 1) - 1) // stride + 1, (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
 
 
-def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, res=None, act=k.ACT_NONE, out=None, tile=0):
+def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, res=None, act=k.ACT_NONE, out=None, tile=0, res_bcast=None,
+           out_dtype=BF16, cin_real=None):
     """NHWC implicit-GEMM convolution: x [N,H,W,C], w [Co,R,S,C] -> [N,OH,OW,Co] with the
     FrozenBatchNorm scale/shift (+residual, +ReLU) fused into the epilogue."""
     Nb, H, W, C = x.shape
@@ -92,7 +93,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, res=None, ac
     assert Cw == C and x.is_contiguous() and w.is_contiguous()
     OH, OW = conv_out_hw(H, W, R, S, stride, pad, dil)
     if out is None:
-        out = torch.empty(Nb, OH, OW, Co, dtype=BF16, device=x.device)
+        out = torch.empty(Nb, OH, OW, Co, dtype=out_dtype, device=x.device)
     M = Nb * OH * OW
     Kred = R * S * C
     if R == 1 and S == 1 and stride == 1 and pad == 0:
@@ -105,7 +106,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, res=None, ac
     if Kred != R * S * C:  # stem only (C = 8): pad the reduction axis of the weights with zeros
         wk = torch.nn.functional.pad(wk, (0, Kred - R * S * C))
     k.gemm(M, Co, Kred, a_kind, a, k.B_ROWK, k.operand(wk, Kred), out, Co, scale=scale, shift=shift, res=res,
-           ldr=Co if res is not None else 0, act=act, tile=tile, flops=2 * M * Co * R * S * (3 if C == 8 else C))
+           ldr=Co if res is not None else 0, act=act, tile=tile, flops=2 * M * Co * R * S * (cin_real or C), res_bcast=res_bcast)
     return out
 
 

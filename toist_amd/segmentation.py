@@ -1,0 +1,352 @@
+"""Segmentation branch of TOIST (config 3) on the MI355X kernels.
+
+Mirrors /root/reference/models/segmentation.py: DETRsegm (:17-168), MaskHeadSmallConv (:170-241),
+MHAttentionMap (:244-273), dice_loss / sigmoid_focal_loss (:276-319) and SetCriterion.loss_masks
+(/root/reference/models/mdetr.py:827-853) -- same module tree / state_dict names (`detr.*`,
+`bbox_attention.{q,k}_linear.*`, `mask_head.lay1..5/gn1..5/out_lay/adapter1..3.*`).
+
+MI355X-first decisions: feature maps stay NHWC bf16; the 256 `src_proj` channels of the mask head's first
+convolution are identical for the 100 queries of an image, so that part is convolved once per image and
+broadcast through the GEMM epilogue (only the 8 attention-map channels are convolved per query: 33x
+fewer MACs in lay1); FPN adapters are computed per image and added inside the 2x-upsample kernel; the
+backward of every per-query broadcast is a sum over queries followed by per-image GEMMs.
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import engine, functions
+from . import kernels as k
+from . import ops
+from .backbone import nearest_mask
+from .misc import NestedTensor
+
+BF16 = torch.bfloat16
+
+
+class MHAttentionMap(nn.Module):
+    """Parameter holder of the 2-D attention map (segmentation.py:244-273)."""
+
+    def __init__(self, query_dim, hidden_dim, num_heads, dropout=0, bias=True):
+        super().__init__()
+        self.num_heads, self.hidden_dim = num_heads, hidden_dim
+        self.q_linear = nn.Linear(query_dim, hidden_dim, bias=bias)
+        self.k_linear = nn.Linear(query_dim, hidden_dim, bias=bias)
+        nn.init.zeros_(self.k_linear.bias)
+        nn.init.zeros_(self.q_linear.bias)
+        nn.init.xavier_uniform_(self.k_linear.weight)
+        nn.init.xavier_uniform_(self.q_linear.weight)
+        self.normalize_fact = float(hidden_dim / num_heads) ** -0.5
+
+
+class MaskHeadSmallConv(nn.Module):
+    """Parameter holder of the FPN mask decoder (segmentation.py:170-241)."""
+
+    def __init__(self, dim, fpn_dims, context_dim):
+        super().__init__()
+        inter = [dim, context_dim // 2, context_dim // 4, context_dim // 8, context_dim // 16, context_dim // 64]
+        self.inter_dims = inter
+        self.lay1, self.gn1 = nn.Conv2d(dim, dim, 3, padding=1), nn.GroupNorm(8, dim)
+        self.lay2, self.gn2 = nn.Conv2d(dim, inter[1], 3, padding=1), nn.GroupNorm(8, inter[1])
+        self.lay3, self.gn3 = nn.Conv2d(inter[1], inter[2], 3, padding=1), nn.GroupNorm(8, inter[2])
+        self.lay4, self.gn4 = nn.Conv2d(inter[2], inter[3], 3, padding=1), nn.GroupNorm(8, inter[3])
+        self.lay5, self.gn5 = nn.Conv2d(inter[3], inter[4], 3, padding=1), nn.GroupNorm(8, inter[4])
+        self.out_lay = nn.Conv2d(inter[4], 1, 3, padding=1)
+        self.dim = dim
+        self.adapter1 = nn.Conv2d(fpn_dims[0], inter[1], 1)
+        self.adapter2 = nn.Conv2d(fpn_dims[1], inter[2], 1)
+        self.adapter3 = nn.Conv2d(fpn_dims[2], inter[3], 1)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=1)
+                nn.init.constant_(m.bias, 0)
+
+
+def _krsc_bf16(w):
+    """[O,I,R,S] fp32 -> contiguous [O,R,S,I] bf16 (the GEMM B operand of an NHWC convolution)."""
+    return w.detach().permute(0, 2, 3, 1).contiguous().to(BF16)
+
+
+def _add_conv_grad(param_grad, tmp_krsc, c_lo=0, c_hi=None):
+    """param_grad [O,I,R,S] (fp32, any strides) += tmp [O,R,S,Cpart] for input channels [c_lo, c_hi)."""
+    c_hi = param_grad.shape[1] if c_hi is None else c_hi
+    param_grad[:, c_lo:c_hi].add_(tmp_krsc.permute(0, 3, 1, 2))
+
+
+def _conv_gn_relu(tape, x, W, b, G_w, G_b, shape, *, extra_res=None, res_bcast=None, w_slice=None):
+    """y = relu(GN8(conv3x3(x) + bias [+ broadcast residual])).  x: Var NHWC; returns Var NHWC.
+    W: ParamView of the [O,I,3,3] weight; w_slice = (lo, hi) restricts the input channels used."""
+    N, H, Wd, C = shape
+    wk = W.w if w_slice is None else W.w[..., w_slice[0]:w_slice[1]].contiguous()
+    Co = wk.shape[0]
+    pre = ops.conv2d(x.data, wk, pad=1, shift=(b.f32 if extra_res is None else None), res=extra_res, res_bcast=res_bcast)
+    stats = torch.empty(N, 8, 2, dtype=torch.float32, device=pre.device)
+    y = torch.empty_like(pre)
+    k.groupnorm_fwd(pre, G_w.f32, G_b.f32, N, H * Wd, Co, 8, 1e-5, True, y, stats)
+    out = engine.Var(y)
+    pre_var = engine.Var(pre)  # gradient w.r.t. the conv output (after GN backward)
+
+    def bwd():
+        g = out.take_grad()
+        if g is None:
+            return
+        dpre = torch.empty_like(g)
+        bstats = torch.empty(N, 8, 2, dtype=torch.float32, device=g.device)
+        k.groupnorm_bwd(g, y, pre, stats, G_w.f32, N, H * Wd, Co, 8, 1e-5, True, dpre, G_w.g, G_b.g if G_w.g is not None else None, bstats)
+        pre_var.grad = dpre
+        if W.g is not None:
+            tmp = ops.conv2d_wgrad(dpre, x.data, wk.shape, pad=1)
+            _add_conv_grad(W.g, tmp, *(w_slice or (0, None)))
+            if extra_res is None and b.g is not None:
+                ops.bias_grad(dpre.view(-1, Co), out=b.g)
+        if x.needs_grad:
+            x.grad = ops.conv2d_dgrad(dpre, wk, (H, Wd), pad=1, res=x.grad)
+
+    tape.record(bwd)
+    return out, pre_var
+
+
+class DETRsegm(nn.Module):
+    def __init__(self, detr, mask_head="smallconv", freeze_detr=False):
+        super().__init__()
+        self.detr = detr
+        if freeze_detr:
+            for p in self.parameters():
+                p.requires_grad_(False)
+        hidden_dim, nheads = detr.transformer.d_model, detr.transformer.nhead
+        self.bbox_attention = MHAttentionMap(hidden_dim, hidden_dim, nheads, dropout=0)
+        if mask_head != "smallconv":
+            raise RuntimeError(f"Unknown mask model {mask_head}")
+        self.mask_head = MaskHeadSmallConv(hidden_dim + nheads, [1024, 512, 256], hidden_dim)
+        self._cache = {}
+
+    # ---- the mask program ---------------------------------------------------------------------------------
+    def _masks(self, hs_last, memory, src_proj, c4, c3, c2, feat_mask, B, Q, h, w):
+        """hs_last [B*Q,d], memory / src_proj [B*h*w, d], c4/c3/c2 NHWC bf16 -> pred mask logits [B,Q,8h,8w] f32."""
+        H = self.bbox_attention.num_heads
+        d = self.bbox_attention.hidden_dim
+        dh = d // H
+        HW = h * w
+        ld = ops.round8(HW)
+        scale = self.bbox_attention.normalize_fact
+        named = OrderedDict(("bbox_attention." + n, p) for n, p in self.bbox_attention.named_parameters())
+        named.update(("mask_head." + n, p) for n, p in self.mask_head.named_parameters())
+        transforms = {n: _krsc_bf16 for n, p in named.items() if p.dim() == 4}
+        key_pad = feat_mask.flatten(1).to(torch.uint8).contiguous()
+        dev = hs_last.device
+
+        def prog(tape, ps, hs, mem, src, f4, f3, f2):
+            A = lambda n: ps["bbox_attention." + n]
+            M = lambda n: ps["mask_head." + n]
+            # -- attention map (segmentation.py:262-273)
+            q = engine.linear_chain(tape, hs, [(A("q_linear.weight"), A("q_linear.bias"), k.ACT_NONE, False)])
+            kk = engine.linear_chain(tape, mem, [(A("k_linear.weight"), A("k_linear.bias"), k.ACT_NONE, False)])
+            scores = torch.empty(B, Q, H, ld, dtype=BF16, device=dev)
+            k.gemm(Q, HW, dh, k.A_ROWK, k.operand(q.data, d, bs_outer=Q * d, bs_inner=dh), k.B_ROWK, k.operand(kk.data, d, bs_outer=HW * d, bs_inner=dh),
+                   scores, H * ld, batch=B * H, batch_inner=H, cs_outer=Q * H * ld, cs_inner=ld, alpha=scale, tile=64)
+            prob = torch.empty(B * Q, h, w, H, dtype=BF16, device=dev)
+            k.attnmap_softmax_fwd(scores, key_pad, B, Q, H, HW, ld, prob)
+            if getattr(self, "_debug", None) is not None:
+                self._debug.update(q=q.data, kk=kk.data, scores=scores)
+            del scores
+            pv = engine.Var(prob)
+            if getattr(self, "_debug", None) is not None:
+                self._debug["pv"] = pv
+
+            def att_bwd():
+                g = pv.take_grad()
+                if g is None:
+                    return
+                if getattr(self, "_debug", None) is not None:
+                    self._debug["dprob"] = g
+                ds = torch.empty(B, Q, H, ld, dtype=BF16, device=dev)
+                k.attnmap_softmax_bwd(prob, g, B * Q, H, HW, ld, ds)
+                dq = torch.empty(B * Q, d, dtype=BF16, device=dev)
+                dk = torch.empty(B * HW, d, dtype=BF16, device=dev)
+                # dq[b,q,n,:] = scale * sum_p ds[b,q,n,p] kk[b,p,n,:] ; dk[b,p,n,:] = scale * sum_q ds[b,q,n,p] q[b,q,n,:]
+                k.gemm(Q, dh, HW, k.A_ROWK, k.operand(ds, H * ld, bs_outer=Q * H * ld, bs_inner=ld), k.B_KROW,
+                       k.operand(kk.data, d, bs_outer=HW * d, bs_inner=dh), dq, d, batch=B * H, batch_inner=H, cs_outer=Q * d, cs_inner=dh,
+                       alpha=scale, tile=64)
+                k.gemm(HW, dh, Q, k.A_KROW, k.operand(ds, H * ld, bs_outer=Q * H * ld, bs_inner=ld), k.B_KROW,
+                       k.operand(q.data, d, bs_outer=Q * d, bs_inner=dh), dk, d, batch=B * H, batch_inner=H, cs_outer=HW * d, cs_inner=dh,
+                       alpha=scale, tile=64)
+                q.grad, kk.grad = dq, dk
+
+            tape.record(att_bwd)
+
+            # -- lay1: image part once per image, attention channels per query, added in the GEMM epilogue
+            W1, b1 = M("lay1.weight"), M("lay1.bias")
+            src4 = engine.Var(src.data.view(B, h, w, d), needs_grad=src.needs_grad)
+            w1_img = W1.w[..., :d].contiguous()
+            y_img = ops.conv2d(src4.data, w1_img, pad=1, shift=b1.f32)            # [B,h,w,264]
+            a1, pre1 = _conv_gn_relu(tape, pv, W1, b1, M("gn1.weight"), M("gn1.bias"), (B * Q, h, w, H), extra_res=y_img.view(B * HW, -1),
+                                     res_bcast=(Q * HW, HW), w_slice=(d, d + H))
+
+            C1 = w1_img.shape[0]
+
+            def img_bwd():
+                g = pre1.take_grad()
+                if g is None:
+                    return
+                gsum = torch.empty(B, h, w, C1, dtype=BF16, device=dev)
+                k.sum_queries(g, B, Q, HW * C1, gsum)
+                if W1.g is not None:
+                    tmp = ops.conv2d_wgrad(gsum, src4.data, w1_img.shape, pad=1)
+                    _add_conv_grad(W1.g, tmp, 0, d)
+                    ops.bias_grad(gsum.view(-1, C1), out=b1.g)
+                if src4.needs_grad:
+                    gs = ops.conv2d_dgrad(gsum, w1_img, (h, w), pad=1)
+                    engine.accumulate(src, gs.view(B * HW, d))
+
+            # the block's backward (recorded inside _conv_gn_relu) must run BEFORE img_bwd: insert img_bwd just before it
+            tape.steps.insert(len(tape.steps) - 1, img_bwd)
+
+            a2, _ = _conv_gn_relu(tape, a1, M("lay2.weight"), M("lay2.bias"), M("gn2.weight"), M("gn2.bias"), (B * Q, h, w, C1))
+
+            def fpn_stage(x, feat, i, H_, W_):
+                """x [BQ,H_,W_,C] -> relu(GN(lay(adapter(feat) + up2(x))))"""
+                Wa, ba = M(f"adapter{i}.weight"), M(f"adapter{i}.bias")
+                Cin_f = feat.data.shape[-1]
+                Cx = x.data.shape[-1]
+                wa = Wa.w.view(Cx, Cin_f)
+                f = ops.linear(feat.data.view(-1, Cin_f), wa, ba.f32)               # [B*2H*2W, Cx]
+                up = torch.empty(B * Q, 2 * H_, 2 * W_, Cx, dtype=BF16, device=dev)
+                k.upsample_add(x.data, f, B * Q, Q, H_, W_, Cx, up)
+                uv = engine.Var(up)
+
+                def up_bwd():
+                    g = uv.take_grad()
+                    if g is None:
+                        return
+                    if x.needs_grad:
+                        gx = torch.empty(B * Q, H_, W_, Cx, dtype=BF16, device=dev)
+                        k.upsample_add_bwd(g, B * Q, H_, W_, Cx, gx)
+                        engine.accumulate(x, gx)
+                    if Wa.g is not None or feat.needs_grad:
+                        gf = torch.empty(B * 4 * H_ * W_, Cx, dtype=BF16, device=dev)
+                        k.sum_queries(g, B, Q, 4 * H_ * W_ * Cx, gf)
+                        if Wa.g is not None:
+                            tmp = torch.zeros(Cx, Cin_f, dtype=torch.float32, device=dev)
+                            ops.linear_wgrad(gf, feat.data.view(-1, Cin_f), out=tmp, bias_out=ba.g)
+                            Wa.g.add_(tmp.view(Cx, Cin_f, 1, 1))
+                        if feat.needs_grad:
+                            gfeat = ops.linear_dgrad(gf, wa)
+                            engine.accumulate(feat, gfeat.view(feat.data.shape))
+
+                tape.record(up_bwd)
+                return _conv_gn_relu(tape, uv, M(f"lay{i + 2}.weight"), M(f"lay{i + 2}.bias"), M(f"gn{i + 2}.weight"), M(f"gn{i + 2}.bias"),
+                                     (B * Q, 2 * H_, 2 * W_, Cx))[0]
+
+            a3 = fpn_stage(a2, f4, 1, h, w)
+            a4 = fpn_stage(a3, f3, 2, 2 * h, 2 * w)
+            a5 = fpn_stage(a4, f2, 3, 4 * h, 4 * w)
+            # -- out_lay: Cout = 1 padded to 8 output channels (16-byte rows for the backward GEMM operands)
+            Wo, bo = M("out_lay.weight"), M("out_lay.bias")
+            C5 = a5.data.shape[-1]
+            wo8 = torch.zeros(8, 3, 3, C5, dtype=BF16, device=dev)
+            wo8[:1] = Wo.w
+            bo8 = torch.zeros(8, dtype=torch.float32, device=dev)
+            bo8[:1] = bo.f32
+            o8 = ops.conv2d(a5.data, wo8, pad=1, shift=bo8)                         # [BQ,8h,8w,8] bf16
+            masks = o8[..., 0].float().view(B, Q, 8 * h, 8 * w).contiguous()
+            mv = engine.Var(masks)
+
+            def out_bwd():
+                g = mv.take_grad()
+                if g is None:
+                    return
+                g8 = torch.zeros(B * Q, 8 * h, 8 * w, 8, dtype=BF16, device=dev)
+                g8[..., 0] = g.view(B * Q, 8 * h, 8 * w).to(BF16)
+                if Wo.g is not None:
+                    tmp = ops.conv2d_wgrad(g8, a5.data, wo8.shape, pad=1)
+                    _add_conv_grad(Wo.g, tmp[:1])
+                    bo.g.add_(g.sum().reshape(1))
+                a5.grad = ops.conv2d_dgrad(g8, wo8, (8 * h, 8 * w), pad=1, res=a5.grad)
+
+            tape.record(out_bwd)
+            return [mv], None
+
+        (masks,) = functions.run_program(prog, named, [hs_last, memory, src_proj, c4, c3, c2], cache=self._cache, training=self.training,
+                                         transforms=transforms)
+        return masks
+
+    # ---- reference-compatible forward ----------------------------------------------------------------------
+    def forward(self, samples: NestedTensor, captions, encode_and_save=True, memory_cache=None):
+        if encode_and_save:
+            assert memory_cache is None
+            if not isinstance(samples, NestedTensor):
+                samples = NestedTensor.from_tensor_list(samples)
+            mc = self.detr.encode(samples, captions, levels=(1, 2, 3, 4))
+            nat = mc["_native"]
+            # reference keys (segmentation.py:76-78): NCHW fp32 views for API users
+            mc["features_4_mask"] = [NestedTensor(f.permute(0, 3, 1, 2), nearest_mask(samples.mask, f.shape[1:3])) for f in nat["features"]]
+            B, HW, d = nat["src_proj"].shape
+            h, w = nat["features"][-1].shape[1:3]
+            mc["src_proj_4_mask"] = nat["src_proj"].view(B, h, w, d).permute(0, 3, 1, 2)
+            return mc
+        assert memory_cache is not None
+        out = self.detr.decode(memory_cache)
+        nat = memory_cache["_native"]
+        c2, c3, c4, c5 = nat["features"]
+        B, h, w, _ = c5.shape
+        HW = h * w
+        stack = out["_stacked"]["hs"]                                   # [L, B*Q, d] bf16
+        Q = stack.shape[1] // B
+        d = stack.shape[-1]
+        mem = nat["memory"].view(B, nat["S"], d)[:, :HW].reshape(B * HW, d)
+        src = nat["src_proj"].reshape(B * HW, d)
+        out["pred_masks"] = self._masks(stack[-1], mem, src, c4, c3, c2, nat["feat_mask"], B, Q, h, w)
+        return out
+
+
+# ------------------------------------------------------------------------------------------ mask losses
+class _MaskLossFn(torch.autograd.Function):
+    """(loss_mask, loss_dice) of SetCriterion.loss_masks for the matched (prediction, target) pairs."""
+
+    @staticmethod
+    def forward(ctx, pred, pred_row, gt, gt_row, num_boxes, TH, TW):
+        T = pred_row.numel()
+        h, w = pred.shape[-2:]
+        sums = torch.zeros(T, 4, dtype=torch.float32, device=pred.device)
+        k.mask_loss_fwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, 0.25, sums)
+        focal = (sums[:, 0] / float(TH * TW)).sum() / num_boxes
+        dice = (1 - (2 * sums[:, 1] + 1) / (sums[:, 2] + sums[:, 3] + 1)).sum() / num_boxes
+        ctx.save_for_backward(pred, pred_row, gt, gt_row, sums, num_boxes)
+        ctx.dims = (T, h, w, TH, TW)
+        return torch.stack([focal, dice])
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, pred_row, gt, gt_row, sums, num_boxes = ctx.saved_tensors
+        T, h, w, TH, TW = ctx.dims
+        coef = torch.stack([g[0] / (float(TH * TW) * num_boxes), g[1] / num_boxes]).float().contiguous()
+        dpred = torch.zeros_like(pred)
+        k.mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, 0.25, sums, coef, dpred)
+        return dpred, None, None, None, None, None, None
+
+
+def mask_losses(outputs, targets, match, layer, num_boxes):
+    """SetCriterion.loss_masks (mdetr.py:827-853) on the device-resident assignment of `layer`."""
+    pred = outputs["pred_masks"].float().contiguous()                      # [B,Q,hm,wm]
+    B, Q = pred.shape[:2]
+    dev = pred.device
+    if match.src.shape[1] == 0:
+        z = pred.sum() * 0
+        return {"loss_mask": z, "loss_dice": z}
+    TH = max(int(t["masks"].shape[-2]) for t in targets)
+    TW = max(int(t["masks"].shape[-1]) for t in targets)
+    rows = []
+    for t in targets:                                                       # zero-padded like NestedTensor.from_tensor_list
+        m = t["masks"].to(torch.uint8)
+        if m.shape[-2:] != (TH, TW):
+            m = torch.nn.functional.pad(m, (0, TW - m.shape[-1], 0, TH - m.shape[-2]))
+        rows.append(m)
+    gt = torch.cat(rows).contiguous()
+    b_idx = torch.cat([torch.full((c,), i, dtype=torch.int64) for i, c in enumerate(match.counts)]).to(dev)
+    t_base = torch.cat([torch.full((c,), sum(match.sizes[:i]), dtype=torch.int64) for i, c in enumerate(match.counts)]).to(dev)
+    pred_row = (b_idx * Q + match.src[layer]).to(torch.int32)
+    gt_row = (t_base + match.tgt[layer]).to(torch.int32)
+    nb = num_boxes.reshape(()).float() if torch.is_tensor(num_boxes) else torch.tensor(float(num_boxes), device=dev)
+    vals = _MaskLossFn.apply(pred.view(B * Q, pred.shape[-2], pred.shape[-1]), pred_row.contiguous(), gt, gt_row.contiguous(), nb, TH, TW)
+    return {"loss_mask": vals[0], "loss_dice": vals[1]}
