@@ -307,7 +307,7 @@ __device__ __forceinline__ bf16x8_t fragment(const bf16_t* s, int r0, int ks, in
     return *reinterpret_cast<const bf16x8_t*>(&s[row * BK + swz_k<BK>(row, ks * 4 + g) * 8]);
 }
 
-template <int BM, int BN, int BK, int AK, int BKD>
+template <int BM, int BN, int BK, int AK, int BKD, int DEEP>
 __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int ACH = BM * BK / 8 / 256, BCH = BN * BK / 8 / 256;  // 1 KiB DMA pieces per wave per tile
@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     constexpr int STAGE = SA_ELEMS + SB_ELEMS;                       // elements per ring slot
     // ring depth: measured on MI355X, occupancy beats depth -- 2 slots (5 workgroups/CU for 64x64x64) run
     // 15-30 % faster than 3 slots (3 workgroups/CU) on the K = 256..2048 hot-path shapes
-    constexpr int NS = (STAGE * 2 <= 8192) ? 4 : 2;
+    // DEEP (small grids, <= 2 workgroups per CU): nothing else hides latency, so spend the idle LDS on a 4-slot ring
+    constexpr int NS = DEEP ? 4 : ((STAGE * 2 <= 8192) ? 4 : 2);
     constexpr int CNT = ACH + BCH;
     static_assert(NS >= 2 && NS <= 4, "wait ladder below covers up to 2 younger tiles");
     __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
@@ -534,7 +535,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <int BM, int BN, int BK, int AK, int BKD>
 static void launch_variant(const toist_gemm& d, hipStream_t st) {
     dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, d.batch * d.split_k);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD>), grid, dim3(256), 0, st, d);
+    const long long wgs = (long long)grid.x * grid.y * grid.z;
+    if (BM == 64 && BN == 64 && BK == 64 && wgs <= 512)
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, (BM == 64 && BN == 64 && BK == 64) ? 1 : 0>), grid, dim3(256), 0, st, d);
+    else
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 0>), grid, dim3(256), 0, st, d);
 }
 
 template <int BM, int BN, int BK>
