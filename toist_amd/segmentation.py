@@ -147,19 +147,13 @@ class DETRsegm(nn.Module):
                    scores, H * ld, batch=B * H, batch_inner=H, cs_outer=Q * H * ld, cs_inner=ld, alpha=scale, tile=64)
             prob = torch.empty(B * Q, h, w, H, dtype=BF16, device=dev)
             k.attnmap_softmax_fwd(scores, key_pad, B, Q, H, HW, ld, prob)
-            if getattr(self, "_debug", None) is not None:
-                self._debug.update(q=q.data, kk=kk.data, scores=scores)
             del scores
             pv = engine.Var(prob)
-            if getattr(self, "_debug", None) is not None:
-                self._debug["pv"] = pv
 
             def att_bwd():
                 g = pv.take_grad()
                 if g is None:
                     return
-                if getattr(self, "_debug", None) is not None:
-                    self._debug["dprob"] = g
                 ds = torch.empty(B, Q, H, ld, dtype=BF16, device=dev)
                 k.attnmap_softmax_bwd(prob, g, B * Q, H, HW, ld, ds)
                 dq = torch.empty(B * Q, d, dtype=BF16, device=dev)
