@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="time every GEMM launch (diagnostic; adds host overhead)")
     ap.add_argument("--masks", action="store_true", help="config 3: add the segmentation head and the mask losses")
+    ap.add_argument("--no-overlap", action="store_true", help="keep the text branch on the main stream (no parallel graph branch)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
     ap.add_argument("--split-graph", action="store_true", help="force the multi-GPU structure (graph: fwd+bwd | eager all-reduce | graph: clip+AdamW+EMA) on one GPU")
     return ap.parse_args()
@@ -117,6 +118,9 @@ def main():
         {"params": [p for n, p in named if "backbone" in n], "lr": args.lr_backbone},
         {"params": [p for n, p in named if "text_encoder" in n], "lr": args.text_encoder_lr},
     ]
+    from toist_amd import engine as _engine
+    if a.no_overlap:
+        _engine.OVERLAP = "off"
     use_graph = not a.no_graph and not a.profile_all and not a.masks
     split_graph = use_graph and (world > 1 or a.split_graph)
     opt = torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay, fused=True, capturable=use_graph)
@@ -248,7 +252,7 @@ def main():
         }
         if prof is not None and prof["records"]:
             tot_ms, tot_fl, per_key = 0.0, 0.0, {}
-            for e0, e1, fl, key in prof["records"]:
+            for e0, e1, fl, key, shape, nbytes in prof["records"]:
                 ms = e0.elapsed_time(e1)
                 tot_ms += ms
                 tot_fl += fl
@@ -264,6 +268,20 @@ def main():
                                "timed": "HIP events around each launch, %d eager steps %s" % (a.steps, "after the graph-replayed timed region" if use_graph else "inside the timed region"),
                                "launches": n, "avg_launch_us": round(1000 * tot_ms / n, 2), "avg_gflop_per_launch": round(tot_fl / n / 1e9, 3)}
             if a.profile_all:
+                shapes = {}
+                for e0, e1, fl, key, shape, nbytes in prof["records"]:
+                    s_ = shapes.setdefault(str(key) + str(shape), [0.0, 0.0, 0, nbytes])
+                    s_[0] += e0.elapsed_time(e1)
+                    s_[1] += fl
+                    s_[2] += 1
+                rows = sorted(shapes.items(), key=lambda kv: -kv[1][0])
+                os.makedirs("gpurun_out", exist_ok=True)
+                with open("gpurun_out/gemm_shapes.txt", "w") as f:
+                    f.write("# (tile,a_kind,b_kind)(M,N,K,batch,split,taps)  ms/step  launches/step  us/launch  TFLOP/s  GB/s(algorithmic)  t_mfma_us  t_hbm_us\n")
+                    for name, (ms, fl, cnt, nb) in rows:
+                        us = 1000 * ms / cnt
+                        f.write("%-60s %8.3f %4d %9.1f %8.1f %8.0f %8.1f %8.1f\n" % (name, ms / a.steps, cnt // a.steps, us, fl / cnt / us / 1e6,
+                                                                                 nb / us / 1e3, fl / cnt / 2.5e9, nb / 6.3e6))
                 res["roofline"]["per_variant"] = {k_: {"ms_per_step": round(v[0] / a.steps, 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
                                                       "launches_per_step": v[2] // a.steps} for k_, v in per_key.items()}
         if not a.no_cpu_baseline and world == 1:

@@ -13,6 +13,12 @@ from . import engine
 # parameter gradients (set by toist_amd.parallel.GradSync).
 GRAD_SYNC = None
 
+# Stream the programs launched right now were forked from (set by MDETR.encode around the text branch).
+# Their parameter gradients are attached to .grad directly, not through AccumulateGrad nodes, so the
+# autograd engine does not know it has to join their stream at the end of backward(): each forked
+# program's backward makes REJOIN wait for it instead.
+REJOIN = None
+
 
 class _TapeFn(torch.autograd.Function):
     @staticmethod
@@ -20,6 +26,7 @@ class _TapeFn(torch.autograd.Function):
         inputs = tensors[:n_in]
         params = tensors[n_in:]
         tape_kw = dict(tape_kw)
+        ctx.rejoin = tape_kw.pop('rejoin')
         need = tape_kw.pop('need_grads')  # grad mode is off inside Function.forward: decided by the caller
         transforms = tape_kw.pop('transforms')
         named = dict(zip(names, params))
@@ -70,6 +77,8 @@ class _TapeFn(torch.autograd.Function):
                 ps.flat = None  # accumulated into an older buffer: nothing to reduce in place
         if GRAD_SYNC is not None and ps.flat is not None:
             GRAD_SYNC(ps.flat)
+        if ctx.rejoin is not None:
+            ctx.rejoin.wait_stream(torch.cuda.current_stream())
         n_par = len(ctx.params)
         ctx.tape = ctx.ps = ctx.in_vars = ctx.out_vars = ctx.params = None
         return (None, None, None, None, None, *in_grads, *([None] * n_par))
@@ -80,5 +89,5 @@ def run_program(body, named_params, inputs, cache=None, training=False, drop_p=0
     names = tuple(named_params.keys())
     params = tuple(named_params.values())
     need = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (*inputs, *params))
-    tape_kw = dict(training=training, drop_p=drop_p, seed=seed, need_grads=need, transforms=transforms)
+    tape_kw = dict(training=training, drop_p=drop_p, seed=seed, need_grads=need, transforms=transforms, rejoin=REJOIN)
     return _TapeFn.apply(body, names, cache, len(inputs), tape_kw, *inputs, *params)

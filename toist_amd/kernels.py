@@ -36,10 +36,11 @@ _WS = {}
 
 def _workspace(elems, device):
     """Caller-owned split-K scratch handed to the library (grown on demand, reused across calls)."""
-    ws = _WS.get(device)
+    key = (device, torch.cuda.current_stream().cuda_stream)  # one scratch per stream: launches on different streams overlap
+    ws = _WS.get(key)
     if ws is None or ws.numel() < elems:
         ws = torch.empty(max(elems, 1 << 22), dtype=torch.float32, device=device)
-        _WS[device] = ws
+        _WS[key] = ws
     return ws
 
 
@@ -119,6 +120,8 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
     if prof is None:
         _lib.check(_lib.lib().toist_gemm_bf16(ctypes.byref(d), _stream()), "toist_gemm_bf16")
         return
+    if not flops:
+        flops = 2 * M * N * K * max(batch, 1)
     t = tile
     if t == 0:
         t128 = ((M + 127) // 128) * ((N + 127) // 128) * max(batch, 1) * max(split_k, 1)
@@ -132,7 +135,12 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
     e0.record()
     _lib.check(_lib.lib().toist_gemm_bf16(ctypes.byref(d), _stream()), "toist_gemm_bf16")
     e1.record()
-    prof["records"].append((e0, e1, flops, key))
+    ta = max(int(a.R) * int(a.S), 1) if a_kind in (A_CONV, A_CONVT) else 1
+    tb = max(int(b.R) * int(b.S), 1) if b_kind == B_CONVX else 1
+    nb = max(batch, 1)
+    nbytes = 2 * M * K * nb // ta + 2 * N * K * nb // tb + (4 if c.dtype == torch.float32 else 2) * M * N * nb
+    nbytes += 2 * M * N * nb * ((res is not None) + (aux is not None) + (pre_out is not None))
+    prof["records"].append((e0, e1, flops, key, (M, N, K, nb, split_k, ta * tb), nbytes))
 
 
 def matcher(logits, boxes, tgt_boxes, pos_map, tgt_off, match_off, max_T, w_class, w_bbox, w_giou, src_idx, tgt_idx,

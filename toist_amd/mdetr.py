@@ -167,7 +167,28 @@ class MDETR(nn.Module):
 
     def encode(self, samples, captions, levels=(4,)):
         body = self.backbone[0]
+        # The text branch (RoBERTa + resizer) and the image branch (ResNet) are independent until the
+        # cross-modal encoder: fork the text branch onto its own HIP stream so its small GEMMs fill the
+        # tails of the backbone kernels (a parallel branch of the captured hipGraph).  torch.autograd
+        # replays each node's backward on the stream of its forward, so the backward pass forks the same way.
+        side = None
+        pre_encoded = isinstance(captions, tuple) and len(captions) == 3 and torch.is_tensor(captions[0])
+        if not pre_encoded and samples.tensors.is_cuda and engine.overlap_enabled():
+            from .transformer import EncodedText
+            main = torch.cuda.current_stream()
+            side = engine.side_stream(samples.tensors.device, "text")
+            side.wait_stream(main)
+            functions.REJOIN = main
+            try:
+                with torch.cuda.stream(side):
+                    tokenized = self.transformer._tokenize(captions, samples.tensors.device)
+                    flat, _ = self.transformer.encode_text(tokenized)
+            finally:
+                functions.REJOIN = None
+            captions = EncodedText(tokenized, flat)
         feats = body.forward_native(samples.tensors, levels, premasked=(len(levels) - 1,))
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         c5 = feats[-1]
         B, h, w, _ = c5.shape
         mask = nearest_mask(samples.mask, (h, w))

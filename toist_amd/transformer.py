@@ -141,6 +141,15 @@ class RobertaTextEncoder(nn.Module):
             p.requires_grad_(False)
 
 
+class EncodedText:
+    """RoBERTa + resizer output produced ahead of the image branch (see MDETR.encode)."""
+
+    __slots__ = ("tokenized", "flat")
+
+    def __init__(self, tokenized, flat):
+        self.tokenized, self.flat = tokenized, flat
+
+
 class TokenizedText(dict):
     """Minimal stand-in for a HF BatchEncoding: dict with attribute access and .to()."""
 
@@ -397,8 +406,11 @@ class Transformer(nn.Module):
             text_tok = text_memory_resized.permute(1, 0, 2).to(BF16)
             L = text_tok.shape[1]
         else:
-            tokenized = self._tokenize(text, dev)
-            flat, key_pad_text = self.encode_text(tokenized)
+            if isinstance(text, EncodedText):  # already launched on the text stream by the caller (and joined)
+                tokenized, flat = text.tokenized, text.flat
+            else:
+                tokenized = self._tokenize(text, dev)
+                flat, key_pad_text = self.encode_text(tokenized)
             L = tokenized["input_ids"].shape[1]
             text_tok = flat.view(B, L, d)
             text_attention_mask = tokenized["attention_mask"].ne(1).bool()

@@ -35,6 +35,8 @@ def lin(name, M, N, K):
     dw = torch.zeros(N, K, device=dev)
     fl = 2 * M * N * K
     row(name + " fwd", fl, lambda: ops.linear(x, w, out=out))
+    wt = w.t()
+    print(f"{name + ' fwd hipBLASLt (target only)':40s} {fl / timeit(lambda: torch.matmul(x, wt, out=out), 20) / 1e9:6.0f}", flush=True)
     row(name + " dgrad", fl, lambda: ops.linear_dgrad(dy, w, out=dx))
     for sp in (1, 4, 16):
         row(name + f" wgrad s{sp}", fl, lambda: ops.linear_wgrad(dy, x, out=dw), splits=(sp,))
