@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--profile-all", action="store_true", help="time every GEMM launch (diagnostic; adds host overhead)")
     ap.add_argument("--masks", action="store_true", help="config 3: add the segmentation head and the mask losses")
     ap.add_argument("--no-overlap", action="store_true", help="keep the text branch on the main stream (no parallel graph branch)")
+    ap.add_argument("--torch-optimizer", action="store_true", help="diagnostic: torch clip_grad_norm_ + fused AdamW + foreach EMA instead of the HIP tail")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
     ap.add_argument("--split-graph", action="store_true", help="force the multi-GPU structure (graph: fwd+bwd | eager all-reduce | graph: clip+AdamW+EMA) on one GPU")
     return ap.parse_args()
@@ -123,11 +124,17 @@ def main():
         _engine.OVERLAP = "off"
     use_graph = not a.no_graph and not a.profile_all and not a.masks
     split_graph = use_graph and (world > 1 or a.split_graph)
-    opt = torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay, fused=True, capturable=use_graph)
+    if a.torch_optimizer:
+        opt = torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay, fused=True, capturable=use_graph)
     kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)  # bumped every step: fresh dropout masks per replay
     ema_src = [v for v in model.state_dict().values() if v.is_floating_point()]
     ema = [v.detach().clone() for v in ema_src]
     all_params = [p for _, p in named]
+    if not a.torch_optimizer:
+        # clip_grad_norm_(0.1) + AdamW (3 groups) + EMA + bf16 compute-copy refresh: csrc/optim.hip, 3 launches per step
+        from toist_amd.optim import FusedClipAdamWEMA
+        opt = FusedClipAdamWEMA(groups, lr=args.lr, weight_decay=args.weight_decay, max_norm=args.clip_max_norm, ema=list(zip(ema_src, ema)),
+                                ema_decay=0.9998)
 
     samples, tok, targets, pmap = harness.synthetic_batch(a.batch, a.size, a.size, tokens=16, seed=1000 + rank, device=dev, with_masks=a.masks)
     sync = parallel.GradSync()
@@ -144,6 +151,9 @@ def main():
         return total
 
     def optimize():
+        if not a.torch_optimizer:
+            opt.step()
+            return
         torch.nn.utils.clip_grad_norm_(all_params, args.clip_max_norm, foreach=True)
         opt.step()
         with torch.no_grad():
@@ -246,7 +256,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("configs[2] (det + mask head + mask losses): " if a.masks else "") + f"configs[1]: ResNet-101 + RoBERTa-base + 6+6 transformer, 100 queries, batch {a.batch}/GPU {a.size}x{a.size}, "
                                    "16-token captions, detection loss (labels+boxes+cardinality, 5 aux layers), dropout 0.1, "
-                                   "clip 0.1 + AdamW + EMA; random-init weights",
+                                   "clip 0.1 + AdamW + EMA" + (" (torch)" if a.torch_optimizer else " (fused HIP tail)") + "; random-init weights",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4), "launch": ("2 hipGraphs + eager all-reduce" if split_graph else "hipGraph replay") if use_graph else "eager",
                        "mfma_frac_whole_step": round(ips / world * GFLOP_PER_IMG_TRAIN / 1000.0 / PEAK_BF16_TFLOPS, 5)},
         }

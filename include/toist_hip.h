@@ -237,6 +237,47 @@ int toist_mask_loss_fwd(const float* pred, const int32_t* pred_row, const uint8_
 int toist_mask_loss_bwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
                         int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred, void* stream);
 
+/* ---- optimizer tail: clip_grad_norm_ + AdamW + EMA + bf16 compute-copy refresh in one multi-tensor pass ------------
+ * Replaces engine.py:87-101 of the reference (torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm);
+ * optimizer.step() with torch.optim.AdamW over the 3 parameter groups of main.py:351-392; update_ema of
+ * util/optim.py:9-26).  All tables live in device memory and are owned by the caller; `grads[i]` is the device
+ * address of tensor i's fp32 gradient (0 = no gradient this step: the tensor is only EMA-averaged).
+ * Work is cut into chunks of toist_opt_chunk_elems() elements: chunks[2*b] = tensor index, chunks[2*b+1] = chunk
+ * index inside that tensor.  State (step count, clip coefficient, bias corrections) stays on the device so a
+ * captured hipGraph replays the tail unchanged; learning rates are read from `groups` at run time. */
+typedef struct toist_opt_tensor {
+    float* p;                 /* fp32 master parameter (or the EMA source for buffers / frozen parameters)            */
+    float* m;                 /* exp_avg     (NULL: never updated by the optimizer)                                   */
+    float* v;                 /* exp_avg_sq                                                                           */
+    float* ema;               /* EMA copy of p, or NULL                                                               */
+    uint16_t* w;              /* bf16 compute copy refreshed from the new p, or NULL                                  */
+    const float* row_scale;   /* optional: w = bf16(p * row_scale[element / row_len]) (folded FrozenBatchNorm scale)  */
+    int64_t numel;
+    int32_t row_len;
+    int32_t group;            /* index into groups[]                                                                  */
+} toist_opt_tensor;           /* 64 bytes */
+
+typedef struct toist_opt_group {
+    float lr;
+    float weight_decay;
+} toist_opt_group;
+
+typedef struct toist_opt_state {
+    float clip_coef;          /* min(1, max_norm / (grad_norm + 1e-6)); 1 when max_norm <= 0                          */
+    float grad_norm;          /* total 2-norm of all gradients before clipping                                        */
+    float bias1;              /* 1 - beta1^step                                                                       */
+    float bias2_sqrt;         /* sqrt(1 - beta2^step)                                                                 */
+    int32_t step;             /* optimizer steps taken (incremented by toist_opt_finish_norm)                         */
+    int32_t reserved[3];
+} toist_opt_state;            /* 32 bytes */
+
+int toist_opt_chunk_elems(void);
+int toist_opt_sqnorm(const toist_opt_tensor* table, const int64_t* grads, const int32_t* chunks, int n_chunks, float* partial, void* stream);
+int toist_opt_finish_norm(const float* partial, int n_chunks, float max_norm, float beta1, float beta2, toist_opt_state* state, void* stream);
+int toist_opt_adamw_ema(const toist_opt_tensor* table, const int64_t* grads, const int32_t* chunks, int n_chunks,
+                        const toist_opt_group* groups, const toist_opt_state* state, float beta1, float beta2, float eps,
+                        float ema_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,6 +138,8 @@ class BackboneBase(nn.Module):
                     wf = torch.nn.functional.pad(wf, (0, 0, 0, 0, 0, 8 - wf.shape[1]))
                 return wf.to(BF16).contiguous(memory_format=torch.channels_last)
 
+            if mod_name != "conv1":  # same physical layout as the master: the optimizer tail may rewrite it
+                make.elementwise, make.row_scale = True, scale
             tr[mod_name + ".weight"] = make
         return tr
 

@@ -27,128 +27,120 @@ __device__ __forceinline__ float gelu_grad_f(float a) {
     return 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * __expf(-0.5f * a * a);
 }
 
-// One 1x4 output fragment: v = acc*alpha*rscale[m] -> *scale[n] + shift[n] -> dropout -> + res -> act -> dropout -> store.
-// Written with compile-time element indices only (no break/continue) so accumulators stay in registers.
-__device__ __forceinline__ void epilogue_frag(const toist_gemm& p, const f32x4_t a, const int m, const int n, const int bz,
-                                              const long long coff) {
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// One 1x8 output chunk (row m, columns n .. n+7; the accumulators reach it through an LDS transpose so that a
+// wavefront touches whole 128-byte row segments):
+//   v = acc*alpha*rscale[m] -> *scale[n] + shift[n] -> dropout -> + res -> (pre_out) -> act -> dropout -> store.
+// Written with compile-time element indices only (no break/continue) so everything stays in registers.
+struct EpiRow {            // addresses of one chunk, resolved once
+    long long crow;        // output row (after the optional scatter map)
+    long long rrow;        // residual row
+    int m, n, nv;          // nv = valid columns (<= 8)
+};
+
+__device__ __forceinline__ EpiRow epi_row(const toist_gemm& p, const int m, const int n) {
     const toist_epilogue& e = p.epi;
-    const int N = p.N, M = p.M;
-    const int nv = (N - n < 4) ? (N - n) : 4;
-    long long crow = m;
+    EpiRow r;
+    r.m = m; r.n = n;
+    r.nv = (p.N - n < 8) ? (p.N - n) : 8;
+    r.crow = m;
     if (e.cmap) {
         const int plane = e.cOH * e.cOW;
         const int n_img = m / plane, rem = m - n_img * plane;
         const int oy = rem / e.cOW, ox = rem - oy * e.cOW;
-        crow = ((long long)n_img * e.cH + (long long)oy * e.cst) * e.cW + (long long)ox * e.cst;
+        r.crow = ((long long)n_img * e.cH + (long long)oy * e.cst) * e.cW + (long long)ox * e.cst;
     }
+    r.rrow = (e.res_div > 0) ? (long long)(m / e.res_div) * e.res_mod + (m % e.res_mod) : r.crow;
+    return r;
+}
+
+__device__ __forceinline__ void unpack8(const uint4 u, float* x) {
+    x[0] = __uint_as_float(u.x << 16); x[1] = __uint_as_float(u.x & 0xffff0000u);
+    x[2] = __uint_as_float(u.y << 16); x[3] = __uint_as_float(u.y & 0xffff0000u);
+    x[4] = __uint_as_float(u.z << 16); x[5] = __uint_as_float(u.z & 0xffff0000u);
+    x[6] = __uint_as_float(u.w << 16); x[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+// 8 bf16 of a row; whole 16-byte load when the chunk is complete and aligned
+__device__ __forceinline__ void load_row8(const bf16_t* rp, const int nv, float* x) {
+    if (nv == 8 && ((((size_t)rp) & 15) == 0)) {
+        unpack8(*reinterpret_cast<const uint4*>(rp), x);
+    } else {
+        static_for<8>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            x[j] = (j < nv) ? bf2f(rp[j]) : 0.f;
+        });
+    }
+}
+
+__device__ __forceinline__ void store_row8_bf16(bf16_t* cp, const int nv, const float* v) {
+    if (nv == 8 && ((((size_t)cp) & 15) == 0)) {
+        *reinterpret_cast<uint4*>(cp) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+    } else {
+        static_for<8>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            if (j < nv) cp[j] = f2bf(v[j]);
+        });
+    }
+}
+
+// res / aux operands of a chunk, fetched ahead of the LDS transpose so their latency overlaps it
+__device__ __forceinline__ void epilogue_fetch(const toist_gemm& p, const EpiRow& r, const long long coff, float* xres, float* xaux) {
+    const toist_epilogue& e = p.epi;
+    if (e.res) load_row8((const bf16_t*)e.res + coff + r.rrow * e.ldr + r.n, r.nv, xres);
+    if (e.act >= TOIST_ACT_MASK_POS) load_row8((const bf16_t*)e.aux + coff + r.crow * e.ldaux + r.n, r.nv, xaux);
+}
+
+__device__ __forceinline__ void epilogue_row8(const toist_gemm& p, float* v, const EpiRow& r, const int bz, const long long coff,
+                                              const float* xres, const float* xaux) {
+    const toist_epilogue& e = p.epi;
+    const int N = p.N, M = p.M, m = r.m, n = r.n, nv = r.nv;
     const float rs = e.rscale ? e.alpha * e.rscale[m] : e.alpha;
-    float v0 = a[0] * rs, v1 = a[1] * rs, v2 = a[2] * rs, v3 = a[3] * rs;
-    if (e.scale) {
-        v0 *= e.scale[n];
-        if (nv > 1) v1 *= e.scale[n + 1];
-        if (nv > 2) v2 *= e.scale[n + 2];
-        if (nv > 3) v3 *= e.scale[n + 3];
-    }
-    if (e.shift) {
-        v0 += e.shift[n];
-        if (nv > 1) v1 += e.shift[n + 1];
-        if (nv > 2) v2 += e.shift[n + 2];
-        if (nv > 3) v3 += e.shift[n + 3];
-    }
+    static_for<8>([&](auto jj) { v[decltype(jj)::value] *= rs; });
+    if (e.scale) static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; if (j < nv) v[j] *= e.scale[n + j]; });
+    if (e.shift) static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; if (j < nv) v[j] += e.shift[n + j]; });
     const unsigned long long didx = ((unsigned long long)bz * M + m) * N + n;
     const unsigned long long dseed = e.drop_where ? e.drop_seed + (e.drop_seed_dev ? *e.drop_seed_dev : 0ull) : 0ull;
     if (e.drop_where == 1) {
         const unsigned th = (unsigned)(e.drop_p * 4294967296.0);
         const float sc = 1.f / (1.f - e.drop_p);
-        v0 = dropout_keep(dseed, didx, th) ? v0 * sc : 0.f;
-        v1 = dropout_keep(dseed, didx + 1, th) ? v1 * sc : 0.f;
-        v2 = dropout_keep(dseed, didx + 2, th) ? v2 * sc : 0.f;
-        v3 = dropout_keep(dseed, didx + 3, th) ? v3 * sc : 0.f;
+        static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] = dropout_keep(dseed, didx + j, th) ? v[j] * sc : 0.f; });
     }
-    if (e.res) {
-        const long long rrow = (e.res_div > 0) ? (long long)(m / e.res_div) * e.res_mod + (m % e.res_mod) : crow;
-        const bf16_t* rp = (const bf16_t*)e.res + coff + rrow * e.ldr + n;
-        if (nv == 4 && ((((size_t)rp) & 7) == 0)) {
-            const uint2 u = *reinterpret_cast<const uint2*>(rp);
-            v0 += __uint_as_float(u.x << 16); v1 += __uint_as_float(u.x & 0xffff0000u);
-            v2 += __uint_as_float(u.y << 16); v3 += __uint_as_float(u.y & 0xffff0000u);
-        } else {
-            v0 += bf2f(rp[0]);
-            if (nv > 1) v1 += bf2f(rp[1]);
-            if (nv > 2) v2 += bf2f(rp[2]);
-            if (nv > 3) v3 += bf2f(rp[3]);
-        }
-    }
-    if (e.pre_out) {
-        bf16_t* pp = (bf16_t*)e.pre_out + coff + crow * p.ldc + n;
-        pp[0] = f2bf(v0);
-        if (nv > 1) pp[1] = f2bf(v1);
-        if (nv > 2) pp[2] = f2bf(v2);
-        if (nv > 3) pp[3] = f2bf(v3);
-    }
-    if (e.act != TOIST_ACT_NONE) {
-        float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
-        if (e.act >= TOIST_ACT_MASK_POS) {
-            const bf16_t* ap = (const bf16_t*)e.aux + coff + crow * e.ldaux + n;
-            if (nv == 4 && ((((size_t)ap) & 7) == 0)) {
-                const uint2 u = *reinterpret_cast<const uint2*>(ap);
-                x0 = __uint_as_float(u.x << 16); x1 = __uint_as_float(u.x & 0xffff0000u);
-                x2 = __uint_as_float(u.y << 16); x3 = __uint_as_float(u.y & 0xffff0000u);
-            } else {
-                x0 = bf2f(ap[0]);
-                if (nv > 1) x1 = bf2f(ap[1]);
-                if (nv > 2) x2 = bf2f(ap[2]);
-                if (nv > 3) x3 = bf2f(ap[3]);
-            }
-        }
-        switch (e.act) {
-            case TOIST_ACT_RELU: v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); break;
-            case TOIST_ACT_GELU: v0 = gelu_f(v0); v1 = gelu_f(v1); v2 = gelu_f(v2); v3 = gelu_f(v3); break;
-            case TOIST_ACT_SIGMOID:
-                v0 = 1.f / (1.f + __expf(-v0)); v1 = 1.f / (1.f + __expf(-v1));
-                v2 = 1.f / (1.f + __expf(-v2)); v3 = 1.f / (1.f + __expf(-v3)); break;
-            case TOIST_ACT_MASK_POS:
-                v0 = x0 > 0.f ? v0 : 0.f; v1 = x1 > 0.f ? v1 : 0.f; v2 = x2 > 0.f ? v2 : 0.f; v3 = x3 > 0.f ? v3 : 0.f; break;
-            case TOIST_ACT_GELU_BWD:
-                v0 *= gelu_grad_f(x0); v1 *= gelu_grad_f(x1); v2 *= gelu_grad_f(x2); v3 *= gelu_grad_f(x3); break;
-            case TOIST_ACT_SIGMOID_BWD:
-                v0 *= x0 * (1.f - x0); v1 *= x1 * (1.f - x1); v2 *= x2 * (1.f - x2); v3 *= x3 * (1.f - x3); break;
-            default: break;
-        }
+    if (e.res) static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] += xres[j]; });
+    if (e.pre_out) store_row8_bf16((bf16_t*)e.pre_out + coff + r.crow * p.ldc + n, nv, v);
+    switch (e.act) {
+        case TOIST_ACT_RELU: static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] = fmaxf(v[j], 0.f); }); break;
+        case TOIST_ACT_GELU: static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] = gelu_f(v[j]); }); break;
+        case TOIST_ACT_SIGMOID: static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] = 1.f / (1.f + __expf(-v[j])); }); break;
+        case TOIST_ACT_MASK_POS: static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] = xaux[j] > 0.f ? v[j] : 0.f; }); break;
+        case TOIST_ACT_GELU_BWD: static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] *= gelu_grad_f(xaux[j]); }); break;
+        case TOIST_ACT_SIGMOID_BWD: static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] *= xaux[j] * (1.f - xaux[j]); }); break;
+        default: break;
     }
     if (e.drop_where == 2) {
         const unsigned th = (unsigned)(e.drop_p * 4294967296.0);
         const float sc = 1.f / (1.f - e.drop_p);
-        v0 = dropout_keep(dseed, didx, th) ? v0 * sc : 0.f;
-        v1 = dropout_keep(dseed, didx + 1, th) ? v1 * sc : 0.f;
-        v2 = dropout_keep(dseed, didx + 2, th) ? v2 * sc : 0.f;
-        v3 = dropout_keep(dseed, didx + 3, th) ? v3 * sc : 0.f;
+        static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] = dropout_keep(dseed, didx + j, th) ? v[j] * sc : 0.f; });
     }
     if (e.out_f32) {
-        float* cp = (float*)p.c + coff + crow * p.ldc + n;
+        float* cp = (float*)p.c + coff + r.crow * p.ldc + n;
         if (e.accumulate) {  // the element is owned by this thread: plain read-modify-write
-            cp[0] += v0;
-            if (nv > 1) cp[1] += v1;
-            if (nv > 2) cp[2] += v2;
-            if (nv > 3) cp[3] += v3;
-        } else if (nv == 4 && ((((size_t)cp) & 15) == 0)) {
-            *reinterpret_cast<float4*>(cp) = make_float4(v0, v1, v2, v3);
+            static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; if (j < nv) cp[j] += v[j]; });
+        } else if (nv == 8 && ((((size_t)cp) & 15) == 0)) {
+            reinterpret_cast<float4*>(cp)[0] = make_float4(v[0], v[1], v[2], v[3]);
+            reinterpret_cast<float4*>(cp)[1] = make_float4(v[4], v[5], v[6], v[7]);
         } else {
-            cp[0] = v0;
-            if (nv > 1) cp[1] = v1;
-            if (nv > 2) cp[2] = v2;
-            if (nv > 3) cp[3] = v3;
+            static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; if (j < nv) cp[j] = v[j]; });
         }
     } else {
-        bf16_t* cp = (bf16_t*)p.c + coff + crow * p.ldc + n;
-        if (nv == 4 && ((((size_t)cp) & 7) == 0)) {
-            *reinterpret_cast<uint2*>(cp) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
-        } else {
-            cp[0] = f2bf(v0);
-            if (nv > 1) cp[1] = f2bf(v1);
-            if (nv > 2) cp[2] = f2bf(v2);
-            if (nv > 3) cp[3] = f2bf(v3);
-        }
+        store_row8_bf16((bf16_t*)p.c + coff + r.crow * p.ldc + n, nv, v);
     }
 }
 
@@ -191,14 +183,6 @@ __device__ __forceinline__ void dma16(unsigned lds_dst, const i32x4_t& r, int el
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
 
 // ---- LDS tile layouts ------------------------------------------------------------------------------
 // k-contiguous tile: [ROWS][BK], 16-byte chunk (row, kc) lives in slot kc ^ ((row / RPL) % CPR) of its row
@@ -307,7 +291,7 @@ __device__ __forceinline__ bf16x8_t fragment(const bf16_t* s, int r0, int ks, in
     return *reinterpret_cast<const bf16x8_t*>(&s[row * BK + swz_k<BK>(row, ks * 4 + g) * 8]);
 }
 
-template <int BM, int BN, int BK, int AK, int BKD, int DEEP>
+template <int BM, int BN, int BK, int AK, int BKD, int NS>
 __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int ACH = BM * BK / 8 / 256, BCH = BN * BK / 8 / 256;  // 1 KiB DMA pieces per wave per tile
@@ -315,10 +299,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     constexpr bool B_KM = (BKD != TOIST_B_ROWK);   // B staged k-major
     constexpr int SA_ELEMS = BM * BK, SB_ELEMS = BN * BK;
     constexpr int STAGE = SA_ELEMS + SB_ELEMS;                       // elements per ring slot
-    // ring depth: measured on MI355X, occupancy beats depth -- 2 slots (5 workgroups/CU for 64x64x64) run
-    // 15-30 % faster than 3 slots (3 workgroups/CU) on the K = 256..2048 hot-path shapes
-    // DEEP (small grids, <= 2 workgroups per CU): nothing else hides latency, so spend the idle LDS on a 4-slot ring
-    constexpr int NS = DEEP ? 4 : ((STAGE * 2 <= 8192) ? 4 : 2);
+    // NS = slots of the DMA ring (NS-1 k-tiles in flight per workgroup).  What the kernel can pull from L2 is
+    // (bytes in flight per CU) / (loaded latency, ~1.4 us): the host picks NS and the tile so that the whole grid
+    // is resident at once with as many staged bytes as the 160 KB of LDS allow (see pick_tile below).
     constexpr int CNT = ACH + BCH;
     static_assert(NS >= 2 && NS <= 4, "wait ladder below covers up to 2 younger tiles");
     __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
@@ -482,33 +465,60 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
         }
     }
 
-    // ---- epilogue: lane owns output row m (c16) and 4 consecutive columns n (4*g .. 4*g+3) ----
-    if (p.split_k > 1) {
-        // k-slice partial: raw f32 tile into the workspace; splitk_reduce_kernel applies the epilogue
-        float* ws = p.workspace + (size_t)ksl * M * N;
-        static_for<FM * FN>([&](auto idx) {
-            constexpr int i = decltype(idx)::value / FN, j = decltype(idx)::value % FN;
-            const int m = m0 + wm * WM + i * 16 + c16;
-            const int n = n0 + wn * WN + j * 16 + g * 4;
-            if (m < M && n < N) {
-                float* cp = ws + (size_t)m * N + n;
-                const f32x4_t a = acc[i][j];
-                if (N - n >= 4 && ((((size_t)cp) & 15) == 0)) *reinterpret_cast<float4*>(cp) = make_float4(a[0], a[1], a[2], a[3]);
-                else {
-                    cp[0] = a[0];
-                    if (N - n > 1) cp[1] = a[1];
-                    if (N - n > 2) cp[2] = a[2];
-                    if (N - n > 3) cp[3] = a[3];
+    // ---- epilogue ------------------------------------------------------------------------------------------
+    // After the MFMAs a lane owns output row c16 and 4 consecutive columns 4*g .. 4*g+3 of each 16x16 fragment:
+    // stored directly, a wavefront store would touch 16 rows x 32 bytes.  Instead the tile goes through LDS in
+    // bands of 32 rows (fragment row i of both wave rows), and every thread finishes 8 consecutive columns of
+    // one row: 16-byte bf16 accesses, whole 128-byte row segments per 8 lanes, for C, res, aux and pre_out alike.
+    constexpr int LDT = BN + 4;                      // f32 band pitch: +4 keeps the float4 writes conflict-free
+    constexpr int CPR = BN / 8;                      // 8-column chunks per band row
+    constexpr int CH = (32 * CPR) / 256;             // chunks per thread per band (1 for BN = 64, 2 for BN = 128)
+    static_assert(32 * CPR % 256 == 0 && 32 * LDT * 4 <= NS * STAGE * 2, "band must fit the (now idle) ring");
+    float* band = reinterpret_cast<float*>(smem);
+    const bool partial = p.split_k > 1;              // k-slice partial: raw f32 into the workspace, epilogue in splitk_reduce_kernel
+    float* ws = partial ? p.workspace + (size_t)ksl * M * N : nullptr;
+    static_for<FM>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        EpiRow rows[CH];
+        float xres[CH][8], xaux[CH][8];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int c = tid + 256 * q;
+            const int br = c / CPR, c8 = c - br * CPR;
+            const int m = m0 + (br >> 4) * WM + i * 16 + (br & 15);
+            rows[q] = epi_row(p, m < M ? m : 0, n0 + c8 * 8);
+            rows[q].m = m;
+            if (!partial && m < M && rows[q].nv > 0) epilogue_fetch(p, rows[q], coff, xres[q], xaux[q]);
+        }
+        __syncthreads();                             // previous band (or the last k-tile / the colsum scratch) is consumed
+        static_for<FN>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            *reinterpret_cast<f32x4_t*>(band + (wm * 16 + c16) * LDT + wn * WN + j * 16 + g * 4) = acc[i][j];
+        });
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int c = tid + 256 * q;
+            const int br = c / CPR, c8 = c - br * CPR;
+            const EpiRow& r = rows[q];
+            if (r.m < M && r.nv > 0) {
+                float v[8];
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(band + br * LDT + c8 * 8);
+                const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(band + br * LDT + c8 * 8 + 4);
+                v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+                if (partial) {
+                    float* cp = ws + (size_t)r.m * N + r.n;
+                    if (r.nv == 8 && ((((size_t)cp) & 15) == 0)) {
+                        reinterpret_cast<float4*>(cp)[0] = make_float4(v[0], v[1], v[2], v[3]);
+                        reinterpret_cast<float4*>(cp)[1] = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+                        static_for<8>([&](auto e8) { constexpr int j = decltype(e8)::value; if (j < r.nv) cp[j] = v[j]; });
+                    }
+                } else {
+                    epilogue_row8(p, v, r, bz, coff, xres[q], xaux[q]);
                 }
             }
-        });
-        return;
-    }
-    static_for<FM * FN>([&](auto idx) {
-        constexpr int i = decltype(idx)::value / FN, j = decltype(idx)::value % FN;
-        const int m = m0 + wm * WM + i * 16 + c16;
-        const int n = n0 + wn * WN + j * 16 + g * 4;
-        if (m < M && n < N) epilogue_frag(p, acc[i][j], m, n, bz, coff);
+        }
     });
 }
 
@@ -533,29 +543,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 template <int BM, int BN, int BK, int AK, int BKD>
-static void launch_variant(const toist_gemm& d, hipStream_t st) {
+static int launch_variant(const toist_gemm& d, int ring, hipStream_t st) {
     dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, d.batch * d.split_k);
-    const long long wgs = (long long)grid.x * grid.y * grid.z;
-    if (BM == 64 && BN == 64 && BK == 64 && wgs <= 512)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, (BM == 64 && BN == 64 && BK == 64) ? 1 : 0>), grid, dim3(256), 0, st, d);
-    else
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 0>), grid, dim3(256), 0, st, d);
+    constexpr int stage = (BM + BN) * BK * 2;
+    if (ring == 0) {
+        const long long wgs = (long long)grid.x * grid.y * grid.z;
+        if (stage <= 8192) ring = 4;
+        else if (BM == 64 && BN == 64) ring = wgs <= 512 ? 3 : 2;
+        else ring = 2;
+    }
+    if (ring * stage > 160 * 1024) {
+        set_last_error("toist_gemm_bf16: ring of %d x %d bytes exceeds the LDS", ring, stage);
+        return TOIST_EINVAL;
+    }
+    // instantiated rings (tools/sweep_gemm.py, MI355X): deeper rings never beat 2 slots once the grid fills the chip --
+    // the kernel is bound by the LDS-DMA issue rate (~35 B/clk/CU), not by latency; 3 slots help 64x64x64 on small grids
+    constexpr bool small = stage <= 8192;
+    constexpr bool t65 = (BM == 64 && BN == 64 && BK == 64);
+    if (small) ring = 4;
+    else if (!t65) ring = 2;
+    else if (ring != 2) ring = 3;
+    if constexpr (small) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 4>), grid, dim3(256), 0, st, d);
+    else if constexpr (t65) {
+        if (ring == 3) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 3>), grid, dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 2>), grid, dim3(256), 0, st, d);
+    } else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 2>), grid, dim3(256), 0, st, d);
+    return TOIST_OK;
 }
 
 template <int BM, int BN, int BK>
-static int launch_tile(const toist_gemm& d, hipStream_t st) {
+static int launch_tile(const toist_gemm& d, int ring, hipStream_t st) {
     const int ak = d.a_kind, bk = d.b_kind;
-    if (ak == TOIST_A_ROWK && bk == TOIST_B_ROWK) launch_variant<BM, BN, BK, TOIST_A_ROWK, TOIST_B_ROWK>(d, st);
-    else if (ak == TOIST_A_ROWK && bk == TOIST_B_KROW) launch_variant<BM, BN, BK, TOIST_A_ROWK, TOIST_B_KROW>(d, st);
-    else if (ak == TOIST_A_CONV && bk == TOIST_B_ROWK) launch_variant<BM, BN, BK, TOIST_A_CONV, TOIST_B_ROWK>(d, st);
-    else if (ak == TOIST_A_CONVT && bk == TOIST_B_KROW) launch_variant<BM, BN, BK, TOIST_A_CONVT, TOIST_B_KROW>(d, st);
-    else if (ak == TOIST_A_KROW && bk == TOIST_B_KROW) launch_variant<BM, BN, BK, TOIST_A_KROW, TOIST_B_KROW>(d, st);
-    else if (ak == TOIST_A_KROW && bk == TOIST_B_CONVX) launch_variant<BM, BN, BK, TOIST_A_KROW, TOIST_B_CONVX>(d, st);
-    else {
-        set_last_error("toist_gemm_bf16: unsupported operand kinds a=%d b=%d", ak, bk);
-        return TOIST_EINVAL;
-    }
-    return TOIST_OK;
+    if (ak == TOIST_A_ROWK && bk == TOIST_B_ROWK) return launch_variant<BM, BN, BK, TOIST_A_ROWK, TOIST_B_ROWK>(d, ring, st);
+    else if (ak == TOIST_A_ROWK && bk == TOIST_B_KROW) return launch_variant<BM, BN, BK, TOIST_A_ROWK, TOIST_B_KROW>(d, ring, st);
+    else if (ak == TOIST_A_CONV && bk == TOIST_B_ROWK) return launch_variant<BM, BN, BK, TOIST_A_CONV, TOIST_B_ROWK>(d, ring, st);
+    else if (ak == TOIST_A_CONVT && bk == TOIST_B_KROW) return launch_variant<BM, BN, BK, TOIST_A_CONVT, TOIST_B_KROW>(d, ring, st);
+    else if (ak == TOIST_A_KROW && bk == TOIST_B_KROW) return launch_variant<BM, BN, BK, TOIST_A_KROW, TOIST_B_KROW>(d, ring, st);
+    else if (ak == TOIST_A_KROW && bk == TOIST_B_CONVX) return launch_variant<BM, BN, BK, TOIST_A_KROW, TOIST_B_CONVX>(d, ring, st);
+    set_last_error("toist_gemm_bf16: unsupported operand kinds a=%d b=%d", ak, bk);
+    return TOIST_EINVAL;
 }
 
 static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
@@ -602,7 +628,8 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     if (d.epi.act >= TOIST_ACT_MASK_POS) TOIST_REQUIRE(d.epi.aux != nullptr, "toist_gemm_bf16: activation %d needs aux", d.epi.act);
     if (d.epi.drop_where) TOIST_REQUIRE(d.epi.drop_p >= 0.f && d.epi.drop_p < 1.f, "toist_gemm_bf16: bad dropout p");
 
-    int tile = d.tile;
+    int tile = d.tile & 255;
+    const int ring = d.tile >> 8;   // 0 = pick; else slots of the DMA ring (2..4)
     if (tile == 0) {
         // measured on MI355X (tools/sweep_gemm.py): 128x128x64 only pays once >= ~4 tiles per CU exist and K
         // is deep; below that 64x64x64 tiles keep more workgroups (and DMA) in flight.
@@ -625,11 +652,11 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     int rc;
     hipStream_t st = (hipStream_t)stream;
     switch (tile) {
-        case 64: rc = launch_tile<64, 64, 32>(d, st); break;
-        case 65: rc = launch_tile<64, 64, 64>(d, st); break;
-        case 128: rc = launch_tile<128, 128, 32>(d, st); break;
-        case 129: rc = launch_tile<128, 128, 64>(d, st); break;
-        case 130: rc = launch_tile<128, 64, 64>(d, st); break;
+        case 64: rc = launch_tile<64, 64, 32>(d, ring, st); break;
+        case 65: rc = launch_tile<64, 64, 64>(d, ring, st); break;
+        case 128: rc = launch_tile<128, 128, 32>(d, ring, st); break;
+        case 129: rc = launch_tile<128, 128, 64>(d, ring, st); break;
+        case 130: rc = launch_tile<128, 64, 64>(d, ring, st); break;
         default: set_last_error("toist_gemm_bf16: bad tile code %d", tile); return TOIST_EINVAL;
     }
     if (rc != TOIST_OK) return rc;

@@ -76,6 +76,63 @@ class Tape:
         self.steps = []
 
 
+# ---- bf16 compute copies of the fp32 master weights ------------------------------------------------------------
+# A copy is valid while the master's version counter, storage and the global WEIGHT_EPOCH are unchanged.  The
+# epoch exists because fused optimizers (torch's fused AdamW, the HIP tail in toist_amd/optim.py) update
+# parameters without touching the version counter: any optimizer step bumps it (global torch hook below), the
+# HIP tail re-validates the copies it has rewritten itself.  Copies are refreshed IN PLACE so their addresses
+# stay valid inside captured hipGraphs and in the optimizer's tensor table.
+WEIGHT_EPOCH = 0
+COPY_GEN = 0          # bumped whenever a copy is (re)allocated: holders of raw pointers rebuild their tables
+COPIES = {}           # master data_ptr -> ComputeCopy
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+try:  # every torch optimizer step invalidates the compute copies
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
+    _reg_post_hook(lambda *a, **k: bump_weight_epoch())
+except Exception:  # pragma: no cover - older torch: copies are refreshed every training forward instead
+    _reg_post_hook = None
+
+
+class ComputeCopy:
+    __slots__ = ("version", "ptr", "epoch", "w", "row_scale", "elementwise")
+
+
+def _cast_bf16(m):
+    return m.detach().to(BF16)
+
+
+_cast_bf16.elementwise = True
+
+
+def compute_copy(t, make, cache, name):
+    global COPY_GEN
+    ent = cache.get(name) if cache is not None else None
+    if ent is not None and ent.version == t._version and ent.ptr == t.data_ptr() and ent.epoch == WEIGHT_EPOCH and _reg_post_hook is not None:
+        return ent.w
+    w = make(t)
+    if ent is not None and ent.w.shape == w.shape and ent.w.stride() == w.stride():
+        ent.w.copy_(w)
+    else:
+        ent = ComputeCopy()
+        ent.w = w
+        # elementwise: the copy has the master's physical element order, so the optimizer tail can rewrite it
+        ent.elementwise = bool(getattr(make, "elementwise", False)) and w.shape == t.shape and w.stride() == t.stride()
+        ent.row_scale = getattr(make, "row_scale", None)
+        COPY_GEN += 1
+        if cache is not None:
+            cache[name] = ent
+    ent.version, ent.ptr, ent.epoch = t._version, t.data_ptr(), WEIGHT_EPOCH
+    if cache is not None:
+        COPIES[t.data_ptr()] = ent
+    return ent.w
+
+
 class ParamView:
     """bf16 compute copy + fp32 gradient slot of one nn.Parameter (or a row slice of one)."""
 
@@ -121,15 +178,8 @@ class ParamSet:
                 off += (t.numel() + 63) // 64 * 64
             wb = None
             if t.dim() >= 2:
-                make = (transforms or {}).get(n) or (lambda m: m.detach().to(BF16))
-                if bf16_cache is not None:
-                    ent = bf16_cache.get(n)
-                    if ent is None or ent[0] != t._version or ent[2] != t.data_ptr():
-                        ent = (t._version, make(t), t.data_ptr())
-                        bf16_cache[n] = ent
-                    wb = ent[1]
-                else:
-                    wb = make(t)
+                make = (transforms or {}).get(n) or _cast_bf16
+                wb = compute_copy(t, make, bf16_cache, n)
             self.views[n] = ParamView(wb, g, t.detach())
 
     def __getitem__(self, name):

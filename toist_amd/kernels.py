@@ -296,3 +296,24 @@ def mask_loss_fwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, alpha, sums):
 def mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, alpha, sums, coef, dpred):
     _lib.check(_lib.lib().toist_mask_loss_bwd(_p(pred, F32), _p(pred_row, torch.int32), _p(gt, torch.uint8), _p(gt_row, torch.int32), T, h, w, TH,
                                               TW, alpha, _p(sums, F32), _p(coef, F32), _p(dpred, F32), _stream()), "toist_mask_loss_bwd")
+
+
+# ---- optimizer tail (include/toist_hip.h: toist_opt_*) ---------------------------------------------------------
+def opt_chunk_elems():
+    return int(_lib.lib().toist_opt_chunk_elems())
+
+
+def opt_sqnorm(table, grads, chunks, n_chunks, partial):
+    _lib.check(_lib.lib().toist_opt_sqnorm(_p(table, torch.uint8), _p(grads, torch.int64), _p(chunks, torch.int32), n_chunks,
+                                           _p(partial, torch.float32), _stream()), "toist_opt_sqnorm")
+
+
+def opt_finish_norm(partial, n_chunks, max_norm, beta1, beta2, state):
+    _lib.check(_lib.lib().toist_opt_finish_norm(_p(partial, torch.float32), n_chunks, max_norm, beta1, beta2, _p(state, torch.uint8),
+                                                _stream()), "toist_opt_finish_norm")
+
+
+def opt_adamw_ema(table, grads, chunks, n_chunks, groups, state, beta1, beta2, eps, ema_decay):
+    _lib.check(_lib.lib().toist_opt_adamw_ema(_p(table, torch.uint8), _p(grads, torch.int64), _p(chunks, torch.int32), n_chunks,
+                                              _p(groups, torch.float32), _p(state, torch.uint8), beta1, beta2, eps, ema_decay, _stream()),
+               "toist_opt_adamw_ema")

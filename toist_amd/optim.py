@@ -1,0 +1,186 @@
+"""Optimizer tail of the TOIST training step on MI355X.
+
+The reference does three library sweeps over ~185 M parameters every step (engine.py:87-101):
+`torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)`, `optimizer.step()` with
+`torch.optim.AdamW` over the three parameter groups of main.py:351-392, then `update_ema`
+(util/optim.py:9-26).  `FusedClipAdamWEMA` does the same arithmetic in three HIP launches
+(csrc/optim.hip) that read every gradient twice and every other tensor once, and it rewrites the bf16
+compute copies of the weights in the same pass (engine.compute_copy), so no cast kernels run in the
+next forward.  All state that changes per step (step count, clip coefficient, bias corrections) lives
+on the device: the tail can be captured in a hipGraph; learning rates are re-read from a device table.
+
+There is no CPU path: tensors must live on the GPU and the HIP library must be loadable.
+"""
+import numpy as np
+import torch
+
+from . import engine
+from . import kernels as k
+
+_TENSOR_DT = np.dtype([("p", "<i8"), ("m", "<i8"), ("v", "<i8"), ("ema", "<i8"), ("w", "<i8"), ("row_scale", "<i8"),
+                       ("numel", "<i8"), ("row_len", "<i4"), ("group", "<i4")])
+assert _TENSOR_DT.itemsize == 64  # toist_opt_tensor
+
+
+def ema_pairs(model, model_ema):
+    """(source, ema) tensor pairs for every floating-point state_dict entry, as update_ema visits them
+    (util/optim.py:23-26; integer buffers carry no average)."""
+    if hasattr(model, "module"):
+        model = model.module
+    msd = model.state_dict()
+    return [(msd[name], ev) for name, ev in model_ema.state_dict().items() if ev.is_floating_point()]
+
+
+def _dense(t):
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+class FusedClipAdamWEMA:
+    """clip_grad_norm_ + AdamW + EMA (+ bf16 compute-copy refresh) in one multi-tensor pass.
+
+    param_groups: like torch.optim.AdamW -- list of {"params": [...], "lr": ..., "weight_decay": ...}; the
+    group dicts are kept in `self.param_groups` so `adjust_learning_rate` (util/optim.py:29-90) can assign
+    `group["lr"]` as it does for a torch optimizer.  ema: list of (source, ema) pairs or None.
+    max_norm <= 0 disables clipping (engine.py:89 `if max_norm > 0`)."""
+
+    def __init__(self, param_groups, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, max_norm=0.1, ema=None, ema_decay=0.9998):
+        if isinstance(param_groups, (list, tuple)) and param_groups and torch.is_tensor(param_groups[0]):
+            param_groups = [{"params": list(param_groups)}]
+        self.param_groups = []
+        for g in param_groups:
+            g = dict(g)
+            g["params"] = [p for p in g["params"]]
+            g.setdefault("lr", lr)
+            g.setdefault("weight_decay", weight_decay)
+            self.param_groups.append(g)
+        self.betas, self.eps, self.max_norm, self.ema_decay = (float(betas[0]), float(betas[1])), float(eps), float(max_norm), float(ema_decay)
+        params = [p for g in self.param_groups for p in g["params"]]
+        if not params:
+            raise ValueError("FusedClipAdamWEMA: no parameters")
+        self.device = params[0].device
+        if self.device.type != "cuda":
+            raise RuntimeError("FusedClipAdamWEMA needs GPU tensors: toist_amd has no CPU fallback")
+        self.params = params
+        self.exp_avg = [torch.zeros_like(p) for p in params]      # preserve_format: same physical layout as p
+        self.exp_avg_sq = [torch.zeros_like(p) for p in params]
+        ema = list(ema or [])
+        by_ptr = {src.data_ptr(): e for src, e in ema}
+        self._ema_of = [by_ptr.pop(p.data_ptr(), None) for p in params]
+        # sources that are averaged but not optimised: frozen parameters and floating-point buffers
+        self._ema_only = [(src, e) for src, e in ema if src.data_ptr() in by_ptr]
+        self._group_of = [gi for gi, g in enumerate(self.param_groups) for _ in g["params"]]
+        for t in params + self.exp_avg + [e for e in self._ema_of if e is not None] + [x for pr in self._ema_only for x in pr]:
+            if t.dtype != torch.float32 or not _dense(t) or t.device != self.device:
+                raise TypeError("FusedClipAdamWEMA: tensors must be dense fp32 tensors on one GPU")
+        for p, e in zip(params, self._ema_of):
+            if e is not None and (e.shape != p.shape or e.stride() != p.stride()):
+                raise ValueError("FusedClipAdamWEMA: an EMA tensor must share its source's shape and strides")
+        self.state = torch.zeros(32, dtype=torch.uint8, device=self.device)          # toist_opt_state
+        self._groups_host = None
+        self._groups_dev = torch.zeros(len(self.param_groups), 2, dtype=torch.float32, device=self.device)
+        self._chunk = k.opt_chunk_elems()
+        n_t = len(params) + len(self._ema_only)
+        self._grads_host = torch.zeros(n_t, dtype=torch.int64).pin_memory()
+        self._grads_dev = torch.zeros(n_t, dtype=torch.int64, device=self.device)
+        self._table = None
+        self._copy_gen = -1
+        self._copies = []
+        self.sync_hyperparams()
+
+    # ---- host-side tables -----------------------------------------------------------------------------------
+    def sync_hyperparams(self):
+        """Upload lr / weight_decay of self.param_groups (call after changing them when the step is replayed
+        from a hipGraph; step() does it by itself otherwise)."""
+        cur = [(float(g["lr"]), float(g["weight_decay"])) for g in self.param_groups]
+        if cur != self._groups_host:
+            self._groups_host = cur
+            self._groups_dev.copy_(torch.tensor(cur, dtype=torch.float32), non_blocking=False)
+
+    def _build_table(self):
+        rows = np.zeros(len(self.params) + len(self._ema_only), dtype=_TENSOR_DT)
+        self._copies = []
+        for i, p in enumerate(self.params):
+            r = rows[i]
+            r["p"], r["m"], r["v"] = p.data_ptr(), self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
+            r["ema"] = self._ema_of[i].data_ptr() if self._ema_of[i] is not None else 0
+            r["numel"], r["group"], r["row_len"] = p.numel(), self._group_of[i], 1
+            ent = engine.COPIES.get(p.data_ptr())
+            if ent is not None and ent.elementwise and ent.ptr == p.data_ptr():
+                r["w"] = ent.w.data_ptr()
+                if ent.row_scale is not None:
+                    r["row_scale"] = ent.row_scale.data_ptr()
+                    r["row_len"] = p.numel() // p.shape[0]
+                self._copies.append((ent, p))
+        for j, (src, e) in enumerate(self._ema_only):
+            r = rows[len(self.params) + j]
+            r["p"], r["ema"], r["numel"], r["row_len"] = src.data_ptr(), e.data_ptr(), src.numel(), 1
+        numels = rows["numel"]
+        nch = (numels + self._chunk - 1) // self._chunk
+        tens = np.repeat(np.arange(len(rows), dtype=np.int32), nch)
+        first = np.repeat(np.cumsum(nch) - nch, nch)
+        idx = (np.arange(int(nch.sum()), dtype=np.int64) - first).astype(np.int32)
+        chunks = np.stack([tens, idx], axis=1).astype(np.int32)
+        self._n_chunks = int(chunks.shape[0])
+        self._table = torch.from_numpy(rows.view(np.uint8).copy()).to(self.device)
+        self._chunks = torch.from_numpy(np.ascontiguousarray(chunks)).to(self.device)
+        self._partial = torch.empty(self._n_chunks, dtype=torch.float32, device=self.device)
+        self._copy_gen = engine.COPY_GEN
+
+    # ---- torch.optim-like surface ---------------------------------------------------------------------------
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._table is None or (self._copy_gen != engine.COPY_GEN and not capturing):
+            self._build_table()
+        if not capturing:
+            self.sync_hyperparams()
+        gh = self._grads_host.numpy()
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None:
+                gh[i] = 0
+                continue
+            if g.dtype != torch.float32 or g.shape != p.shape or g.stride() != p.stride():
+                raise TypeError("FusedClipAdamWEMA: every gradient must be fp32 with its parameter's shape and strides")
+            gh[i] = g.data_ptr()
+        self._grads_dev.copy_(self._grads_host, non_blocking=True)
+        k.opt_sqnorm(self._table, self._grads_dev, self._chunks, self._n_chunks, self._partial)
+        k.opt_finish_norm(self._partial, self._n_chunks, self.max_norm, self.betas[0], self.betas[1], self.state)
+        k.opt_adamw_ema(self._table, self._grads_dev, self._chunks, self._n_chunks, self._groups_dev, self.state, self.betas[0],
+                        self.betas[1], self.eps, self.ema_decay)
+        # the masters changed behind torch's version counters: every compute copy is stale except the ones just rewritten
+        engine.bump_weight_epoch()
+        for ent, p in self._copies:
+            if p.grad is not None:
+                ent.epoch = engine.WEIGHT_EPOCH
+
+    # ---- introspection / checkpointing ----------------------------------------------------------------------
+    def device_state(self):
+        """{'clip_coef', 'grad_norm', 'bias1', 'bias2_sqrt', 'step'} read back from the device (synchronises)."""
+        raw = self.state.cpu().numpy()
+        f = raw[:16].view(np.float32)
+        return {"clip_coef": float(f[0]), "grad_norm": float(f[1]), "bias1": float(f[2]), "bias2_sqrt": float(f[3]),
+                "step": int(raw[16:20].view(np.int32)[0])}
+
+    def state_dict(self):
+        return {"step": self.device_state()["step"], "exp_avg": [t.clone() for t in self.exp_avg], "exp_avg_sq": [t.clone() for t in self.exp_avg_sq],
+                "param_groups": [{kk: vv for kk, vv in g.items() if kk != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        for dst, src in zip(self.exp_avg, sd["exp_avg"]):
+            dst.copy_(src)
+        for dst, src in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
+            dst.copy_(src)
+        raw = np.zeros(32, dtype=np.uint8)
+        raw[16:20] = np.array([int(sd["step"])], dtype=np.int32).view(np.uint8)
+        self.state.copy_(torch.from_numpy(raw))
+        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update(s)
+        self.sync_hyperparams()

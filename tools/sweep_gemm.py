@@ -10,7 +10,8 @@ from tools.bench_gemm import timeit  # noqa: E402
 
 BF = torch.bfloat16
 dev = torch.device("cuda")
-TILES = [64, 65, 128, 129, 130]
+R = 256
+TILES = [65, 65 + 3 * R, 65 + 4 * R, 130, 130 + 3 * R, 130 + 4 * R, 129, 129 + 3 * R, 129 + 4 * R]
 
 
 def row(name, fl, fn, splits=(0,)):
@@ -20,7 +21,7 @@ def row(name, fl, fn, splits=(0,)):
             k.FORCE_TILE, k.FORCE_SPLIT = t, sp
             try:
                 ms = timeit(fn, 20)
-                out.append(f"{t}{'/s%d' % sp if sp else ''}:{fl / ms / 1e9:6.0f}")
+                out.append(f"{t & 255}r{t >> 8}{'/s%d' % sp if sp else ''}:{fl / ms / 1e9:5.0f}")
             except RuntimeError as e:
                 out.append(f"{t}:ERR")
     k.FORCE_TILE = k.FORCE_SPLIT = 0
