@@ -271,9 +271,22 @@ def main():
                 k_[1] += fl
                 k_[2] += 1
             n = len(prof["records"])
+            alg_bytes = sum(r[5] for r in prof["records"]) / n
+            traffic, traffic_src = None, None
+            if prof["key"] is not None:
+                # HBM bytes per launch of this kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+                # --pmc WRITE_SIZE in separate runs of this same script, tools/run_gpu_round.sh + tools/pmc_traffic.py)
+                pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+                if os.path.exists(pj):
+                    ks = {k_: v for k_, v in json.load(open(pj))["kernels"].items() if "gemm_kernel<64, 64, 64, 2, 0," in k_}
+                    disp = sum(v["dispatches"] for v in ks.values())
+                    if disp:
+                        traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in ks.values()) / disp)
+                        traffic_src = "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction applied)"
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 5), "traffic": None,
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 5), "traffic": traffic, "traffic_unit": "bytes/launch",
+                               "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes),
                                "kernel": "gemm_kernel<64,64,64,A_CONV,B_ROWK> (implicit-GEMM conv forward)" if prof["key"] else "all gemm_kernel launches",
                                "timed": "HIP events around each launch, %d eager steps %s" % (a.steps, "after the graph-replayed timed region" if use_graph else "inside the timed region"),
                                "launches": n, "avg_launch_us": round(1000 * tot_ms / n, 2), "avg_gflop_per_launch": round(tot_fl / n / 1e9, 3)}

@@ -311,7 +311,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     const int g = lane >> 4, c16 = lane & 15;
 
     const int M = p.M, N = p.N, K = p.K;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs (id % 8), each with its own
+    // 4 MB L2.  Tile L = (id % 8) * ceil(tiles / 8) + id / 8 gives every XCD one contiguous run of tiles, n fastest:
+    // the N tiles of an M row share their A tile in ONE L2, and neighbouring M tiles (the halo rows of a 3x3
+    // gather) stay there too, instead of every XCD streaming the whole A operand through its L2.
+    const int nt_n = (p.N + BN - 1) / BN;
+    const int tiles = ((p.M + BM - 1) / BM) * nt_n;
+    const int tile_id = (int)(blockIdx.x & 7) * ((tiles + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (tile_id >= tiles) return;            // grid.x is padded to a multiple of 8
+    const int tile_m = tile_id / nt_n, tile_n = tile_id - tile_m * nt_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z;
     const int bz = z / p.split_k, ksl = z - bz * p.split_k;
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     float csum[ACH][8];
-    const bool want_csum = A_KM && p.a_colsum != nullptr && blockIdx.y == 0;
+    const bool want_csum = A_KM && p.a_colsum != nullptr && tile_n == 0;
 #pragma unroll
     for (int it = 0; it < ACH; ++it)
 #pragma unroll
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     }
     wait_vm<0>();
 
-    if (A_KM && p.a_colsum != nullptr && blockIdx.y == 0) {
+    if (want_csum) {
         // bias gradient: column sums of the staged A tiles, reduced over the k rows held by other threads
         float* red = reinterpret_cast<float*>(smem);  // main loop is done: LDS is free
         __syncthreads();
@@ -544,10 +553,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 template <int BM, int BN, int BK, int AK, int BKD>
 static int launch_variant(const toist_gemm& d, int ring, hipStream_t st) {
-    dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, d.batch * d.split_k);
+    const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    dim3 grid((tiles + 7) & ~7, 1, d.batch * d.split_k);   // 1-D over tiles (XCD-aware order in the kernel), padded to 8
     constexpr int stage = (BM + BN) * BK * 2;
     if (ring == 0) {
-        const long long wgs = (long long)grid.x * grid.y * grid.z;
+        const long long wgs = (long long)tiles * grid.z;
         if (stage <= 8192) ring = 4;
         else if (BM == 64 && BN == 64) ring = wgs <= 512 ? 3 : 2;
         else ring = 2;

@@ -1,18 +1,20 @@
+# usage (on the GPU box): bash tools/run_gpu_round.sh <tag>   -- default bench, per-shape profile, rocprof stats, timeline, PMC passes
+TAG=${1:-rX}
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-( time timeout 900 python bench.py ) > gpurun_out/bench_default.log 2>&1
-tail -5 gpurun_out/bench_default.log
-timeout 600 python bench.py --profile-all --no-cpu-baseline --steps 5 --warmup 2 > gpurun_out/bench_profall.log 2>&1
-tail -3 gpurun_out/bench_profall.log
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r1d -o r1d -- python bench.py --no-cpu-baseline > gpurun_out/bench_rocprof.log 2>&1
-tail -2 gpurun_out/bench_rocprof.log
-rm -f gpurun_out/prof_r1d/*kernel_trace.csv gpurun_out/prof_r1d/*.db
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python bench.py --no-cpu-baseline --no-graph --no-roofline --steps 2 --warmup 1 > gpurun_out/pmc_fetch.log 2>&1
-tail -2 gpurun_out/pmc_fetch.log
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- python bench.py --no-cpu-baseline --no-graph --no-roofline --steps 2 --warmup 1 > gpurun_out/pmc_write.log 2>&1
-tail -2 gpurun_out/pmc_write.log
-python tools/pmc_summary.py gpurun_out/pmc_fetch/f_counter_collection.csv FETCH_SIZE > gpurun_out/pmc_fetch_summary.txt 2>&1
-python tools/pmc_summary.py gpurun_out/pmc_write/w_counter_collection.csv WRITE_SIZE > gpurun_out/pmc_write_summary.txt 2>&1
-rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
-du -sh gpurun_out
+O=gpurun_out/$TAG
+mkdir -p $O
+( time timeout 900 python bench.py ) > $O/bench_default.log 2>&1
+tail -4 $O/bench_default.log | cut -c1-1800
+timeout 600 python bench.py --profile-all --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_profall.log 2>&1
+mv gpurun_out/gemm_shapes.txt $O/gemm_shapes.txt
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o $TAG -- python bench.py --no-cpu-baseline > $O/bench_rocprof.log 2>&1
+python tools/timeline.py $O/prof/${TAG}_kernel_trace.csv $O/timeline.txt
+rm -f $O/prof/*kernel_trace.csv $O/prof/*.db
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python bench.py --no-cpu-baseline --no-graph --no-roofline --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python bench.py --no-cpu-baseline --no-graph --no-roofline --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
+python tools/pmc_summary.py $O/pmc_fetch/f_counter_collection.csv FETCH_SIZE > $O/pmc_fetch_summary.txt 2>&1
+python tools/pmc_summary.py $O/pmc_write/w_counter_collection.csv WRITE_SIZE > $O/pmc_write_summary.txt 2>&1
+rm -rf $O/pmc_fetch $O/pmc_write
+du -sh $O
