@@ -98,10 +98,16 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    backend = os.environ.get("TOIST_DIST_BACKEND", "nccl")   # "gloo": single-GPU smoke test of the N > 1 control flow
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        torch.distributed.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
 
     import toist_amd
     from toist_amd import harness, kernels, parallel
@@ -212,9 +218,7 @@ def main():
             def run_step():
                 graph_a.replay()
                 if world > 1:
-                    works = [torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.AVG, async_op=True) for f in flats]
-                    for w_ in works:
-                        w_.wait()
+                    parallel.all_reduce_mean(flats)
                 graph_b.replay()
                 return static_loss
         run_step()
@@ -234,11 +238,13 @@ def main():
     dt = time.perf_counter() - t0
     kernels.PROFILE = None
     loss_val = float(last)
-    if rank == 0 and not a.no_roofline and use_graph:
+    if not a.no_roofline and use_graph:
         # kernel-level timing needs per-launch HIP events, which a replayed graph cannot carry: time the
-        # same K steps once more, eagerly, on the same stream right after the timed region
-        prof = {"key": (65, kernels.A_CONV, kernels.B_ROWK), "records": [], "other": {}}
-        kernels.PROFILE = prof
+        # same K steps once more, eagerly, on the same stream right after the timed region (every rank runs
+        # them -- they contain the gradient / num_boxes collectives -- only rank 0 records)
+        if rank == 0:
+            prof = {"key": (65, kernels.A_CONV, kernels.B_ROWK), "records": [], "other": {}}
+            kernels.PROFILE = prof
         for _ in range(a.steps):
             step()
         torch.cuda.synchronize()

@@ -241,7 +241,7 @@ class SetCriterion(nn.Module):
         self.losses = losses
         self.temperature = temperature
         self.last_match = None
-        self._maps, self._nb = {}, {}
+        self._maps, self._nb, self._nb_reduced = {}, {}, {}
 
     # -- helpers ------------------------------------------------------------------------------------------
     def _slot_maps(self, match, device):
@@ -269,10 +269,20 @@ class SetCriterion(nn.Module):
         if n is None:
             n = torch.as_tensor([total], dtype=torch.float, device=device)
             self._nb = {key: n}
-        n = n.clone()
-        if dist.is_dist_avail_and_initialized():
-            torch.distributed.all_reduce(n)
-        return torch.clamp(n / dist.get_world_size(), min=1)[0]
+        if not dist.is_dist_avail_and_initialized():
+            return torch.clamp(n, min=1)[0]
+        if n.is_cuda and torch.cuda.is_current_stream_capturing():
+            # no collective inside a captured hipGraph: the graph's inputs are static, so the world sum of the
+            # preceding eager (warm-up) step for the same local count is the value to bake in
+            red = self._nb_reduced.get(key)
+            if red is None:
+                raise RuntimeError("SetCriterion: run one eager step before capturing a hipGraph in a distributed job")
+            return red
+        red = n.clone()
+        torch.distributed.all_reduce(red)   # mdetr.py:997-1001 of the reference
+        red = torch.clamp(red / dist.get_world_size(), min=1)[0]
+        self._nb_reduced = {key: red}
+        return red
 
     def _stack(self, outputs):
         st = outputs.get("_stacked")

@@ -29,7 +29,7 @@ class GradSync:
         return False
 
     def _launch(self, flat):
-        op = dist.ReduceOp.AVG if flat.is_cuda else dist.ReduceOp.SUM
+        op = _mean_op(self.group)
         work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
         self.pending.append((work, flat, op))
 
@@ -40,6 +40,23 @@ class GradSync:
             if op == dist.ReduceOp.SUM:
                 flat.div_(self.world)
         self.pending = []
+
+
+def _mean_op(group=None):
+    """RCCL averages in the collective; gloo (CPU tests, smoke runs) sums and the caller divides."""
+    return dist.ReduceOp.AVG if dist.get_backend(group) == "nccl" else dist.ReduceOp.SUM
+
+
+def all_reduce_mean(flats, group=None):
+    """Blocking mean all-reduce of a list of flat gradient buffers (used between the two hipGraphs of bench.py)."""
+    op = _mean_op(group)
+    works = [dist.all_reduce(f, op=op, group=group, async_op=True) for f in flats]
+    for w in works:
+        w.wait()
+    if op == dist.ReduceOp.SUM:
+        world = dist.get_world_size(group)
+        for f in flats:
+            f.div_(world)
 
 
 def broadcast_parameters(module, src=0, group=None):
