@@ -81,7 +81,9 @@ def _nhwc(t):
 
 
 @pytest.mark.parametrize("C,Co,R,stride,pad,H,W", [(64, 64, 3, 1, 1, 20, 24), (64, 128, 3, 2, 1, 21, 20), (256, 512, 1, 2, 0, 16, 16),
-                                                   (128, 256, 1, 1, 0, 10, 12), (8, 64, 7, 2, 3, 40, 40)])
+                                                   (128, 256, 1, 1, 0, 10, 12), (8, 64, 7, 2, 3, 40, 40),
+                                                   # 3x3 / stride 1 at >= 2048 pixels: the shared-halo kernel (conv3_kernel), forward and dgrad
+                                                   (128, 192, 3, 1, 1, 40, 40), (64, 72, 3, 1, 1, 31, 23), (256, 64, 3, 1, 1, 46, 46)])
 def test_conv_fwd_bwd(dev, C, Co, R, stride, pad, H, W):
     from toist_amd import kernels as k, ops
     g = torch.Generator().manual_seed(C + Co + R)
@@ -111,6 +113,22 @@ def test_conv_fwd_bwd(dev, C, Co, R, stride, pad, H, W):
         _close(dx, _nhwc(xr.grad), Co * R * R, f"conv dgrad flags={flags}")
         dw = ops.conv2d_wgrad(_nhwc(dy).to(dev), x_d, (Co, R, R, C), stride=stride, pad=pad, flags=flags)
         _close(dw, _nhwc(wr.grad), Nb * OH * OW, f"conv wgrad flags={flags}", rtol=3e-3, atol_unit=2e-4)
+
+
+def test_conv3_halo_kernel_is_used_and_agrees_with_generic(dev):
+    """tile code 131 forces the shared-halo 3x3 kernel (error if it does not apply); it must agree with the generic
+    implicit-GEMM tiles to bf16 rounding (fp32 sums in a different order) on a ResNet layer3-shaped problem."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 40, 40, 256, generator=g).to(BF).to(dev)
+    w = (torch.randn(256, 3, 3, 256, generator=g) * 0.02).to(BF).to(dev)
+    shift = torch.randn(256, generator=g).to(dev)
+    a = ops.conv2d(x, w, stride=1, pad=1, shift=shift, act=k.ACT_RELU, tile=131).float()
+    b = ops.conv2d(x, w, stride=1, pad=1, shift=shift, act=k.ACT_RELU, tile=65).float()
+    assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
+    assert float((a - b).abs().mean()) <= 1e-3 * float(b.abs().mean())
+    with pytest.raises(RuntimeError):   # stride 2 is not covered
+        ops.conv2d(x, w, stride=2, pad=1, tile=131)
 
 
 def test_attention_products(dev):

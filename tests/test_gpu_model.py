@@ -219,3 +219,45 @@ def test_stream_overlap_is_bit_identical(dev, setup):
     for n in g0:
         if atomic(n):
             torch.testing.assert_close(g1[n], g0[n], rtol=1e-3, atol=1e-5 * float(g0[n].abs().max()) + 1e-12)
+
+
+def test_ragged_batch_padding_masks(dev, setup):
+    """Images of different sizes padded by NestedTensor.from_tensor_list (util/misc.py:185-209) and captions of
+    different lengths: the key-padding masks of both modalities, the mask-aware sine encoding and the <pad>-aware
+    RoBERTa position ids must reproduce the oracle (same tolerances as the dense case); matcher bit-identical."""
+    from oracle import matcher_ref, model_ref
+    from toist_amd import harness
+    from toist_amd.misc import NestedTensor
+    from toist_amd.transformer import TokenizedText
+    model, criterion, weight_dict, sd, args = setup
+    model.eval()
+    g = torch.Generator().manual_seed(21)
+    imgs = [torch.randn(3, 160, 192, generator=g), torch.randn(3, 128, 150, generator=g), torch.randn(3, 96, 192, generator=g)]
+    samples = NestedTensor.from_tensor_list(imgs)
+    assert samples.mask.any() and not samples.mask.all()
+    ids = torch.randint(3, 50265, (3, 12), generator=g)
+    att = torch.ones(3, 12, dtype=torch.int64)
+    ids[:, 0] = 0
+    for b, n in enumerate([12, 7, 9]):          # <s> ... </s> <pad>*
+        ids[b, n - 1] = 2
+        ids[b, n:] = 1
+        att[b, n:] = 0
+    tok = TokenizedText({"input_ids": ids, "attention_mask": att})
+    with torch.no_grad():
+        mc = model(samples.to(dev), tok.to(dev), encode_and_save=True)
+        out = model(samples.to(dev), tok.to(dev), encode_and_save=False, memory_cache=mc)
+    rmc = model_ref.mdetr_encode(sd, samples.tensors, samples.mask, ids, att)
+    rout = model_ref.mdetr_decode(sd, rmc)
+    assert torch.equal(mc["mask"].cpu(), rmc["mask"])
+    keep = ~rmc["mask"].t().unsqueeze(-1)                      # [S,B,1]: padded positions carry garbage in both
+    assert rel_err(mc["img_memory"].cpu() * keep, rmc["img_memory"] * keep) < 3e-2
+    assert rel_err(out["pred_logits"], rout["pred_logits"]) < 5e-2
+    assert (out["pred_boxes"].cpu() - rout["pred_boxes"]).abs().max() < 2e-2
+    # matcher on the GPU model's own outputs, targets with 0 / 3 / 5 boxes
+    _, _, targets, pmap = harness.synthetic_batch(3, 64, 64, tokens=12, seed=22, max_targets=5)
+    lo, bo = out["pred_logits"].float(), out["pred_boxes"].float()
+    got = criterion.matcher({"pred_logits": lo, "pred_boxes": bo}, [{k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in t.items()} for t in targets],
+                            pmap.to(dev))
+    ref = matcher_ref.hungarian_match(lo.cpu(), bo.cpu(), [t["boxes"] for t in targets], pmap)
+    for (gi, gj), (ri, rj) in zip(got, ref):
+        assert torch.equal(gi.cpu(), ri) and torch.equal(gj.cpu(), rj)

@@ -210,33 +210,56 @@ struct ChunkA {            // per-thread, per-piece invariants of the A tile
     bool ok;
 };
 
-template <int AK, int BK>
-__device__ __forceinline__ void load_a(unsigned lds, const i32x4_t& rs, const ChunkA& c, const toist_operand& o, int k0, int K, int lda) {
-    if (AK == TOIST_A_ROWK) { dma16(lds, rs, c.base + k0, c.ok && (k0 + c.kc * 8 < K)); return; }
-    if (AK == TOIST_A_KROW) {
-        const int k = k0 + c.row;
-        dma16(lds, rs, c.base + k * lda, c.ok && k < K);
-        return;
+// Source walkers.  The k-loop visits k-tiles in order, so everything that depends on k is kept as running state and
+// advanced once per tile instead of being re-derived (integer divisions by runtime extents, tap decomposition, bounds)
+// for every 1 KiB piece: the gather arithmetic used to be 120-280 VALU/SALU instructions per k-tile against 8 MFMAs
+// and bounded every convolution kernel by instruction issue.
+//
+// Uniform position inside a two-level reduction index k = tap * span + inner (conv gathers: span = source channels;
+// k-major KRSC weights: span = kin).  `fast` = a k-tile never straddles two taps (span % BK == 0).
+struct TapPos {
+    int tap, inner, r, s;
+    __device__ __forceinline__ void init(int k0, int span, int S) {
+        tap = k0 / span; inner = k0 - tap * span; r = tap / S; s = tap - r * S;
     }
-    int tap, c0;
-    if (o.SC % BK == 0) { tap = k0 / o.SC; c0 = k0 - tap * o.SC + c.kc * 8; }
-    else { const int kk = k0 + c.kc * 8; tap = kk / o.SC; c0 = kk - tap * o.SC; }
-    const int r = tap / o.S, s = tap - r * o.S;
+    // returns true when the tap changed
+    __device__ __forceinline__ bool advance(int step, int span, int S) {
+        inner += step;
+        if (inner < span) return false;
+        inner -= span; ++tap;
+        if (++s == S) { s = 0; ++r; }
+        return true;
+    }
+};
+
+// per-piece, per-tap state of a conv gather: element offset of the tap's pixel (+ this lane's k-chunk) and validity
+template <int AK>
+__device__ __forceinline__ void conv_tap(const ChunkA& c, const toist_operand& o, const TapPos& tp, int& off, bool& in) {
     int iy, ix;
-    bool in = c.ok && tap < o.R * o.S;
+    in = c.ok && tp.tap < o.R * o.S;
     if (AK == TOIST_A_CONVT) {
-        const int ty = c.y0 - r * o.dil, tx = c.x0 - s * o.dil;
+        const int ty = c.y0 - tp.r * o.dil, tx = c.x0 - tp.s * o.dil;
         in = in && (ty >= 0) && (tx >= 0);
-        if (o.stride > 1) {
-            in = in && ((ty % o.stride) == 0) && ((tx % o.stride) == 0);
-            iy = ty / o.stride; ix = tx / o.stride;
-        } else { iy = ty; ix = tx; }
+        if (o.stride == 2) { in = in && !((ty | tx) & 1); iy = ty >> 1; ix = tx >> 1; }
+        else if (o.stride > 1) { in = in && ((ty % o.stride) == 0) && ((tx % o.stride) == 0); iy = ty / o.stride; ix = tx / o.stride; }
+        else { iy = ty; ix = tx; }
     } else {
-        iy = c.y0 + r * o.dil; ix = c.x0 + s * o.dil;
+        iy = c.y0 + tp.r * o.dil; ix = c.x0 + tp.s * o.dil;
         in = in && (iy >= 0) && (ix >= 0);
     }
     in = in && iy < o.SH && ix < o.SW;
-    dma16(lds, rs, c.base + (iy * o.SW + ix) * o.SC + c0, in);
+    off = c.base + (iy * o.SW + ix) * o.SC + c.kc * 8;
+}
+
+// slow path of the conv gathers (source channels not a multiple of BK, e.g. the 8-channel stem): per-chunk taps
+template <int AK, int BK>
+__device__ __forceinline__ void load_a_slow(unsigned lds, const i32x4_t& rs, const ChunkA& c, const toist_operand& o, int k0) {
+    const int kk = k0 + c.kc * 8;
+    TapPos tp;
+    tp.tap = kk / o.SC; tp.inner = kk - tp.tap * o.SC; tp.r = tp.tap / o.S; tp.s = tp.tap - tp.r * o.S;
+    int off; bool in;
+    conv_tap<AK>(c, o, tp, off, in);
+    dma16(lds, rs, off - c.kc * 8 + tp.inner, in);
 }
 
 struct ChunkB {
@@ -246,29 +269,21 @@ struct ChunkB {
     bool ok;
 };
 
-template <int BKD, int BK>
-__device__ __forceinline__ void load_b(unsigned lds, const i32x4_t& rs, const ChunkB& c, const toist_operand& o, int k0, int K, int ldb) {
-    if (BKD == TOIST_B_ROWK) { dma16(lds, rs, c.base + k0, c.ok && (k0 + c.kc * 8 < K)); return; }
-    if (BKD == TOIST_B_KROW) {
-        const int k = k0 + c.row;
-        int off;
-        if (o.kin > 0) {
-            const int tap = (o.kin % BK == 0) ? k0 / o.kin : k / o.kin;   // tile-uniform when a k-tile never straddles taps
-            off = c.base + (k - tap * o.kin) * ldb + tap * (int)o.tap_stride;
-        } else off = c.base + k * ldb;
-        dma16(lds, rs, off, c.ok && k < K);
-        return;
+// CONVX columns: pixel walk of k = output pixel index (wgrad: the reduction runs over pixels)
+struct PixPos {
+    int n, py, px;
+    __device__ __forceinline__ void init(int pix, int PH, int PW) {
+        const int plane = PH * PW;
+        n = pix / plane;
+        const int rem = pix - n * plane;
+        py = rem / PW; px = rem - py * PW;
     }
-    // CONVX: k = output pixel, columns = (tap, c)
-    const int pix = k0 + c.row;
-    const int plane = o.PH * o.PW;
-    const int n = pix / plane;
-    const int rem = pix - n * plane;
-    const int py = rem / o.PW, px = rem - py * o.PW;
-    const int iy = py * o.stride - o.pad + c.r * o.dil, ix = px * o.stride - o.pad + c.s * o.dil;
-    const bool in = c.ok && pix < K && iy >= 0 && ix >= 0 && iy < o.SH && ix < o.SW;
-    dma16(lds, rs, c.base + ((n * o.SH + iy) * o.SW + ix) * o.SC, in);
-}
+    __device__ __forceinline__ void advance(int dq, int dr, int PH, int PW) {   // += dq rows + dr pixels
+        px += dr; py += dq;
+        if (px >= PW) { px -= PW; ++py; }
+        while (py >= PH) { py -= PH; ++n; }
+    }
+};
 
 // MFMA operand fragment: 8 consecutive k (k = 32*ks + 8*g + j) of tile row (r0 + c16)
 template <bool KM, int ROWS, int BK>
@@ -289,6 +304,79 @@ __device__ __forceinline__ bf16x8_t fragment(const bf16_t* s, int r0, int ks, in
     }
     const int row = r0 + c16;
     return *reinterpret_cast<const bf16x8_t*>(&s[row * BK + swz_k<BK>(row, ks * 4 + g) * 8]);
+}
+
+// logical tile index -> (tile_m, tile_n): panels of 8 M tiles, M fastest inside a panel, then N, then the next panel
+__device__ __forceinline__ void tile_order(int L, int nt_m, int nt_n, int& tile_m, int& tile_n) {
+    constexpr int G = 8;
+    const int per = G * nt_n;
+    const int panel = L / per, rem = L - panel * per;
+    const int rows = (nt_m - panel * G < G) ? nt_m - panel * G : G;   // the last panel may be short
+    tile_n = rem / rows;
+    tile_m = panel * G + (rem - tile_n * rows);
+}
+
+// ---- epilogue of one workgroup tile -----------------------------------------------------------------------
+// After the MFMAs a lane owns output row c16 and 4 consecutive columns 4*g .. 4*g+3 of each 16x16 fragment:
+// stored directly, a wavefront store would touch 16 rows x 32 bytes.  Instead the tile goes through LDS in
+// bands of 32 rows (fragment row i of both wave rows), and every thread finishes 8 consecutive columns of
+// one row: 16-byte bf16 accesses, whole 128-byte row segments per 8 lanes, for C, res, aux and pre_out alike.
+// 256 threads = 2x2 waves of WM x WN; `band` = at least 32 x (BN + 4) floats of idle LDS.
+template <int BN, int WM, int WN, int FM, int FN>
+__device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc)[FM][FN], float* band, const int m0, const int n0,
+                                              const int bz, const long long coff, const int ksl) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c16 = lane & 15;
+    const int M = p.M, N = p.N;
+    constexpr int LDT = BN + 4;                      // f32 band pitch: +4 keeps the float4 writes conflict-free
+    constexpr int CPR = BN / 8;                      // 8-column chunks per band row
+    constexpr int CH = (32 * CPR) / 256;             // chunks per thread per band (1 for BN = 64, 2 for BN = 128)
+    static_assert(32 * CPR % 256 == 0, "band chunks must divide over 256 threads");
+    const bool partial = p.split_k > 1;              // k-slice partial: raw f32 into the workspace, epilogue in splitk_reduce_kernel
+    float* ws = partial ? p.workspace + (size_t)ksl * M * N : nullptr;
+    static_for<FM>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        EpiRow rows[CH];
+        float xres[CH][8], xaux[CH][8];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int c = tid + 256 * q;
+            const int br = c / CPR, c8 = c - br * CPR;
+            const int m = m0 + (br >> 4) * WM + i * 16 + (br & 15);
+            rows[q] = epi_row(p, m < M ? m : 0, n0 + c8 * 8);
+            rows[q].m = m;
+            if (!partial && m < M && rows[q].nv > 0) epilogue_fetch(p, rows[q], coff, xres[q], xaux[q]);
+        }
+        __syncthreads();                             // previous band (or the last k-tile / the colsum scratch) is consumed
+        static_for<FN>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            *reinterpret_cast<f32x4_t*>(band + (wm * 16 + c16) * LDT + wn * WN + j * 16 + g * 4) = acc[i][j];
+        });
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int c = tid + 256 * q;
+            const int br = c / CPR, c8 = c - br * CPR;
+            const EpiRow& r = rows[q];
+            if (r.m < M && r.nv > 0) {
+                float v[8];
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(band + br * LDT + c8 * 8);
+                const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(band + br * LDT + c8 * 8 + 4);
+                v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+                if (partial) {
+                    float* cp = ws + (size_t)r.m * N + r.n;
+                    if (r.nv == 8 && ((((size_t)cp) & 15) == 0)) {
+                        reinterpret_cast<float4*>(cp)[0] = make_float4(v[0], v[1], v[2], v[3]);
+                        reinterpret_cast<float4*>(cp)[1] = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+                        static_for<8>([&](auto e8) { constexpr int j = decltype(e8)::value; if (j < r.nv) cp[j] = v[j]; });
+                    }
+                } else {
+                    epilogue_row8(p, v, r, bz, coff, xres[q], xaux[q]);
+                }
+            }
+        }
+    });
 }
 
 template <int BM, int BN, int BK, int AK, int BKD, int NS>
@@ -312,14 +400,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
 
     const int M = p.M, N = p.N, K = p.K;
     // XCD-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs (id % 8), each with its own
-    // 4 MB L2.  Tile L = (id % 8) * ceil(tiles / 8) + id / 8 gives every XCD one contiguous run of tiles, n fastest:
-    // the N tiles of an M row share their A tile in ONE L2, and neighbouring M tiles (the halo rows of a 3x3
-    // gather) stay there too, instead of every XCD streaming the whole A operand through its L2.
+    // 4 MB L2.  Tile L = (id % 8) * ceil(tiles / 8) + id / 8 gives every XCD one contiguous run of tiles, visited in
+    // panels of 8 M rows (tile_order): the workgroups resident on an XCD at one time cover ~8 M tiles x a few N tiles,
+    // so both operands are re-used from ONE L2 -- the N tiles of an M row share their A tile, neighbouring M tiles share
+    // the halo rows of a 3x3 gather -- instead of every XCD streaming a whole operand through its L2.
     const int nt_n = (p.N + BN - 1) / BN;
-    const int tiles = ((p.M + BM - 1) / BM) * nt_n;
+    const int nt_m = (p.M + BM - 1) / BM;
+    const int tiles = nt_m * nt_n;
     const int tile_id = (int)(blockIdx.x & 7) * ((tiles + 7) >> 3) + (int)(blockIdx.x >> 3);
     if (tile_id >= tiles) return;            // grid.x is padded to a multiple of 8
-    const int tile_m = tile_id / nt_n, tile_n = tile_id - tile_m * nt_n;
+    int tile_m, tile_n;
+    tile_order(tile_id, nt_m, nt_n, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z;
     const int bz = z / p.split_k, ksl = z - bz * p.split_k;
@@ -404,19 +495,91 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) csum[it][j] = 0.f;
 
+    // ---- walker state of the issue stream (next tile to issue = kt_issue) --------------------------------------
+    constexpr bool A_GATHER = (AK == TOIST_A_CONV || AK == TOIST_A_CONVT);
+    const bool a_fast = A_GATHER && (oa.SC % BK) == 0;
+    const bool b_two = (BKD == TOIST_B_KROW) && ob.kin > 0;
+    const bool b_fast = b_two && (ob.kin % BK) == 0;
+    int k_issue = kt_beg * BK;
+    TapPos ta, tb;
+    ta.tap = ta.inner = ta.r = ta.s = 0; tb = ta;
+    int a_off[ACH]; bool a_in[ACH];          // gathers: per-tap offset/validity; KROW: running offset
+    int b_off[BCH]; bool b_in[BCH];
+    PixPos bp[BCH];
+    int b_u = 0;                             // KROW two-level k: uniform part of the offset
+#pragma unroll
+    for (int it = 0; it < ACH; ++it) { a_off[it] = 0; a_in[it] = false; }
+#pragma unroll
+    for (int it = 0; it < BCH; ++it) { b_off[it] = 0; b_in[it] = false; bp[it].n = bp[it].py = bp[it].px = 0; }
+    if (A_GATHER && a_fast) {
+        ta.init(k_issue, oa.SC, oa.S);
+#pragma unroll
+        for (int it = 0; it < ACH; ++it) conv_tap<AK>(ca[it], oa, ta, a_off[it], a_in[it]);
+    }
+    if (AK == TOIST_A_KROW) {
+#pragma unroll
+        for (int it = 0; it < ACH; ++it) a_off[it] = ca[it].base + (k_issue + ca[it].row) * lda;
+    }
+    if (BKD == TOIST_B_KROW) {
+        if (b_fast) { tb.init(k_issue, ob.kin, 1); b_u = tb.inner * ldb + tb.tap * (int)ob.tap_stride; }
+#pragma unroll
+        for (int it = 0; it < BCH; ++it) b_off[it] = cb[it].base + cb[it].row * ldb + (b_two ? 0 : k_issue * ldb);
+    }
+    const int cx_dq = (BKD == TOIST_B_CONVX) ? BK / ob.PW : 0, cx_dr = (BKD == TOIST_B_CONVX) ? BK - cx_dq * ob.PW : 0;
+    if (BKD == TOIST_B_CONVX) {
+#pragma unroll
+        for (int it = 0; it < BCH; ++it) bp[it].init(k_issue + cb[it].row, ob.PH, ob.PW);
+    }
+
     const unsigned lds0 = (unsigned)(size_t)smem;  // LDS byte address of the ring
-    auto issue = [&](int kt, int slot) {
+    auto issue = [&](int slot) {                   // stages tile k_issue / BK into `slot`, then advances the walkers
         const unsigned sbase = lds0 + (unsigned)slot * (STAGE * 2) + (unsigned)wave * 1024u;
+        const int k0 = k_issue;
 #pragma unroll
-        for (int it = 0; it < ACH; ++it) load_a<AK, BK>(sbase + it * 4096u, rsA, ca[it], oa, kt * BK, K, lda);
+        for (int it = 0; it < ACH; ++it) {
+            const unsigned dst = sbase + it * 4096u;
+            if (AK == TOIST_A_ROWK) dma16(dst, rsA, ca[it].base + k0, ca[it].ok && (k0 + ca[it].kc * 8 < K));
+            else if (AK == TOIST_A_KROW) { dma16(dst, rsA, a_off[it], ca[it].ok && (k0 + ca[it].row < K)); a_off[it] += BK * lda; }
+            else if (a_fast) dma16(dst, rsA, a_off[it] + ta.inner, a_in[it]);
+            else load_a_slow<AK, BK>(dst, rsA, ca[it], oa, k0);
+        }
 #pragma unroll
-        for (int it = 0; it < BCH; ++it) load_b<BKD, BK>(sbase + SA_ELEMS * 2 + it * 4096u, rsB, cb[it], ob, kt * BK, K, ldb);
+        for (int it = 0; it < BCH; ++it) {
+            const unsigned dst = sbase + SA_ELEMS * 2 + it * 4096u;
+            if (BKD == TOIST_B_ROWK) dma16(dst, rsB, cb[it].base + k0, cb[it].ok && (k0 + cb[it].kc * 8 < K));
+            else if (BKD == TOIST_B_KROW) {
+                const int k = k0 + cb[it].row;
+                if (!b_two) { dma16(dst, rsB, b_off[it], cb[it].ok && k < K); b_off[it] += BK * ldb; }
+                else if (b_fast) dma16(dst, rsB, b_off[it] + b_u, cb[it].ok && k < K);
+                else {   // a k-tile straddles taps: per-row tap
+                    const int tap = k / ob.kin;
+                    dma16(dst, rsB, cb[it].base + (k - tap * ob.kin) * ldb + tap * (int)ob.tap_stride, cb[it].ok && k < K);
+                }
+            } else {     // CONVX: k = output pixel, columns = (tap, c)
+                const PixPos& q = bp[it];
+                const int iy = q.py * ob.stride - ob.pad + cb[it].r * ob.dil, ix = q.px * ob.stride - ob.pad + cb[it].s * ob.dil;
+                const bool in = cb[it].ok && (k0 + cb[it].row < K) && iy >= 0 && ix >= 0 && iy < ob.SH && ix < ob.SW;
+                dma16(dst, rsB, cb[it].base + ((q.n * ob.SH + iy) * ob.SW + ix) * ob.SC, in);
+                bp[it].advance(cx_dq, cx_dr, ob.PH, ob.PW);
+            }
+        }
+        k_issue += BK;
+        if (A_GATHER && a_fast) {
+            if (ta.advance(BK, oa.SC, oa.S)) {
+#pragma unroll
+                for (int it = 0; it < ACH; ++it) conv_tap<AK>(ca[it], oa, ta, a_off[it], a_in[it]);
+            }
+        }
+        if (BKD == TOIST_B_KROW && b_fast) {
+            tb.advance(BK, ob.kin, 1);
+            b_u = tb.inner * ldb + tb.tap * (int)ob.tap_stride;
+        }
     };
 
     const int ntiles = kt_end - kt_beg;
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
-        if (t < ntiles) issue(kt_beg + t, t);
+        if (t < ntiles) issue(t);
 
     int slot = 0;
     for (int t = 0; t < ntiles; ++t) {
@@ -430,7 +593,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
         if (t + NS - 1 < ntiles) {
             int ns = slot + NS - 1;
             if (ns >= NS) ns -= NS;
-            issue(kt_beg + t + NS - 1, ns);  // refills the slot tile t-1 was read from
+            issue(ns);  // next tile in order; refills the slot tile t-1 was read from
         }
         const bf16_t* sA = smem + slot * STAGE;
         const bf16_t* sB = sA + SA_ELEMS;
@@ -474,61 +637,180 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
         }
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------------------
-    // After the MFMAs a lane owns output row c16 and 4 consecutive columns 4*g .. 4*g+3 of each 16x16 fragment:
-    // stored directly, a wavefront store would touch 16 rows x 32 bytes.  Instead the tile goes through LDS in
-    // bands of 32 rows (fragment row i of both wave rows), and every thread finishes 8 consecutive columns of
-    // one row: 16-byte bf16 accesses, whole 128-byte row segments per 8 lanes, for C, res, aux and pre_out alike.
-    constexpr int LDT = BN + 4;                      // f32 band pitch: +4 keeps the float4 writes conflict-free
-    constexpr int CPR = BN / 8;                      // 8-column chunks per band row
-    constexpr int CH = (32 * CPR) / 256;             // chunks per thread per band (1 for BN = 64, 2 for BN = 128)
-    static_assert(32 * CPR % 256 == 0 && 32 * LDT * 4 <= NS * STAGE * 2, "band must fit the (now idle) ring");
-    float* band = reinterpret_cast<float*>(smem);
-    const bool partial = p.split_k > 1;              // k-slice partial: raw f32 into the workspace, epilogue in splitk_reduce_kernel
-    float* ws = partial ? p.workspace + (size_t)ksl * M * N : nullptr;
-    static_for<FM>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        EpiRow rows[CH];
-        float xres[CH][8], xaux[CH][8];
+    static_assert(32 * (BN + 4) * 4 <= NS * STAGE * 2, "epilogue band must fit the (now idle) ring");
+    epilogue_tile<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, bz, coff, ksl);
+}
+
+// ---- 3x3 / stride 1 / pad 1 convolution with a shared halo patch -------------------------------------------------
+// The implicit GEMM above stages every tap's A tile separately: the same input pixels travel L2 -> LDS nine times,
+// and that transfer (LDS-DMA issue rate, ~35 B/clk/CU) is what bounds the kernel.  Here a workgroup computes
+// BM = 128 consecutive (flattened NHWC) pixels x 64 output channels and, per 64-channel chunk of the reduction,
+// stages ONE patch of BM + 2(W+1) pixel rows; the nine taps read their A fragments from that patch at row offset
+// dy*W + dx (rows that fall outside the image are zeroed in registers).  Only the 8 KB weight tile changes per tap:
+// 100 KB of DMA per (chunk, 9 taps) instead of 216 KB for the same tile through the generic kernel, 288 KB at 64x64.
+//   forward  (A_CONV,  B_ROWK): src = x  [N,H,W,C],  dy = r-1, dx = s-1, B rows = output channels, k-contiguous
+//   dgrad    (A_CONVT, B_KROW): src = dy [N,H,W,Co], dy = 1-r, dx = 1-s, B tile k-major (k = co, columns = c)
+// Pipeline: patch double-buffered per chunk (its 28 pieces are issued one per wave during the first 7 taps of the
+// previous chunk), weight tiles in a 3-slot ring, one raw s_barrier per (chunk, tap) step, hand-counted vmcnt.
+constexpr int C3_BM = 128, C3_BN = 64, C3_BK = 64, C3_NP = 28, C3_NB = 3;
+constexpr int C3_PATCH = C3_NP * 512;                 // elements per patch buffer (28 KiB)
+constexpr int C3_BT = C3_BN * C3_BK;                  // elements per weight tile (8 KiB)
+constexpr int C3_LDS = (2 * C3_PATCH + C3_NB * C3_BT) * 2;   // 80 KiB: two workgroups per CU
+
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void conv3_kernel(const toist_gemm p) {
+    constexpr int BM = C3_BM, BN = C3_BN, BK = C3_BK, WM = 64, WN = 32, FM = 4, FN = 2;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    bf16_t* const patch = smem;
+    bf16_t* const btile = smem + 2 * C3_PATCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c16 = lane & 15;
+    const int M = p.M, N = p.N;
+    const toist_operand oa = p.a, ob = p.b;
+    const int W = oa.SW, H = oa.SH, C = oa.SC;        // source plane and channels (= reduction width per tap)
+    const int nt_n = (N + BN - 1) / BN, nt_m = (M + BM - 1) / BM;
+    const int tiles = nt_m * nt_n;
+    const int tile_id = (int)(blockIdx.x & 7) * ((tiles + 7) >> 3) + (int)(blockIdx.x >> 3);   // XCD-aware order (see gemm_kernel)
+    if (tile_id >= tiles) return;
+    int tile_m, tile_n;
+    tile_order(tile_id, nt_m, nt_n, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const i32x4_t rsA = make_rsrc(oa.ptr), rsB = make_rsrc(ob.ptr);
+    const int halo = W + 1;
+    const int nchunks = C / BK, nsteps = nchunks * 9;
+
+    // ---- per-lane tap validity of the FM output rows this lane feeds into the MFMAs ----
+    unsigned vmask[FM];
 #pragma unroll
-        for (int q = 0; q < CH; ++q) {
-            const int c = tid + 256 * q;
-            const int br = c / CPR, c8 = c - br * CPR;
-            const int m = m0 + (br >> 4) * WM + i * 16 + (br & 15);
-            rows[q] = epi_row(p, m < M ? m : 0, n0 + c8 * 8);
-            rows[q].m = m;
-            if (!partial && m < M && rows[q].nv > 0) epilogue_fetch(p, rows[q], coff, xres[q], xaux[q]);
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * WM + i * 16 + c16;
+        const int rem = m % (H * W);
+        const int y = rem / W, x = rem - y * W;
+        unsigned v = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int r = t / 3, s_ = t - r * 3;
+            const int dy = DGRAD ? 1 - r : r - 1, dx = DGRAD ? 1 - s_ : s_ - 1;
+            if (m < M && y + dy >= 0 && y + dy < H && x + dx >= 0 && x + dx < W) v |= 1u << t;
         }
-        __syncthreads();                             // previous band (or the last k-tile / the colsum scratch) is consumed
-        static_for<FN>([&](auto jj) {
-            constexpr int j = decltype(jj)::value;
-            *reinterpret_cast<f32x4_t*>(band + (wm * 16 + c16) * LDT + wn * WN + j * 16 + g * 4) = acc[i][j];
-        });
-        __syncthreads();
+        vmask[i] = v;
+    }
+
+    // ---- DMA pieces ----
+    // patch piece q (0..27) of a chunk: LDS chunks q*64 + lane -> patch row (q*64+lane)/8, slot (..)%8
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    auto issue_patch = [&](int chunk, int q) {
+        const int pch = q * 64 + lane;
+        const int row = pch >> 3, kc = swz_k<BK>(row, pch & 7);
+        const int pix = m0 - halo + row;
+        const bool ok = pix >= 0 && pix < M && row < BM + 2 * halo;
+        dma16(lds0 + (unsigned)(chunk & 1) * (C3_PATCH * 2) + (unsigned)q * 1024u, rsA, pix * C + chunk * BK + kc * 8, ok);
+    };
+    // weight tile of step t: 8 pieces, 2 per wave
+    auto issue_b = [&](int t) {
+        const int chunk = t / 9, tap = t - chunk * 9;
+        const unsigned dst = lds0 + (unsigned)(2 * C3_PATCH + (t % C3_NB) * C3_BT) * 2u;
 #pragma unroll
-        for (int q = 0; q < CH; ++q) {
-            const int c = tid + 256 * q;
-            const int br = c / CPR, c8 = c - br * CPR;
-            const EpiRow& r = rows[q];
-            if (r.m < M && r.nv > 0) {
-                float v[8];
-                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(band + br * LDT + c8 * 8);
-                const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(band + br * LDT + c8 * 8 + 4);
-                v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-                if (partial) {
-                    float* cp = ws + (size_t)r.m * N + r.n;
-                    if (r.nv == 8 && ((((size_t)cp) & 15) == 0)) {
-                        reinterpret_cast<float4*>(cp)[0] = make_float4(v[0], v[1], v[2], v[3]);
-                        reinterpret_cast<float4*>(cp)[1] = make_float4(v[4], v[5], v[6], v[7]);
-                    } else {
-                        static_for<8>([&](auto e8) { constexpr int j = decltype(e8)::value; if (j < r.nv) cp[j] = v[j]; });
-                    }
-                } else {
-                    epilogue_row8(p, v, r, bz, coff, xres[q], xaux[q]);
-                }
+        for (int it = 0; it < 2; ++it) {
+            const int pch = (it * 4 + wave) * 64 + lane;
+            if (DGRAD) {   // k-major tile [BK k = co][BN n = c]
+                const int krow = pch / (BN / 8), rc = swz_m<BN>(krow, pch % (BN / 8));
+                const int nn = n0 + rc * 8;
+                dma16(dst + (unsigned)(it * 4 + wave) * 1024u, rsB, nn + (chunk * BK + krow) * ob.ld + tap * (int)ob.tap_stride, nn < N);
+            } else {       // k-contiguous tile [BN n = co][BK k = c]
+                const int row = pch >> 3, kc = swz_k<BK>(row, pch & 7);
+                const int n = n0 + row;
+                dma16(dst + (unsigned)(it * 4 + wave) * 1024u, rsB, n * ob.ld + tap * C + chunk * BK + kc * 8, n < N);
             }
         }
-    });
+    };
+
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: whole patch of chunk 0 (7 pieces per wave), weight tiles of steps 0 and 1
+#pragma unroll
+    for (int q = 0; q < 7; ++q) issue_patch(0, q * 4 + wave);
+    issue_b(0);
+    if (nsteps > 1) issue_b(1);
+
+    for (int t = 0; t < nsteps; ++t) {
+        const int chunk = t / 9, tap = t - chunk * 9;
+        // loads issued after weight tile t by this wave: group(t-1) = [patch piece if tap(t-1) < 7 and a next chunk exists] + tile t+1
+        if (t + 1 >= nsteps) wait_vm<0>();
+        else if (t == 0) wait_vm<2>();
+        else {
+            const int ptap = (tap == 0) ? 8 : tap - 1, pchunk = (tap == 0) ? chunk - 1 : chunk;
+            if (ptap < 7 && pchunk + 1 < nchunks) wait_vm<3>();
+            else wait_vm<2>();
+        }
+        __builtin_amdgcn_s_barrier();
+        // group(t): next chunk's patch piece (first 7 taps), then weight tile t+2 -- refills the slot step t-1 read
+        if (tap < 7 && chunk + 1 < nchunks) issue_patch(chunk + 1, tap * 4 + wave);
+        if (t + 2 < nsteps) issue_b(t + 2);
+
+        const bf16_t* sP = patch + (chunk & 1) * C3_PATCH;
+        const bf16_t* sB = btile + (t % C3_NB) * C3_BT;
+        const int r = tap / 3, s_ = tap - r * 3;
+        const int roff = halo + (DGRAD ? (1 - r) * W + (1 - s_) : (r - 1) * W + (s_ - 1));
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8_t af[FM], bfr[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int row = wm * WM + i * 16 + roff + c16;
+                const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(&sP[row * BK + swz_k<BK>(row, ks * 4 + g) * 8]);
+                const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                af[i] = ((vmask[i] >> tap) & 1u) ? v : zero;
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bfr[j] = fragment<DGRAD, BN, BK>(sB, wn * WN + j * 16, ks, g, c16);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    wait_vm<0>();
+    epilogue_tile<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, 0, 0, 0);
+}
+
+// true when the halo kernel covers this call (the dispatcher then never looks at the tile code)
+static bool conv3_applies(const toist_gemm& d) {
+    const bool fwd = d.a_kind == TOIST_A_CONV && d.b_kind == TOIST_B_ROWK;
+    const bool dgr = d.a_kind == TOIST_A_CONVT && d.b_kind == TOIST_B_KROW;
+    if (!fwd && !dgr) return false;
+    const toist_operand& a = d.a;
+    if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.dil != 1) return false;
+    if (a.PH != a.SH || a.PW != a.SW || (a.SC % C3_BK) != 0 || d.K != 9 * a.SC) return false;
+    if (C3_BM + 2 * (a.SW + 1) > C3_NP * 8) return false;            // patch rows must fit the 28 pieces
+    if (d.batch != 1 || d.split_k != 1 || d.a_colsum != nullptr) return false;
+    if ((long long)d.M * a.SC >= (1ll << 30)) return false;           // 32-bit element offsets
+    if (fwd && d.b.ld != d.K) return false;
+    if (dgr && (d.b.kin != a.SC || (d.N % 8) != 0)) return false;
+    return d.M >= 2048;                                                // tiny grids: the generic 64x64 tiles fill more CUs
+}
+
+static int launch_conv3(const toist_gemm& d, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {   // > 64 KiB of dynamic LDS has to be enabled per kernel (idempotent, not a mutable result)
+        if (hipFuncSetAttribute((const void*)conv3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess) {
+            set_last_error("toist_gemm_bf16: cannot enable %d bytes of LDS for the 3x3 kernel", C3_LDS);
+            return TOIST_EHIP;
+        }
+        attr_set = true;
+    }
+    const int tiles = ((d.M + C3_BM - 1) / C3_BM) * ((d.N + C3_BN - 1) / C3_BN);
+    dim3 grid((tiles + 7) & ~7, 1, 1);
+    if (d.a_kind == TOIST_A_CONVT) hipLaunchKernelGGL(conv3_kernel<true>, grid, dim3(256), C3_LDS, st, d);
+    else hipLaunchKernelGGL(conv3_kernel<false>, grid, dim3(256), C3_LDS, st, d);
+    return TOIST_OK;
 }
 
 // C[m][n] (+)= alpha * rscale[m] * sum_s ws[s][m][n]   (second half of a split-K GEMM)
@@ -638,6 +920,12 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     if (d.epi.act >= TOIST_ACT_MASK_POS) TOIST_REQUIRE(d.epi.aux != nullptr, "toist_gemm_bf16: activation %d needs aux", d.epi.act);
     if (d.epi.drop_where) TOIST_REQUIRE(d.epi.drop_p >= 0.f && d.epi.drop_p < 1.f, "toist_gemm_bf16: bad dropout p");
 
+    hipStream_t st = (hipStream_t)stream;
+    if (d.tile == 131 && conv3_applies(d)) {   // tile code 131 = the 3x3 shared-halo kernel (explicit only: see DESIGN.md)
+        const int rc3 = launch_conv3(d, st);
+        return rc3 != TOIST_OK ? rc3 : check_launch("toist_gemm_bf16(conv3)");
+    }
+    TOIST_REQUIRE(d.tile != 131, "toist_gemm_bf16: the 3x3 halo kernel does not cover this call");
     int tile = d.tile & 255;
     const int ring = d.tile >> 8;   // 0 = pick; else slots of the DMA ring (2..4)
     if (tile == 0) {
@@ -660,7 +948,6 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     if (d.b_kind == TOIST_B_KROW && d.b.kin > 0) TOIST_REQUIRE((d.b.kin % 8) == 0, "toist_gemm_bf16: kin %% 8 != 0");
     (void)bkt;
     int rc;
-    hipStream_t st = (hipStream_t)stream;
     switch (tile) {
         case 64: rc = launch_tile<64, 64, 32>(d, ring, st); break;
         case 65: rc = launch_tile<64, 64, 64>(d, ring, st); break;

@@ -11,7 +11,7 @@ from tools.bench_gemm import timeit  # noqa: E402
 BF = torch.bfloat16
 dev = torch.device("cuda")
 R = 256
-TILES = [65, 65 + 3 * R, 65 + 4 * R, 130, 130 + 3 * R, 130 + 4 * R, 129, 129 + 3 * R, 129 + 4 * R]
+TILES = [64, 65, 65 + 3 * R, 130, 129]
 
 
 def row(name, fl, fn, splits=(0,)):
