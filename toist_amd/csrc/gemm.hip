@@ -91,21 +91,78 @@ __device__ __forceinline__ void store_row8_bf16(bf16_t* cp, const int nv, const 
     }
 }
 
-// res / aux operands of a chunk, fetched ahead of the LDS transpose so their latency overlaps it
-__device__ __forceinline__ void epilogue_fetch(const toist_gemm& p, const EpiRow& r, const long long coff, float* xres, float* xaux) {
+// res / aux operands of a chunk are requested (raw 16-byte loads, nothing depends on them yet) ahead of the LDS
+// transpose so their latency overlaps it; chunks that are incomplete or misaligned are loaded element-wise at use.
+struct EpiPre {
+    uint4 res, aux;
+    bool res_vec, aux_vec;
+};
+
+// per-column epilogue vectors (scale, shift) of a thread's 8 columns: the column does not change from band to band,
+// so they are read once per tile, as two 16-byte loads when the chunk is complete (8 scalar loads per chunk used to
+// cost a quarter of the 1x1-conv kernels)
+struct EpiCols {
+    float scale[8], shift[8];
+};
+
+__device__ __forceinline__ void load_cols8(const float* src, const int nv, float* x, const float fill) {
+    if (nv == 8 && ((((size_t)src) & 15) == 0)) {
+        const float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+        static_for<8>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            x[j] = (j < nv) ? src[j] : fill;
+        });
+    }
+}
+
+__device__ __forceinline__ void epilogue_cols(const toist_gemm& p, const int n, EpiCols& c) {
     const toist_epilogue& e = p.epi;
-    if (e.res) load_row8((const bf16_t*)e.res + coff + r.rrow * e.ldr + r.n, r.nv, xres);
-    if (e.act >= TOIST_ACT_MASK_POS) load_row8((const bf16_t*)e.aux + coff + r.crow * e.ldaux + r.n, r.nv, xaux);
+    const int nv = (p.N - n < 8) ? (p.N - n) : 8;
+    if (nv <= 0) return;
+    if (e.scale) load_cols8(e.scale + n, nv, c.scale, 1.f);
+    if (e.shift) load_cols8(e.shift + n, nv, c.shift, 0.f);
+}
+
+__device__ __forceinline__ bool row8_vec(const bf16_t* rp, const int nv) { return nv == 8 && ((((size_t)rp) & 15) == 0); }
+
+__device__ __forceinline__ void epilogue_fetch(const toist_gemm& p, const EpiRow& r, const long long coff, EpiPre& pre) {
+    const toist_epilogue& e = p.epi;
+    pre.res_vec = pre.aux_vec = false;
+    if (e.res) {
+        const bf16_t* rp = (const bf16_t*)e.res + coff + r.rrow * e.ldr + r.n;
+        pre.res_vec = row8_vec(rp, r.nv);
+        if (pre.res_vec) pre.res = *reinterpret_cast<const uint4*>(rp);
+    }
+    if (e.act >= TOIST_ACT_MASK_POS) {
+        const bf16_t* ap = (const bf16_t*)e.aux + coff + r.crow * e.ldaux + r.n;
+        pre.aux_vec = row8_vec(ap, r.nv);
+        if (pre.aux_vec) pre.aux = *reinterpret_cast<const uint4*>(ap);
+    }
+}
+
+__device__ __forceinline__ void epilogue_operands(const toist_gemm& p, const EpiRow& r, const long long coff, const EpiPre& pre, float* xres,
+                                                  float* xaux) {
+    const toist_epilogue& e = p.epi;
+    if (e.res) {
+        if (pre.res_vec) unpack8(pre.res, xres);
+        else load_row8((const bf16_t*)e.res + coff + r.rrow * e.ldr + r.n, r.nv, xres);
+    }
+    if (e.act >= TOIST_ACT_MASK_POS) {
+        if (pre.aux_vec) unpack8(pre.aux, xaux);
+        else load_row8((const bf16_t*)e.aux + coff + r.crow * e.ldaux + r.n, r.nv, xaux);
+    }
 }
 
 __device__ __forceinline__ void epilogue_row8(const toist_gemm& p, float* v, const EpiRow& r, const int bz, const long long coff,
-                                              const float* xres, const float* xaux) {
+                                              const float* xres, const float* xaux, const EpiCols& cols) {
     const toist_epilogue& e = p.epi;
     const int N = p.N, M = p.M, m = r.m, n = r.n, nv = r.nv;
     const float rs = e.rscale ? e.alpha * e.rscale[m] : e.alpha;
     static_for<8>([&](auto jj) { v[decltype(jj)::value] *= rs; });
-    if (e.scale) static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; if (j < nv) v[j] *= e.scale[n + j]; });
-    if (e.shift) static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; if (j < nv) v[j] += e.shift[n + j]; });
+    if (e.scale) static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] *= cols.scale[j]; });
+    if (e.shift) static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] += cols.shift[j]; });
     const unsigned long long didx = ((unsigned long long)bz * M + m) * N + n;
     const unsigned long long dseed = e.drop_where ? e.drop_seed + (e.drop_seed_dev ? *e.drop_seed_dev : 0ull) : 0ull;
     if (e.drop_where == 1) {
@@ -334,19 +391,28 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
     static_assert(32 * CPR % 256 == 0, "band chunks must divide over 256 threads");
     const bool partial = p.split_k > 1;              // k-slice partial: raw f32 into the workspace, epilogue in splitk_reduce_kernel
     float* ws = partial ? p.workspace + (size_t)ksl * M * N : nullptr;
+    // residual / aux operands of EVERY band are requested up front: one exposed load latency per tile, not one per band
+    EpiRow rows_all[FM][CH];
+    EpiPre pre_all[FM][CH];
+    EpiCols cols[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q)
+        if (!partial) epilogue_cols(p, n0 + ((tid + 256 * q) % CPR) * 8, cols[q]);
     static_for<FM>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
-        EpiRow rows[CH];
-        float xres[CH][8], xaux[CH][8];
 #pragma unroll
         for (int q = 0; q < CH; ++q) {
             const int c = tid + 256 * q;
             const int br = c / CPR, c8 = c - br * CPR;
             const int m = m0 + (br >> 4) * WM + i * 16 + (br & 15);
-            rows[q] = epi_row(p, m < M ? m : 0, n0 + c8 * 8);
-            rows[q].m = m;
-            if (!partial && m < M && rows[q].nv > 0) epilogue_fetch(p, rows[q], coff, xres[q], xaux[q]);
+            rows_all[i][q] = epi_row(p, m < M ? m : 0, n0 + c8 * 8);
+            rows_all[i][q].m = m;
+            if (!partial && m < M && rows_all[i][q].nv > 0) epilogue_fetch(p, rows_all[i][q], coff, pre_all[i][q]);
         }
+    });
+    static_for<FM>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        EpiRow (&rows)[CH] = rows_all[i];
         __syncthreads();                             // previous band (or the last k-tile / the colsum scratch) is consumed
         static_for<FN>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
@@ -372,7 +438,9 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
                         static_for<8>([&](auto e8) { constexpr int j = decltype(e8)::value; if (j < r.nv) cp[j] = v[j]; });
                     }
                 } else {
-                    epilogue_row8(p, v, r, bz, coff, xres[q], xaux[q]);
+                    float xres[8], xaux[8];
+                    epilogue_operands(p, r, coff, pre_all[i][q], xres, xaux);
+                    epilogue_row8(p, v, r, bz, coff, xres, xaux, cols[q]);
                 }
             }
         }
