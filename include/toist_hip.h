@@ -271,6 +271,24 @@ typedef struct toist_opt_state {
     int32_t reserved[3];
 } toist_opt_state;            /* 32 bytes */
 
+/* ---- deferred split-K reductions ------------------------------------------------------------------------
+ * toist_gemm_bf16 with flags bit1 (TOIST_GEMM_DEFER_REDUCE) writes the k-slice partials to `workspace` and returns
+ * without launching the reduction; the caller later folds up to many such GEMMs with ONE launch per 48 descriptors:
+ *   out[m][n] (+)= alpha * rscale[m] * sum_s ws[s][m][n].
+ * toist_gemm_effective_split tells how many slices the kernel really wrote (k-slices that would own no k-tile are
+ * dropped).  `descs` is a HOST array (copied into the kernel arguments); nothing is kept after the call returns. */
+#define TOIST_GEMM_DEFER_REDUCE 2
+typedef struct toist_reduce_desc {
+    const float* ws;          /* [splits][M][N] fp32 partials                */
+    float* out;               /* [M][ldc] fp32                               */
+    const float* rscale;      /* optional per-row scale [M]                  */
+    int32_t splits, M, N, ldc;
+    float alpha;
+    int32_t accumulate;       /* 1: out += ..., 0: out = ...                 */
+} toist_reduce_desc;          /* 48 bytes */
+int toist_gemm_effective_split(const toist_gemm* desc);
+int toist_splitk_reduce_batch(const toist_reduce_desc* descs, int n, void* stream);
+
 int toist_opt_chunk_elems(void);
 int toist_opt_sqnorm(const toist_opt_tensor* table, const int64_t* grads, const int32_t* chunks, int n_chunks, float* partial, void* stream);
 int toist_opt_finish_norm(const float* partial, int n_chunks, float max_norm, float beta1, float beta2, toist_opt_state* state, void* stream);

@@ -43,6 +43,11 @@ class Gemm(Structure):
     ]
 
 
+class ReduceDesc(Structure):
+    _fields_ = [("ws", c_void_p), ("out", c_void_p), ("rscale", c_void_p), ("splits", c_int32), ("M", c_int32), ("N", c_int32),
+                ("ldc", c_int32), ("alpha", c_float), ("accumulate", c_int32)]
+
+
 _SIGNATURES = {
     "toist_version": ([], ctypes.c_int),
     "toist_last_error": ([c_char_p, c_size_t], ctypes.c_int),
@@ -72,6 +77,8 @@ _SIGNATURES = {
     "toist_mask_loss_fwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p], ctypes.c_int),
     "toist_mask_loss_bwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_dropout_bf16": ([c_void_p, c_int64, c_float, c_uint64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_gemm_effective_split": ([POINTER(Gemm)], ctypes.c_int),
+    "toist_splitk_reduce_batch": ([c_void_p, c_int32, c_void_p], ctypes.c_int),
     "toist_opt_chunk_elems": ([], ctypes.c_int),
     "toist_opt_sqnorm": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_opt_finish_norm": ([c_void_p, c_int32, c_float, c_float, c_float, c_void_p, c_void_p], ctypes.c_int),

@@ -901,6 +901,38 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// many split-K reductions in one launch: descriptors travel in the kernel arguments, block -> descriptor by a
+// prefix table; a block folds 4096 consecutive elements (16 KiB per slice) of one output
+constexpr int RB_MAX = 48, RB_ELEMS = 4096;
+struct ReduceBatch {
+    toist_reduce_desc d[RB_MAX];
+    int blk_end[RB_MAX];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const ReduceBatch a) {
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.blk_end[i]) ++i;
+    const toist_reduce_desc d = a.d[i];
+    const int b0 = (i == 0) ? 0 : a.blk_end[i - 1];
+    const long long total = (long long)d.M * d.N, stride = total;
+    const long long beg = (long long)(blockIdx.x - b0) * RB_ELEMS;
+    for (int q = 0; q < RB_ELEMS / 1024; ++q) {
+        const long long e = beg + (long long)(q * 256 + threadIdx.x) * 4;
+        if (e >= total) break;
+        float4 s4 = *reinterpret_cast<const float4*>(d.ws + e);
+        for (int k = 1; k < d.splits; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(d.ws + (size_t)k * stride + e);
+            s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w;
+        }
+        const int m = (int)(e / d.N), n = (int)(e - (long long)m * d.N);
+        const float f = d.rscale ? d.alpha * d.rscale[m] : d.alpha;
+        float* cp = d.out + (long long)m * d.ldc + n;
+        if (d.accumulate) { cp[0] += s4.x * f; cp[1] += s4.y * f; cp[2] += s4.z * f; cp[3] += s4.w * f; }
+        else { cp[0] = s4.x * f; cp[1] = s4.y * f; cp[2] = s4.z * f; cp[3] = s4.w * f; }
+    }
+}
+
 template <int BM, int BN, int BK, int AK, int BKD>
 static int launch_variant(const toist_gemm& d, int ring, hipStream_t st) {
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
@@ -946,7 +978,56 @@ static int launch_tile(const toist_gemm& d, int ring, hipStream_t st) {
 
 static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
 
+// tile code the dispatcher picks for tile == 0
+static int auto_tile(const toist_gemm& d) {
+    // measured on MI355X (tools/sweep_gemm.py): 128x128x64 only pays once >= ~4 tiles per CU exist and K
+    // is deep; below that 64x64x64 tiles keep more workgroups (and DMA) in flight.
+    const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.batch > 0 ? d.batch : 1) * (d.split_k > 0 ? d.split_k : 1);
+    if (t128 >= 1024 && d.K >= 1024) return 129;
+    return (d.K > 64) ? 65 : 64;
+}
+
+// drop k-slices that would own no k-tile
+static int clamp_split(int split_k, int K, int tile) {
+    const int bk0 = (tile == 64 || tile == 128) ? 32 : 64;
+    const int ktiles = (K + bk0 - 1) / bk0;
+    if (split_k < 1) split_k = 1;
+    if (split_k > ktiles) split_k = ktiles;
+    const int kper = (ktiles + split_k - 1) / split_k;
+    return (ktiles + kper - 1) / kper;
+}
+
 }  // namespace toist
+
+extern "C" int toist_gemm_effective_split(const toist_gemm* desc) {
+    using namespace toist;
+    if (desc == nullptr) return 0;
+    const int tile = (desc->tile & 255) ? (desc->tile & 255) : auto_tile(*desc);
+    return clamp_split(desc->split_k, desc->K, tile);
+}
+
+extern "C" int toist_splitk_reduce_batch(const toist_reduce_desc* descs, int n, void* stream) {
+    using namespace toist;
+    TOIST_REQUIRE(descs != nullptr && n > 0, "toist_splitk_reduce_batch: no descriptors");
+    for (int base = 0; base < n; base += RB_MAX) {
+        ReduceBatch a;
+        a.n = (n - base < RB_MAX) ? n - base : RB_MAX;
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const toist_reduce_desc& d = descs[base + i];
+            TOIST_REQUIRE(d.ws && d.out && d.splits >= 1 && d.M > 0 && d.N > 0 && (d.N % 4) == 0 && (d.ldc % 4) == 0 &&
+                              ((((size_t)d.ws) | ((size_t)d.out)) & 15) == 0,
+                          "toist_splitk_reduce_batch: descriptor %d is malformed", base + i);
+            a.d[i] = d;
+            blocks += (int)(((long long)d.M * d.N + RB_ELEMS - 1) / RB_ELEMS);
+            a.blk_end[i] = blocks;
+        }
+        hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        const int rc = check_launch("toist_splitk_reduce_batch");
+        if (rc != TOIST_OK) return rc;
+    }
+    return TOIST_OK;
+}
 
 extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     using namespace toist;
@@ -996,21 +1077,8 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     TOIST_REQUIRE(d.tile != 131, "toist_gemm_bf16: the 3x3 halo kernel does not cover this call");
     int tile = d.tile & 255;
     const int ring = d.tile >> 8;   // 0 = pick; else slots of the DMA ring (2..4)
-    if (tile == 0) {
-        // measured on MI355X (tools/sweep_gemm.py): 128x128x64 only pays once >= ~4 tiles per CU exist and K
-        // is deep; below that 64x64x64 tiles keep more workgroups (and DMA) in flight.
-        const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.split_k;
-        if (t128 >= 1024 && d.K >= 1024) tile = 129;
-        else tile = (d.K > 64) ? 65 : 64;
-    }
-    {
-        // drop k-slices that would own no k-tile
-        const int bk0 = (tile == 64 || tile == 128) ? 32 : 64;
-        const int ktiles = (d.K + bk0 - 1) / bk0;
-        if (d.split_k > ktiles) d.split_k = ktiles;
-        const int kper = (ktiles + d.split_k - 1) / d.split_k;
-        d.split_k = (ktiles + kper - 1) / kper;
-    }
+    if (tile == 0) tile = auto_tile(d);
+    d.split_k = clamp_split(d.split_k, d.K, tile);
     // tile codes: 64 = 64x64x32, 65 = 64x64x64, 128 = 128x128x32, 129 = 128x128x64, 130 = 128x64x64
     const int bkt = (tile == 64 || tile == 128) ? 32 : 64;
     if (d.b_kind == TOIST_B_KROW && d.b.kin > 0) TOIST_REQUIRE((d.b.kin % 8) == 0, "toist_gemm_bf16: kin %% 8 != 0");
@@ -1026,7 +1094,7 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     }
     if (rc != TOIST_OK) return rc;
     rc = check_launch("toist_gemm_bf16");
-    if (rc != TOIST_OK || d.split_k <= 1) return rc;
+    if (rc != TOIST_OK || d.split_k <= 1 || (d.flags & TOIST_GEMM_DEFER_REDUCE)) return rc;
     const long long total4 = ((long long)d.M * d.N) / 4;
     int grid = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)d.workspace, d.split_k, d.M, d.N, d.epi.alpha,

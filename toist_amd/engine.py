@@ -74,6 +74,7 @@ class Tape:
         for fn in reversed(self.steps):
             fn()
         self.steps = []
+        k.flush_reductions()   # deferred split-K partials of this program -> parameter gradients
 
 
 # ---- bf16 compute copies of the fp32 master weights ------------------------------------------------------------
@@ -256,7 +257,7 @@ def linear_chain(tape, x, layers, res=None, final_drop=False, out_dtype=BF16, la
                     raise NotImplementedError("activation on the last layer of a chain needs last_act_external")
             # g is now the gradient w.r.t. the pre-activation output of layer i
             if W.g is not None:
-                ops.linear_wgrad(g, xin, out=W.g, bias_out=b.g if b is not None else None)
+                ops.linear_wgrad(g, xin, out=W.g, bias_out=b.g if b is not None else None, defer=True)
             if i == 0:
                 if x.needs_grad:
                     if in_relu_mask:  # x is a ReLU output whose producer wants d/d(pre-ReLU): mask in the epilogue
@@ -409,7 +410,7 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
         else:
             go = g
         if Wo.g is not None:
-            ops.linear_wgrad(go, ctx, out=Wo.g, bias_out=bo.g)
+            ops.linear_wgrad(go, ctx, out=Wo.g, bias_out=bo.g, defer=True)
         dctx = ops.linear_dgrad(go, Wo.w)
         if fused:
             dqk = torch.empty(B * Sq, 2 * d, dtype=BF16, device=dev)
@@ -427,20 +428,20 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
         ops.attn_backward(prob_used, scale, qb, kb, vb, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
         if fused:
             if packed_qk[0].g is not None:
-                ops.linear_wgrad(dqk, q_in.data, out=packed_qk[0].g, bias_out=packed_qk[1].g)
+                ops.linear_wgrad(dqk, q_in.data, out=packed_qk[0].g, bias_out=packed_qk[1].g, defer=True)
             if q_in.needs_grad:
                 q_in.grad = ops.linear_dgrad(dqk, packed_qk[0].w, res=q_in.grad)
         else:
             if Pq[0].g is not None:
-                ops.linear_wgrad(dq, q_in.data, out=Pq[0].g, bias_out=Pq[1].g)
+                ops.linear_wgrad(dq, q_in.data, out=Pq[0].g, bias_out=Pq[1].g, defer=True)
             if Pk[0].g is not None:
-                ops.linear_wgrad(dk, k_in.data, out=Pk[0].g, bias_out=Pk[1].g)
+                ops.linear_wgrad(dk, k_in.data, out=Pk[0].g, bias_out=Pk[1].g, defer=True)
             if q_in.needs_grad:
                 q_in.grad = ops.linear_dgrad(dq, Pq[0].w, res=q_in.grad)
             if k_in.needs_grad:
                 k_in.grad = ops.linear_dgrad(dk, Pk[0].w, res=k_in.grad)
         if Pv[0].g is not None:
-            ops.linear_wgrad(dv, v_in.data, out=Pv[0].g, bias_out=Pv[1].g)
+            ops.linear_wgrad(dv, v_in.data, out=Pv[0].g, bias_out=Pv[1].g, defer=True)
         if v_in.needs_grad:
             v_in.grad = ops.linear_dgrad(dv, Pv[0].w, res=v_in.grad)
 
@@ -478,13 +479,13 @@ def bottleneck(tape, x, W, bn, stride, has_down, train):
         g3 = out.take_grad()  # w.r.t. the pre-ReLU sum (masked by the consumer)
         if g3 is None:
             return
-        ops.conv2d_wgrad(g3, a2, w3.shape, out=krsc(W["conv3"].g), rscale=s3)
+        ops.conv2d_wgrad(g3, a2, w3.shape, out=krsc(W["conv3"].g), rscale=s3, defer=True)
         g2 = ops.conv2d_dgrad(g3, w3, a2.shape[1:3], act=k.ACT_MASK_POS, aux=a2)
-        ops.conv2d_wgrad(g2, a1, w2.shape, stride=stride, pad=1, out=krsc(W["conv2"].g), rscale=s2)
+        ops.conv2d_wgrad(g2, a1, w2.shape, stride=stride, pad=1, out=krsc(W["conv2"].g), rscale=s2, defer=True)
         g1 = ops.conv2d_dgrad(g2, w2, (H, Wd), stride=stride, pad=1, act=k.ACT_MASK_POS, aux=a1)
-        ops.conv2d_wgrad(g1, x.data, w1.shape, out=krsc(W["conv1"].g), rscale=s1)
+        ops.conv2d_wgrad(g1, x.data, w1.shape, out=krsc(W["conv1"].g), rscale=s1, defer=True)
         if has_down:
-            ops.conv2d_wgrad(g3, x.data, wd.shape, stride=stride, out=krsc(W["down"].g), rscale=sd)
+            ops.conv2d_wgrad(g3, x.data, wd.shape, stride=stride, out=krsc(W["down"].g), rscale=sd, defer=True)
         if not x.needs_grad:
             return
         prev = x.take_grad()

@@ -44,6 +44,44 @@ def _workspace(elems, device):
     return ws
 
 
+# ---- deferred split-K reductions -----------------------------------------------------------------------------
+# A weight-gradient GEMM with few output tiles is cut into k-slices whose fp32 partials land in an arena; with
+# defer_reduce=True the fold into the gradient buffer is not launched per GEMM (178 launches of ~6 us per step) but
+# queued, and flush_reductions() folds everything queued on the current stream with one launch per 48 GEMMs.
+# The queue must be flushed before anything reads those outputs: engine.Tape.backward() does it at program end.
+GEMM_DEFER_REDUCE = 2
+_ARENA = {}     # (device, stream) -> [buffer, used elements]
+_PENDING = {}   # (device, stream) -> list of (ReduceDesc, keep-alive tensors)
+
+
+def _arena_take(elems, device):
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ent = _ARENA.get(key)
+    elems = (elems + 63) // 64 * 64
+    if ent is None or ent[1] + elems > ent[0].numel():
+        flush_reductions()                      # queued descriptors point into the old arena
+        size = max(elems, 1 << 26 if ent is None else 2 * ent[0].numel())
+        ent = _ARENA[key] = [torch.empty(size, dtype=torch.float32, device=device), 0]
+    off = ent[1]
+    ent[1] += elems
+    return ent[0][off:off + elems]
+
+
+def flush_reductions():
+    """Fold every queued split-K partial of the current stream into its output (one launch per 48 GEMMs)."""
+    if not torch.cuda.is_available():
+        return
+    key_s = torch.cuda.current_stream().cuda_stream
+    for key in [kk for kk in _PENDING if kk[1] == key_s]:
+        items = _PENDING.pop(key)
+        if items:
+            arr = (_lib.ReduceDesc * len(items))(*[it[0] for it in items])
+            _lib.check(_lib.lib().toist_splitk_reduce_batch(ctypes.cast(arr, ctypes.c_void_p), len(items), _stream()), "toist_splitk_reduce_batch")
+        ent = _ARENA.get(key)
+        if ent is not None:
+            ent[1] = 0
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -81,7 +119,8 @@ def operand(t, ld=0, bs_outer=0, bs_inner=0, kin=0, tap_stride=0, geom=None):
 
 def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_outer=0, cs_inner=0, split_k=1, tile=0,
          flags=0, alpha=1.0, scale=None, shift=None, rscale=None, res=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, pre_out=None,
-         accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0, flops=0, a_colsum=None, res_bcast=None):
+         accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0, flops=0, a_colsum=None, res_bcast=None,
+         defer_reduce=False):
     """C = epilogue(A @ B^T); see include/toist_hip.h.  `a`/`b` are Operand structs from operand().
     `flops` = algorithmic FLOPs of the call (bench.py's roofline accounting only)."""
     if tile == 0 and FORCE_TILE:
@@ -114,8 +153,23 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
     e.drop_where, e.drop_p, e.drop_seed = drop_where, drop_p, drop_seed
     e.drop_seed_dev = _p(SEED_DEV) if drop_where else None
     d.a_colsum = _p(a_colsum, torch.float32)
+    deferred = None
     if split_k > 1:
-        d.workspace = _p(_workspace(split_k * M * N, c.device), torch.float32)
+        eff = int(_lib.lib().toist_gemm_effective_split(ctypes.byref(d))) if defer_reduce else 0
+        if eff > 1:
+            # a second deferred reduction into the same output would race with the queued one: fold first
+            key = (c.device, torch.cuda.current_stream().cuda_stream)
+            if any(it[0].out == c.data_ptr() for it in _PENDING.get(key, ())):
+                flush_reductions()
+            ws = _arena_take(eff * M * N, c.device)
+            d.workspace = _p(ws, torch.float32)
+            d.flags |= GEMM_DEFER_REDUCE
+            rd = _lib.ReduceDesc(ws.data_ptr(), c.data_ptr(), _p(rscale, torch.float32), eff, M, N, ldc, alpha, 1 if accumulate else 0)
+            deferred = (key, (rd, (c, rscale)))
+        else:
+            d.workspace = _p(_workspace(split_k * M * N, c.device), torch.float32)
+    if deferred is not None:
+        _PENDING.setdefault(deferred[0], []).append(deferred[1])
     prof = PROFILE
     if prof is None:
         _lib.check(_lib.lib().toist_gemm_bf16(ctypes.byref(d), _stream()), "toist_gemm_bf16")

@@ -119,6 +119,7 @@ class MDETR(nn.Module):
 
             def pad_bwd():
                 if need:
+                    k.flush_reductions()  # g2w comes from a split-K weight gradient whose fold may still be queued
                     W2.g.add_(g2w[:4])
                     b2.g.add_(g2b[:4])
 

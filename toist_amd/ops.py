@@ -55,7 +55,7 @@ def linear_dgrad(dy, w, *, out=None, res=None, act=k.ACT_NONE, aux=None, alpha=1
     return out
 
 
-def linear_wgrad(dy, x, *, out=None, alpha=1.0, flags=0, split_k=None, bias_out=None):
+def linear_wgrad(dy, x, *, out=None, alpha=1.0, flags=0, split_k=None, bias_out=None, defer=False):
     """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]; `out` must be zero-initialised or hold a running sum.
     bias_out (f32 [N]) additionally receives += sum_m dy[m, :] from the same kernel."""
     M, N = dy.shape
@@ -67,7 +67,7 @@ def linear_wgrad(dy, x, *, out=None, alpha=1.0, flags=0, split_k=None, bias_out=
         tiles = ((N + 63) // 64) * ((K + 63) // 64)
         split_k = _split_k_for(tiles, (M + 63) // 64)
     k.gemm(N, K, M, k.A_KROW, k.operand(dy, _ld(dy)), k.B_KROW, k.operand(x, _ld(x)), out, _ld(out), alpha=alpha,
-           accumulate=True, split_k=split_k, flags=flags, flops=2 * M * N * K, a_colsum=bias_out)
+           accumulate=True, split_k=split_k, flags=flags, flops=2 * M * N * K, a_colsum=bias_out, defer_reduce=defer)
     return out
 
 
@@ -137,7 +137,7 @@ def conv2d_dgrad(dy, w, in_hw, *, stride=1, pad=0, dil=1, scale=None, res=None, 
     return out
 
 
-def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, split_k=None, rscale=None):
+def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, split_k=None, rscale=None, defer=False):
     """dw [Co,R,S,C] (f32, accumulated) = sum over output pixels of dy (x) gathered x."""
     Nb, OH, OW, Co = dy.shape
     _, H, W, C = x.shape
@@ -156,7 +156,7 @@ def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, s
     else:
         b_kind, b = k.B_CONVX, k.operand(x, 0, geom=k.ConvGeom(H, W, C, OH, OW, R, S, stride, pad, dil))
     k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out, Nn, accumulate=True, split_k=split_k, flags=flags, rscale=rscale,
-           flops=2 * P * Co * Nn)
+           flops=2 * P * Co * Nn, defer_reduce=defer)
     return out
 
 
