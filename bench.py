@@ -128,7 +128,7 @@ def main():
     from toist_amd import engine as _engine
     if a.no_overlap:
         _engine.OVERLAP = "off"
-    use_graph = not a.no_graph and not a.profile_all and not a.masks
+    use_graph = not a.no_graph and not a.profile_all
     split_graph = use_graph and (world > 1 or a.split_graph)
     if a.torch_optimizer:
         opt = torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay, fused=True, capturable=use_graph)

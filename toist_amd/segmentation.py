@@ -320,6 +320,23 @@ class _MaskLossFn(torch.autograd.Function):
         return dpred, None, None, None, None, None, None
 
 
+_OFFSETS = {}
+
+
+def _match_offsets(counts, sizes, dev):
+    """Per matched pair: image index and first target row of that image (device int64, cached per batch signature so
+    a steady-state step does no host-to-device copy -- needed for hipGraph capture)."""
+    key = (counts, sizes, str(dev))
+    ent = _OFFSETS.get(key)
+    if ent is None:
+        if len(_OFFSETS) > 64:
+            _OFFSETS.clear()
+        b_idx = torch.cat([torch.full((c,), i, dtype=torch.int64) for i, c in enumerate(counts)]).to(dev)
+        t_base = torch.cat([torch.full((c,), sum(sizes[:i]), dtype=torch.int64) for i, c in enumerate(counts)]).to(dev)
+        ent = _OFFSETS[key] = (b_idx, t_base)
+    return ent
+
+
 def mask_losses(outputs, targets, match, layer, num_boxes):
     """SetCriterion.loss_masks (mdetr.py:827-853) on the device-resident assignment of `layer`."""
     pred = outputs["pred_masks"].float().contiguous()                      # [B,Q,hm,wm]
@@ -337,8 +354,7 @@ def mask_losses(outputs, targets, match, layer, num_boxes):
             m = torch.nn.functional.pad(m, (0, TW - m.shape[-1], 0, TH - m.shape[-2]))
         rows.append(m)
     gt = torch.cat(rows).contiguous()
-    b_idx = torch.cat([torch.full((c,), i, dtype=torch.int64) for i, c in enumerate(match.counts)]).to(dev)
-    t_base = torch.cat([torch.full((c,), sum(match.sizes[:i]), dtype=torch.int64) for i, c in enumerate(match.counts)]).to(dev)
+    b_idx, t_base = _match_offsets(tuple(match.counts), tuple(match.sizes), dev)
     pred_row = (b_idx * Q + match.src[layer]).to(torch.int32)
     gt_row = (t_base + match.tgt[layer]).to(torch.int32)
     nb = num_boxes.reshape(()).float() if torch.is_tensor(num_boxes) else torch.tensor(float(num_boxes), device=dev)
