@@ -130,6 +130,7 @@ def main():
         _engine.OVERLAP = "off"
     use_graph = not a.no_graph and not a.profile_all
     split_graph = use_graph and (world > 1 or a.split_graph)
+    parallel.enable_backward_cuts(model, split_graph)
     if a.torch_optimizer:
         opt = torch.optim.AdamW(groups, lr=args.lr, weight_decay=args.weight_decay, fused=True, capturable=use_graph)
     kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)  # bumped every step: fresh dropout masks per replay
@@ -147,14 +148,20 @@ def main():
 
     flats = []  # flat fp32 gradient buffers of the backward programs (filled by the GradSync hook)
 
+    cut_state = {}
+
     def fwd_bwd():
         kernels.SEED_DEV.add_(1000003)
         mc = model(samples, tok, encode_and_save=True)
         out = model(samples, tok, encode_and_save=False, memory_cache=mc)
         losses = criterion(mc, out, targets, pmap, None)
         total = sum(losses[k] * weight_dict[k] for k in losses if k in weight_dict)
-        total.backward()
+        total.backward()                     # with the backbone cut (N > 1): everything but the backbone
+        cut_state["mc"] = mc
         return total
+
+    def bwd_cut(name):
+        parallel.backward_cut(cut_state["mc"], name)
 
     def optimize():
         if not a.torch_optimizer:
@@ -172,6 +179,8 @@ def main():
             opt.zero_grad(set_to_none=True)
         with sync:
             total = fwd_bwd()
+            bwd_cut("text")
+            bwd_cut("backbone")
             sync.finish()
         optimize()
         return total
@@ -185,8 +194,9 @@ def main():
         # The step (forward, criterion, backward, clip, AdamW, EMA: ~1500 kernel launches) is captured once into
         # hipGraphs and replayed: the Python/ctypes launch path (~10-20 us per launch) would otherwise bound the
         # step.  Inputs are static device tensors; dropout masks change per replay through the device-side seed
-        # word.  With several ranks the step is two graphs around an eager RCCL all-reduce (mean) of the flat
-        # gradient buffers: [forward + criterion + backward] | all-reduce | [clip + AdamW + EMA].
+        # word.  With several ranks the step is four graphs (see run_step below): the autograd graph is cut at the
+        # outputs of the backbone and of the text encoder so the all-reduce of every other gradient (RoBERTa +
+        # transformer + heads, 80 % of the bytes) runs on RCCL's stream underneath the backbone backward.
         from toist_amd import functions
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -200,10 +210,19 @@ def main():
                     static_loss = fwd_bwd()
                     optimize()
             else:
-                functions.GRAD_SYNC = flats.append          # collect the flat gradient buffers, no collective inside capture
+                # no collective inside a capture: the hook only collects the flat gradient buffers of each segment
+                functions.GRAD_SYNC = flats.append
                 graph_a = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph_a, stream=side):
                     static_loss = fwd_bwd()
+                n_head = len(flats)
+                graph_text = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_text, stream=side):
+                    bwd_cut("text")
+                n_text = len(flats)
+                graph_bb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_bb, stream=side):
+                    bwd_cut("backbone")
                 functions.GRAD_SYNC = None
                 graph_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph_b, stream=side):
@@ -215,10 +234,28 @@ def main():
                 graph.replay()
                 return static_loss
         else:
+            text_stream = torch.cuda.Stream()
+
             def run_step():
+                # main stream: [forward + criterion + backward of heads / decoder / encoder] -> [backbone backward] -> tail
+                # text stream:                                                  [RoBERTa backward] (beside the backbone)
+                # RCCL stream:               all-reduce(transformer) -> all-reduce(text) ............ all-reduce(backbone)
+                main = torch.cuda.current_stream()
                 graph_a.replay()
                 if world > 1:
-                    parallel.all_reduce_mean(flats)
+                    h_head = parallel.all_reduce_mean_async(flats[:n_head])
+                text_stream.wait_stream(main)
+                with torch.cuda.stream(text_stream):
+                    graph_text.replay()
+                    if world > 1:
+                        h_text = parallel.all_reduce_mean_async(flats[n_head:n_text])
+                graph_bb.replay()
+                if world > 1:
+                    h_bb = parallel.all_reduce_mean_async(flats[n_text:])
+                    h_head.wait()
+                    h_text.wait()
+                    h_bb.wait()
+                main.wait_stream(text_stream)
                 graph_b.replay()
                 return static_loss
         run_step()
@@ -263,7 +300,7 @@ def main():
             "config": {"workload": ("configs[2] (det + mask head + mask losses): " if a.masks else "") + f"configs[1]: ResNet-101 + RoBERTa-base + 6+6 transformer, 100 queries, batch {a.batch}/GPU {a.size}x{a.size}, "
                                    "16-token captions, detection loss (labels+boxes+cardinality, 5 aux layers), dropout 0.1, "
                                    "clip 0.1 + AdamW + EMA" + (" (torch)" if a.torch_optimizer else " (fused HIP tail)") + "; random-init weights",
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4), "launch": ("2 hipGraphs + eager all-reduce" if split_graph else "hipGraph replay") if use_graph else "eager",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4), "launch": ("4 hipGraphs (head | text || backbone | tail), gradient all-reduces under the backbone backward" if split_graph else "hipGraph replay") if use_graph else "eager",
                        "mfma_frac_whole_step": round(ips / world * GFLOP_PER_IMG_TRAIN / 1000.0 / PEAK_BF16_TFLOPS, 5)},
         }
         if prof is not None and prof["records"]:

@@ -261,3 +261,43 @@ def test_ragged_batch_padding_masks(dev, setup):
     ref = matcher_ref.hungarian_match(lo.cpu(), bo.cpu(), [t["boxes"] for t in targets], pmap)
     for (gi, gj), (ri, rj) in zip(got, ref):
         assert torch.equal(gi.cpu(), ri) and torch.equal(gj.cpu(), rj)
+
+
+def test_backward_cuts_reproduce_the_uncut_gradients(dev, setup):
+    """toist_amd.parallel.enable_backward_cuts splits loss.backward() into three segments (head | text | backbone) for
+    the data-parallel step; the segmented pass must produce the same gradients as the plain one."""
+    from toist_amd import harness, parallel
+    model, criterion, weight_dict, sd, args = setup
+    model.eval()
+    samples, tok, targets, pmap = harness.synthetic_batch(2, 160, 192, tokens=16, seed=9, max_targets=6)
+    t_dev = [{k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in t.items()} for t in targets]
+
+    def run(cuts):
+        parallel.enable_backward_cuts(model, cuts)
+        model.zero_grad(set_to_none=True)
+        mc = model(samples.to(dev), tok.to(dev), encode_and_save=True)
+        out = model(samples.to(dev), tok.to(dev), encode_and_save=False, memory_cache=mc)
+        losses = criterion(mc, out, t_dev, pmap.to(dev), None)
+        total = sum(losses[k_] * weight_dict[k_] for k_ in losses if k_ in weight_dict)
+        total.backward()
+        if cuts:
+            text_w = model.transformer.text_encoder.encoder.layer[0].output.dense.weight
+            bb_w = model.backbone[0].body.layer4[2].conv3.weight
+            assert text_w.grad is None and bb_w.grad is None          # the first backward stopped at the cuts
+            parallel.backward_cut(mc, "text")
+            assert text_w.grad is not None and bb_w.grad is None
+            parallel.backward_cut(mc, "backbone")
+        return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    try:
+        g0 = run(False)
+        g1 = run(True)
+    finally:
+        parallel.enable_backward_cuts(model, False)
+    assert set(g0) == set(g1)
+    atomic = lambda n: "norm" in n.lower() or "embeddings" in n or n.endswith("query_embed.weight")
+    for n in g0:
+        if atomic(n):
+            torch.testing.assert_close(g1[n], g0[n], rtol=1e-3, atol=1e-5 * float(g0[n].abs().max()) + 1e-12)
+        else:
+            assert torch.equal(g0[n], g1[n]), n

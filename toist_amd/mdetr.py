@@ -173,23 +173,39 @@ class MDETR(nn.Module):
         # tails of the backbone kernels (a parallel branch of the captured hipGraph).  torch.autograd
         # replays each node's backward on the stream of its forward, so the backward pass forks the same way.
         side = None
+        cuts = {}
+        cut_on = getattr(self, "split_backward", False) and torch.is_grad_enabled()
         pre_encoded = isinstance(captions, tuple) and len(captions) == 3 and torch.is_tensor(captions[0])
-        if not pre_encoded and samples.tensors.is_cuda and engine.overlap_enabled():
+        fork = not pre_encoded and samples.tensors.is_cuda and engine.overlap_enabled()
+        if fork or (cut_on and not pre_encoded):
             from .transformer import EncodedText
-            main = torch.cuda.current_stream()
-            side = engine.side_stream(samples.tensors.device, "text")
-            side.wait_stream(main)
-            functions.REJOIN = main
+            if fork:
+                main = torch.cuda.current_stream()
+                side = engine.side_stream(samples.tensors.device, "text")
+                side.wait_stream(main)
+                functions.REJOIN = main
             try:
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(side if fork else torch.cuda.current_stream()):
                     tokenized = self.transformer._tokenize(captions, samples.tensors.device)
                     flat, _ = self.transformer.encode_text(tokenized)
             finally:
                 functions.REJOIN = None
+            if cut_on and flat.requires_grad:
+                leaf = flat.detach().requires_grad_(True)
+                cuts["text"] = ([flat], [leaf])
+                flat = leaf
             captions = EncodedText(tokenized, flat)
         feats = body.forward_native(samples.tensors, levels, premasked=(len(levels) - 1,))
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+        # Data-parallel jobs may cut the autograd graph at the outputs of the backbone and of the text encoder
+        # (toist_amd.parallel.enable_backward_cuts): loss.backward() then stops there and the two long leaf programs are
+        # run by backward_cut(memory_cache, name), so each gradient all-reduce can start as soon as its segment is done
+        # and run underneath the remaining backward work.
+        if cut_on and any(f.requires_grad for f in feats):
+            leaves = [f.detach().requires_grad_(f.requires_grad) for f in feats]
+            cuts["backbone"] = (list(feats), leaves)
+            feats = leaves
         c5 = feats[-1]
         B, h, w, _ = c5.shape
         mask = nearest_mask(samples.mask, (h, w))
@@ -198,6 +214,7 @@ class MDETR(nn.Module):
         tok = self._project(c5).view(B, h * w, -1)
         mc = self.transformer.encode_native(tok, pos_tok, mask.flatten(1), self.query_embed.weight, captions)
         mc["_native"]["features"] = feats
+        mc["_native"]["cuts"] = cuts
         mc["_native"]["feat_mask"] = mask
         mc["_native"]["src_proj"] = tok
         return mc

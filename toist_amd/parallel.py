@@ -47,16 +47,45 @@ def _mean_op(group=None):
     return dist.ReduceOp.AVG if dist.get_backend(group) == "nccl" else dist.ReduceOp.SUM
 
 
-def all_reduce_mean(flats, group=None):
-    """Blocking mean all-reduce of a list of flat gradient buffers (used between the two hipGraphs of bench.py)."""
+class _MeanHandle:
+    def __init__(self, works, flats, op, world):
+        self.works, self.flats, self.op, self.world = works, flats, op, world
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        if self.op == dist.ReduceOp.SUM:
+            for f in self.flats:
+                f.div_(self.world)
+
+
+def all_reduce_mean_async(flats, group=None):
+    """Start the mean all-reduce of a list of flat gradient buffers on the collective stream; .wait() joins."""
     op = _mean_op(group)
     works = [dist.all_reduce(f, op=op, group=group, async_op=True) for f in flats]
-    for w in works:
-        w.wait()
-    if op == dist.ReduceOp.SUM:
-        world = dist.get_world_size(group)
-        for f in flats:
-            f.div_(world)
+    return _MeanHandle(works, list(flats), op, dist.get_world_size(group))
+
+
+def all_reduce_mean(flats, group=None):
+    """Blocking mean all-reduce of a list of flat gradient buffers."""
+    all_reduce_mean_async(flats, group).wait()
+
+
+def enable_backward_cuts(model, on=True):
+    """Make `model` (MDETR or DETRsegm) cut the autograd graph at the outputs of the backbone and of the text encoder:
+    loss.backward() then leaves those two programs to backward_cut(memory_cache, "text" / "backbone"), so the gradients
+    of every finished segment can be all-reduced underneath the segments still running."""
+    getattr(model, "detr", model).split_backward = bool(on)
+
+
+def backward_cut(memory_cache, name):
+    """Run the backward pass of the segment cut off under `name` ("text" or "backbone") from the gradients left at the cut."""
+    cut = memory_cache.get("_native", {}).get("cuts", {}).get(name)
+    if not cut:
+        return
+    pairs = [(src, leaf.grad) for src, leaf in zip(*cut) if leaf.grad is not None and src.requires_grad]
+    if pairs:
+        torch.autograd.backward([s for s, _ in pairs], [g for _, g in pairs])
 
 
 def broadcast_parameters(module, src=0, group=None):
