@@ -301,3 +301,22 @@ def test_backward_cuts_reproduce_the_uncut_gradients(dev, setup):
             torch.testing.assert_close(g1[n], g0[n], rtol=1e-3, atol=1e-5 * float(g0[n].abs().max()) + 1e-12)
         else:
             assert torch.equal(g0[n], g1[n]), n
+
+
+def test_device_stager_delivers_the_collated_batch(dev):
+    """Pinned-memory asynchronous staging (toist_amd.misc.DeviceStager): the tensors that arrive in HBM equal the host batch."""
+    from toist_amd.misc import DeviceStager, collate_fn_plain
+    g = torch.Generator().manual_seed(4)
+    batch = []
+    for h, w, t in [(64, 96, 2), (80, 64, 0), (96, 96, 3)]:
+        tgt = {"boxes": torch.rand(t, 4, generator=g), "labels": torch.ones(t, dtype=torch.int64), "positive_map": torch.rand(t, 256, generator=g) > 0.9,
+               "dataset_name": "task_3_train.json", "caption": "x"}
+        batch.append(([torch.randn(3, h, w, generator=g)], [tgt]))
+    host = collate_fn_plain(False, batch)
+    stager = DeviceStager(dev)
+    got = stager.stage(host)
+    stager.wait()
+    assert got["samples"].tensors.is_cuda and torch.equal(got["samples"].tensors.cpu(), host["samples"].tensors)
+    assert torch.equal(got["samples"].mask.cpu(), host["samples"].mask) and torch.equal(got["positive_map"].cpu(), host["positive_map"])
+    for a, b in zip(got["targets"], host["targets"]):
+        assert "caption" not in a and a["dataset_name"] == b["dataset_name"] and torch.equal(a["boxes"].cpu(), b["boxes"])
