@@ -85,3 +85,22 @@ def test_invalid_cost_flagged(dev):
     logits[0, 1, 5, 7] = float("nan")
     _, _, status, _, _ = _run_gpu(dev, logits, boxes, tgt, pm)
     assert status.tolist() == [0, 1]
+
+
+def test_generic_lsap_matches_oracle(dev):
+    """toist_lsap (arbitrary cost matrices: memory-bank replacement mdetr.py:100, softkd matcher mdetr.py:539) against
+    oracle/lsap.c, which is pinned to SciPy: tall, wide, square, tied and 1024-column problems in one launch."""
+    import numpy as np
+    from oracle import lsap as oracle_lsap
+    from toist_amd.matcher import linear_sum_assignment_batch
+    g = torch.Generator().manual_seed(7)
+    costs = [torch.rand(97, 97, generator=g), torch.rand(5, 1024, generator=g) * 3, torch.rand(40, 7, generator=g),
+             torch.randint(0, 4, (30, 30), generator=g).float(), torch.rand(1, 1, generator=g), torch.rand(16, 100, generator=g) - 0.5]
+    got = linear_sum_assignment_batch([c.to(dev) for c in costs])
+    for c, (r, col) in zip(costs, got):
+        rr, cc = oracle_lsap.linear_sum_assignment(c.double().numpy())
+        assert np.array_equal(r.cpu().numpy(), rr) and np.array_equal(col.cpu().numpy(), cc), c.shape
+    bad = torch.rand(4, 4)
+    bad[1, 2] = float("nan")
+    with pytest.raises(ValueError):
+        linear_sum_assignment_batch([bad.to(dev)])

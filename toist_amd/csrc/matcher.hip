@@ -51,6 +51,79 @@ __device__ __forceinline__ void wave_lds_fence() {
 // status codes written per (layer,image)
 enum { ST_OK = 0, ST_INVALID = 1, ST_INFEASIBLE = 2 };
 
+// Rectangular LSAP (R <= C) on an LDS-resident fp32 cost block, solved in fp64 by ONE wavefront with SciPy's
+// shortest-augmenting-path traversal and tie rules (oracle/lsap.c restates the same traversal).  Leaves the
+// assignment in col4row[R] / row4col[C]; returns ST_OK or ST_INFEASIBLE.
+__device__ __forceinline__ int lsap_solve_wave(const float* cw, const int R, const int C, double* du, double* dv, double* spc, int* path,
+                                               int* row4col, int* remaining, int* col4row, int* in_sr, int* in_sc, const int lane) {
+    for (int j = lane; j < C; j += 64) { dv[j] = 0.0; path[j] = -1; row4col[j] = -1; }
+    for (int i = lane; i < R; i += 64) { du[i] = 0.0; col4row[i] = -1; }
+    wave_lds_fence();
+
+    int st = ST_OK;
+    for (int cur = 0; cur < R; ++cur) {
+        for (int t = lane; t < C; t += 64) { remaining[t] = C - 1 - t; spc[t] = INFINITY; in_sc[t] = 0; }
+        for (int i = lane; i < R; i += 64) in_sr[i] = 0;
+        wave_lds_fence();
+
+        int live = C, sink = -1, i = cur;
+        double floor_val = 0.0;
+        while (sink < 0) {
+            if (lane == 0) in_sr[i] = 1;
+            const double ui = du[i];
+            const float* crow = cw + (size_t)i * C;
+            PickKey best;  // per-lane replay of the reference scan, starting from lowest = +inf
+            best.val = INFINITY; best.it = 0x7fffffff; best.una = 0;
+            for (int t = lane; t < live; t += 64) {
+                const int j = remaining[t];
+                const double r = ((floor_val + (double)crow[j]) - ui) - dv[j];
+                double s = spc[j];
+                if (r < s) { path[j] = i; spc[j] = r; s = r; }
+                const int una = row4col[j] < 0;
+                if (s < best.val || (s == best.val && una)) { best.val = s; best.it = t; best.una = una; }
+            }
+            best = wave_pick(best);
+            floor_val = best.val;
+            if (!(floor_val < INFINITY)) { st = ST_INFEASIBLE; break; }
+            const int pick = best.it;
+            const int j = remaining[pick];
+            const int owner = row4col[j];
+            if (owner < 0) sink = j; else i = owner;
+            wave_lds_fence();
+            if (lane == 0) {
+                in_sc[j] = 1;
+                remaining[pick] = remaining[live - 1];
+            }
+            --live;
+            wave_lds_fence();
+        }
+        if (st != ST_OK) break;
+
+        // dual variables
+        if (lane == 0) du[cur] += floor_val;
+        for (int r = lane; r < R; r += 64)
+            if (in_sr[r] && r != cur) du[r] += floor_val - spc[col4row[r]];
+        for (int j = lane; j < C; j += 64)
+            if (in_sc[j]) dv[j] -= floor_val - spc[j];
+        wave_lds_fence();
+        // augment along the path (serial, short)
+        if (lane == 0) {
+            int j = sink;
+            for (;;) {
+                const int pi = path[j];
+                row4col[j] = pi;
+                const int prev = col4row[pi];
+                col4row[pi] = j;
+                j = prev;
+                if (pi == cur) break;
+            }
+        }
+        wave_lds_fence();
+    }
+
+    return st;
+}
+
 __global__ __launch_bounds__(256) void matcher_kernel(
     const float* __restrict__ logits,   // [L,B,Q,K]
     const float* __restrict__ boxes,    // [L,B,Q,4] cxcywh
@@ -164,71 +237,7 @@ __global__ __launch_bounds__(256) void matcher_kernel(
     }
     if (wave != 0) return;
 
-    // ---- rectangular LSAP, one wavefront (oracle/lsap.c restates the same traversal) --
-    for (int j = lane; j < C; j += 64) { dv[j] = 0.0; path[j] = -1; row4col[j] = -1; }
-    for (int i = lane; i < R; i += 64) { du[i] = 0.0; col4row[i] = -1; }
-    wave_lds_fence();
-
-    int st = ST_OK;
-    for (int cur = 0; cur < R; ++cur) {
-        for (int t = lane; t < C; t += 64) { remaining[t] = C - 1 - t; spc[t] = INFINITY; in_sc[t] = 0; }
-        for (int i = lane; i < R; i += 64) in_sr[i] = 0;
-        wave_lds_fence();
-
-        int live = C, sink = -1, i = cur;
-        double floor_val = 0.0;
-        while (sink < 0) {
-            if (lane == 0) in_sr[i] = 1;
-            const double ui = du[i];
-            const float* crow = cw + (size_t)i * C;
-            PickKey best;  // per-lane replay of the reference scan, starting from lowest = +inf
-            best.val = INFINITY; best.it = 0x7fffffff; best.una = 0;
-            for (int t = lane; t < live; t += 64) {
-                const int j = remaining[t];
-                const double r = ((floor_val + (double)crow[j]) - ui) - dv[j];
-                double s = spc[j];
-                if (r < s) { path[j] = i; spc[j] = r; s = r; }
-                const int una = row4col[j] < 0;
-                if (s < best.val || (s == best.val && una)) { best.val = s; best.it = t; best.una = una; }
-            }
-            best = wave_pick(best);
-            floor_val = best.val;
-            if (!(floor_val < INFINITY)) { st = ST_INFEASIBLE; break; }
-            const int pick = best.it;
-            const int j = remaining[pick];
-            const int owner = row4col[j];
-            if (owner < 0) sink = j; else i = owner;
-            wave_lds_fence();
-            if (lane == 0) {
-                in_sc[j] = 1;
-                remaining[pick] = remaining[live - 1];
-            }
-            --live;
-            wave_lds_fence();
-        }
-        if (st != ST_OK) break;
-
-        // dual variables
-        if (lane == 0) du[cur] += floor_val;
-        for (int r = lane; r < R; r += 64)
-            if (in_sr[r] && r != cur) du[r] += floor_val - spc[col4row[r]];
-        for (int j = lane; j < C; j += 64)
-            if (in_sc[j]) dv[j] -= floor_val - spc[j];
-        wave_lds_fence();
-        // augment along the path (serial, short)
-        if (lane == 0) {
-            int j = sink;
-            for (;;) {
-                const int pi = path[j];
-                row4col[j] = pi;
-                const int prev = col4row[pi];
-                col4row[pi] = j;
-                j = prev;
-                if (pi == cur) break;
-            }
-        }
-        wave_lds_fence();
-    }
+    const int st = lsap_solve_wave(cw, R, C, du, dv, spc, path, row4col, remaining, col4row, in_sr, in_sc, lane);
 
     if (lane == 0) status[lb] = st;
     if (st != ST_OK) return;
@@ -247,6 +256,69 @@ __global__ __launch_bounds__(256) void matcher_kernel(
     } else {
         for (int q = lane; q < R; q += 64) { so[q] = q; to[q] = col4row[q]; }
     }
+}
+
+// Batched LSAP on caller-supplied cost matrices (scipy.optimize.linear_sum_assignment semantics: rows sorted
+// ascending in the output, the transpose is solved when rows > cols, NaN / -inf entries are invalid).  One workgroup
+// (one solving wavefront) per problem; problem p is [rows[p], cols[p]] fp32, row-major, at cost + offset[p].
+__global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost, const long long* __restrict__ offset,
+                                                  const int* __restrict__ rows, const int* __restrict__ cols,
+                                                  const long long* __restrict__ out_off, long long* __restrict__ row_idx,
+                                                  long long* __restrict__ col_idx, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int nr = rows[p], nc = cols[p];
+    if (nr == 0 || nc == 0) {
+        if (lane == 0) status[p] = ST_OK;
+        return;
+    }
+    const bool flip = nc < nr;
+    const int R = flip ? nc : nr, C = flip ? nr : nc;
+    double* du = reinterpret_cast<double*>(smem);
+    double* dv = du + R;
+    double* spc = dv + C;
+    int* path = reinterpret_cast<int*>(spc + C);
+    int* row4col = path + C;
+    int* remaining = row4col + C;
+    int* col4row = remaining + C;
+    int* in_sr = col4row + R;
+    int* in_sc = in_sr + R;
+    float* cw = reinterpret_cast<float*>(in_sc + C);
+    const float* src = cost + offset[p];
+    int bad = 0;
+    for (int e = lane; e < nr * nc; e += 64) {
+        const float c = src[e];
+        if (c != c || c == -INFINITY) bad = 1;
+        const int i = e / nc, j = e - i * nc;
+        cw[flip ? (j * nr + i) : e] = c;
+    }
+    bad = __any(bad);
+    wave_lds_fence();
+    if (bad) {
+        if (lane == 0) status[p] = ST_INVALID;
+        return;
+    }
+    const int st = lsap_solve_wave(cw, R, C, du, dv, spc, path, row4col, remaining, col4row, in_sr, in_sc, lane);
+    if (lane == 0) status[p] = st;
+    if (st != ST_OK) return;
+    long long* ro = row_idx + out_off[p];
+    long long* co = col_idx + out_off[p];
+    if (flip) {   // solved on the transpose: pairs (row = col4row[t], col = t), sorted by row
+        for (int t = lane; t < R; t += 64) {
+            const int r = col4row[t];
+            int rank = 0;
+            for (int o = 0; o < R; ++o) rank += (col4row[o] < r);
+            ro[rank] = r;
+            co[rank] = t;
+        }
+    } else {
+        for (int r = lane; r < R; r += 64) { ro[r] = r; co[r] = col4row[r]; }
+    }
+}
+
+static size_t lsap_lds_bytes(int R, int C, long long cells) {
+    size_t bytes = sizeof(double) * ((size_t)R + 2 * (size_t)C) + sizeof(int) * (4 * (size_t)C + 2 * (size_t)R) + sizeof(float) * (size_t)cells;
+    return (bytes + 15) & ~(size_t)15;
 }
 
 static size_t matcher_lds_bytes(int Q, int maxT) {
@@ -284,4 +356,27 @@ extern "C" int toist_matcher(const float* logits, const float* boxes, const floa
                        pos_map, tgt_off_dev, match_off_dev, L, B, Q, K, w_class, w_bbox, w_giou,
                        (long long*)src_idx, (long long*)tgt_idx, status, cost_out);
     return check_launch("toist_matcher");
+}
+
+extern "C" int toist_lsap(const float* cost, const int64_t* offset, const int32_t* rows, const int32_t* cols, int n, int max_rows,
+                          int max_cols, int64_t max_cells, const int64_t* out_off, int64_t* row_idx, int64_t* col_idx, int32_t* status,
+                          void* stream) {
+    using namespace toist;
+    TOIST_REQUIRE(cost && offset && rows && cols && out_off && row_idx && col_idx && status && n > 0, "toist_lsap: bad args");
+    TOIST_REQUIRE(max_rows >= 0 && max_cols >= 0 && max_cells >= 0, "toist_lsap: negative extent");
+    const int R = max_rows < max_cols ? max_rows : max_cols, C = max_rows < max_cols ? max_cols : max_rows;
+    const size_t lds = lsap_lds_bytes(R, C, max_cells);
+    TOIST_REQUIRE(lds <= 160 * 1024, "toist_lsap: problems up to %d x %d (%lld cells) need %zu B of LDS (> 160 KiB)", max_rows, max_cols,
+                  (long long)max_cells, lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)lsap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            set_last_error("toist_lsap: cannot enable large LDS");
+            return TOIST_EHIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lsap_kernel, dim3(n), dim3(64), lds, (hipStream_t)stream, cost, (const long long*)offset, rows, cols,
+                       (const long long*)out_off, (long long*)row_idx, (long long*)col_idx, status);
+    return check_launch("toist_lsap");
 }

@@ -87,3 +87,33 @@ def build_matcher(args):
     if args.set_loss != "hungarian":
         raise ValueError(f"Only hungarian accepted, got {args.set_loss}")
     return HungarianMatcher(cost_class=args.set_cost_class, cost_bbox=args.set_cost_bbox, cost_giou=args.set_cost_giou)
+
+
+def linear_sum_assignment_batch(costs):
+    """scipy.optimize.linear_sum_assignment for a list of 2-D fp32 device cost matrices, solved in one launch of the
+    HIP LSAP kernel (csrc/matcher.hip).  Returns a list of (row_ind, col_ind) int64 device tensors (rows ascending, as
+    SciPy returns them).  Raises ValueError on NaN / -inf entries or an infeasible matrix, like SciPy."""
+    from . import kernels as k
+    if not costs:
+        return []
+    dev = costs[0].device
+    shapes = [(int(c.shape[0]), int(c.shape[1])) for c in costs]
+    flat = torch.cat([c.reshape(-1).float() for c in costs]) if sum(r * c for r, c in shapes) else torch.zeros(1, device=dev)
+    sizes = [r * c for r, c in shapes]
+    pairs = [min(r, c) for r, c in shapes]
+    off = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], dtype=torch.int64, device=dev)
+    out_off_h = [sum(pairs[:i]) for i in range(len(pairs))]
+    out_off = torch.tensor(out_off_h, dtype=torch.int64, device=dev)
+    rows = torch.tensor([r for r, _ in shapes], dtype=torch.int32, device=dev)
+    cols = torch.tensor([c for _, c in shapes], dtype=torch.int32, device=dev)
+    total = max(sum(pairs), 1)
+    ri = torch.zeros(total, dtype=torch.int64, device=dev)
+    ci = torch.zeros(total, dtype=torch.int64, device=dev)
+    status = torch.zeros(len(costs), dtype=torch.int32, device=dev)
+    k.lsap(flat.contiguous(), off, rows, cols, len(costs), max(r for r, _ in shapes), max(c for _, c in shapes), max(sizes), out_off, ri, ci, status)
+    st = status.cpu()
+    if bool((st == 1).any()):
+        raise ValueError("matrix contains invalid numeric entries")
+    if bool((st == 2).any()):
+        raise ValueError("cost matrix is infeasible")
+    return [(ri[o:o + n], ci[o:o + n]) for o, n in zip(out_off_h, pairs)]
