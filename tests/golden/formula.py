@@ -53,3 +53,21 @@ def sample_indices(n, count=4096):
     if n <= count:
         return np.arange(n)
     return (np.arange(count, dtype=np.int64) * 7919 + 13) % n
+
+
+class FakeTokenized(dict):
+    """Stand-in for a HF BatchEncoding in fixtures: deterministic char -> token map (4 characters per token, every 4th
+    character is a separator that maps to no token; like BatchEncoding, a single argument means batch 0)."""
+
+    def __init__(self, length):
+        super().__init__(length=length)
+
+    def to(self, device):
+        return self
+
+    def char_to_token(self, batch_or_char, char=None):
+        c = batch_or_char if char is None else char
+        if c < 0 or c % 4 == 3:
+            return None
+        t = c // 4 + 1
+        return t if t < self["length"] - 1 else None

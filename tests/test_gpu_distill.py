@@ -1,0 +1,85 @@
+"""Distillation path (BASELINE config 5 pieces) on the GPU against vectors produced by the REAL reference
+(tests/golden/make_golden_distill.py): the (noun, pronoun) branch of SetCriterion with loss_nsthl2 and loss_softkd
+on every layer, and ClusterCriterion.update_memory / forward with a full memory bank (nearest-replacement through
+the device LSAP kernel, k-means, prototype substitution).  fp32 throughout: rtol 1e-4."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import formula  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "distill.npz"))
+B, Q, K, LT, D, LAYERS = 2, 12, 256, 10, 16, 3
+SPANS = {"noun": [[[(0, 7)], [(8, 11), (16, 19)]], [[(3, 10)]]], "sth": [[[(4, 7)], [(12, 19)]], [[(0, 3)]]]}
+T = [2, 1]
+
+
+def side(tag, dev):
+    def layer(l):
+        return {"pred_logits": formula.tensor(f"dst.{tag}.logits{l}", (B, Q, K), 4.0).to(dev).requires_grad_(tag == "sth"),
+                "pred_boxes": formula.tensor(f"dst.{tag}.boxes{l}", (B, Q, 4), 0.3, 0.5).to(dev), "proj_queries": torch.zeros(B, Q, 4, device=dev),
+                "tokenized": formula.FakeTokenized(LT)}
+    out = layer(LAYERS - 1)
+    out["aux_outputs"] = [layer(l) for l in range(LAYERS - 1)]
+    targets, pms = [], []
+    for i in range(B):
+        pm = torch.zeros(T[i], K)
+        pm[:, 1 + i:4 + i] = 1.0 / 3
+        targets.append({"boxes": formula.tensor(f"dst.{tag}.tbox{i}", (T[i], 4), 0.25, 0.5).to(dev), "labels": torch.ones(T[i], dtype=torch.int64, device=dev),
+                        "noun_tokens_positive": SPANS[tag][i], "dataset_name": f"task_{3 + 2 * i}_train.json"})
+        pms.append(pm)
+    mc = {"text_memory": formula.tensor(f"dst.{tag}.text", (LT, B, D), 2.0).to(dev), "tokenized": formula.FakeTokenized(LT)}
+    return out, targets, torch.cat(pms).to(dev), mc
+
+
+def test_criterion_noun_pronoun_branch(dev):
+    from toist_amd.matcher import HungarianMatcher
+    from toist_amd.mdetr import SetCriterion
+    args = types.SimpleNamespace(num_queries=Q, nsthl2_loss=True, softkd_loss=True)
+    crit = SetCriterion(args, 255, matcher=HungarianMatcher(1, 5, 2), eos_coef=0.1, losses=["labels", "boxes", "cardinality", "nsthl2", "softkd"],
+                        temperature=0.07)
+    (on, tn, pn, mn), (os_, ts, ps, ms) = side("noun", dev), side("sth", dev)
+    losses = crit([mn, ms], [on, os_], [tn, ts], [pn, ps], None)
+    want = {k[5:]: float(Z[k]) for k in Z.files if k.startswith("pair.")}
+    assert set(losses) == set(want), (sorted(set(losses) ^ set(want)))
+    for k, v in want.items():
+        assert abs(float(losses[k]) - v) <= 1e-4 * abs(v) + 1e-6, (k, float(losses[k]), v)
+    # the cross losses must reach the student only
+    (losses["loss_softkd"] + losses["loss_softkd_0"]).backward()
+    assert os_["pred_logits"].grad is not None and float(os_["pred_logits"].grad.abs().sum()) > 0
+    assert on["pred_logits"].grad is None
+
+
+def test_cluster_criterion_full_bank(dev):
+    from toist_amd.distill import ClusterCriterion
+    MEM, HW = 24, 6
+    args = types.SimpleNamespace(train_batch_size=B, fifo_memory=False)
+    cc = ClusterCriterion(feature_dim=D, memory_size=MEM, cluster_num=3, task_count=14, args=args).to(dev)
+    cc.feature_bank.copy_(formula.tensor("dst.bank", (14, MEM, D), 2.0))
+    cc.cluster_centers.copy_(formula.tensor("dst.centers", (14, 3, D), 2.0))
+    cc.full_label.fill_(1)
+    cc.update_count.fill_(100)
+    assert set(cc.state_dict()) == {"feature_bank", "cluster_centers", "update_count", "full_label"}
+    _, tn, _, mn = side("noun", dev)
+    mn["img_memory"] = formula.tensor("dst.noun.img", (HW + LT, B, D), 1.5).to(dev)
+    mn["text_memory"] = mn["img_memory"][-LT:]
+    mc = cc.update_memory(mn, tn, ["a noun caption"] * B)
+    np.testing.assert_allclose(cc.feature_bank.cpu().numpy(), Z["cl.bank_after_update"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(cc.cluster_centers.cpu().numpy(), Z["cl.centers_after_update"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(mc["img_memory_mod"].cpu().numpy(), Z["cl.noun.img_memory_mod"], rtol=1e-4, atol=1e-5)
+    _, ts, _, ms = side("sth", dev)
+    ms["img_memory"] = formula.tensor("dst.sth.img", (HW + LT, B, D), 1.5).to(dev).requires_grad_(True)
+    ms["text_memory"] = ms["img_memory"][-LT:]
+    mc2, loss = cc(ms, ts, ["put something on it", "use something"])
+    np.testing.assert_allclose(mc2["img_memory_mod"].detach().cpu().numpy(), Z["cl.sth.img_memory_mod"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(cc.cluster_centers.cpu().numpy(), Z["cl.centers_after_forward"], rtol=1e-4, atol=1e-5)
+    assert abs(float(loss["loss_cluster_feature"]) - float(Z["cl.loss_cluster_feature"])) <= 1e-4 * float(Z["cl.loss_cluster_feature"])
+    assert float(loss["loss_cluster_choice"]) == 0.0
+    loss["loss_cluster_feature"].backward()
+    assert ms["img_memory"].grad is not None

@@ -1,0 +1,213 @@
+"""Noun -> pronoun distillation pieces of TOIST (BASELINE config 5).
+
+Mirrors the reference's ClusterCriterion (/root/reference/models/mdetr.py:29-312), its k-means
+(/root/reference/models/kmeans.py) and the char-span -> token-span lookup shared by the contrastive, nsthl2 and
+cluster code (mdetr.py:112-141, 614-643, 684-711).  Everything stays on the device: the memory-bank
+replacement assignment (mdetr.py:98-103) runs on the HIP LSAP kernel instead of SciPy on the host, k-means
+is a handful of device tensor ops per iteration ([1024, 256] bank, 3 centres), and nothing calls `.cpu()`.
+Buffer names and shapes equal the reference's, so a reference checkpoint of the criterion loads unchanged.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .matcher import linear_sum_assignment_batch
+
+
+# ---- char spans -> token positions --------------------------------------------------------------------------
+def char_span_to_tokens(tokenized, batch_index, beg, end):
+    """(first, last) token of the character span [beg, end) of caption `batch_index`, or None.  Same lookup
+    and the same fallbacks as the reference (note that its retries drop the batch index, mdetr.py:126-139)."""
+    first = tokenized.char_to_token(batch_index, beg)
+    last = tokenized.char_to_token(batch_index, end - 1)
+    if first is None:
+        try:
+            first = tokenized.char_to_token(beg + 1)
+            if first is None:
+                first = tokenized.char_to_token(beg + 2)
+        except Exception:
+            first = None
+    if last is None:
+        try:
+            last = tokenized.char_to_token(end - 2)
+            if last is None:
+                last = tokenized.char_to_token(end - 3)
+        except Exception:
+            last = None
+    if first is None or last is None:
+        return None
+    return first, last
+
+
+def span_positions(tokenized, batch_index, spans, length):
+    """int64 token positions (ascending, unique) covered by a list of character spans."""
+    hit = torch.zeros(length, dtype=torch.bool)
+    for beg, end in spans:
+        ft = char_span_to_tokens(tokenized, batch_index, beg, end)
+        if ft is not None:
+            hit[ft[0]:ft[1] + 1] = True
+    return hit.nonzero().reshape(-1)
+
+
+def noun_token_features(text_feature, tokenized, targets):
+    """[B, d]: per image, the mean over its boxes of the mean text feature of each box's noun tokens
+    (mdetr.py:112-145, 684-711); zero rows for images without boxes."""
+    B, L, d = text_feature.shape
+    out = torch.zeros(B, d, device=text_feature.device, dtype=text_feature.dtype)
+    for i, tgt in enumerate(targets):
+        per_box = []
+        for spans in tgt["noun_tokens_positive"]:
+            pos = span_positions(tokenized, i, spans, L).to(text_feature.device)
+            per_box.append(text_feature[i][pos].mean(0))
+        if per_box:
+            out[i] = torch.stack(per_box, 0).mean(0)
+    return out
+
+
+def task_index(dataset_name):
+    """'task_3_train.json' -> 2 (mdetr.py:162)."""
+    return int(dataset_name.split("_")[1]) - 1
+
+
+# ---- k-means (kmeans.py) ---------------------------------------------------------------------------------------
+def _sq_dist(x, centers):
+    return ((x.unsqueeze(1) - centers.unsqueeze(0)) ** 2.0).sum(-1)
+
+
+def kmeans(X, init_cluster_centers, num_clusters, tol=1e-4, full_label=0):
+    """Lloyd iterations until (sum_k |shift_k|)^2 < tol (kmeans.py:21-94).  With full_label == 0 the start is
+    `np.random.choice` rows of X (kmeans.py:8-18: parity with the reference is only defined once the bank is full)."""
+    X = X.float()
+    if full_label == 0:
+        centers = X[torch.as_tensor(np.random.choice(len(X), num_clusters, replace=False), device=X.device)].clone()
+    else:
+        centers = init_cluster_centers
+    while True:
+        choice = torch.argmin(_sq_dist(X, centers), dim=1)
+        before = centers.clone()
+        for c in range(num_clusters):          # K = 3: the reference's own per-cluster mean (same reduction order)
+            members = X[choice == c]
+            if len(members) != 0:              # an empty cluster keeps its centre (kmeans.py:72)
+                centers[c] = members.mean(dim=0)
+        shift = torch.sqrt(((centers - before) ** 2).sum(1)).sum()
+        if float(shift) ** 2 < tol:
+            return choice, centers
+
+
+def kmeans_predict(X, centers):
+    return torch.argmin(_sq_dist(X.float(), centers), dim=1)
+
+
+# ---- ClusterCriterion ------------------------------------------------------------------------------------------
+class ClusterCriterion(nn.Module):
+    """Per-task memory bank of noun text features + k-means prototypes (mdetr.py:29-312)."""
+
+    def __init__(self, feature_dim, memory_size, cluster_num, task_count, args):
+        super().__init__()
+        self.args = args
+        self.feature_dim, self.memory_size, self.cluster_num, self.task_count = feature_dim, memory_size, cluster_num, task_count
+        self.register_buffer("feature_bank", torch.randn(task_count, memory_size, feature_dim))
+        self.register_buffer("cluster_centers", torch.randn(task_count, cluster_num, feature_dim))
+        self.register_buffer("update_count", torch.zeros(task_count))
+        self.register_buffer("full_label", torch.zeros(task_count))
+
+    @staticmethod
+    def _world():
+        return torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+
+    def syn_memory(self):
+        """Average the banks and centres over the ranks (mdetr.py:54-61)."""
+        world = self._world()
+        if world > 1:
+            torch.distributed.all_reduce(self.feature_bank)
+            torch.distributed.all_reduce(self.cluster_centers)
+        self.feature_bank /= world
+        self.cluster_centers /= world
+
+    def update_memory_queue(self, feature_idx):
+        """feature_idx [B, d+1]: feature | task index (-1 = none).  All ranks' rows enter every rank's bank in rank
+        order (mdetr.py:63-103): FIFO until a task's bank has been filled, then FIFO or nearest-replacement."""
+        world = self._world()
+        if world > 1:
+            parts = [torch.zeros_like(feature_idx) for _ in range(world)]
+            torch.distributed.all_gather(parts, feature_idx)
+            feature_idx = torch.cat(parts, 0)
+        tasks = feature_idx[:, -1].round().to(torch.int64).tolist()   # one host read per step; the values are small integers
+        for t in sorted(set(tasks) - {-1}):
+            new = feature_idx[[i for i, x in enumerate(tasks) if x == t], :-1]
+            n = new.shape[0]
+            bank = self.feature_bank[t]
+            filling = float(self.full_label[t]) == 0
+            if filling or self.args.fifo_memory:
+                bank.copy_(torch.cat([bank[n:], new], 0))
+                if filling:
+                    if float(self.update_count[t]) > self.memory_size:
+                        self.full_label[t] = 1
+                    self.update_count[t] += n
+            else:   # replace the entries closest (L1) to the new features: one LSAP on the device
+                (rows, cols), = linear_sum_assignment_batch([torch.cdist(new, bank, p=1)])
+                bank[cols] = new[rows]
+
+    def memory_cluster(self, feature, t):
+        choice, centers = kmeans(self.feature_bank[t], self.cluster_centers[t].clone(), self.cluster_num, full_label=float(self.full_label[t]))
+        self.cluster_centers[t] = centers
+        pick = kmeans_predict(feature.reshape(1, -1), centers)[0]
+        return pick, centers[pick]
+
+    def _substitute(self, memory_cache, i, pos, t, feature):
+        """Overwrite the text-memory rows `pos` of sample i in img_memory_mod with the chosen prototype."""
+        pick, center = self.memory_cluster(feature.clone().detach(), t)
+        L = len(memory_cache["text_memory"])
+        memory_cache["img_memory_mod"][-L:, i, :][pos.to(center.device)] = self.cluster_centers[t, pick]
+        return center
+
+    def update_memory(self, memory_cache_noun, targets_noun, captions_noun):
+        """Teacher side (mdetr.py:105-205): push this batch's noun features into the banks, then replace the noun
+        tokens of the teacher's text memory by their prototype."""
+        text = memory_cache_noun["text_memory"].permute(1, 0, 2)
+        B, L, d = text.shape
+        tokenized = memory_cache_noun["tokenized"]
+        feats = noun_token_features(text, tokenized, targets_noun)
+        empty = [len(t["boxes"]) == 0 for t in targets_noun]
+        rows = torch.zeros(B, d + 1, device=text.device)
+        rows[:, -1] = -1
+        for i, tgt in enumerate(targets_noun):
+            if not empty[i]:
+                rows[i, :-1] = feats[i].detach()
+                rows[i, -1] = task_index(tgt["dataset_name"])
+        self.update_memory_queue(rows)
+        memory_cache_noun["img_memory_mod"] = memory_cache_noun["img_memory"].clone()
+        for i, tgt in enumerate(targets_noun):
+            if empty[i]:
+                continue
+            spans = [s for box in tgt["noun_tokens_positive"] for s in box]
+            self._substitute(memory_cache_noun, i, span_positions(tokenized, i, spans, L), task_index(tgt["dataset_name"]), feats[i])
+        memory_cache_noun["full_label"], memory_cache_noun["update_count"] = self.full_label, self.update_count
+        return memory_cache_noun
+
+    def _something(self, memory_cache, names, captions, with_loss):
+        text = memory_cache["text_memory"].permute(1, 0, 2)
+        B, L, _ = text.shape
+        tokenized = memory_cache["tokenized"]
+        memory_cache["img_memory_mod"] = memory_cache["img_memory"].clone()
+        loss_feature = torch.zeros((), device=text.device)
+        for i in range(B):
+            beg = captions[i].find("something")
+            pos = torch.arange(tokenized.char_to_token(i, beg), tokenized.char_to_token(i, beg + len("something") - 1) + 1)
+            feature = text[i][pos.to(text.device)].mean(0)
+            center = self._substitute(memory_cache, i, pos, task_index(names[i]), feature)
+            if with_loss:
+                loss_feature = loss_feature + F.mse_loss(feature, center)
+        return memory_cache, loss_feature / max(B, 1)
+
+    def forward(self, memory_cache_sth, targets_sth, captions_sth):
+        """Student side (mdetr.py:230-277): the pronoun 'something' is replaced by the prototype closest to its own
+        feature; loss_cluster_feature pulls that feature towards the prototype (loss_cluster_choice stays 0)."""
+        mc, loss = self._something(memory_cache_sth, [t["dataset_name"] for t in targets_sth], captions_sth, True)
+        return mc, {"loss_cluster_choice": torch.zeros((), device=loss.device), "loss_cluster_feature": loss}
+
+    @torch.no_grad()
+    def infer_choice(self, memory_cache_sth, dataset_name_list, captions):
+        """mdetr.py:279-312"""
+        return self._something(memory_cache_sth, dataset_name_list, captions, False)[0]

@@ -17,6 +17,7 @@ from .backbone import build_backbone, nearest_mask
 from .matcher import build_matcher
 from .misc import NestedTensor
 from .transformer import build_transformer
+from .distill import ClusterCriterion, char_span_to_tokens, noun_token_features
 
 BF16 = torch.bfloat16
 
@@ -342,11 +343,10 @@ class SetCriterion(nn.Module):
                     spans = tgt["token_spans"][t]
                 else:
                     spans = []
-                    for beg, end in tgt["tokens_positive"][t]:
-                        bp, ep = tokenized.char_to_token(i, beg), tokenized.char_to_token(i, end - 1)
-                        if bp is None or ep is None:
-                            continue
-                        spans.append((bp, ep))
+                    for beg, end in tgt["tokens_positive" if "tokens_positive" in tgt else "tokens"][t]:
+                        ft = char_span_to_tokens(tokenized, i, beg, end)
+                        if ft is not None:
+                            spans.append(ft)
                 for bp, ep in spans:
                     pm[i, q, bp:ep + 1] = True
         pm = pm.to(logits.device)
@@ -357,7 +357,7 @@ class SetCriterion(nn.Module):
 
     def forward(self, memory_cache, outputs, targets, positive_map, example_rel=None):
         if isinstance(outputs, list):
-            raise NotImplementedError("distillation (teacher, student) criterion branch is SURVEY 8(f) 'next'")
+            return self._forward_pair(memory_cache, outputs, targets, positive_map)
         logits, boxes = self._stack(outputs)
         L = logits.shape[0]
         match = self.matcher.match_layers(logits.detach(), boxes.detach(), targets, positive_map)
@@ -373,6 +373,89 @@ class SetCriterion(nn.Module):
             from .segmentation import mask_losses
             losses.update(mask_losses(outputs, targets, match, L - 1, num_boxes))
         return losses
+
+
+    # ---- distillation: [teacher (noun), student (pronoun)] -------------------------------------------------------
+    def _forward_pair(self, memory_cache, outputs, targets, positive_map):
+        """List branch of the reference (mdetr.py:887-987): every detection loss for both models under the prefixes
+        noun_ / sth_, then the cross losses nsthl2 (main layer) and softkd (every layer)."""
+        losses, sides = {}, []
+        for prefix, out, tgt, pm in zip(("noun", "sth"), outputs, targets, positive_map):
+            logits, boxes = self._stack(out)
+            L = logits.shape[0]
+            match = self.matcher.match_layers(logits.detach(), boxes.detach(), tgt, pm)
+            num_boxes = self._num_boxes(tgt, logits.device)
+            side = self._detection_losses(logits, boxes, match, tgt, pm, num_boxes)
+            if "contrastive_align" in self.losses:
+                layers = list(out.get("aux_outputs", [])) + [out]
+                for l, o in enumerate(layers):
+                    side["loss_contrastive_align" + ("" if l == L - 1 else f"_{l}")] = self._contrastive_align(o, match, tgt, num_boxes, l, L)
+            if "masks" in self.losses:
+                from .segmentation import mask_losses
+                side.update(mask_losses(out, tgt, match, L - 1, num_boxes))
+            losses.update({prefix + "_" + k_: v for k_, v in side.items()})
+            sides.append((logits, boxes, match, L))
+        self.last_match = sides[1][2]
+        if getattr(self.args, "nsthl2_loss", False):
+            losses["loss_nsthl2"] = self._loss_nsthl2(memory_cache, outputs, targets, sides[1][2])
+        if getattr(self.args, "softkd_loss", False):
+            L = sides[0][3]
+            for l in range(L):
+                losses["loss_softkd" + ("" if l == L - 1 else f"_{l}")] = self._loss_softkd(sides[0], sides[1], l)
+        return losses
+
+    def _loss_nsthl2(self, memory_cache, outputs, targets, match_sth):
+        """mdetr.py:668-781: MSE between the student's and the (detached) teacher's mean noun-token text feature, over
+        the images in which the student's main layer matched at least one box."""
+        feats = []
+        for mc, out, tgt in zip(memory_cache, outputs, targets):
+            feats.append(noun_token_features(mc["text_memory"].permute(1, 0, 2), out["tokenized"], tgt))
+        keep = [i for i, c in enumerate(match_sth.counts) if c > 0]
+        if not keep:
+            return torch.zeros((), device=feats[0].device)
+        idx = torch.as_tensor(keep, device=feats[0].device)
+        per_image = ((feats[1][idx] - feats[0][idx].detach()) ** 2).mean(1)     # F.mse_loss per image
+        return per_image.sum() / len(keep)
+
+    def _loss_softkd(self, noun, sth, layer):
+        """mdetr.py:543-599 for one decoder layer: KL(student || teacher) on the binarised (object, no-object)
+        probabilities -- matched queries paired through their target, unmatched ones through an LSAP on KL + L1 + GIoU
+        cost (mdetr.py:520-541), all images in one launch of the device LSAP kernel."""
+        from .box_ops import box_cxcywh_to_xyxy, generalized_box_iou
+        from .matcher import linear_sum_assignment_batch
+        (lg_n, bx_n, m_n, _), (lg_s, bx_s, m_s, _) = noun, sth
+        B, Q = lg_n.shape[1], lg_n.shape[2]
+        dev = lg_n.device
+
+        def binarise(lg):
+            p = lg[layer].float().softmax(-1)
+            return torch.cat([p[..., :-1].sum(-1, keepdim=True), p[..., -1:]], dim=-1)      # [B,Q,2]
+
+        p_n, p_s = binarise(lg_n).detach(), binarise(lg_s)
+        parts, costs = [], []
+        for i in range(B):
+            side = []
+            for p, bx, m in ((p_n, bx_n, m_n), (p_s, bx_s, m_s)):
+                c, o = m.counts[i], m.match_off[i]
+                src, tgt = m.src[layer, o:o + c], m.tgt[layer, o:o + c]
+                tp = torch.zeros(c, 2, device=dev, dtype=p.dtype).index_copy(0, tgt, p[i][src]) if c else p[i][:0]
+                free = torch.ones(Q, dtype=torch.int8, device=dev)
+                if c:
+                    free[src] = 0
+                fp_idx = torch.sort(free, descending=True, stable=True).indices[:Q - c]       # unmatched queries, ascending
+                side.append((tp, p[i][fp_idx], bx[layer, i].float()[fp_idx]))
+            (tp_n, fp_n, fb_n), (tp_s, fp_s, fb_s) = side
+            with torch.no_grad():
+                cost_class = (fp_n * (fp_n.unsqueeze(0).log() - fp_s.log().unsqueeze(1))).sum(-1)      # [S, T]
+                cost = torch.cdist(fb_s, fb_n, p=1) + cost_class - generalized_box_iou(box_cxcywh_to_xyxy(fb_s), box_cxcywh_to_xyxy(fb_n))
+            costs.append(cost)
+            parts.append((tp_n, fp_n, tp_s, fp_s))
+        total = torch.zeros((), device=dev)
+        for (tp_n, fp_n, tp_s, fp_s), (rows, cols) in zip(parts, linear_sum_assignment_batch(costs)):
+            teacher = torch.cat([tp_n, fp_n[cols]], 0)
+            student = torch.cat([tp_s, fp_s[rows]], 0)
+            total = total + F.kl_div(student.log(), teacher, reduction="batchmean")
+        return total / B
 
 
 class _SetLossFn(torch.autograd.Function):
@@ -430,13 +513,29 @@ def build(args):
     weight_dict = {"loss_ce": args.ce_loss_coef, "loss_bbox": args.bbox_loss_coef}
     if args.contrastive_align_loss:
         weight_dict["loss_contrastive_align"] = args.contrastive_align_loss_coef
-    if getattr(args, "nsthl2_loss", False) or getattr(args, "softkd_loss", False) or getattr(args, "cluster", False) \
-            or getattr(args, "distillation", False):
-        raise NotImplementedError("noun-pronoun distillation (config 5) is SURVEY 8(f) 'next', not built yet")
+    nsthl2, softkd = getattr(args, "nsthl2_loss", False), getattr(args, "softkd_loss", False)
+    cluster, distillation = getattr(args, "cluster", False), getattr(args, "distillation", False)
+    if nsthl2:
+        weight_dict["loss_nsthl2"] = args.nsthl2_coef
+    if softkd:
+        weight_dict["loss_softkd"] = args.softkd_coef
+    if cluster and distillation:
+        weight_dict["loss_cluster_choice"] = args.cluster_choice_loss
+        weight_dict["loss_cluster_feature"] = args.cluster_feature_loss
     weight_dict["loss_giou"] = args.giou_loss_coef
     if args.masks:
         weight_dict["loss_mask"] = args.mask_loss_coef
         weight_dict["loss_dice"] = args.dice_loss_coef
+    if distillation:   # per-model losses get the noun_ / sth_ prefixes, the cross losses keep their names (mdetr.py:1083-1097)
+        cross = ("loss_nsthl2", "loss_softkd", "loss_cluster_choice", "loss_cluster_feature")
+        prefixed = {}
+        for kk, v in weight_dict.items():
+            if kk in cross:
+                prefixed[kk] = v
+            else:
+                prefixed["noun_" + kk] = v
+                prefixed["sth_" + kk] = v
+        weight_dict = prefixed
     if args.aux_loss:
         aux = {}
         for i in range(args.dec_layers - 1):
@@ -447,7 +546,15 @@ def build(args):
         losses += ["masks"]
     if args.contrastive_align_loss:
         losses += ["contrastive_align"]
+    if nsthl2:
+        losses += ["nsthl2"]
+    if softkd:
+        losses += ["softkd"]
     criterion = SetCriterion(args, num_classes, matcher=matcher, eos_coef=args.eos_coef, losses=losses,
                              temperature=args.temperature_NCE, contrastive_hdim=args.contrastive_loss_hdim)
     criterion.to(device)
-    return model, criterion, None, weight_dict
+    cluster_criterion = None
+    if cluster:
+        cluster_criterion = ClusterCriterion(feature_dim=args.hidden_dim, memory_size=args.cluster_memory_size, cluster_num=args.cluster_num,
+                                             task_count=14, args=args)
+    return model, criterion, cluster_criterion, weight_dict
