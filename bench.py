@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="time every GEMM launch (diagnostic; adds host overhead)")
+    ap.add_argument("--distill", action="store_true", help="config 5 on this GPU: teacher + student forward, cluster criterion, paired criterion "
+                    "(eager launch: the k-means loop reads the device); use with --batch 4")
     ap.add_argument("--masks", action="store_true", help="config 3: add the segmentation head and the mask losses")
     ap.add_argument("--no-overlap", action="store_true", help="keep the text branch on the main stream (no parallel graph branch)")
     ap.add_argument("--torch-optimizer", action="store_true", help="diagnostic: torch clip_grad_norm_ + fused AdamW + foreach EMA instead of the HIP tail")
@@ -90,6 +92,77 @@ def cpu_baseline(size):
         return {"value": None, "unit": "images/s (forward + matcher, B=1)", "cores": threads, "kind": "port", "sample": f"not measured: {type(e).__name__}"}
 
 
+def bench_distillation(a, dev, rank, world):
+    """BASELINE configs[4] per GPU: noun-pronoun distillation step (engine.py:119-250) -- teacher and student forward,
+    memory-bank update + k-means prototypes, paired criterion with softkd / nsthl2, backward through both models, one
+    fused optimizer tail per model (the reference clips the two models separately)."""
+    import toist_amd
+    from toist_amd import harness, kernels, parallel
+    from toist_amd.optim import FusedClipAdamWEMA
+    args = harness.default_args(device="cuda", distillation=True, cluster=True, nsthl2_loss=True, softkd_loss=True, train_batch_size=a.batch)
+    torch.manual_seed(0)
+    model, criterion, cluster_criterion, weight_dict = toist_amd.build_model(args)
+    model_noun, _, _, _ = toist_amd.build_model(args)
+    for m in (model, model_noun):
+        m.to(dev)
+        parallel.broadcast_parameters(m)
+        m.train()
+    cluster_criterion.to(dev)
+    cluster_criterion.full_label.fill_(1)   # steady state: banks full, k-means starts from the stored centres
+    kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def tail(m):
+        named = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+        groups = [{"params": [p for n, p in named if "backbone" not in n and "text_encoder" not in n]},
+                  {"params": [p for n, p in named if "backbone" in n], "lr": args.lr_backbone},
+                  {"params": [p for n, p in named if "text_encoder" in n], "lr": args.text_encoder_lr}]
+        src = [v for v in m.state_dict().values() if v.is_floating_point()]
+        return FusedClipAdamWEMA(groups, lr=args.lr, weight_decay=args.weight_decay, max_norm=args.clip_max_norm,
+                                 ema=list(zip(src, [v.detach().clone() for v in src])), ema_decay=0.9998)
+
+    opts = [tail(model), tail(model_noun)]
+    batch = harness.synthetic_distill_batch(a.batch, a.size, a.size, tokens=16, seed=1000 + rank, device=dev)
+    sync = parallel.GradSync()
+
+    def step():
+        kernels.SEED_DEV.add_(1000003)
+        for o in opts:
+            o.zero_grad(set_to_none=True)
+        with sync:
+            total, _ = harness.distillation_step(model, model_noun, criterion, cluster_criterion, weight_dict, batch)
+            total.backward()
+            sync.finish()
+        for o in opts:
+            o.step()
+        return total
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    if rank == 0:
+        print(json.dumps({"metric": "train images/sec/node (640x640) + matcher index bit-match", "value": round(a.batch * world * a.steps / dt, 3), "unit": "images/s (pairs)",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": f"configs[4]: noun-pronoun distillation, teacher + student (ResNet-101 + RoBERTa-base + 6+6 each), batch {a.batch} pairs/GPU "
+                                                 f"{a.size}x{a.size}, cluster memory 1024 x 14 tasks + k-means(3), softkd + nsthl2 + cluster losses, two fused optimizer tails",
+                                     "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(float(last.detach()), 4), "launch": "eager"}}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
         cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
@@ -111,6 +184,8 @@ def main():
 
     import toist_amd
     from toist_amd import harness, kernels, parallel
+    if a.distill:
+        return bench_distillation(a, dev, rank, world)
     args = harness.default_args(device="cuda", masks=a.masks, mask_model="smallconv" if a.masks else "none")
     torch.manual_seed(0)
     model, criterion, _, weight_dict = toist_amd.build_model(args)

@@ -83,3 +83,32 @@ def test_cluster_criterion_full_bank(dev):
     assert float(loss["loss_cluster_choice"]) == 0.0
     loss["loss_cluster_feature"].backward()
     assert ms["img_memory"].grad is not None
+
+
+def test_distillation_step_end_to_end(dev):
+    """Teacher + student double forward with the cluster criterion and the paired criterion (engine.py:152-204) on
+    synthetic (noun, pronoun) pairs: every reference loss key is produced, the loss is finite, and the backward pass
+    reaches both models (the teacher through its own noun_ losses, the student also through softkd / nsthl2 / cluster)."""
+    import toist_amd
+    from toist_amd import harness
+    args = harness.default_args(device="cuda", distillation=True, cluster=True, nsthl2_loss=True, softkd_loss=True, cluster_memory_size=32,
+                                num_queries=20, enc_layers=2, dec_layers=2)
+    torch.manual_seed(0)
+    model, criterion, cluster_criterion, weight_dict = toist_amd.build_model(args)
+    model_noun, _, _, _ = toist_amd.build_model(args)
+    model.to(dev).train()
+    model_noun.to(dev).train()
+    cluster_criterion.to(dev)
+    cluster_criterion.full_label.fill_(1)          # k-means starts from the stored centres (deterministic)
+    assert {"noun_loss_ce", "sth_loss_giou_0", "loss_softkd", "loss_softkd_0", "loss_nsthl2", "loss_cluster_feature"} <= set(weight_dict)
+    batch = harness.synthetic_distill_batch(2, 128, 160, tokens=16, seed=3, device=dev, max_targets=4)
+    total, losses = harness.distillation_step(model, model_noun, criterion, cluster_criterion, weight_dict, batch)
+    # the reference's weight_dict also carries _{i} copies of nsthl2 / cluster keys that no loss ever produces (mdetr.py:1093-1097)
+    never = {k_ for k_ in weight_dict if k_.startswith(("loss_nsthl2_", "loss_cluster_"))}
+    assert torch.isfinite(total) and set(weight_dict) - never <= set(losses)
+    total.backward()
+    g_s = model.transformer.decoder.layers[0].linear1.weight.grad
+    g_n = model_noun.transformer.decoder.layers[0].linear1.weight.grad
+    g_t = model.transformer.text_encoder.encoder.layer[0].output.dense.weight.grad
+    assert g_s is not None and g_n is not None and g_t is not None
+    assert float(g_s.abs().sum()) > 0 and float(g_n.abs().sum()) > 0 and float(g_t.abs().sum()) > 0

@@ -17,6 +17,8 @@ def default_args(**over):
         contrastive_align_loss_coef=1.0, set_loss="hungarian", set_cost_class=1.0, set_cost_bbox=5.0, set_cost_giou=2.0,
         lr_backbone=1e-5, backbone="resnet101", dilation=False, position_embedding="sine", nsthl2_loss=False, softkd_loss=False,
         cluster=False, distillation=False, lr=1e-4, text_encoder_lr=5e-5, weight_decay=1e-4, clip_max_norm=0.1,
+        nsthl2_coef=1e4, softkd_coef=1.0, cluster_choice_loss=0.0, cluster_feature_loss=1e4, cluster_memory_size=1024, fifo_memory=False,
+        train_batch_size=4,
     )
     a.update(over)
     return SimpleNamespace(**a)
@@ -60,3 +62,56 @@ def synthetic_batch(batch, height=640, width=640, tokens=16, seed=1000, device="
     samples = NestedTensor(images.to(device), mask.to(device))
     targets = [{k: (to(v) if k != "token_spans" else v) for k, v in t.items()} for t in targets]
     return samples, tokenized.to(device), targets, positive_map.to(device)
+
+
+# ---- distillation (BASELINE config 5): (noun, pronoun) pairs -------------------------------------------------------
+class SyntheticCaptions(TokenizedText):
+    """Pre-tokenised synthetic captions that also answer char_to_token the way a HF BatchEncoding does, for the
+    span lookups of the distillation losses (no tokenizer files exist offline): 4 characters per token, token 0 = <s>."""
+
+    def char_to_token(self, batch_or_char, char=None):
+        c = batch_or_char if char is None else char
+        t = c // 4 + 1
+        return t if 0 <= c and t < self["input_ids"].shape[1] - 1 else None
+
+
+def synthetic_distill_batch(batch, height=640, width=640, tokens=16, seed=1000, device="cpu", max_targets=10):
+    """What collate_fn (util/misc.py:40-91) delivers for `batch` (noun, pronoun) pairs: the two sides share image and
+    boxes; the noun caption names the object (characters 8..15 -> tokens 3..4), the pronoun caption says 'something'
+    at the same place.  Returns dict(samples, targets, positive_map, captions, tokenized) with two-element lists."""
+    samples, tok, targets, pmap = synthetic_batch(batch, height, width, tokens=tokens, seed=seed, device=device, max_targets=max_targets)
+    out = {"samples": [samples, samples], "positive_map": [pmap, pmap], "example_rel": list(range(batch)), "targets": [], "captions": [], "tokenized": []}
+    for side, word in enumerate(("scissors", "something")):
+        caption = ("use the " + word + " to cut the paper up")[:4 * (tokens - 2)]
+        out["captions"].append([caption] * batch)
+        tg = []
+        for i, t in enumerate(targets):
+            t = dict(t)
+            t["noun_tokens_positive"] = [[(8, 8 + len(word))] for _ in range(len(t["boxes"]))]
+            t["dataset_name"] = f"task_{1 + (i + side * 0) % 14}_train.json"
+            tg.append(t)
+        out["targets"].append(tg)
+        out["tokenized"].append(SyntheticCaptions(dict(tok)))
+    return out
+
+
+def distillation_step(model, model_noun, criterion, cluster_criterion, weight_dict, batch):
+    """Forward half of engine.py:152-190 (train_one_epoch_distillation): teacher and student encode, memory-bank update
+    and prototype substitution, both decodes, the paired criterion.  Returns (total loss, loss dict)."""
+    s_noun, s_sth = batch["samples"]
+    t_noun, t_sth = batch["targets"]
+    c_noun, c_sth = batch["captions"]
+    k_noun, k_sth = batch["tokenized"]
+    mc_noun = model_noun(s_noun, k_noun, encode_and_save=True)
+    if cluster_criterion is not None:
+        mc_noun = cluster_criterion.update_memory(mc_noun, t_noun, c_noun)
+    out_noun = model_noun(s_noun, k_noun, encode_and_save=False, memory_cache=mc_noun)
+    mc_sth = model(s_sth, k_sth, encode_and_save=True)
+    loss_cluster = {}
+    if cluster_criterion is not None:
+        mc_sth, loss_cluster = cluster_criterion(mc_sth, t_sth, c_sth)
+    out_sth = model(s_sth, k_sth, encode_and_save=False, memory_cache=mc_sth)
+    losses = criterion([mc_noun, mc_sth], [out_noun, out_sth], [t_noun, t_sth], batch["positive_map"], batch.get("example_rel"))
+    losses.update(loss_cluster)
+    total = sum(losses[k] * weight_dict[k] for k in losses if k in weight_dict)
+    return total, losses

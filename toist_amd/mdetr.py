@@ -409,7 +409,7 @@ class SetCriterion(nn.Module):
         the images in which the student's main layer matched at least one box."""
         feats = []
         for mc, out, tgt in zip(memory_cache, outputs, targets):
-            feats.append(noun_token_features(mc["text_memory"].permute(1, 0, 2), out["tokenized"], tgt))
+            feats.append(noun_token_features(mc["text_memory"].permute(1, 0, 2), out.get("tokenized", mc.get("tokenized")), tgt))
         keep = [i for i, c in enumerate(match_sth.counts) if c > 0]
         if not keep:
             return torch.zeros((), device=feats[0].device)

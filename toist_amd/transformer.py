@@ -160,7 +160,7 @@ class TokenizedText(dict):
             raise AttributeError(key) from e
 
     def to(self, device):
-        return TokenizedText({k_: (v.to(device) if torch.is_tensor(v) else v) for k_, v in self.items()})
+        return type(self)({k_: (v.to(device) if torch.is_tensor(v) else v) for k_, v in self.items()})
 
 
 # ------------------------------------------------------------------------------------------ the module
