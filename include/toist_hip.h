@@ -276,7 +276,8 @@ typedef struct toist_opt_state {
  * an L1 cdist, mdetr.py:539 softkd matcher): problem p is the row-major fp32 matrix [rows[p], cols[p]] at
  * cost + offset[p]; min(rows, cols) pairs are written at row_idx / col_idx + out_off[p], rows ascending (SciPy's
  * order).  status[p]: 0 ok, 1 NaN or -inf in the matrix (SciPy: ValueError), 2 infeasible. */
-int toist_lsap(const float* cost, const int64_t* offset, const int32_t* rows, const int32_t* cols, int n, int max_rows, int max_cols,
+int toist_lsap(const float* cost, const int64_t* offset, const int32_t* rows, const int32_t* cols, int ld /* row stride, 0 = cols[p] */,
+               int n, int max_rows, int max_cols,
                int64_t max_cells /* max over problems of rows*cols: sizes the LDS */, const int64_t* out_off, int64_t* row_idx, int64_t* col_idx, int32_t* status, void* stream);
 
 /* ---- deferred split-K reductions ------------------------------------------------------------------------

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void matcher_kernel(
 // ascending in the output, the transpose is solved when rows > cols, NaN / -inf entries are invalid).  One workgroup
 // (one solving wavefront) per problem; problem p is [rows[p], cols[p]] fp32, row-major, at cost + offset[p].
 __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost, const long long* __restrict__ offset,
-                                                  const int* __restrict__ rows, const int* __restrict__ cols,
+                                                  const int* __restrict__ rows, const int* __restrict__ cols, const int ld,
                                                   const long long* __restrict__ out_off, long long* __restrict__ row_idx,
                                                   long long* __restrict__ col_idx, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -286,10 +286,11 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
     float* cw = reinterpret_cast<float*>(in_sc + C);
     const float* src = cost + offset[p];
     int bad = 0;
+    const int pitch = ld > 0 ? ld : nc;     // row stride of the caller's matrix (a block of a larger one when ld > cols)
     for (int e = lane; e < nr * nc; e += 64) {
-        const float c = src[e];
-        if (c != c || c == -INFINITY) bad = 1;
         const int i = e / nc, j = e - i * nc;
+        const float c = src[(long long)i * pitch + j];
+        if (c != c || c == -INFINITY) bad = 1;
         cw[flip ? (j * nr + i) : e] = c;
     }
     bad = __any(bad);
@@ -358,12 +359,12 @@ extern "C" int toist_matcher(const float* logits, const float* boxes, const floa
     return check_launch("toist_matcher");
 }
 
-extern "C" int toist_lsap(const float* cost, const int64_t* offset, const int32_t* rows, const int32_t* cols, int n, int max_rows,
+extern "C" int toist_lsap(const float* cost, const int64_t* offset, const int32_t* rows, const int32_t* cols, int ld, int n, int max_rows,
                           int max_cols, int64_t max_cells, const int64_t* out_off, int64_t* row_idx, int64_t* col_idx, int32_t* status,
                           void* stream) {
     using namespace toist;
     TOIST_REQUIRE(cost && offset && rows && cols && out_off && row_idx && col_idx && status && n > 0, "toist_lsap: bad args");
-    TOIST_REQUIRE(max_rows >= 0 && max_cols >= 0 && max_cells >= 0, "toist_lsap: negative extent");
+    TOIST_REQUIRE(max_rows >= 0 && max_cols >= 0 && max_cells >= 0 && (ld == 0 || ld >= max_cols), "toist_lsap: negative extent or ld < cols");
     const int R = max_rows < max_cols ? max_rows : max_cols, C = max_rows < max_cols ? max_cols : max_rows;
     const size_t lds = lsap_lds_bytes(R, C, max_cells);
     TOIST_REQUIRE(lds <= 160 * 1024, "toist_lsap: problems up to %d x %d (%lld cells) need %zu B of LDS (> 160 KiB)", max_rows, max_cols,
@@ -376,7 +377,7 @@ extern "C" int toist_lsap(const float* cost, const int64_t* offset, const int32_
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(lsap_kernel, dim3(n), dim3(64), lds, (hipStream_t)stream, cost, (const long long*)offset, rows, cols,
+    hipLaunchKernelGGL(lsap_kernel, dim3(n), dim3(64), lds, (hipStream_t)stream, cost, (const long long*)offset, rows, cols, ld,
                        (const long long*)out_off, (long long*)row_idx, (long long*)col_idx, status);
     return check_launch("toist_lsap");
 }

@@ -373,7 +373,7 @@ def opt_adamw_ema(table, grads, chunks, n_chunks, groups, state, beta1, beta2, e
                "toist_opt_adamw_ema")
 
 
-def lsap(cost, offset, rows, cols, n, max_rows, max_cols, max_cells, out_off, row_idx, col_idx, status):
-    _lib.check(_lib.lib().toist_lsap(_p(cost, torch.float32), _p(offset, torch.int64), _p(rows, torch.int32), _p(cols, torch.int32), n, max_rows,
+def lsap(cost, offset, rows, cols, n, max_rows, max_cols, max_cells, out_off, row_idx, col_idx, status, ld=0):
+    _lib.check(_lib.lib().toist_lsap(_p(cost, torch.float32), _p(offset, torch.int64), _p(rows, torch.int32), _p(cols, torch.int32), ld, n, max_rows,
                                      max_cols, max_cells, _p(out_off, torch.int64), _p(row_idx, torch.int64), _p(col_idx, torch.int64),
                                      _p(status, torch.int32), _stream()), "toist_lsap")

@@ -89,31 +89,57 @@ def build_matcher(args):
     return HungarianMatcher(cost_class=args.set_cost_class, cost_bbox=args.set_cost_bbox, cost_giou=args.set_cost_giou)
 
 
-def linear_sum_assignment_batch(costs):
-    """scipy.optimize.linear_sum_assignment for a list of 2-D fp32 device cost matrices, solved in one launch of the
-    HIP LSAP kernel (csrc/matcher.hip).  Returns a list of (row_ind, col_ind) int64 device tensors (rows ascending, as
-    SciPy returns them).  Raises ValueError on NaN / -inf entries or an infeasible matrix, like SciPy."""
-    from . import kernels as k
-    if not costs:
-        return []
-    dev = costs[0].device
-    shapes = [(int(c.shape[0]), int(c.shape[1])) for c in costs]
-    flat = torch.cat([c.reshape(-1).float() for c in costs]) if sum(r * c for r, c in shapes) else torch.zeros(1, device=dev)
-    sizes = [r * c for r, c in shapes]
-    pairs = [min(r, c) for r, c in shapes]
-    off = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], dtype=torch.int64, device=dev)
-    out_off_h = [sum(pairs[:i]) for i in range(len(pairs))]
-    out_off = torch.tensor(out_off_h, dtype=torch.int64, device=dev)
-    rows = torch.tensor([r for r, _ in shapes], dtype=torch.int32, device=dev)
-    cols = torch.tensor([c for _, c in shapes], dtype=torch.int32, device=dev)
-    total = max(sum(pairs), 1)
-    ri = torch.zeros(total, dtype=torch.int64, device=dev)
-    ci = torch.zeros(total, dtype=torch.int64, device=dev)
-    status = torch.zeros(len(costs), dtype=torch.int32, device=dev)
-    k.lsap(flat.contiguous(), off, rows, cols, len(costs), max(r for r, _ in shapes), max(c for _, c in shapes), max(sizes), out_off, ri, ci, status)
+_LSAP_META = {}
+
+
+def _lsap_meta(shapes, offsets, dev):
+    """Device copies of the per-problem tables, cached per signature (a steady-state step uploads nothing)."""
+    key = (tuple(shapes), tuple(offsets), str(dev))
+    ent = _LSAP_META.get(key)
+    if ent is None:
+        if len(_LSAP_META) > 64:
+            _LSAP_META.clear()
+        pairs = [min(r, c) for r, c in shapes]
+        out_off = [sum(pairs[:i]) for i in range(len(pairs))]
+        ent = _LSAP_META[key] = (torch.tensor(list(offsets), dtype=torch.int64, device=dev), torch.tensor([r for r, _ in shapes], dtype=torch.int32, device=dev),
+                                 torch.tensor([c for _, c in shapes], dtype=torch.int32, device=dev), torch.tensor(out_off, dtype=torch.int64, device=dev), out_off, pairs)
+    return ent
+
+
+def check_lsap_status(status):
+    """Raise like SciPy for invalid / infeasible matrices (reads the device: call once per step, not per launch)."""
     st = status.cpu()
     if bool((st == 1).any()):
         raise ValueError("matrix contains invalid numeric entries")
     if bool((st == 2).any()):
         raise ValueError("cost matrix is infeasible")
-    return [(ri[o:o + n], ci[o:o + n]) for o, n in zip(out_off_h, pairs)]
+
+
+def lsap_blocks(cost, shapes, offsets, ld):
+    """LSAP on blocks of one device buffer: problem p is the [rows, cols] block with row stride `ld` starting at element
+    offsets[p] of `cost`.  One launch, no host sync: returns (row_idx, col_idx, out_off, pairs, status) -- the pairs of
+    problem p are row_idx[out_off[p] : out_off[p] + pairs[p]]; pass `status` to check_lsap_status when convenient."""
+    from . import kernels as k
+    dev = cost.device
+    off, rows, cols, out_off_dev, out_off, pairs = _lsap_meta(shapes, offsets, dev)
+    total = max(sum(pairs), 1)
+    ri = torch.zeros(total, dtype=torch.int64, device=dev)
+    ci = torch.zeros(total, dtype=torch.int64, device=dev)
+    status = torch.zeros(len(shapes), dtype=torch.int32, device=dev)
+    k.lsap(cost, off, rows, cols, len(shapes), max(r for r, _ in shapes), max(c for _, c in shapes), max(r * c for r, c in shapes), out_off_dev, ri, ci,
+           status, ld=ld)
+    return ri, ci, out_off, pairs, status
+
+
+def linear_sum_assignment_batch(costs):
+    """scipy.optimize.linear_sum_assignment for a list of 2-D fp32 device cost matrices, solved in one launch of the
+    HIP LSAP kernel (csrc/matcher.hip).  Returns a list of (row_ind, col_ind) int64 device tensors (rows ascending, as
+    SciPy returns them).  Raises ValueError on NaN / -inf entries or an infeasible matrix, like SciPy."""
+    if not costs:
+        return []
+    shapes = [(int(c.shape[0]), int(c.shape[1])) for c in costs]
+    sizes = [r * c for r, c in shapes]
+    flat = torch.cat([c.reshape(-1).float() for c in costs]) if sum(sizes) else torch.zeros(1, device=costs[0].device)
+    ri, ci, out_off, pairs, status = lsap_blocks(flat.contiguous(), shapes, [sum(sizes[:i]) for i in range(len(sizes))], 0)
+    check_lsap_status(status)
+    return [(ri[o:o + n], ci[o:o + n]) for o, n in zip(out_off, pairs)]

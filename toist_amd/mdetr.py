@@ -400,8 +400,9 @@ class SetCriterion(nn.Module):
             losses["loss_nsthl2"] = self._loss_nsthl2(memory_cache, outputs, targets, sides[1][2])
         if getattr(self.args, "softkd_loss", False):
             L = sides[0][3]
+            per_layer = self._loss_softkd(sides[0], sides[1])
             for l in range(L):
-                losses["loss_softkd" + ("" if l == L - 1 else f"_{l}")] = self._loss_softkd(sides[0], sides[1], l)
+                losses["loss_softkd" + ("" if l == L - 1 else f"_{l}")] = per_layer[l]
         return losses
 
     def _loss_nsthl2(self, memory_cache, outputs, targets, match_sth):
@@ -417,45 +418,122 @@ class SetCriterion(nn.Module):
         per_image = ((feats[1][idx] - feats[0][idx].detach()) ** 2).mean(1)     # F.mse_loss per image
         return per_image.sum() / len(keep)
 
-    def _loss_softkd(self, noun, sth, layer):
-        """mdetr.py:543-599 for one decoder layer: KL(student || teacher) on the binarised (object, no-object)
-        probabilities -- matched queries paired through their target, unmatched ones through an LSAP on KL + L1 + GIoU
-        cost (mdetr.py:520-541), all images in one launch of the device LSAP kernel."""
-        from .box_ops import box_cxcywh_to_xyxy, generalized_box_iou
-        from .matcher import linear_sum_assignment_batch
+    def _loss_softkd(self, noun, sth):
+        """mdetr.py:543-599 for every decoder layer at once -> [L]: KL(student || teacher) on the binarised (object,
+        no-object) probabilities -- matched queries paired through their target, unmatched ones through an LSAP on a
+        KL + L1 + GIoU cost (mdetr.py:520-541).  All layers x images are one launch of the device LSAP kernel on blocks
+        of one [L,B,Q,Q] cost tensor; no per-image Python work, no host sync except the final status check."""
+        from .matcher import check_lsap_status, lsap_blocks
         (lg_n, bx_n, m_n, _), (lg_s, bx_s, m_s, _) = noun, sth
-        B, Q = lg_n.shape[1], lg_n.shape[2]
+        L, B, Q = lg_n.shape[0], lg_n.shape[1], lg_n.shape[2]
         dev = lg_n.device
+        if m_n.counts != m_s.counts:
+            raise ValueError("softkd needs the same number of targets on the noun and the pronoun side of every pair")
 
         def binarise(lg):
-            p = lg[layer].float().softmax(-1)
-            return torch.cat([p[..., :-1].sum(-1, keepdim=True), p[..., -1:]], dim=-1)      # [B,Q,2]
+            p = lg.float().softmax(-1)
+            return torch.cat([p[..., :-1].sum(-1, keepdim=True), p[..., -1:]], dim=-1)                  # [L,B,Q,2]
+
+        def unmatched_first(m):
+            """[L,B,Q] query order with the unmatched queries first (ascending), the matched ones after."""
+            free = torch.ones(L, B, Q, dtype=torch.int8, device=dev)
+            if m.src.shape[1]:
+                b_of = _pair_image_index(tuple(m.counts), dev)                                         # [Mtot]
+                free[torch.arange(L, device=dev)[:, None], b_of[None, :], m.src] = 0
+            return torch.sort(free, dim=-1, descending=True, stable=True).indices
 
         p_n, p_s = binarise(lg_n).detach(), binarise(lg_s)
-        parts, costs = [], []
-        for i in range(B):
-            side = []
-            for p, bx, m in ((p_n, bx_n, m_n), (p_s, bx_s, m_s)):
-                c, o = m.counts[i], m.match_off[i]
-                src, tgt = m.src[layer, o:o + c], m.tgt[layer, o:o + c]
-                tp = torch.zeros(c, 2, device=dev, dtype=p.dtype).index_copy(0, tgt, p[i][src]) if c else p[i][:0]
-                free = torch.ones(Q, dtype=torch.int8, device=dev)
-                if c:
-                    free[src] = 0
-                fp_idx = torch.sort(free, descending=True, stable=True).indices[:Q - c]       # unmatched queries, ascending
-                side.append((tp, p[i][fp_idx], bx[layer, i].float()[fp_idx]))
-            (tp_n, fp_n, fb_n), (tp_s, fp_s, fb_s) = side
-            with torch.no_grad():
-                cost_class = (fp_n * (fp_n.unsqueeze(0).log() - fp_s.log().unsqueeze(1))).sum(-1)      # [S, T]
-                cost = torch.cdist(fb_s, fb_n, p=1) + cost_class - generalized_box_iou(box_cxcywh_to_xyxy(fb_s), box_cxcywh_to_xyxy(fb_n))
-            costs.append(cost)
-            parts.append((tp_n, fp_n, tp_s, fp_s))
-        total = torch.zeros((), device=dev)
-        for (tp_n, fp_n, tp_s, fp_s), (rows, cols) in zip(parts, linear_sum_assignment_batch(costs)):
-            teacher = torch.cat([tp_n, fp_n[cols]], 0)
-            student = torch.cat([tp_s, fp_s[rows]], 0)
-            total = total + F.kl_div(student.log(), teacher, reduction="batchmean")
-        return total / B
+        ord_n, ord_s = unmatched_first(m_n), unmatched_first(m_s)
+        take = lambda t, order: torch.gather(t, 2, order[..., None].expand(-1, -1, -1, t.shape[-1]))
+        fp_n, fp_s = take(p_n, ord_n), take(p_s, ord_s)                                                 # unmatched first
+        with torch.no_grad():
+            fb_n, fb_s = take(bx_n.float(), ord_n), take(bx_s.float(), ord_s)
+            cost_class = (fp_n[:, :, None, :, :] * (fp_n.log()[:, :, None, :, :] - fp_s.log()[:, :, :, None, :])).sum(-1)   # [L,B,S,T]
+            cost = (torch.cdist(fb_s, fb_n, p=1) + cost_class - _paired_giou_matrix(fb_s, fb_n)).contiguous()
+        shapes = [(Q - c, Q - c) for _ in range(L) for c in m_n.counts]
+        offsets = [(l * B + i) * Q * Q for l in range(L) for i in range(B)]
+        rows, cols, out_off, pairs, status = lsap_blocks(cost, shapes, offsets, Q)
+        # unmatched pairs: student row `rows`, teacher row `cols` of problem (l, i)
+        pl, pb = _problem_index(L, tuple(pairs), dev)
+        kl_fp = _kl_rows(fp_n[pl, pb, cols], fp_s[pl, pb, rows])                                        # [sum pairs]
+        # matched pairs: both sides indexed by target -> position match_off[i] + tgt inside the image's run
+        def by_target(p, m):
+            out = torch.zeros(L, max(m.src.shape[1], 1), 2, device=dev, dtype=p.dtype)
+            if m.src.shape[1]:
+                b_of = _pair_image_index(tuple(m.counts), dev)
+                base = _pair_image_offset(tuple(m.counts), dev)
+                lidx = torch.arange(L, device=dev)[:, None].expand_as(m.src)
+                out = out.index_put((lidx, base[None, :] + m.tgt), p[lidx, b_of[None, :].expand_as(m.src), m.src])
+            return out
+        kl_tp = _kl_rows(by_target(p_n, m_n), by_target(p_s, m_s))                                      # [L, Mtot]
+        # per image: batchmean over its (matched + assigned unmatched) rows; then mean over images
+        n_rows = [c + (Q - c) for c in m_n.counts]
+        w_tp = torch.tensor([1.0 / (n_rows[i] * B) for i, c in enumerate(m_n.counts) for _ in range(c)] or [0.0], device=dev)
+        w_fp = torch.tensor([1.0 / (n_rows[i] * B) for _ in range(L) for i, c in enumerate(m_n.counts) for _ in range(Q - c)] or [0.0], device=dev)
+        per_layer = (kl_tp * w_tp[None, :kl_tp.shape[1]]).sum(1) if m_n.src.shape[1] else torch.zeros(L, device=dev)
+        per_layer = per_layer + (kl_fp * w_fp[:kl_fp.shape[0]]).view(L, -1).sum(1)
+        check_lsap_status(status)
+        return per_layer
+
+
+def _kl_rows(teacher, student):
+    """sum_c t * (log t - log s) per row, with F.kl_div's 0 * log 0 = 0 convention."""
+    return (torch.xlogy(teacher, teacher) - teacher * student.log()).sum(-1)
+
+
+def _paired_giou_matrix(a, b):
+    """generalized_box_iou(box_cxcywh_to_xyxy(a), box_cxcywh_to_xyxy(b)) for batched cxcywh boxes [..., S, 4] x [..., T, 4] -> [..., S, T]
+    (util/box_ops.py:11-61, same operation order)."""
+    def xyxy(x):
+        cx, cy, w, h = x.unbind(-1)
+        return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1)
+    a, b = xyxy(a), xyxy(b)
+    area_a = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
+    area_b = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    lt = torch.max(a[..., :, None, :2], b[..., None, :, :2])
+    rb = torch.min(a[..., :, None, 2:], b[..., None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    union = area_a[..., :, None] + area_b[..., None, :] - inter
+    iou = inter / union
+    lt = torch.min(a[..., :, None, :2], b[..., None, :, :2])
+    rb = torch.max(a[..., :, None, 2:], b[..., None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    area = wh[..., 0] * wh[..., 1]
+    return iou - (area - union) / area
+
+
+_INDEX_CACHE = {}
+
+
+def _cached(key, make):
+    ent = _INDEX_CACHE.get(key)
+    if ent is None:
+        if len(_INDEX_CACHE) > 128:
+            _INDEX_CACHE.clear()
+        ent = _INDEX_CACHE[key] = make()
+    return ent
+
+
+def _pair_image_index(counts, dev):
+    """[Mtot] image index of every matched pair."""
+    return _cached(("img", counts, str(dev)), lambda: torch.tensor([i for i, c in enumerate(counts) for _ in range(c)], dtype=torch.int64, device=dev))
+
+
+def _pair_image_offset(counts, dev):
+    """[Mtot] first position of the pair's image inside the [Mtot] run."""
+    offs = [sum(counts[:i]) for i in range(len(counts))]
+    return _cached(("off", counts, str(dev)), lambda: torch.tensor([offs[i] for i, c in enumerate(counts) for _ in range(c)], dtype=torch.int64, device=dev))
+
+
+def _problem_index(L, pairs, dev):
+    """(layer, image) of every LSAP output pair; problems are ordered layer-major."""
+    B = len(pairs) // L
+    def make():
+        pl = [l for l in range(L) for i in range(B) for _ in range(pairs[l * B + i])]
+        pb = [i for l in range(L) for i in range(B) for _ in range(pairs[l * B + i])]
+        return torch.tensor(pl, dtype=torch.int64, device=dev), torch.tensor(pb, dtype=torch.int64, device=dev)
+    return _cached(("prob", L, pairs, str(dev)), make)
 
 
 class _SetLossFn(torch.autograd.Function):
