@@ -765,33 +765,72 @@ __global__ __launch_bounds__(256) void conv3_kernel(const toist_gemm p) {
         vmask[i] = v;
     }
 
-    // ---- DMA pieces ----
-    // patch piece q (0..27) of a chunk: LDS chunks q*64 + lane -> patch row (q*64+lane)/8, slot (..)%8
-    const unsigned lds0 = (unsigned)(size_t)smem;
-    auto issue_patch = [&](int chunk, int q) {
-        const int pch = q * 64 + lane;
-        const int row = pch >> 3, kc = swz_k<BK>(row, pch & 7);
-        const int pix = m0 - halo + row;
-        const bool ok = pix >= 0 && pix < M && row < BM + 2 * halo;
-        dma16(lds0 + (unsigned)(chunk & 1) * (C3_PATCH * 2) + (unsigned)q * 1024u, rsA, pix * C + chunk * BK + kc * 8, ok);
-    };
-    // weight tile of step t: 8 pieces, 2 per wave
-    auto issue_b = [&](int t) {
-        const int chunk = t / 9, tap = t - chunk * 9;
-        const unsigned dst = lds0 + (unsigned)(2 * C3_PATCH + (t % C3_NB) * C3_BT) * 2u;
+    // wave-uniform: taps for which fragment row i needs no masking at all (every lane valid) -> the select is skipped
+    unsigned clean[FM];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int pch = (it * 4 + wave) * 64 + lane;
-            if (DGRAD) {   // k-major tile [BK k = co][BN n = c]
-                const int krow = pch / (BN / 8), rc = swz_m<BN>(krow, pch % (BN / 8));
-                const int nn = n0 + rc * 8;
-                dma16(dst + (unsigned)(it * 4 + wave) * 1024u, rsB, nn + (chunk * BK + krow) * ob.ld + tap * (int)ob.tap_stride, nn < N);
-            } else {       // k-contiguous tile [BN n = co][BK k = c]
-                const int row = pch >> 3, kc = swz_k<BK>(row, pch & 7);
-                const int n = n0 + row;
-                dma16(dst + (unsigned)(it * 4 + wave) * 1024u, rsB, n * ob.ld + tap * C + chunk * BK + kc * 8, n < N);
+    for (int i = 0; i < FM; ++i) {
+        unsigned c = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (__builtin_amdgcn_ballot_w64((vmask[i] >> t) & 1u) == ~0ull) c |= 1u << t;
+        clean[i] = __builtin_amdgcn_readfirstlane(c);
+    }
+
+    // ---- lane invariants of the DMA pieces and of the fragment reads (everything that varies per step is wave-uniform) ----
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    // patch piece q = tap*4 + wave of a chunk covers patch rows q*8 + (lane >> 3); its swizzle does not depend on the tap
+    const int p_row0 = wave * 8 + (lane >> 3);                              // + tap*32
+    const int p_kc = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+    const int p_pix0 = m0 - halo + p_row0;                                  // + tap*32
+    const int p_off0 = p_pix0 * C + p_kc * 8;                               // + tap*32*C + chunk*BK
+    const int p_rows = BM + 2 * halo;
+    // weight-tile pieces (2 per wave)
+    int b_off0[2];
+    bool b_ok[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int pch = (it * 4 + wave) * 64 + lane;
+        if (DGRAD) {   // k-major tile [BK k = co][BN n = c]
+            const int krow = pch / (BN / 8), rc = swz_m<BN>(krow, pch % (BN / 8));
+            const int nn = n0 + rc * 8;
+            b_off0[it] = nn + krow * ob.ld;                                 // + chunk*BK*ld + tap*tap_stride
+            b_ok[it] = nn < N;
+        } else {       // k-contiguous tile [BN n = co][BK k = c]
+            const int row = pch >> 3, kc = swz_k<BK>(row, pch & 7);
+            b_off0[it] = (n0 + row) * ob.ld + kc * 8;                        // + tap*C + chunk*BK
+            b_ok[it] = (n0 + row) < N;
+        }
+    }
+    const int b_chunk_step = DGRAD ? BK * ob.ld : BK, b_tap_step = DGRAD ? (int)ob.tap_stride : C;
+    // fragment reads: rows 16 apart share their swizzle, so fragments i / j are constant byte offsets from one address
+    const int a_row0 = wm * WM + c16;                                       // + roff(tap)
+    int b_frag[2][FN][2];                                                   // [ks][j][lo/hi] element offsets inside a weight tile
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            if (DGRAD) {   // k-major tile: the swizzle mixes the row chunk, so every j has its own pair of addresses
+                const int k = ks * 32 + 8 * g + (c16 >> 2);
+                const int rc = ((wn * WN + j * 16) >> 3) + ((c16 & 3) >> 1), sub = (c16 & 1) * 4;
+                b_frag[ks][j][0] = k * BN + swz_m<BN>(k, rc) * 8 + sub;
+                b_frag[ks][j][1] = (k + 4) * BN + swz_m<BN>(k + 4, rc) * 8 + sub;
+            } else {
+                const int row = wn * WN + j * 16 + c16;
+                b_frag[ks][j][0] = row * BK + swz_k<BK>(row, ks * 4 + g) * 8;
+                b_frag[ks][j][1] = 0;
             }
         }
+
+    auto issue_patch = [&](int chunk, int tap) {                            // patch piece (tap, wave) of `chunk`
+        const int row = p_row0 + tap * 32, pix = p_pix0 + tap * 32;
+        const bool ok = pix >= 0 && pix < M && row < p_rows;
+        dma16(lds0 + (unsigned)(chunk & 1) * (C3_PATCH * 2) + (unsigned)(tap * 4 + wave) * 1024u, rsA, p_off0 + tap * 32 * C + chunk * BK, ok);
+    };
+    auto issue_b = [&](int slot, int chunk, int tap) {
+        const unsigned dst = lds0 + (unsigned)(2 * C3_PATCH + slot * C3_BT) * 2u + (unsigned)wave * 1024u;
+        const int u = chunk * b_chunk_step + tap * b_tap_step;
+        dma16(dst, rsB, b_off0[0] + u, b_ok[0]);
+        dma16(dst + 4096u, rsB, b_off0[1] + u, b_ok[1]);
     };
 
     f32x4_t acc[FM][FN];
@@ -802,47 +841,63 @@ __global__ __launch_bounds__(256) void conv3_kernel(const toist_gemm p) {
 
     // prologue: whole patch of chunk 0 (7 pieces per wave), weight tiles of steps 0 and 1
 #pragma unroll
-    for (int q = 0; q < 7; ++q) issue_patch(0, q * 4 + wave);
-    issue_b(0);
-    if (nsteps > 1) issue_b(1);
+    for (int q = 0; q < 7; ++q) issue_patch(0, q);
+    issue_b(0, 0, 0);
+    issue_b(1, 0, 1);                                                       // nsteps >= 9
 
+    int chunk = 0, tap = 0, slot = 0;                                       // step t = chunk*9 + tap reads weight slot t % 3
+    int ichunk = 0, itap = 2, islot = 2;                                    // weight tile t + 2 (the next one to issue)
+    bool prev_patch = false;                                                // did step t-1 issue a patch piece?
     for (int t = 0; t < nsteps; ++t) {
-        const int chunk = t / 9, tap = t - chunk * 9;
-        // loads issued after weight tile t by this wave: group(t-1) = [patch piece if tap(t-1) < 7 and a next chunk exists] + tile t+1
+        // loads this wave issued after weight tile t: step t-1's group = [patch piece?] + tile t+1
         if (t + 1 >= nsteps) wait_vm<0>();
-        else if (t == 0) wait_vm<2>();
-        else {
-            const int ptap = (tap == 0) ? 8 : tap - 1, pchunk = (tap == 0) ? chunk - 1 : chunk;
-            if (ptap < 7 && pchunk + 1 < nchunks) wait_vm<3>();
-            else wait_vm<2>();
-        }
+        else if (prev_patch) wait_vm<3>();
+        else wait_vm<2>();
         __builtin_amdgcn_s_barrier();
         // group(t): next chunk's patch piece (first 7 taps), then weight tile t+2 -- refills the slot step t-1 read
-        if (tap < 7 && chunk + 1 < nchunks) issue_patch(chunk + 1, tap * 4 + wave);
-        if (t + 2 < nsteps) issue_b(t + 2);
+        prev_patch = tap < 7 && chunk + 1 < nchunks;
+        if (prev_patch) issue_patch(chunk + 1, tap);
+        if (t + 2 < nsteps) issue_b(islot, ichunk, itap);
+        if (++itap == 9) { itap = 0; ++ichunk; }
+        if (++islot == C3_NB) islot = 0;
 
         const bf16_t* sP = patch + (chunk & 1) * C3_PATCH;
-        const bf16_t* sB = btile + (t % C3_NB) * C3_BT;
-        const int r = tap / 3, s_ = tap - r * 3;
-        const int roff = halo + (DGRAD ? (1 - r) * W + (1 - s_) : (r - 1) * W + (s_ - 1));
+        const bf16_t* sB = btile + slot * C3_BT;
+        const int r = (tap >= 6) ? 2 : (tap >= 3 ? 1 : 0), s_ = tap - r * 3;
+        const int arow = a_row0 + halo + (DGRAD ? (1 - r) * W + (1 - s_) : (r - 1) * W + (s_ - 1));
+        const int asw = (arow >> 1) & 7;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8_t af[FM], bfr[FN];
+            const bf16_t* ap = sP + arow * BK + ((ks * 4 + g) ^ asw) * 8;
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int row = wm * WM + i * 16 + roff + c16;
-                const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(&sP[row * BK + swz_k<BK>(row, ks * 4 + g) * 8]);
-                const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
-                af[i] = ((vmask[i] >> tap) & 1u) ? v : zero;
+                af[i] = *reinterpret_cast<const bf16x8_t*>(ap + i * 16 * BK);
+                if (!((clean[i] >> tap) & 1u)) {                            // wave-uniform: some lane of this fragment is outside the image
+                    const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                    af[i] = ((vmask[i] >> tap) & 1u) ? af[i] : zero;
+                }
             }
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j] = fragment<DGRAD, BN, BK>(sB, wn * WN + j * 16, ks, g, c16);
+            for (int j = 0; j < FN; ++j) {
+                if (DGRAD) {
+                    typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+                    union { struct { s16x4_t a, b; } h; bf16x8_t v; } u;
+                    u.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sB + b_frag[ks][j][0]));
+                    u.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sB + b_frag[ks][j][1]));
+                    bfr[j] = u.v;
+                } else {
+                    bfr[j] = *reinterpret_cast<const bf16x8_t*>(sB + b_frag[ks][j][0]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
+        if (++tap == 9) { tap = 0; ++chunk; }
+        if (++slot == C3_NB) slot = 0;
     }
     wait_vm<0>();
     epilogue_tile<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, 0, 0, 0);
@@ -1070,7 +1125,9 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     if (d.epi.drop_where) TOIST_REQUIRE(d.epi.drop_p >= 0.f && d.epi.drop_p < 1.f, "toist_gemm_bf16: bad dropout p");
 
     hipStream_t st = (hipStream_t)stream;
-    if (d.tile == 131 && conv3_applies(d)) {   // tile code 131 = the 3x3 shared-halo kernel (explicit only: see DESIGN.md)
+    // the 3x3 shared-halo kernel: picked for dgrad (measured 395 vs 351 TFLOP/s on layer 3), explicit tile code 131 otherwise
+    // (forward: 384 vs 451 for the generic tiles)
+    if ((d.tile == 131 || (d.tile == 0 && d.a_kind == TOIST_A_CONVT)) && conv3_applies(d)) {
         const int rc3 = launch_conv3(d, st);
         return rc3 != TOIST_OK ? rc3 : check_launch("toist_gemm_bf16(conv3)");
     }
