@@ -272,36 +272,46 @@ def main():
         # word.  With several ranks the step is four graphs (see run_step below): the autograd graph is cut at the
         # outputs of the backbone and of the text encoder so the all-reduce of every other gradient (RoBERTa +
         # transformer + heads, 80 % of the bytes) runs on RCCL's stream underneath the backbone backward.
-        from toist_amd import functions
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(a.warmup, 2)):
-                step()
-            opt.zero_grad(set_to_none=True)
-            if not split_graph:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
-                    static_loss = fwd_bwd()
-                    optimize()
-            else:
-                # no collective inside a capture: the hook only collects the flat gradient buffers of each segment
-                functions.GRAD_SYNC = flats.append
-                graph_a = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_a, stream=side):
-                    static_loss = fwd_bwd()
-                n_head = len(flats)
-                graph_text = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_text, stream=side):
-                    bwd_cut("text")
-                n_text = len(flats)
-                graph_bb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_bb, stream=side):
-                    bwd_cut("backbone")
-                functions.GRAD_SYNC = None
-                graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_b, stream=side):
-                    optimize()
+        try:
+            from toist_amd import functions
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(a.warmup, 2)):
+                    step()
+                opt.zero_grad(set_to_none=True)
+                if not split_graph:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=side):
+                        static_loss = fwd_bwd()
+                        optimize()
+                else:
+                    # no collective inside a capture: the hook only collects the flat gradient buffers of each segment
+                    functions.GRAD_SYNC = flats.append
+                    graph_a = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_a, stream=side):
+                        static_loss = fwd_bwd()
+                    n_head = len(flats)
+                    graph_text = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_text, stream=side):
+                        bwd_cut("text")
+                    n_text = len(flats)
+                    graph_bb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_bb, stream=side):
+                        bwd_cut("backbone")
+                    functions.GRAD_SYNC = None
+                    graph_b = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_b, stream=side):
+                        optimize()
+        except Exception as e:   # a distributed job must still produce a number: fall back to eager launches with overlapped all-reduces
+            if world == 1:
+                raise
+            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            functions.GRAD_SYNC = None
+            parallel.enable_backward_cuts(model, False)
+            torch.cuda.synchronize()
+            use_graph = split_graph = False
+    if use_graph:
         torch.cuda.current_stream().wait_stream(side)
 
         if not split_graph:
