@@ -134,7 +134,8 @@ typedef struct toist_gemm {
     int32_t split_k;            /* >= 1; > 1 needs out_f32 and `workspace`: every k-slice stores its raw f32
                                    partial tile there and a second kernel reduces them into C */
     int32_t tile;               /* 0 = auto; 64 = 64x64x32, 65 = 64x64x64, 128 = 128x128x32, 129 = 128x128x64,
-                                   130 = 128x64x64 (BM x BN x BK) */
+                                   130 = 128x64x64, 132 = 128x32x64, 133 = 32x128x64 (BM x BN x BK);
+                                   131 = shared-halo 3x3 kernel; + 256 * ring slots (optional) */
     int32_t flags;              /* bit0: build K-strided fragments with ds_write_b16 instead of
                                    ds_read_b64_tr_b16 (validation fallback) */
     toist_epilogue epi;
@@ -270,6 +271,18 @@ typedef struct toist_opt_state {
     int32_t step;             /* optimizer steps taken (incremented by toist_opt_finish_norm)                         */
     int32_t reserved[3];
 } toist_opt_state;            /* 32 bytes */
+
+/* ---- 3x3 / stride 1 / pad 1 convolution with <= 32 channels on either side (mask-head stages at 160x160,
+ * segmentation.py:176-241 lay5 / out_lay; HBM-bound): NHWC bf16 in / out, weights [w_co][3][3][w_ci] bf16.
+ * dgrad = 0: out[p, co] = shift[co] + sum x[p + tap, ci] w[co, tap, ci] (+ res);  c_src = w_ci, c_out = w_co.
+ * dgrad = 1: out[p, ci] = sum dy[p - tap, co] w[co, tap, ci] (+ res);             c_src = w_co, c_out = w_ci. */
+int toist_conv3x3_small(int dgrad, const void* src, const void* w, const float* shift, const void* res, void* out, int n_img, int H, int W,
+                        int c_src, int c_out, int w_co, int w_ci, void* stream);
+
+/* weight gradient of the same convolutions: every one of toist_wgrad3x3_small_blocks() workgroups writes an fp32 partial
+ * [c_out][9 * c_in] to ws; fold them with toist_splitk_reduce_batch (splits = blocks, M = c_out, N = 9 * c_in). */
+int toist_wgrad3x3_small_blocks(void);
+int toist_wgrad3x3_small(const void* dy, const void* x, float* ws, int n_img, int H, int W, int c_in, int c_out, void* stream);
 
 /* ---- batched linear sum assignment on caller-supplied cost matrices ---------------------------------------------
  * scipy.optimize.linear_sum_assignment for the reference's other call sites (mdetr.py:100 memory-bank replacement on

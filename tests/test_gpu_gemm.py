@@ -83,7 +83,9 @@ def _nhwc(t):
 @pytest.mark.parametrize("C,Co,R,stride,pad,H,W", [(64, 64, 3, 1, 1, 20, 24), (64, 128, 3, 2, 1, 21, 20), (256, 512, 1, 2, 0, 16, 16),
                                                    (128, 256, 1, 1, 0, 10, 12), (8, 64, 7, 2, 3, 40, 40),
                                                    # 3x3 / stride 1 at >= 2048 pixels: the shared-halo kernel (conv3_kernel), forward and dgrad
-                                                   (128, 192, 3, 1, 1, 40, 40), (64, 72, 3, 1, 1, 31, 23), (256, 64, 3, 1, 1, 46, 46)])
+                                                   (128, 192, 3, 1, 1, 40, 40), (64, 72, 3, 1, 1, 31, 23), (256, 64, 3, 1, 1, 46, 46),
+                                                   # mask-head shapes: <= 32 output channels -> the narrow 128x32 / 32x128 tiles
+                                                   (32, 16, 3, 1, 1, 48, 64), (64, 32, 3, 1, 1, 40, 40)])
 def test_conv_fwd_bwd(dev, C, Co, R, stride, pad, H, W):
     from toist_amd import kernels as k, ops
     g = torch.Generator().manual_seed(C + Co + R)
@@ -129,6 +131,38 @@ def test_conv3_halo_kernel_is_used_and_agrees_with_generic(dev):
     assert float((a - b).abs().mean()) <= 1e-3 * float(b.abs().mean())
     with pytest.raises(RuntimeError):   # stride 2 is not covered
         ops.conv2d(x, w, stride=2, pad=1, tile=131)
+
+
+@pytest.mark.parametrize("C,Co", [(32, 16), (16, 8), (32, 32), (8, 16)])
+def test_small_channel_conv_direct_kernel(dev, C, Co):
+    """csrc/smallconv.hip (3x3 / s1 / p1, <= 32 channels, the 160x160 mask-head stages): forward with bias (+ residual) and the
+    data gradient against fp32 conv2d on the same bf16-rounded inputs; >= 65536 pixels so ops.conv2d dispatches to it."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(C * 100 + Co)
+    Nb, H, W = 3, 150, 152
+    x = torch.randn(Nb, C, H, W, generator=g).to(BF)
+    w = (torch.randn(Co, C, 3, 3, generator=g) * (1.0 / math.sqrt(C * 9))).to(BF)
+    bias = torch.randn(Co, generator=g)
+    res = torch.randn(Nb, Co, H, W, generator=g).to(BF)
+    xr, wr = x.float().requires_grad_(True), w.float()
+    y = F.conv2d(xr, wr, padding=1)
+    x_d, w_d = _nhwc(x).to(dev), _nhwc(w).to(dev)
+    assert ops._small_conv_ok(3, 3, 1, 1, 1, C, Co, Nb * H * W)
+    out = ops.conv2d(x_d, w_d, pad=1, shift=bias.to(dev), res=_nhwc(res).to(dev))
+    _close(out, _nhwc((y + bias.view(1, -1, 1, 1) + res.float()).detach()), C * 9, "small conv fwd")
+    generic = ops.conv2d(x_d, w_d, pad=1, shift=bias.to(dev), res=_nhwc(res).to(dev), tile=65)       # the tiled kernel on the same call
+    assert float((out.float() - generic.float()).abs().max()) <= 2.0 ** -6 * float(generic.float().abs().max())
+    dy = torch.randn(Nb, Co, H, W, generator=g).to(BF)
+    y.backward(dy.float())
+    if C in (16, 32) and Co in (8, 16):
+        dw = ops.conv2d_wgrad(_nhwc(dy).to(dev), x_d, (Co, 3, 3, C), pad=1)
+        wr2 = w.float().requires_grad_(True)
+        F.conv2d(x.float(), wr2, padding=1).backward(dy.float())
+        _close(dw, _nhwc(wr2.grad), Nb * H * W, "small conv wgrad", rtol=3e-3, atol_unit=2e-4)
+    if Co in (8, 16, 32):
+        prev = torch.randn(Nb, C, H, W, generator=g).to(BF)
+        dx = ops.conv2d_dgrad(_nhwc(dy).to(dev), w_d, (H, W), pad=1, res=_nhwc(prev).to(dev))
+        _close(dx, _nhwc(xr.grad + prev.float()), Co * 9, "small conv dgrad")
 
 
 def test_attention_products(dev):

@@ -387,8 +387,8 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
     const int M = p.M, N = p.N;
     constexpr int LDT = BN + 4;                      // f32 band pitch: +4 keeps the float4 writes conflict-free
     constexpr int CPR = BN / 8;                      // 8-column chunks per band row
-    constexpr int CH = (32 * CPR) / 256;             // chunks per thread per band (1 for BN = 64, 2 for BN = 128)
-    static_assert(32 * CPR % 256 == 0, "band chunks must divide over 256 threads");
+    constexpr int CH = (32 * CPR + 255) / 256;       // chunks per thread per band (1 for BN <= 64, 2 for BN = 128)
+    static_assert(32 * CPR % 256 == 0 || 32 * CPR < 256, "band chunks must divide over 256 threads");
     const bool partial = p.split_k > 1;              // k-slice partial: raw f32 into the workspace, epilogue in splitk_reduce_kernel
     float* ws = partial ? p.workspace + (size_t)ksl * M * N : nullptr;
     // residual / aux operands of EVERY band are requested up front: one exposed load latency per tile, not one per band
@@ -404,7 +404,7 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
         for (int q = 0; q < CH; ++q) {
             const int c = tid + 256 * q;
             const int br = c / CPR, c8 = c - br * CPR;
-            const int m = m0 + (br >> 4) * WM + i * 16 + (br & 15);
+            const int m = (c < 32 * CPR) ? m0 + (br >> 4) * WM + i * 16 + (br & 15) : M;   // narrow tiles: the upper threads idle
             rows_all[i][q] = epi_row(p, m < M ? m : 0, n0 + c8 * 8);
             rows_all[i][q].m = m;
             if (!partial && m < M && rows_all[i][q].nv > 0) epilogue_fetch(p, rows_all[i][q], coff, pre_all[i][q]);
@@ -1039,6 +1039,8 @@ static int auto_tile(const toist_gemm& d) {
     // is deep; below that 64x64x64 tiles keep more workgroups (and DMA) in flight.
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.batch > 0 ? d.batch : 1) * (d.split_k > 0 ? d.split_k : 1);
     if (t128 >= 1024 && d.K >= 1024) return 129;
+    if (d.K > 64 && d.N <= 32 && d.M >= 4096) return 132;   // a 64-wide tile would idle half (or more) of its MFMA columns
+    if (d.K > 64 && d.M <= 32 && d.N >= 128) return 133;
     return (d.K > 64) ? 65 : 64;
 }
 
@@ -1136,7 +1138,7 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     const int ring = d.tile >> 8;   // 0 = pick; else slots of the DMA ring (2..4)
     if (tile == 0) tile = auto_tile(d);
     d.split_k = clamp_split(d.split_k, d.K, tile);
-    // tile codes: 64 = 64x64x32, 65 = 64x64x64, 128 = 128x128x32, 129 = 128x128x64, 130 = 128x64x64
+    // tile codes: 64 = 64x64x32, 65 = 64x64x64, 128 = 128x128x32, 129 = 128x128x64, 130 = 128x64x64, 132 = 128x32x64, 133 = 32x128x64
     const int bkt = (tile == 64 || tile == 128) ? 32 : 64;
     if (d.b_kind == TOIST_B_KROW && d.b.kin > 0) TOIST_REQUIRE((d.b.kin % 8) == 0, "toist_gemm_bf16: kin %% 8 != 0");
     (void)bkt;
@@ -1147,6 +1149,8 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
         case 128: rc = launch_tile<128, 128, 32>(d, ring, st); break;
         case 129: rc = launch_tile<128, 128, 64>(d, ring, st); break;
         case 130: rc = launch_tile<128, 64, 64>(d, ring, st); break;
+        case 132: rc = launch_tile<128, 32, 64>(d, ring, st); break;   // narrow N (<= 32 output columns: mask-head convolutions)
+        case 133: rc = launch_tile<32, 128, 64>(d, ring, st); break;   // narrow M (their weight gradients)
         default: set_last_error("toist_gemm_bf16: bad tile code %d", tile); return TOIST_EINVAL;
     }
     if (rc != TOIST_OK) return rc;

@@ -377,3 +377,29 @@ def lsap(cost, offset, rows, cols, n, max_rows, max_cols, max_cells, out_off, ro
     _lib.check(_lib.lib().toist_lsap(_p(cost, torch.float32), _p(offset, torch.int64), _p(rows, torch.int32), _p(cols, torch.int32), ld, n, max_rows,
                                      max_cols, max_cells, _p(out_off, torch.int64), _p(row_idx, torch.int64), _p(col_idx, torch.int64),
                                      _p(status, torch.int32), _stream()), "toist_lsap")
+
+
+def conv3x3_small(dgrad, src, w, shift, res, out, n_img, H, W, c_src, c_out):
+    """3x3 / s1 / p1 convolution (or its data gradient) with <= 32 channels on both sides; w is [Co,3,3,Ci] bf16."""
+    w_co, w_ci = int(w.shape[0]), int(w.shape[3])
+    _lib.check(_lib.lib().toist_conv3x3_small(1 if dgrad else 0, _p(src, torch.bfloat16), _p(w, torch.bfloat16), _p(shift, torch.float32),
+                                              _p(res, torch.bfloat16), _p(out, torch.bfloat16), n_img, H, W, c_src, c_out, w_co, w_ci, _stream()),
+               "toist_conv3x3_small")
+
+
+def wgrad3x3_small(dy, x, out, defer=False):
+    """out [Co,3,3,C] (f32) += weight gradient of a 3x3 / s1 / p1 convolution with C in {16, 32}, Co in {8, 16} (csrc/smallconv.hip):
+    per-workgroup partials into the split-K arena, folded by the batched reduction (queued when defer=True)."""
+    n_img, H, W, C = x.shape
+    Co = dy.shape[-1]
+    blocks = int(_lib.lib().toist_wgrad3x3_small_blocks())
+    ws = _arena_take(blocks * Co * 9 * C, x.device)
+    _lib.check(_lib.lib().toist_wgrad3x3_small(_p(dy, torch.bfloat16), _p(x, torch.bfloat16), _p(ws, torch.float32), n_img, H, W, C, Co, _stream()),
+               "toist_wgrad3x3_small")
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    if any(it[0].out == out.data_ptr() for it in _PENDING.get(key, ())):
+        flush_reductions()
+    rd = _lib.ReduceDesc(ws.data_ptr(), out.data_ptr(), None, blocks, Co, 9 * C, 9 * C, 1.0, 1)
+    _PENDING.setdefault(key, []).append((rd, (out,)))
+    if not defer:
+        flush_reductions()

@@ -84,6 +84,13 @@ def conv_out_hw(H, W, R, S, stride, pad, dil=1):
     return (H + 2 * pad - dil * (R - 1) - 1) // stride + 1, (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
 
 
+def _small_conv_ok(R, S, stride, pad, dil, c_src, c_out, pixels):
+    """csrc/smallconv.hip covers 3x3 / stride 1 / pad 1 with 8 / 16 / 32 source channels and <= 32 outputs; it pays
+    where the tiled implicit GEMM is mostly padding: large pixel counts (measured at 160x160 x 800 maps)."""
+    return R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and c_src in (8, 16, 32) and 0 < c_out <= 32 and c_out % 4 == 0 \
+        and pixels >= (1 << 16)
+
+
 def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, res=None, act=k.ACT_NONE, out=None, tile=0, res_bcast=None,
            out_dtype=BF16, cin_real=None):
     """NHWC implicit-GEMM convolution: x [N,H,W,C], w [Co,R,S,C] -> [N,OH,OW,Co] with the
@@ -94,6 +101,10 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, res=None, ac
     OH, OW = conv_out_hw(H, W, R, S, stride, pad, dil)
     if out is None:
         out = torch.empty(Nb, OH, OW, Co, dtype=out_dtype, device=x.device)
+    if tile == 0 and _small_conv_ok(R, S, stride, pad, dil, C, Co, Nb * H * W) and scale is None and act == k.ACT_NONE and res_bcast is None \
+            and out.dtype == BF16 and out.is_contiguous() and (res is None or (res.is_contiguous() and res.numel() == out.numel())):
+        k.conv3x3_small(False, x, w, shift, res, out, Nb, H, W, C, Co)   # HBM-bound few-channel stage: direct kernel
+        return out
     M = Nb * OH * OW
     Kred = R * S * C
     if R == 1 and S == 1 and stride == 1 and pad == 0:
@@ -118,6 +129,10 @@ def conv2d_dgrad(dy, w, in_hw, *, stride=1, pad=0, dil=1, scale=None, res=None, 
     assert Cw == Co and dy.is_contiguous() and w.is_contiguous()
     if out is None:
         out = torch.empty(Nb, H, W, C, dtype=BF16, device=dy.device)
+    if (OH, OW) == (H, W) and _small_conv_ok(R, S, stride, pad, dil, Co, C, Nb * H * W) and scale is None and act == k.ACT_NONE and aux is None \
+            and out.is_contiguous() and (res is None or (res.is_contiguous() and res.numel() == out.numel())):
+        k.conv3x3_small(True, dy, w, None, res, out, Nb, H, W, Co, C)
+        return out
     M = Nb * H * W
     ldr = C if res is not None else 0
     ldaux = C if aux is not None else 0
@@ -145,6 +160,10 @@ def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, s
     assert Cw == Co and Cc == C and dy.is_contiguous() and x.is_contiguous()
     if out is None:
         out = torch.zeros(Co, R, S, C, dtype=torch.float32, device=dy.device)
+    if (OH, OW) == (H, W) and R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and C in (16, 32) and Co in (8, 16) and rscale is None \
+            and split_k is None and Nb * H * W >= (1 << 16) and out.is_contiguous():
+        k.wgrad3x3_small(dy, x, out, defer=defer)     # few-channel stage: direct kernel + batched fold
+        return out
     P = Nb * OH * OW
     Nn = R * S * C
     if split_k is None:
