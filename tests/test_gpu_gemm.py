@@ -250,3 +250,13 @@ def test_rows(dev):
     keep = (o1 != 0).float().mean().item()
     assert abs(keep - 0.9) < 0.01, keep
     assert abs(float(o1.float().max()) - 1.0 / 0.9) < 1e-2
+
+
+@pytest.mark.parametrize("N", [8, 16, 32, 128])
+def test_colsum_tall_narrow(dev, N):
+    """Bias gradient of a few-channel convolution over millions of pixels: the narrow column-sum kernel (all threads busy)."""
+    from toist_amd import ops
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(70000, N, generator=g).to(BF)
+    out = ops.bias_grad(x.to(dev))
+    _close(out, x.float().sum(0), 70000, f"colsum N={N}", rtol=2e-3, atol_unit=2e-4)

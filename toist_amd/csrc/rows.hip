@@ -271,6 +271,35 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restri
 // ---------------------------------------------------------------------------------- column sum
 // out[n] += sum_m g[m][n]  (bias gradient).  Block = 32 column-chunks (8 columns, 16-byte loads) x 8 row
 // lanes over a 256-row slab; LDS reduction over the row lanes, one atomic per column per block.
+// column sums of a tall, narrow matrix (N <= 128 columns, e.g. the bias gradient of a 16-channel convolution over 20 M
+// pixels): all 256 threads stream 16-byte chunks, thread t always lands on column chunk t % (N/8); one fp32 atomic per
+// column per 8192-row block
+constexpr int CS_ROWS = 8192;
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const bf16_t* __restrict__ g, long long M, int N, float* __restrict__ out) {
+    __shared__ float red[256][9];
+    const int cpr = N >> 3;                         // 16-byte chunks per row; divides 256
+    const int rpp = 256 / cpr;                      // rows per pass
+    const int cx = threadIdx.x % cpr, ry = threadIdx.x / cpr;
+    const long long m_beg = (long long)blockIdx.x * CS_ROWS;
+    const long long m_end = (m_beg + CS_ROWS < M) ? m_beg + CS_ROWS : M;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long m = m_beg + ry; m < m_end; m += rpp) {
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4*>(g + m * N + cx * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = a[j];
+    __syncthreads();
+    if ((int)threadIdx.x < N) {
+        const int c = threadIdx.x, cc = c >> 3, j = c & 7;
+        float t = 0.f;
+        for (int r = 0; r < rpp; ++r) t += red[r * cpr + cc][j];
+        atomicAdd(out + c, t);
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ g, int M, int N, int ld, float* __restrict__ out) {
     __shared__ float red[8][256];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -421,6 +450,11 @@ extern "C" int toist_softmax_bwd(const void* p, const void* dp, int rows, int Sk
 
 extern "C" int toist_colsum(const void* g, int M, int N, int ld, float* out, void* stream) {
     TOIST_REQUIRE(M > 0 && N > 0 && ld >= N, "toist_colsum: bad shape");
+    if (ld == N && N <= 128 && (N & 7) == 0 && (256 % (N >> 3)) == 0 && M >= 4 * CS_ROWS && ((((size_t)g) & 15) == 0)) {
+        hipLaunchKernelGGL(colsum_narrow_kernel, dim3((unsigned)((M + CS_ROWS - 1) / CS_ROWS)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g,
+                           (long long)M, N, out);
+        return check_launch("toist_colsum(narrow)");
+    }
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, M,
                        N, ld, out);
     return check_launch("toist_colsum");
