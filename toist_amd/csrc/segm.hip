@@ -339,24 +339,39 @@ __global__ __launch_bounds__(256) void mask_loss_fwd_kernel(const float* __restr
 }
 // d(loss_mask*g_f + loss_dice*g_d)/d pred, scattered back through the bilinear weights (f32 atomics into dpred,
 // which the caller zeroes).  scale_f = g_f / (TH*TW*num_boxes), scale_d = g_d / num_boxes are read from `coef`.
+// Tiled form: a workgroup owns a 32 x 32 block of target pixels of one pair, whose bilinear footprint in the prediction is
+// at most MLB_SRC x MLB_SRC source pixels; contributions are summed in LDS and only the footprint goes out as global
+// atomics (the plain form issued four global atomics per target pixel: 65 M per step).
+constexpr int MLB_TILE = 32, MLB_SRC = 36;
 __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restrict__ pred, const int* __restrict__ pred_row,
                                                              const unsigned char* __restrict__ gt, const int* __restrict__ gt_row,
                                                              int h, int w, int TH, int TW, float alpha, const float* __restrict__ sums,
                                                              const float* __restrict__ coef, float* __restrict__ dpred) {
+    __shared__ float acc[MLB_SRC * MLB_SRC];
     const int t = blockIdx.y;
     const float* pm = pred + (size_t)pred_row[t] * h * w;
     float* dp = dpred + (size_t)pred_row[t] * h * w;
     const unsigned char* gm = gt + (size_t)gt_row[t] * TH * TW;
     const float sf = coef[0], sd = coef[1];
     const float num = 2.f * sums[t * 4 + 1] + 1.f, den = sums[t * 4 + 2] + sums[t * 4 + 3] + 1.f;
-    const int total = TH * TW;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int Y = i / TW, X = i - Y * TW;
+    const int tiles_x = (TW + MLB_TILE - 1) / MLB_TILE;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int Y0 = ty * MLB_TILE, X0 = tx * MLB_TILE;
+    // source origin of this tile (first source row / column any of its pixels touches)
+    int sy0, sx0, dummy; float wdummy;
+    bilinear_src(Y0, h, TH, sy0, dummy, wdummy);
+    bilinear_src(X0, w, TW, sx0, dummy, wdummy);
+    for (int i = threadIdx.x; i < MLB_SRC * MLB_SRC; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    bool spill = false;   // a footprint larger than the LDS window (down-sampling ratios): those pixels use global atomics
+    for (int i = threadIdx.x; i < MLB_TILE * MLB_TILE; i += 256) {
+        const int Y = Y0 + i / MLB_TILE, X = X0 + i % MLB_TILE;
+        if (Y >= TH || X >= TW) continue;
         int y0, y1, x0, x1; float wy, wx;
         bilinear_src(Y, h, TH, y0, y1, wy);
         bilinear_src(X, w, TW, x0, x1, wx);
         const float v = (1.f - wy) * ((1.f - wx) * pm[y0 * w + x0] + wx * pm[y0 * w + x1]) + wy * ((1.f - wx) * pm[y1 * w + x0] + wx * pm[y1 * w + x1]);
-        const float tg = gm[i] ? 1.f : 0.f;
+        const float tg = gm[(size_t)Y * TW + X] ? 1.f : 0.f;
         const float p = 1.f / (1.f + __expf(-v));
         const float ce = fmaxf(v, 0.f) - v * tg + log1pf(__expf(-fabsf(v)));
         const float pt = p * tg + (1.f - p) * (1.f - tg);
@@ -366,10 +381,26 @@ __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restr
         // dice: loss = 1 - num/den ; d/dp = -(2 t den - num) / den^2
         const float ddice = -(2.f * tg * den - num) / (den * den) * p * (1.f - p);
         const float gv = sf * dfocal + sd * ddice;
-        atomicAdd(dp + y0 * w + x0, gv * (1.f - wy) * (1.f - wx));
-        atomicAdd(dp + y0 * w + x1, gv * (1.f - wy) * wx);
-        atomicAdd(dp + y1 * w + x0, gv * wy * (1.f - wx));
-        atomicAdd(dp + y1 * w + x1, gv * wy * wx);
+        const int ly0 = y0 - sy0, ly1 = y1 - sy0, lx0 = x0 - sx0, lx1 = x1 - sx0;
+        if (ly1 < MLB_SRC && lx1 < MLB_SRC) {
+            atomicAdd(&acc[ly0 * MLB_SRC + lx0], gv * (1.f - wy) * (1.f - wx));
+            atomicAdd(&acc[ly0 * MLB_SRC + lx1], gv * (1.f - wy) * wx);
+            atomicAdd(&acc[ly1 * MLB_SRC + lx0], gv * wy * (1.f - wx));
+            atomicAdd(&acc[ly1 * MLB_SRC + lx1], gv * wy * wx);
+        } else {
+            spill = true;
+            atomicAdd(dp + y0 * w + x0, gv * (1.f - wy) * (1.f - wx));
+            atomicAdd(dp + y0 * w + x1, gv * (1.f - wy) * wx);
+            atomicAdd(dp + y1 * w + x0, gv * wy * (1.f - wx));
+            atomicAdd(dp + y1 * w + x1, gv * wy * wx);
+        }
+    }
+    (void)spill;
+    __syncthreads();
+    for (int i = threadIdx.x; i < MLB_SRC * MLB_SRC; i += 256) {
+        const float a = acc[i];
+        const int y = sy0 + i / MLB_SRC, x = sx0 + i % MLB_SRC;
+        if (a != 0.f && y < h && x < w) atomicAdd(dp + y * w + x, a);
     }
 }
 
@@ -459,7 +490,7 @@ extern "C" int toist_mask_loss_fwd(const float* pred, const int32_t* pred_row, c
 extern "C" int toist_mask_loss_bwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
                                    int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred, void* stream) {
     TOIST_REQUIRE(T > 0 && h > 0 && w > 0 && TH > 0 && TW > 0, "toist_mask_loss_bwd: bad shape");
-    hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(grid_cap((long long)TH * TW, 64), T), dim3(256), 0, (hipStream_t)stream, pred, pred_row, gt, gt_row, h, w,
+    hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(((TH + MLB_TILE - 1) / MLB_TILE) * ((TW + MLB_TILE - 1) / MLB_TILE), T), dim3(256), 0, (hipStream_t)stream, pred, pred_row, gt, gt_row, h, w,
                        TH, TW, alpha, sums, coef, dpred);
     return check_launch("toist_mask_loss_bwd");
 }
