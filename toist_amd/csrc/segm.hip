@@ -133,17 +133,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     const int Cg = C / G, c8 = C >> 3;
     const float cnt = (float)HW * (float)Cg;
     const long long total = (long long)HW * c8;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cc = (int)(i % c8);
-        float v[8];
-        const size_t off = ((size_t)n * HW * C) + (size_t)i * 8;
-        unpack8(*reinterpret_cast<const uint4*>(x + off), v);
+    const long long stride = (long long)gridDim.x * 256;
+    // when the grid stride is a multiple of the chunks per pixel a thread always meets the same 8 channels: their affine
+    // coefficients y = x * a + b are then computed once instead of a division, two loads and an rsqrt per element
+    const bool fixed = (stride % c8) == 0;
+    float ca[8], cb[8];
+    auto coeffs = [&](int cc) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = cc * 8 + j, g = c / Cg;
             const float mean = stats[((size_t)n * G + g) * 2] / cnt;
             const float var = fmaxf(stats[((size_t)n * G + g) * 2 + 1] / cnt - mean * mean, 0.f);
-            const float o = (v[j] - mean) * rsqrtf(var + eps) * gamma[c] + beta[c];
+            ca[j] = rsqrtf(var + eps) * gamma[c];
+            cb[j] = beta[c] - mean * ca[j];
+        }
+    };
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (fixed) coeffs((int)(i0 % c8));
+    for (long long i = i0; i < total; i += stride) {
+        if (!fixed) coeffs((int)(i % c8));
+        float v[8];
+        const size_t off = ((size_t)n * HW * C) + (size_t)i * 8;
+        unpack8(*reinterpret_cast<const uint4*>(x + off), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float o = v[j] * ca[j] + cb[j];
             v[j] = relu ? fmaxf(o, 0.f) : o;
         }
         *reinterpret_cast<uint4*>(y + off) = pack8(v);
@@ -217,8 +231,25 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restr
     const int Cg = C / G, c8 = C >> 3;
     const float cnt = (float)HW * (float)Cg;
     const long long total = (long long)HW * c8;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cc = (int)(i % c8);
+    const long long stride = (long long)gridDim.x * 256;
+    const bool fixed = (stride % c8) == 0;          // see gn_apply_kernel: per-thread channel coefficients
+    float mu[8], rsd[8], gm[8], m1[8], m2[8];
+    auto coeffs = [&](int cc) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cc * 8 + j, g = c / Cg;
+            mu[j] = stats[((size_t)n * G + g) * 2] / cnt;
+            const float var = fmaxf(stats[((size_t)n * G + g) * 2 + 1] / cnt - mu[j] * mu[j], 0.f);
+            rsd[j] = rsqrtf(var + eps);
+            gm[j] = gamma[c];
+            m1[j] = bstats[((size_t)n * G + g) * 2] / cnt;
+            m2[j] = bstats[((size_t)n * G + g) * 2 + 1] / cnt;
+        }
+    };
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (fixed) coeffs((int)(i0 % c8));
+    for (long long i = i0; i < total; i += stride) {
+        if (!fixed) coeffs((int)(i % c8));
         float d[8], yy[8], xv[8];
         const size_t off = ((size_t)n * HW * C) + (size_t)i * 8;
         unpack8(*reinterpret_cast<const uint4*>(dy + off), d);
@@ -226,14 +257,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restr
         if (relu) unpack8(*reinterpret_cast<const uint4*>(y + off), yy);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = cc * 8 + j, g = c / Cg;
-            const float mean = stats[((size_t)n * G + g) * 2] / cnt;
-            const float var = fmaxf(stats[((size_t)n * G + g) * 2 + 1] / cnt - mean * mean, 0.f);
-            const float rs = rsqrtf(var + eps);
-            const float xh = (xv[j] - mean) * rs;
+            const float xh = (xv[j] - mu[j]) * rsd[j];
             const float gj = (relu && !(yy[j] > 0.f)) ? 0.f : d[j];
-            const float m1 = bstats[((size_t)n * G + g) * 2] / cnt, m2 = bstats[((size_t)n * G + g) * 2 + 1] / cnt;
-            d[j] = rs * (gj * gamma[c] - m1 - xh * m2);
+            d[j] = rsd[j] * (gj * gm[j] - m1[j] - xh * m2[j]);
         }
         *reinterpret_cast<uint4*>(dx + off) = pack8(d);
     }
