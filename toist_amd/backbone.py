@@ -22,6 +22,9 @@ from .position_encoding import build_position_encoding
 BF16 = torch.bfloat16
 
 
+_BN_EPOCH = [0]   # bumped whenever any FrozenBatchNorm2d invalidates its folded scale/shift
+
+
 class FrozenBatchNorm2d(nn.Module):
     """Buffers only (weight, bias, running_mean, running_var); reference backbone.py:21-58."""
 
@@ -32,16 +35,20 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(n))
         self.register_buffer("running_var", torch.ones(n))
         self._ss = None
+        _BN_EPOCH[0] += 1
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         state_dict.pop(prefix + "num_batches_tracked", None)
         self._ss = None
+        _BN_EPOCH[0] += 1
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
         self._ss = None
+        _BN_EPOCH[0] += 1
 
     def _apply(self, fn, *a, **kw):
         self._ss = None
+        _BN_EPOCH[0] += 1
         return super()._apply(fn, *a, **kw)
 
     def scale_shift(self):
@@ -124,7 +131,11 @@ class BackboneBase(nn.Module):
 
     # ---- native path ----------------------------------------------------------------------------
     def _transforms(self):
-        """bf16 compute weights: KRSC, BN scale folded in; the stem additionally padded to 8 channels."""
+        """bf16 compute weights: KRSC, BN scale folded in; the stem additionally padded to 8 channels.  Rebuilt only when a
+        FrozenBatchNorm2d dropped its cached scale/shift (load / device move)."""
+        cached = self.__dict__.get("_tr_cache")
+        if cached is not None and cached[0] == (_BN_EPOCH[0], id(self)):   # id: a deepcopy must fold its own BN buffers
+            return cached[1]
         tr = {}
         for mod_name, m in self.body.named_modules():
             if not isinstance(m, ConvWeight):
@@ -141,6 +152,7 @@ class BackboneBase(nn.Module):
             if mod_name != "conv1":  # same physical layout as the master: the optimizer tail may rewrite it
                 make.elementwise, make.row_scale = True, scale
             tr[mod_name + ".weight"] = make
+        self.__dict__["_tr_cache"] = ((_BN_EPOCH[0], id(self)), tr)
         return tr
 
     def _bn_of(self, conv_name):
@@ -200,7 +212,7 @@ class BackboneBase(nn.Module):
         A gradient fed back into an output is taken w.r.t. the post-ReLU values and masked by (out > 0)
         here, unless its index is listed in `premasked` (the consumer's dgrad epilogue already did it:
         input_proj, toist_amd/mdetr.py)."""
-        named = OrderedDict(self.body.named_parameters())
+        named = engine.named_cache(self, "body", lambda: OrderedDict(self.body.named_parameters()))
         prog = self._program(levels)
 
         def wrapped(tape, ps, img):

@@ -134,6 +134,17 @@ def compute_copy(t, make, cache, name):
     return ent.w
 
 
+def named_cache(owner, key, build):
+    """Per-module memo of an ordered {name: Parameter} dict (module traversals cost ~1 ms per step when repeated every
+    forward).  Parameters are moved / loaded in place by nn.Module, so the objects stay valid; deepcopy copies the memo
+    together with the parameters it points to."""
+    memo = owner.__dict__.setdefault("_named_memo", {})
+    ent = memo.get(key)
+    if ent is None:
+        ent = memo[key] = build()
+    return ent
+
+
 class ParamView:
     """bf16 compute copy + fp32 gradient slot of one nn.Parameter (or a row slice of one)."""
 

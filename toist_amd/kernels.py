@@ -36,7 +36,7 @@ _WS = {}
 
 def _workspace(elems, device):
     """Caller-owned split-K scratch handed to the library (grown on demand, reused across calls)."""
-    key = (device, torch.cuda.current_stream().cuda_stream)  # one scratch per stream: launches on different streams overlap
+    key = (device, _raw_stream())  # one scratch per stream: launches on different streams overlap
     ws = _WS.get(key)
     if ws is None or ws.numel() < elems:
         ws = torch.empty(max(elems, 1 << 22), dtype=torch.float32, device=device)
@@ -55,7 +55,7 @@ _PENDING = {}   # (device, stream) -> list of (ReduceDesc, keep-alive tensors)
 
 
 def _arena_take(elems, device):
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, _raw_stream())
     ent = _ARENA.get(key)
     elems = (elems + 63) // 64 * 64
     if ent is None or ent[1] + elems > ent[0].numel():
@@ -71,7 +71,7 @@ def flush_reductions():
     """Fold every queued split-K partial of the current stream into its output (one launch per 48 GEMMs)."""
     if not torch.cuda.is_available():
         return
-    key_s = torch.cuda.current_stream().cuda_stream
+    key_s = _raw_stream()
     for key in [kk for kk in _PENDING if kk[1] == key_s]:
         items = _PENDING.pop(key)
         if items:
@@ -82,8 +82,14 @@ def flush_reductions():
             ent[1] = 0
 
 
+def _raw_stream():
+    """hipStream_t of torch's current stream as an int.  torch.cuda.current_stream() builds a Stream object through three
+    Python layers (~9 us): at ~1500 launches per step that alone was 13 ms of host time; the C accessor takes ~0.3 us."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream())
 
 
 def _p(t, dtype=None):
@@ -158,7 +164,7 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
         eff = int(_lib.lib().toist_gemm_effective_split(ctypes.byref(d))) if defer_reduce else 0
         if eff > 1:
             # a second deferred reduction into the same output would race with the queued one: fold first
-            key = (c.device, torch.cuda.current_stream().cuda_stream)
+            key = (c.device, _raw_stream())
             if any(it[0].out == c.data_ptr() for it in _PENDING.get(key, ())):
                 flush_reductions()
             ws = _arena_take(eff * M * N, c.device)
@@ -396,7 +402,7 @@ def wgrad3x3_small(dy, x, out, defer=False):
     ws = _arena_take(blocks * Co * 9 * C, x.device)
     _lib.check(_lib.lib().toist_wgrad3x3_small(_p(dy, torch.bfloat16), _p(x, torch.bfloat16), _p(ws, torch.float32), n_img, H, W, C, Co, _stream()),
                "toist_wgrad3x3_small")
-    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    key = (x.device, _raw_stream())
     if any(it[0].out == out.data_ptr() for it in _PENDING.get(key, ())):
         flush_reductions()
     rd = _lib.ReduceDesc(ws.data_ptr(), out.data_ptr(), None, blocks, Co, 9 * C, 9 * C, 1.0, 1)

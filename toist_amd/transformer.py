@@ -245,8 +245,11 @@ class Transformer(nn.Module):
         pos_ids = (torch.cumsum(keep, dim=1) * keep + cfg.pad_token_id).contiguous()
         ids_flat = ids.contiguous().view(-1)
         key_pad = att.ne(1).to(torch.uint8).contiguous()
-        named = OrderedDict(("text_encoder." + n, p) for n, p in te.named_parameters())
-        named.update(("resizer." + n, p) for n, p in self.resizer.named_parameters())
+        def _named():
+            d = OrderedDict(("text_encoder." + n, p) for n, p in te.named_parameters())
+            d.update(("resizer." + n, p) for n, p in self.resizer.named_parameters())
+            return d
+        named = engine.named_cache(self, "text", _named)
 
         def prog(tape, ps):
             P = lambda n: ps["text_encoder." + n]
@@ -290,7 +293,7 @@ class Transformer(nn.Module):
     def encode_tokens(self, tokens, pos, key_pad, B, S):
         """6 post-norm encoder layers over batch-major tokens [B*S, d]; pos is a bf16 constant."""
         d, H = self.d_model, self.nhead
-        named = OrderedDict(self.encoder.named_parameters())
+        named = engine.named_cache(self, "encoder", lambda: OrderedDict(self.encoder.named_parameters()))
         n_layers = self.encoder.num_layers
 
         def prog(tape, ps, x):
@@ -317,7 +320,7 @@ class Transformer(nn.Module):
         """6 decoder layers; returns the stack of shared-LayerNorm'ed layer outputs [L, B*Q, d] bf16."""
         d, H = self.d_model, self.nhead
         Q = query_embed.shape[0]
-        named = OrderedDict(self.decoder.named_parameters())
+        named = engine.named_cache(self, "decoder", lambda: OrderedDict(self.decoder.named_parameters()))
         n_layers = self.decoder.num_layers
         dev = memory.device
 
