@@ -109,6 +109,8 @@ def bench_distillation(a, dev, rank, world):
         m.train()
     cluster_criterion.to(dev)
     cluster_criterion.full_label.fill_(1)   # steady state: banks full, k-means starts from the stored centres
+    from toist_amd import engine as _engine
+    _engine.REUSE_GRAD_BUFFERS = True
     kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def tail(m):
@@ -201,6 +203,7 @@ def main():
         {"params": [p for n, p in named if "text_encoder" in n], "lr": args.text_encoder_lr},
     ]
     from toist_amd import engine as _engine
+    _engine.REUSE_GRAD_BUFFERS = True   # this loop never keeps a gradient across optimizer.zero_grad()
     if a.no_overlap:
         _engine.OVERLAP = "off"
     use_graph = not a.no_graph and not a.profile_all

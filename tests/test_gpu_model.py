@@ -263,6 +263,46 @@ def test_ragged_batch_padding_masks(dev, setup):
         assert torch.equal(gi.cpu(), ri) and torch.equal(gj.cpu(), rj)
 
 
+def test_reused_gradient_buffers_match_fresh_ones(dev, setup):
+    """engine.REUSE_GRAD_BUFFERS (opt-in for training loops): gradients of consecutive steps equal the ones computed with
+    freshly allocated buffers, and gradient accumulation (two backward passes without zero_grad) still sums."""
+    from toist_amd import engine, harness
+    model, criterion, weight_dict, sd, args = setup
+    model.eval()
+    samples, tok, targets, pmap = harness.synthetic_batch(2, 160, 192, tokens=16, seed=12, max_targets=6)
+    t_dev = [{k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in t.items()} for t in targets]
+
+    def fwd_bwd():
+        mc = model(samples.to(dev), tok.to(dev), encode_and_save=True)
+        out = model(samples.to(dev), tok.to(dev), encode_and_save=False, memory_cache=mc)
+        losses = criterion(mc, out, t_dev, pmap.to(dev), None)
+        sum(losses[k_] * weight_dict[k_] for k_ in losses if k_ in weight_dict).backward()
+
+    names = ["class_embed.weight", "transformer.encoder.layers.0.linear1.weight", "backbone.0.body.layer3.5.conv2.weight",
+             "transformer.text_encoder.encoder.layer.3.output.dense.weight"]
+    params = dict(model.named_parameters())
+    grads = {}
+    try:
+        for mode in (False, True):
+            engine.REUSE_GRAD_BUFFERS = mode
+            out = []
+            for _ in range(3):                       # steps 2 and 3 run on the reused buffers when the option is on
+                model.zero_grad(set_to_none=True)
+                fwd_bwd()
+                out.append({n: params[n].grad.clone() for n in names})
+            fwd_bwd()                                # accumulation on top of step 3
+            out.append({n: params[n].grad.clone() for n in names})
+            grads[mode] = out
+    finally:
+        engine.REUSE_GRAD_BUFFERS = False
+        model.zero_grad(set_to_none=True)
+    for n in names:
+        for step in range(3):
+            assert torch.equal(grads[True][step][n], grads[False][0][n]), (n, step)
+        torch.testing.assert_close(grads[True][3][n], 2 * grads[False][0][n], rtol=1e-5, atol=1e-8)
+        torch.testing.assert_close(grads[False][3][n], 2 * grads[False][0][n], rtol=1e-5, atol=1e-8)
+
+
 def test_backward_cuts_reproduce_the_uncut_gradients(dev, setup):
     """toist_amd.parallel.enable_backward_cuts splits loss.backward() into three segments (head | text | backbone) for
     the data-parallel step; the segmented pass must produce the same gradients as the plain one."""
