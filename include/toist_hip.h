@@ -272,6 +272,14 @@ typedef struct toist_opt_state {
     int32_t reserved[3];
 } toist_opt_state;            /* 32 bytes */
 
+/* ---- fused attention core, forward (head dim 32): prob = softmax(scale * q k^T + key padding), prob_drop = dropout(prob),
+ * ctx = prob_drop v, one launch (transformer.py:297,370-400 through nn.MultiheadAttention).  q / k / v / ctx are per-head
+ * column slices of [B*S, ld*] buffers (row b*S + s, feature h*32 + e); prob / prob_drop are [B*H, Sq, ld] bf16, ld =
+ * round8(Sk), and feed toist_softmax_bwd and the backward GEMMs; prob_drop may be NULL (no dropout: ctx uses prob). */
+int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int Sq, int Sk,
+                   int dh, int ld, float scale, void* prob, void* prob_drop, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* ctx,
+                   int ldo, void* stream);
+
 /* ---- 3x3 / stride 1 / pad 1 convolution with <= 32 channels on either side (mask-head stages at 160x160,
  * segmentation.py:176-241 lay5 / out_lay; HBM-bound): NHWC bf16 in / out, weights [w_co][3][3][w_ci] bf16.
  * dgrad = 0: out[p, co] = shift[co] + sum x[p + tap, ci] w[co, tap, ci] (+ res);  c_src = w_ci, c_out = w_co.

@@ -260,3 +260,52 @@ def test_colsum_tall_narrow(dev, N):
     x = torch.randn(70000, N, generator=g).to(BF)
     out = ops.bias_grad(x.to(dev))
     _close(out, x.float().sum(0), 70000, f"colsum N={N}", rtol=2e-3, atol_unit=2e-4)
+
+
+@pytest.mark.parametrize("Sq,Sk,drop", [(416, 416, 0.0), (100, 416, 0.1), (100, 100, 0.1), (37, 16, 0.0)])
+def test_fused_attention_forward_matches_three_kernel_path(dev, Sq, Sk, drop):
+    """csrc/attn.hip (scores -> mask -> softmax -> dropout -> P V in one launch) against the score GEMM + softmax kernel +
+    context GEMM it replaces, on packed per-head slices with a key-padding mask; same dropout seed -> the same kept set."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(Sq * 1000 + Sk)
+    B, H, dh = 3, 8, 32
+    d = H * dh
+    qk = torch.randn(B * Sq, 2 * d, generator=g).to(BF).to(dev)
+    q, kk = (qk[:, :d], torch.randn(B * Sk, d, generator=g).to(BF).to(dev)) if Sq != Sk else (qk[:, :d], qk[:, d:])
+    v = torch.randn(B * Sk, d, generator=g).to(BF).to(dev)
+    pad = torch.zeros(B, Sk, dtype=torch.uint8)
+    pad[1, Sk - Sk // 3:] = 1
+    pad = pad.to(dev)
+    scale = 1.0 / math.sqrt(dh)
+    k.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+    ld = ops.round8(Sk)
+    # reference path
+    s = ops.attn_scores(q, kk, B, H, Sq, Sk, dh, scale)
+    p0 = torch.empty_like(s)
+    pu0 = torch.empty_like(s) if drop > 0 else None
+    k.softmax_fwd(s, pad, B, H, Sq, Sk, ld, p0, pu0, drop, 1234)
+    c0 = torch.empty(B * Sq, d, dtype=BF, device=dev)
+    ops.attn_context(pu0 if pu0 is not None else p0, v, B, H, Sq, Sk, dh, c0)
+    # fused
+    p1 = torch.empty(B * H, Sq, ld, dtype=BF, device=dev)
+    pu1 = torch.empty_like(p1) if drop > 0 else None
+    c1 = torch.empty(B * Sq, d, dtype=BF, device=dev)
+    k.attn_fwd(q, kk, v, pad, B, H, Sq, Sk, dh, scale, p1, pu1, drop, 1234, c1)
+    # the fused kernel keeps the scores in fp32 (the unfused path rounds them to bf16 first): probabilities agree to bf16 rounding
+    assert float((p1.float() - p0.float()).abs().max()) <= 2e-2
+    assert float((p1.float() - p0.float()).abs().mean()) <= 2e-4
+    assert bool((p1.view(B, H, Sq, ld)[1, :, :, Sk - Sk // 3:Sk] == 0).all())   # padded keys get no probability
+    if drop > 0:
+        assert bool(((pu1 == 0) == (pu0 == 0)).float().mean() > 0.999)         # same kept set (ties only where p underflows)
+    assert float((c1.float() - c0.float()).abs().max()) <= 3e-2 * max(1.0, float(c0.float().abs().max()))
+    # and against fp32 math on the same inputs
+    qf = q.float().view(B, Sq, H, dh).permute(0, 2, 1, 3)
+    kf = kk.float().view(B, Sk, H, dh).permute(0, 2, 1, 3)
+    vf = v.float().view(B, Sk, H, dh).permute(0, 2, 1, 3)
+    sc = (qf @ kf.transpose(-1, -2)) * scale
+    sc = sc.masked_fill(pad.bool()[:, None, None, :], float("-inf"))
+    pr = sc.softmax(-1)
+    assert float((p1.float().view(B, H, Sq, ld)[..., :Sk] - pr).abs().max()) <= 1e-2
+    if drop == 0:
+        ref = (pr @ vf).permute(0, 2, 1, 3).reshape(B * Sq, d)
+        assert float((c1.float() - ref).abs().max()) <= 3e-2 * max(1.0, float(ref.abs().max()))

@@ -38,6 +38,7 @@ class Var:
 # GEMMs from the data-gradient chain was measured too (0 % to -6 %: those kernels already fill the chip and
 # every fork is a cross-stream edge of the graph) and is deliberately not done.
 OVERLAP = "capture"
+FUSED_ATTENTION = True   # head-dim-32 attention cores run as one fused forward launch (csrc/attn.hip); False = 3 launches
 _SIDE = {}
 
 
@@ -421,17 +422,26 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
         qb = ops.linear(q_in.data, Pq[0].w, Pq[1].f32)
         kb = ops.linear(k_in.data, Pk[0].w, Pk[1].f32)
     vb = ops.linear(v_in.data, Pv[0].w, Pv[1].f32)
-    s = ops.attn_scores(qb, kb, B, H, Sq, Sk, dh, scale)
-    ld = s.shape[-1]
-    prob = torch.empty_like(s)
     seed_p = tape.next_seed() if p > 0 else 0
-    prob_used = torch.empty_like(s) if p > 0 else None
-    k.softmax_fwd(s, key_pad, B, H, Sq, Sk, ld, prob, prob_used, p, seed_p)
-    del s
+    ctx = torch.empty(B * Sq, d, dtype=BF16, device=dev)
+    if FUSED_ATTENTION and dh == 32 and Sk <= 512 and (Sq >= 256 or Sk <= 128):
+        # scores -> mask -> softmax -> dropout -> P V in one launch (csrc/attn.hip); the probabilities are kept for backward.
+        # Measured (tools/bench_attn_core.py, B=8): 45.7 vs 62.7 us at 416x416, 12.0 vs 21.3 us at 100x100, but 33.3 vs 31.0 us
+        # at 100x416 (two query blocks per head re-stage all of K and V), which therefore keeps the three-kernel path
+        ld = ops.round8(Sk)
+        prob = torch.empty(B * H, Sq, ld, dtype=BF16, device=dev)
+        prob_used = torch.empty_like(prob) if p > 0 else None
+        k.attn_fwd(qb, kb, vb, key_pad, B, H, Sq, Sk, dh, scale, prob, prob_used, p, seed_p, ctx)
+    else:
+        s = ops.attn_scores(qb, kb, B, H, Sq, Sk, dh, scale)
+        ld = s.shape[-1]
+        prob = torch.empty_like(s)
+        prob_used = torch.empty_like(s) if p > 0 else None
+        k.softmax_fwd(s, key_pad, B, H, Sq, Sk, ld, prob, prob_used, p, seed_p)
+        del s
+        ops.attn_context(prob_used if prob_used is not None else prob, vb, B, H, Sq, Sk, dh, ctx)
     if prob_used is None:
         prob_used = prob
-    ctx = torch.empty(B * Sq, d, dtype=BF16, device=dev)
-    ops.attn_context(prob_used, vb, B, H, Sq, Sk, dh, ctx)
     seed_o = tape.next_seed() if p > 0 else 0
     z = ops.linear(ctx, Wo.w, bo.f32, res=resid.data, drop_where=1 if p > 0 else 0, drop_p=p, drop_seed=seed_o)
     out = Var(z)

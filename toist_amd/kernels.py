@@ -409,3 +409,11 @@ def wgrad3x3_small(dy, x, out, defer=False):
     _PENDING.setdefault(key, []).append((rd, (out,)))
     if not defer:
         flush_reductions()
+
+
+def attn_fwd(q, kmat, v, key_pad, B, H, Sq, Sk, dh, scale, prob, prob_drop, drop_p, seed, ctx):
+    """Fused attention core (csrc/attn.hip): q/k/v/ctx are column slices of packed [B*S, ld] bf16 buffers."""
+    _lib.check(_lib.lib().toist_attn_fwd(_p(q, torch.bfloat16), q.stride(0), _p(kmat, torch.bfloat16), kmat.stride(0), _p(v, torch.bfloat16), v.stride(0),
+                                         _p(key_pad, torch.uint8), B, H, Sq, Sk, dh, prob.shape[-1], scale, _p(prob, torch.bfloat16),
+                                         _p(prob_drop, torch.bfloat16), drop_p, seed, _p(SEED_DEV) if prob_drop is not None else None,
+                                         _p(ctx, torch.bfloat16), ctx.stride(0), _stream()), "toist_attn_fwd")

@@ -1,0 +1,34 @@
+"""Attention core forward: fused kernel (csrc/attn.hip) vs score GEMM + softmax + context GEMM.  GPU only."""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from toist_amd import kernels as k, ops  # noqa: E402
+from tools.bench_gemm import timeit  # noqa: E402
+
+BF = torch.bfloat16
+dev = torch.device("cuda")
+B, H, dh = 8, 8, 32
+d = H * dh
+k.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+for Sq, Sk in [(416, 416), (100, 416), (100, 100)]:
+    q = torch.randn(B * Sq, d, device=dev).to(BF)
+    kk = torch.randn(B * Sk, d, device=dev).to(BF)
+    v = torch.randn(B * Sk, d, device=dev).to(BF)
+    pad = torch.zeros(B, Sk, dtype=torch.uint8, device=dev)
+    ld = ops.round8(Sk)
+    s = torch.empty(B * H, Sq, ld, dtype=BF, device=dev)
+    p0, pu0 = torch.empty_like(s), torch.empty_like(s)
+    c = torch.empty(B * Sq, d, dtype=BF, device=dev)
+    sc = 1 / math.sqrt(dh)
+
+    def unfused():
+        ops.attn_scores(q, kk, B, H, Sq, Sk, dh, sc, out=s)
+        k.softmax_fwd(s, pad, B, H, Sq, Sk, ld, p0, pu0, 0.1, 7)
+        ops.attn_context(pu0, v, B, H, Sq, Sk, dh, c)
+
+    fused = lambda: k.attn_fwd(q, kk, v, pad, B, H, Sq, Sk, dh, sc, p0, pu0, 0.1, 7, c)
+    print(f"Sq={Sq} Sk={Sk}: three kernels {1000 * timeit(unfused, 30):7.1f} us   fused {1000 * timeit(fused, 30):7.1f} us", flush=True)
