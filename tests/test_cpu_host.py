@@ -35,6 +35,15 @@ def test_struct_layouts_match_header(tmp_path):
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert got == [ctypes.sizeof(_lib.Operand), ctypes.sizeof(_lib.Epilogue), ctypes.sizeof(_lib.Gemm), _lib.Gemm.epi.offset,
                    _lib.Gemm.a_colsum.offset]
+    # the optimizer-tail table rows (built with numpy in toist_amd/optim.py) and the split-K reduction descriptor
+    src.write_text('#include "toist_hip.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(toist_opt_tensor), '
+                   'offsetof(toist_opt_tensor, numel), offsetof(toist_opt_tensor, group), sizeof(toist_opt_state), offsetof(toist_opt_state, step), '
+                   'sizeof(toist_reduce_desc));return 0;}\n')
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    from toist_amd import optim
+    dt = optim._TENSOR_DT
+    assert got == [dt.itemsize, dt.fields["numel"][1], dt.fields["group"][1], 32, 16, ctypes.sizeof(_lib.ReduceDesc)]
 
 
 def test_bad_arguments_return_error_codes_without_a_gpu():
