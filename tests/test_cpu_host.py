@@ -152,3 +152,22 @@ def test_segmentation_wrapper_state_dict():
     assert trainable == sum(p.numel() for n, p in model.named_parameters() if not n.startswith("detr."))  # only the mask branch
     assert 1_300_000 < trainable < 1_400_000  # SURVEY: 1.33 M parameters
     assert "masks" in criterion.losses and wd["loss_mask"] == 1.0 and wd["loss_dice"] == 1.0
+
+
+def test_compute_copy_registry_is_keyed_by_tensor_identity():
+    """The caching allocator reuses a freed parameter's address for the next model: a registry hit must be the same tensor
+    object, not merely the same address (a stale row in the optimizer's pointer table writes past the smaller copy)."""
+    import gc
+    import torch
+    from toist_amd import engine
+    cache = {}
+    t = torch.nn.Parameter(torch.randn(8, 4))
+    w = engine.compute_copy(t, engine._cast_bf16, cache, "w")
+    assert engine.copy_of(t) is not None and engine.copy_of(t).w is w
+    alias = t.detach()[:2]                                    # same address, another tensor (and another size)
+    assert alias.data_ptr() == t.data_ptr() and engine.copy_of(alias) is None
+    ptr = t.data_ptr()
+    del t, alias
+    gc.collect()
+    engine.prune_copies()
+    assert ptr not in engine.COPIES

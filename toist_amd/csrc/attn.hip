@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     bf16_t* sK = smem;               // [SKP][32], 16-byte chunk (key, c) stored in slot c ^ ((key >> 1) & 3)
     bf16_t* sV = smem + SKP * DH;    // [SKP][32] plain (read k-major)
+    unsigned char* sDead = reinterpret_cast<unsigned char*>(smem + 2 * SKP * DH);   // [SKP] 1 = key masked (padding or beyond Sk)
     typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
     if (seed_dev) seed += *seed_dev;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         *reinterpret_cast<uint4*>(sK + key * DH + ((ch ^ ((key >> 1) & 3)) << 3)) = kv;
         *reinterpret_cast<uint4*>(sV + key * DH + (ch << 3)) = vv;
     }
+    for (int kk = tid; kk < SKP; kk += 256) sDead[kk] = (kk >= Sk || (key_pad != nullptr && key_pad[(size_t)b * Sk + kk])) ? 1 : 0;
     __syncthreads();
 
     const int qi = blockIdx.x * 64 + wave * 16 + c16;           // this lane's query
@@ -54,11 +56,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         const int key = j * 16 + c16;                           // B-operand row of this lane
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + key * DH + ((g ^ ((key >> 1) & 3)) << 3));
         f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const unsigned dead4 = *reinterpret_cast<const unsigned*>(sDead + j * 16 + g * 4);   // this lane's 4 keys
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int kk = j * 16 + g * 4 + r;
-            const bool dead = kk >= Sk || (key_pad != nullptr && key_pad[(size_t)b * Sk + (kk < Sk ? kk : 0)]);
-            a[r] = dead ? -INFINITY : a[r] * scale;
+            a[r] = ((dead4 >> (8 * r)) & 0xffu) ? -INFINITY : a[r] * scale;
             mx = fmaxf(mx, a[r]);
         }
         s[j] = a;
@@ -127,18 +128,18 @@ extern "C" int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk,
                               void* ctx, int ldo, void* stream) {
     TOIST_REQUIRE(q && kmat && v && prob && ctx && B > 0 && H > 0 && Sq > 0 && Sk > 0, "toist_attn_fwd: bad args");
     TOIST_REQUIRE(dh == 32, "toist_attn_fwd: head dim must be 32 (got %d)", dh);
-    TOIST_REQUIRE(Sk <= 512 && ld >= Sk && (ld % 8) == 0, "toist_attn_fwd: Sk <= 512 and ld = round8(Sk) (got %d, %d)", Sk, ld);
+    TOIST_REQUIRE(Sk <= 480 && ld >= Sk && (ld % 8) == 0, "toist_attn_fwd: Sk <= 480 (K, V and the mask of a head must fit 64 KB of LDS) and ld = round8(Sk) (got %d, %d)", Sk, ld);
     TOIST_REQUIRE((ldq % 8) == 0 && (ldk % 8) == 0 && (ldv % 8) == 0 && (ldo % 4) == 0, "toist_attn_fwd: row strides must keep 16-byte alignment");
     TOIST_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "toist_attn_fwd: bad dropout p");
     const dim3 grid((Sq + 63) / 64, B * H), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define TOIST_ATTN(NB)                                                                                                                       \
-    hipLaunchKernelGGL((attn_fwd_kernel<NB>), grid, block, 2 * (NB) * 16 * 32 * sizeof(bf16_t), st, (const bf16_t*)q, ldq, (const bf16_t*)kmat, ldk, \
+    hipLaunchKernelGGL((attn_fwd_kernel<NB>), grid, block, 2 * (NB) * 16 * 32 * sizeof(bf16_t) + (NB) * 16, st, (const bf16_t*)q, ldq, (const bf16_t*)kmat, ldk, \
                        (const bf16_t*)v, ldv, key_pad, H, Sq, Sk, ld, scale, (bf16_t*)prob, (bf16_t*)prob_drop, drop_p,                      \
                        (unsigned long long)seed, (const unsigned long long*)seed_dev, (bf16_t*)ctx, ldo)
     if (Sk <= 128) TOIST_ATTN(8);
     else if (Sk <= 416) TOIST_ATTN(26);
-    else TOIST_ATTN(32);
+    else TOIST_ATTN(30);
 #undef TOIST_ATTN
     return check_launch("toist_attn_fwd");
 }

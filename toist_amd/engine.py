@@ -8,6 +8,8 @@ and FrozenBN backward steps are folded into the epilogue of the GEMM that produc
 """
 import math
 
+import weakref
+
 import torch
 
 from . import kernels as k
@@ -102,7 +104,20 @@ except Exception:  # pragma: no cover - older torch: copies are refreshed every 
 
 
 class ComputeCopy:
-    __slots__ = ("version", "ptr", "epoch", "w", "row_scale", "elementwise")
+    __slots__ = ("version", "ptr", "epoch", "w", "row_scale", "elementwise", "master")
+
+
+def prune_copies():
+    """Drop registry entries whose master tensor is gone (their address may since belong to another tensor)."""
+    for ptr in [ptr for ptr, ent in COPIES.items() if ent.master() is None]:
+        del COPIES[ptr]
+
+
+def copy_of(t):
+    """The registered compute copy of exactly this tensor object, or None (an address match alone is not enough: the
+    caching allocator hands a freed parameter's address to the next model)."""
+    ent = COPIES.get(t.data_ptr())
+    return ent if ent is not None and ent.master() is t and ent.ptr == t.data_ptr() else None
 
 
 def _cast_bf16(m):
@@ -129,7 +144,7 @@ def compute_copy(t, make, cache, name):
         COPY_GEN += 1
         if cache is not None:
             cache[name] = ent
-    ent.version, ent.ptr, ent.epoch = t._version, t.data_ptr(), WEIGHT_EPOCH
+    ent.version, ent.ptr, ent.epoch, ent.master = t._version, t.data_ptr(), WEIGHT_EPOCH, weakref.ref(t)
     if cache is not None:
         COPIES[t.data_ptr()] = ent
     return ent.w
@@ -424,10 +439,9 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
     vb = ops.linear(v_in.data, Pv[0].w, Pv[1].f32)
     seed_p = tape.next_seed() if p > 0 else 0
     ctx = torch.empty(B * Sq, d, dtype=BF16, device=dev)
-    if FUSED_ATTENTION and dh == 32 and Sk <= 512 and (Sq >= 256 or Sk <= 128):
+    if FUSED_ATTENTION and dh == 32 and Sk <= 480:
         # scores -> mask -> softmax -> dropout -> P V in one launch (csrc/attn.hip); the probabilities are kept for backward.
-        # Measured (tools/bench_attn_core.py, B=8): 45.7 vs 62.7 us at 416x416, 12.0 vs 21.3 us at 100x100, but 33.3 vs 31.0 us
-        # at 100x416 (two query blocks per head re-stage all of K and V), which therefore keeps the three-kernel path
+        # Measured (tools/bench_attn_core.py, B=8): 37.2 vs 61.2 us at 416x416, 25.2 vs 30.9 us at 100x416, 9.4 vs 21.2 us at 100x100
         ld = ops.round8(Sk)
         prob = torch.empty(B * H, Sq, ld, dtype=BF16, device=dev)
         prob_used = torch.empty_like(prob) if p > 0 else None

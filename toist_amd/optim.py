@@ -98,14 +98,15 @@ class FusedClipAdamWEMA:
 
     def _build_table(self):
         rows = np.zeros(len(self.params) + len(self._ema_only), dtype=_TENSOR_DT)
+        engine.prune_copies()
         self._copies = []
         for i, p in enumerate(self.params):
             r = rows[i]
             r["p"], r["m"], r["v"] = p.data_ptr(), self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
             r["ema"] = self._ema_of[i].data_ptr() if self._ema_of[i] is not None else 0
             r["numel"], r["group"], r["row_len"] = p.numel(), self._group_of[i], 1
-            ent = engine.COPIES.get(p.data_ptr())
-            if ent is not None and ent.elementwise and ent.ptr == p.data_ptr():
+            ent = engine.copy_of(p)
+            if ent is not None and ent.elementwise and ent.w.numel() == p.numel():
                 r["w"] = ent.w.data_ptr()
                 if ent.row_scale is not None:
                     r["row_scale"] = ent.row_scale.data_ptr()
