@@ -326,6 +326,45 @@ int toist_opt_adamw_ema(const toist_opt_tensor* table, const int64_t* grads, con
                         const toist_opt_group* groups, const toist_opt_state* state, float beta1, float beta2, float eps,
                         float ema_decay, void* stream);
 
+/* ---- evaluation masks (replaces PostProcessSegm's dense resizes, models/postprocessors.py:73-109, and what
+ * datasets/coco_eval.py:307-332 asks of pycocotools: mask_util.encode, and maskUtils.iou / area inside COCOeval).
+ * A binary mask [h, w] is a column-major bit plane: uint64 bits[mask][x][yw], yw < ceil(h/64), bit b of word yw = pixel
+ * (y = 64*yw + b, x), bits beyond h zero -- RLE's pixel order (index x*h + y).  n <= 65535 masks per call.
+ *   resize_pack : src [n, h0, w0] fp32 mask logits -> bilinear (align_corners false) to [max_h, max_w], its
+ *                 [crop_h, crop_w] corner -> bilinear to [h, w], sigmoid(v) > threshold, packed
+ *   pack/unpack : dense [n, h, w] bytes (non-zero = foreground; unpack writes 0/1)
+ *   area        : foreground pixels per mask
+ *   iou         : iou[d, g] (row-major double) = i / (iscrowd[g] ? area_dt[d] : area_dt[d] + area_gt[g] - i), 0 when i = 0
+ *   rle_count   : column_transitions[m, x] = value changes inside column x, counted against the preceding pixel in RLE
+ *                 order (the last pixel of column x-1; 0 before the first pixel)
+ *   rle_emit    : positions[column_offset[m, x] ...] = pixel indices of those changes, ascending (column_offset = an
+ *                 exclusive prefix sum of column_transitions over the flattened [n, w] array)
+ *   rle_counts  : mask m owns positions[first_position[m] .. first_position[m+1]) and writes its
+ *                 (transitions + 1) run lengths, zeros first, to counts[first_run[m] ...]  (= rleEncode's cnts) */
+int toist_mask_resize_pack(const float* src, int n, int h0, int w0, int max_h, int max_w, int crop_h, int crop_w, int h, int w,
+                           float threshold, uint64_t* bits, void* stream);
+int toist_mask_pack(const uint8_t* dense, int n, int h, int w, uint64_t* bits, void* stream);
+int toist_mask_unpack(const uint64_t* bits, int n, int h, int w, uint8_t* dense, void* stream);
+int toist_mask_area(const uint64_t* bits, int n, int h, int w, uint32_t* area, void* stream);
+int toist_mask_iou(const uint64_t* dt, int n_dt, const uint64_t* gt, int n_gt, const uint8_t* iscrowd, const uint32_t* area_dt,
+                   const uint32_t* area_gt, int h, int w, double* iou, void* stream);
+int toist_mask_rle_count(const uint64_t* bits, int n, int h, int w, int32_t* column_transitions, void* stream);
+int toist_mask_rle_emit(const uint64_t* bits, int n, int h, int w, const int64_t* column_offset, uint32_t* positions, void* stream);
+int toist_mask_rle_counts(const uint32_t* positions, const int64_t* first_position, const int64_t* first_run, int n, int h, int w,
+                          uint32_t* counts, void* stream);
+
+/* COCOeval.evaluateImg over a batch of images (pycocotools cocoeval.py; reached from datasets/coco_eval.py:368-399).  Image i owns
+ * detections [dt_offset[i], dt_offset[i+1]) (score-descending, already cut to maxDets[-1]), ground truth [gt_offset[i], gt_offset[i+1])
+ * and the row-major [D_i, G_i] block of `iou` at iou_offset[i].  For every area range a = [lo, hi] and IoU threshold t:
+ *   dt_match [A*T*dt_offset[i] + (a*T + t)*D_i + d] = ground-truth index matched by detection d (within the image), or -1
+ *   dt_ignore[same index]                          = matched an ignored ground truth, or unmatched with its area outside the range
+ *   gt_range_ignore[A*gt_offset[i] + a*G_i + g]    = gt_ignore[g] or its area outside the range
+ * gt_taken (A*T bytes per ground truth) is scratch.  Offsets tables have n_images + 1 entries. */
+int toist_coco_match(const double* iou, const int64_t* iou_offset, const double* dt_area, const int64_t* dt_offset, const double* gt_area,
+                     const uint8_t* gt_ignore, const uint8_t* gt_crowd, const int64_t* gt_offset, int n_images, const double* area_ranges,
+                     int n_ranges, const double* iou_thresholds, int n_thresholds, int32_t* dt_match, uint8_t* dt_ignore,
+                     uint8_t* gt_range_ignore, uint8_t* gt_taken, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,15 @@ _SIGNATURES = {
     "toist_opt_sqnorm": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_opt_finish_norm": ([c_void_p, c_int32, c_float, c_float, c_float, c_void_p, c_void_p], ctypes.c_int),
     "toist_opt_adamw_ema": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p], ctypes.c_int),
+    "toist_mask_resize_pack": ([c_void_p] + [c_int32] * 9 + [c_float, c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_pack": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_unpack": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_area": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_iou": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_rle_count": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_rle_emit": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_coco_match": ([c_void_p] * 8 + [c_int32, c_void_p, c_int32, c_void_p, c_int32] + [c_void_p] * 5, ctypes.c_int),
+    "toist_mask_rle_counts": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
 }
 
 _lib = None

@@ -417,3 +417,89 @@ def attn_fwd(q, kmat, v, key_pad, B, H, Sq, Sk, dh, scale, prob, prob_drop, drop
                                          _p(key_pad, torch.uint8), B, H, Sq, Sk, dh, prob.shape[-1], scale, _p(prob, torch.bfloat16),
                                          _p(prob_drop, torch.bfloat16), drop_p, seed, _p(SEED_DEV) if prob_drop is not None else None,
                                          _p(ctx, torch.bfloat16), ctx.stride(0), _stream()), "toist_attn_fwd")
+
+
+# ---- evaluation masks (csrc/evalmask.hip): column-major bit planes [n, W, ceil(H/64)] stored in int64 tensors --------------
+def mask_words(h):
+    return (h + 63) // 64
+
+
+def _plane(n, h, w, device):
+    if h * w >= 2 ** 31:
+        raise ValueError("mask planes address pixels with 31 bits")
+    return torch.empty(n, w, mask_words(h), dtype=torch.int64, device=device)
+
+
+def mask_resize_pack(logits, max_size, crop, out_size, threshold=0.5):
+    """[n, h0, w0] fp32 mask logits -> bit planes of sigmoid(resize(resize(.)[:crop])) > threshold (PostProcessSegm's arithmetic)."""
+    n, h0, w0 = logits.shape
+    bits = _plane(n, out_size[0], out_size[1], logits.device)
+    _lib.check(_lib.lib().toist_mask_resize_pack(_p(logits.contiguous(), torch.float32), n, h0, w0, int(max_size[0]), int(max_size[1]), int(crop[0]),
+                                                 int(crop[1]), int(out_size[0]), int(out_size[1]), float(threshold), _p(bits), _stream()),
+               "toist_mask_resize_pack")
+    return bits
+
+
+def mask_pack(dense):
+    """[n, h, w] bool / uint8 -> bit planes."""
+    n, h, w = dense.shape
+    src = dense.contiguous().view(torch.uint8) if dense.dtype == torch.bool else dense.contiguous()
+    bits = _plane(n, h, w, dense.device)
+    _lib.check(_lib.lib().toist_mask_pack(_p(src, torch.uint8), n, h, w, _p(bits), _stream()), "toist_mask_pack")
+    return bits
+
+
+def mask_unpack(bits, h, w):
+    n = bits.shape[0]
+    dense = torch.empty(n, h, w, dtype=torch.uint8, device=bits.device)
+    _lib.check(_lib.lib().toist_mask_unpack(_p(bits, torch.int64), n, h, w, _p(dense), _stream()), "toist_mask_unpack")
+    return dense.view(torch.bool)
+
+
+def mask_area(bits, h, w):
+    area = torch.empty(bits.shape[0], dtype=torch.int32, device=bits.device)
+    _lib.check(_lib.lib().toist_mask_area(_p(bits, torch.int64), bits.shape[0], h, w, _p(area), _stream()), "toist_mask_area")
+    return area
+
+
+def mask_iou(dt, gt, iscrowd, area_dt, area_gt, h, w):
+    """[n_dt, n_gt] float64 IoU of two sets of bit planes (crowd ground truth: union = detection area)."""
+    iou = torch.zeros(dt.shape[0], gt.shape[0], dtype=torch.float64, device=dt.device)
+    _lib.check(_lib.lib().toist_mask_iou(_p(dt, torch.int64), dt.shape[0], _p(gt, torch.int64), gt.shape[0], _p(iscrowd, torch.uint8),
+                                         _p(area_dt, torch.int32), _p(area_gt, torch.int32), h, w, _p(iou), _stream()), "toist_mask_iou")
+    return iou
+
+
+def mask_rle(bits, h, w):
+    """Run lengths of every plane, zeros first (mask_util.encode's counts): (counts int32 [total], first_run int64 [n + 1])."""
+    n = bits.shape[0]
+    trans = torch.empty(n, w, dtype=torch.int32, device=bits.device)
+    _lib.check(_lib.lib().toist_mask_rle_count(_p(bits, torch.int64), n, h, w, _p(trans), _stream()), "toist_mask_rle_count")
+    ends = torch.cumsum(trans.view(-1).to(torch.int64), 0)
+    col_off = ends - trans.view(-1)
+    first_pos = torch.zeros(n + 1, dtype=torch.int64, device=bits.device)
+    first_pos[1:] = ends.view(n, w)[:, -1]
+    first_run = first_pos + torch.arange(n + 1, device=bits.device)
+    total = int(first_pos[-1])                       # the one synchronisation: sizes the output
+    pos = torch.empty(max(total, 1), dtype=torch.int32, device=bits.device)
+    _lib.check(_lib.lib().toist_mask_rle_emit(_p(bits, torch.int64), n, h, w, _p(col_off), _p(pos), _stream()), "toist_mask_rle_emit")
+    counts = torch.empty(total + n, dtype=torch.int32, device=bits.device)
+    _lib.check(_lib.lib().toist_mask_rle_counts(_p(pos), _p(first_pos), _p(first_run), n, h, w, _p(counts), _stream()), "toist_mask_rle_counts")
+    return counts, first_run
+
+
+def coco_match(iou, iou_off, dt_area, dt_off, gt_area, gt_ignore, gt_crowd, gt_off, area_rng, thrs):
+    """Batched COCOeval.evaluateImg (csrc/evalmask.hip): -> (dt_match int32, dt_ignore uint8) flat [sum_i A*T*D_i],
+    gt_range_ignore uint8 flat [sum_i A*G_i]; offsets are int64 device tensors with n_images + 1 entries."""
+    n_img, A, T = dt_off.numel() - 1, area_rng.shape[0], thrs.numel()
+    n_dt, n_gt = dt_area.numel(), gt_area.numel()
+    dev = dt_off.device
+    dt_match = torch.empty(A * T * n_dt, dtype=torch.int32, device=dev)
+    dt_ignore = torch.empty(A * T * n_dt, dtype=torch.uint8, device=dev)
+    gt_flag = torch.empty(A * n_gt, dtype=torch.uint8, device=dev)
+    taken = torch.empty(A * T * n_gt, dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().toist_coco_match(_p(iou, torch.float64), _p(iou_off, torch.int64), _p(dt_area, torch.float64), _p(dt_off, torch.int64),
+                                           _p(gt_area, torch.float64), _p(gt_ignore, torch.uint8), _p(gt_crowd, torch.uint8), _p(gt_off, torch.int64),
+                                           n_img, _p(area_rng, torch.float64), A, _p(thrs, torch.float64), T, _p(dt_match), _p(dt_ignore),
+                                           _p(gt_flag), _p(taken), _stream()), "toist_coco_match")
+    return dt_match, dt_ignore, gt_flag

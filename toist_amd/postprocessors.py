@@ -1,5 +1,6 @@
 """Post-processing (reference: /root/reference/models/postprocessors.py:15-117).  Inference-side,
-tiny tensors; kept as device torch ops ("keep in torch unless profiled hot")."""
+PostProcess works on [B, Q] scalars and stays device torch ops; PostProcessSegm is HBM-bound mask work and
+runs in csrc/evalmask.hip."""
 from typing import Dict
 
 import torch
@@ -7,6 +8,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import box_ops
+from . import kernels as k
 
 
 class PostProcess(nn.Module):
@@ -31,28 +33,30 @@ class PostProcess(nn.Module):
 
 
 class PostProcessSegm(nn.Module):
-    def __init__(self, threshold=0.5):
+    """postprocessors.py:59-109.  The reference resizes [B, Q, H, W] in fp32 twice (to the padded batch size, then each image's
+    un-padded corner to its original size), thresholds the sigmoid and copies Q dense masks per image to the host.  Here
+    one kernel (csrc/evalmask.hip: mask_resize_pack) does both bilinear resizes, the sigmoid and the threshold straight from
+    the [h0, w0] mask logits and writes column-major bit planes (1/32 of one fp32 mask).  packed=False (default) unpacks
+    them into the reference's result format, results[i]["masks"] = bool [Q, 1, H_i, W_i] on the host; packed=True leaves
+    results[i]["mask_bits"] (int64 [Q, W_i, ceil(H_i/64)]) and ["mask_size"] on the device for TDODCocoEvaluator."""
+
+    def __init__(self, threshold=0.5, packed=False):
         super().__init__()
-        self.threshold = threshold
+        self.threshold, self.packed = threshold, packed
 
     @torch.no_grad()
     def forward(self, results, outputs, orig_target_sizes, max_target_sizes):
         assert len(orig_target_sizes) == len(max_target_sizes)
-        max_h, max_w = max_target_sizes.max(0)[0].tolist()
-        masks = outputs["pred_masks"].squeeze(2).float()
-        masks = F.interpolate(masks, size=(max_h, max_w), mode="bilinear", align_corners=False)
-        min_h, min_w = max_target_sizes.min(0)[0].tolist()
-        min_oh, min_ow = orig_target_sizes.min(0)[0].tolist()
-        max_oh, max_ow = orig_target_sizes.max(0)[0].tolist()
-        if min_h == max_h and min_w == max_w and min_oh == max_oh and min_ow == max_ow:
-            masks = (F.interpolate(masks, size=(min_oh, min_ow), mode="bilinear").sigmoid() > self.threshold).cpu()
-            for i, m in enumerate(masks):
-                results[i]["masks"] = m.unsqueeze(1)
-            return results
-        for i, (m, t, tt) in enumerate(zip(masks, max_target_sizes, orig_target_sizes)):
-            h, w = int(t[0]), int(t[1])
-            crop = m[:, :h, :w].unsqueeze(1)
-            results[i]["masks"] = (F.interpolate(crop.float(), size=tuple(tt.tolist()), mode="bilinear").sigmoid() > self.threshold).cpu()
+        sizes, origs = max_target_sizes.tolist(), orig_target_sizes.tolist()
+        max_h, max_w = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        logits = outputs["pred_masks"].squeeze(2).float()                     # [B, Q, h0, w0]
+        for i, (size, orig) in enumerate(zip(sizes, origs)):
+            h, w = int(orig[0]), int(orig[1])
+            bits = k.mask_resize_pack(logits[i], (max_h, max_w), (int(size[0]), int(size[1])), (h, w), self.threshold)
+            if self.packed:
+                results[i]["mask_bits"], results[i]["mask_size"] = bits, (h, w)
+            else:
+                results[i]["masks"] = k.mask_unpack(bits, h, w).unsqueeze(1).cpu()
         return results
 
 
