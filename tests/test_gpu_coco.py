@@ -218,3 +218,33 @@ def test_full_size_round_trip_and_packed_evaluation(dev):
     ev.summarize(verbose=False)
     stats = ev.coco_eval["segm"].stats
     assert stats[0] == pytest.approx(1.0, abs=1e-12) and stats[8] == pytest.approx(1.0, abs=1e-12)
+
+
+def test_evaluation_loop_end_to_end(dev):
+    """engine.evaluate's shape on a random-init segmentation model: two batches through encode / decode / losses / PostProcess /
+    PostProcessSegm(packed) / TDODCocoEvaluator; the packed route and the reference-format route (dense host masks) agree."""
+    import toist_amd
+    from toist_amd import harness
+    from toist_amd.postprocessors import PostProcess, PostProcessSegm
+    torch.manual_seed(0)
+    args = harness.default_args(device="cuda", masks=True, mask_model="smallconv", enc_layers=1, dec_layers=1, num_queries=20)
+    model, criterion, _, weight_dict = toist_amd.build_model(args)
+    model.to(dev)
+    batches = []
+    for b in range(2):
+        samples, tok, targets, pmap = harness.synthetic_batch(2, 128, 160, tokens=12, seed=20 + b, device=dev, max_targets=4, with_masks=True)
+        for i, t in enumerate(targets):
+            t["image_id"] = torch.tensor([100 + 2 * b + i], device=dev)
+            t["orig_size"], t["size"] = torch.tensor([128, 160], device=dev), torch.tensor([128, 160], device=dev)
+        batches.append({"samples": samples, "tokenized": tok, "targets": targets, "positive_map": pmap})
+    gt = harness.synthetic_ground_truth([b["targets"] for b in batches])
+    stats = {}
+    for packed in (True, False):
+        post = {"bbox": PostProcess(), "segm": PostProcessSegm(packed=packed)}
+        ev = toist_amd.TDODCocoEvaluator(gt, ["bbox", "segm"], device=dev)
+        stats[packed] = harness.evaluate(model, criterion, None, post, weight_dict, batches, [ev], dev, args)
+        assert sorted(ev.img_ids) == [100, 101, 102, 103]
+    for name in ("coco_eval_bbox", "coco_eval_masks"):
+        assert len(stats[True][name]) == 12 and stats[True][name] == stats[False][name]
+        assert all(-1.0 <= v <= 1.0 for v in stats[True][name])
+    assert stats[True]["loss"] > 0 and "loss_dice" in stats[True]

@@ -21,6 +21,7 @@ def __getattr__(name):
         "build_matcher": ("matcher", "build_matcher"), "PostProcess": ("postprocessors", "PostProcess"),
         "PostProcessSegm": ("postprocessors", "PostProcessSegm"), "build_postprocessors": ("postprocessors", "build_postprocessors"),
         "NestedTensor": ("misc", "NestedTensor"), "targets_to": ("misc", "targets_to"),
+        "TDODCocoEvaluator": ("coco_eval", "TDODCocoEvaluator"), "CocoGroundTruth": ("coco_eval", "CocoGroundTruth"),
     }
     if name in table:
         mod, attr = table[name]

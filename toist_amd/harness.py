@@ -115,3 +115,70 @@ def distillation_step(model, model_noun, criterion, cluster_criterion, weight_di
     losses.update(loss_cluster)
     total = sum(losses[k] * weight_dict[k] for k in losses if k in weight_dict)
     return total, losses
+
+
+# ---- evaluation (engine.py:253-342) ---------------------------------------------------------------------------------
+def synthetic_ground_truth(batches):
+    """COCO-format ground truth of synthetic batches (lists of target dicts carrying "image_id", "orig_size", "boxes" in
+    normalised cxcywh and optionally "masks" at the original size): what COCO(annFile) holds for the evaluator."""
+    images, anns = [], []
+    for targets in batches:
+        for t in targets:
+            h, w = (int(v) for v in t["orig_size"].tolist())
+            img = int(t["image_id"])
+            images.append({"id": img, "height": h, "width": w})
+            boxes = t["boxes"].detach().float().cpu()
+            for j in range(boxes.shape[0]):
+                cx, cy, bw, bh = (float(v) for v in boxes[j])
+                ann = {"id": len(anns) + 1, "image_id": img, "category_id": 1, "iscrowd": 0,
+                       "bbox": [(cx - bw / 2) * w, (cy - bh / 2) * h, bw * w, bh * h], "area": bw * w * bh * h}
+                if "masks" in t:
+                    m = t["masks"][j].cpu().numpy()
+                    ann["segmentation"], ann["area"] = m, float(m.sum())
+                anns.append(ann)
+    return {"images": images, "annotations": anns, "categories": [{"id": 1, "name": "preferred"}]}
+
+
+@torch.no_grad()
+def evaluate(model, criterion, cluster_criterion, postprocessors, weight_dict, batches, evaluator_list, device, args):
+    """The reference's evaluation loop: per batch encode -> (prototype choice) -> decode -> losses for logging -> PostProcess
+    (-> PostProcessSegm) -> evaluator.update; then gather across ranks, accumulate, summarize.  `batches` yields dicts with
+    "samples", "tokenized" (or captions), "targets", "positive_map"; returns {"loss": ..., "coco_eval_bbox": [12 numbers],
+    "coco_eval_masks": [...]}."""
+    from . import dist as tdist
+    model.eval()
+    if criterion is not None:
+        criterion.eval()
+    if cluster_criterion is not None:
+        cluster_criterion.eval()
+    sums, n = {}, 0
+    for batch in batches:
+        samples, targets = batch["samples"], batch["targets"]
+        text = batch["tokenized"] if "tokenized" in batch else [t["caption"] for t in targets]
+        memory_cache = model(samples, text, encode_and_save=True)
+        if getattr(args, "cluster", False):
+            memory_cache = cluster_criterion.infer_choice(memory_cache, [t["dataset_name"] for t in targets], [t["caption"] for t in targets])
+        outputs = model(samples, text, encode_and_save=False, memory_cache=memory_cache)
+        if criterion is not None:
+            loss_dict = tdist.reduce_dict(criterion(memory_cache, outputs, targets, batch.get("positive_map"), batch.get("example_rel")))
+            for name, v in loss_dict.items():
+                sums[name] = sums.get(name, 0.0) + float(v)
+            sums["loss"] = sums.get("loss", 0.0) + float(sum(loss_dict[name] * weight_dict[name] for name in loss_dict if name in weight_dict))
+        n += 1
+        orig = torch.stack([t["orig_size"] for t in targets], dim=0)
+        results = postprocessors["bbox"](outputs, orig)
+        if "segm" in postprocessors:
+            results = postprocessors["segm"](results, outputs, orig, torch.stack([t["size"] for t in targets], dim=0))
+        res = {int(t["image_id"]): r for t, r in zip(targets, results)}
+        for evaluator in evaluator_list:
+            evaluator.update(res)
+    stats = {name: v / max(n, 1) for name, v in sums.items()}
+    for evaluator in evaluator_list:
+        evaluator.synchronize_between_processes()
+        evaluator.accumulate()
+        evaluator.summarize(verbose=tdist.is_main_process() and getattr(args, "verbose_eval", False))
+        if "bbox" in evaluator.coco_eval:
+            stats["coco_eval_bbox"] = evaluator.coco_eval["bbox"].stats.tolist()
+        if "segm" in evaluator.coco_eval:
+            stats["coco_eval_masks"] = evaluator.coco_eval["segm"].stats.tolist()
+    return stats
