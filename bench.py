@@ -186,6 +186,7 @@ def main():
 
     import toist_amd
     from toist_amd import harness, kernels, parallel
+    from toist_amd.mdetr import weighted_total
     if a.distill:
         return bench_distillation(a, dev, rank, world)
     args = harness.default_args(device="cuda", masks=a.masks, mask_model="smallconv" if a.masks else "none")
@@ -233,7 +234,7 @@ def main():
         mc = model(samples, tok, encode_and_save=True)
         out = model(samples, tok, encode_and_save=False, memory_cache=mc)
         losses = criterion(mc, out, targets, pmap, None)
-        total = sum(losses[k] * weight_dict[k] for k in losses if k in weight_dict)
+        total = weighted_total(losses, weight_dict)
         total.backward()                     # with the backbone cut (N > 1): everything but the backbone
         cut_state["mc"] = mc
         return total

@@ -78,3 +78,31 @@ def test_losses_and_gradients_vs_oracle(dev, seed, B, sizes):
         err = (got.cpu() - ref).abs().max()
         scale = ref.abs().max() + 1e-12
         assert float(err) <= 1e-3 * float(scale) + 1e-7, f"{name}: max err {float(err)} (scale {float(scale)})"
+
+
+def test_weighted_total_equals_the_key_by_key_sum(dev):
+    """engine.py:77 sums the loss dict key by key; weighted_total forms the same value and the same gradients from the stacked tensors."""
+    import toist_amd
+    from toist_amd import harness
+    torch.manual_seed(0)
+    args = harness.default_args(device="cuda", enc_layers=1, dec_layers=3, num_queries=12)
+    _, criterion, _, weight_dict = toist_amd.build_model(args)
+    _, _, targets, pmap = harness.synthetic_batch(3, 64, 64, tokens=8, seed=2, device=dev, max_targets=4)
+
+    def run(fused):
+        g = torch.Generator().manual_seed(1)
+        logits = torch.randn(3, 3, 12, 256, generator=g).to(dev).requires_grad_(True)
+        boxes = (torch.rand(3, 3, 12, 4, generator=g) * 0.5 + 0.2).to(dev).requires_grad_(True)
+        outputs = {"pred_logits": logits[-1], "pred_boxes": boxes[-1],
+                   "aux_outputs": [{"pred_logits": logits[l], "pred_boxes": boxes[l]} for l in range(2)]}
+        losses = criterion({}, outputs, targets, pmap, None)
+        assert hasattr(losses, "groups") and "loss_giou_1" in losses
+        total = toist_amd.weighted_total(losses, weight_dict) if fused else sum(losses[k_] * weight_dict[k_] for k_ in losses if k_ in weight_dict)
+        total.backward()
+        return float(total), logits.grad.clone(), boxes.grad.clone()
+    a, b = run(True), run(False)
+    assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0])
+    assert torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-8) and torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-8)
+    # a plain dict (e.g. after reduce_dict) takes the key-by-key route
+    plain = {"loss_ce": torch.tensor(2.0, device=dev), "other": torch.tensor(5.0, device=dev)}
+    assert float(toist_amd.weighted_total(plain, {"loss_ce": 3.0})) == 6.0

@@ -17,7 +17,7 @@ def build_model(args):
 def __getattr__(name):
     import importlib
     table = {
-        "SetCriterion": ("mdetr", "SetCriterion"), "MDETR": ("mdetr", "MDETR"), "HungarianMatcher": ("matcher", "HungarianMatcher"),
+        "SetCriterion": ("mdetr", "SetCriterion"), "weighted_total": ("mdetr", "weighted_total"), "MDETR": ("mdetr", "MDETR"), "HungarianMatcher": ("matcher", "HungarianMatcher"),
         "build_matcher": ("matcher", "build_matcher"), "PostProcess": ("postprocessors", "PostProcess"),
         "PostProcessSegm": ("postprocessors", "PostProcessSegm"), "build_postprocessors": ("postprocessors", "build_postprocessors"),
         "NestedTensor": ("misc", "NestedTensor"), "targets_to": ("misc", "targets_to"),

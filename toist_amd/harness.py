@@ -113,7 +113,8 @@ def distillation_step(model, model_noun, criterion, cluster_criterion, weight_di
     out_sth = model(s_sth, k_sth, encode_and_save=False, memory_cache=mc_sth)
     losses = criterion([mc_noun, mc_sth], [out_noun, out_sth], [t_noun, t_sth], batch["positive_map"], batch.get("example_rel"))
     losses.update(loss_cluster)
-    total = sum(losses[k] * weight_dict[k] for k in losses if k in weight_dict)
+    from .mdetr import weighted_total
+    total = weighted_total(losses, weight_dict)
     return total, losses
 
 
@@ -146,6 +147,7 @@ def evaluate(model, criterion, cluster_criterion, postprocessors, weight_dict, b
     "samples", "tokenized" (or captions), "targets", "positive_map"; returns {"loss": ..., "coco_eval_bbox": [12 numbers],
     "coco_eval_masks": [...]}."""
     from . import dist as tdist
+    from .mdetr import weighted_total
     model.eval()
     if criterion is not None:
         criterion.eval()
@@ -163,7 +165,7 @@ def evaluate(model, criterion, cluster_criterion, postprocessors, weight_dict, b
             loss_dict = tdist.reduce_dict(criterion(memory_cache, outputs, targets, batch.get("positive_map"), batch.get("example_rel")))
             for name, v in loss_dict.items():
                 sums[name] = sums.get(name, 0.0) + float(v)
-            sums["loss"] = sums.get("loss", 0.0) + float(sum(loss_dict[name] * weight_dict[name] for name in loss_dict if name in weight_dict))
+            sums["loss"] = sums.get("loss", 0.0) + float(weighted_total(loss_dict, weight_dict))
         n += 1
         orig = torch.stack([t["orig_size"] for t in targets], dim=0)
         results = postprocessors["bbox"](outputs, orig)

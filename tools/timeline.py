@@ -63,3 +63,32 @@ for s, e, _ in step:
     us = (e - s) / 1e3
     bk["<4us" if us < 4 else "4-8us" if us < 8 else "8-16us" if us < 16 else "16-32us" if us < 32 else "32-64us" if us < 64 else ">=64us"] += 1
 print("duration histogram:", dict(bk), file=out)
+
+# phases of the replayed step (matcher -> ... -> next matcher), delimited by kernels that occur once per step
+def first(pred, start=0):
+    for i in range(start, len(step)):
+        if pred(step[i][2]):
+            return i
+    return None
+
+
+conv_like = lambda n: "conv3_kernel" in n or re.search(r"gemm_kernel<\d+, \d+, \d+, [23],", n) is not None or re.search(r"gemm_kernel<\d+, \d+, \d+, \d, 2,", n) is not None
+i_bb_bwd = first(conv_like)
+i_opt = first(lambda n: "sqnorm_kernel" in n)
+i_opt_end = first(lambda n: "adamw_ema_kernel" in n)
+i_pos = first(lambda n: "sine_pos" in n, i_opt_end or 0)
+if None not in (i_bb_bwd, i_opt, i_opt_end, i_pos):
+    cuts = [("criterion + transformer backward", 0, i_bb_bwd), ("backbone backward (+ text branch)", i_bb_bwd, i_opt),
+            ("optimizer tail", i_opt, i_opt_end + 1), ("stem + backbone forward (+ text branch)", i_opt_end + 1, i_pos),
+            ("transformer forward + heads", i_pos, len(step))]
+    print("phases (wall between first kernels):", file=out)
+    for name, a, b in cuts:
+        if b <= a:
+            continue
+        w0 = step[a][0]
+        w1 = step[b][0] if b < len(step) else t1
+        print(f"  {name:45s} {1e-6 * (w1 - w0):7.3f} ms  {b - a:5d} kernels  sum {1e-6 * sum(e - s for s, e, _ in step[a:b]):7.3f} ms", file=out)
+if len(sys.argv) > 3:                      # optional: dump the kernel sequence (name, us) of the analysed step
+    with open(sys.argv[3], "w") as f:
+        for s, e, n in step:
+            f.write(f"{1e-3 * (s - t0):9.1f} {1e-3 * (e - s):7.1f} {short(n)}\n")
