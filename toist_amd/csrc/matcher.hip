@@ -124,7 +124,9 @@ __device__ __forceinline__ int lsap_solve_wave(const float* cw, const int R, con
     return st;
 }
 
-__global__ __launch_bounds__(256) void matcher_kernel(
+static constexpr int MATCH_THREADS = 1024;   // 16 waves build the cost block (one query per wave at a time); wave 0 solves
+
+__global__ __launch_bounds__(MATCH_THREADS) void matcher_kernel(
     const float* __restrict__ logits,   // [L,B,Q,K]
     const float* __restrict__ boxes,    // [L,B,Q,4] cxcywh
     const float* __restrict__ tgt_box,  // [Ttot,4] cxcywh
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(256) void matcher_kernel(
     long long* __restrict__ src_idx,    // [L, Mtot]
     long long* __restrict__ tgt_idx,    // [L, Mtot]
     int* __restrict__ status,           // [L*B]
-    float* __restrict__ cost_out)       // optional [L, B*Q, Ttot]
+    float* __restrict__ cost_out,       // optional [L, B*Q, Ttot]
+    int stage_bytes)                    // > 0: LDS offset of a staging area for this image's positive-map rows and boxes
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lb = blockIdx.x;
@@ -167,6 +170,17 @@ __global__ __launch_bounds__(256) void matcher_kernel(
     int* bad = in_sc + C;                                     // [1]
     float* cw = reinterpret_cast<float*>(bad + 1);            // [R*C] oriented cost
 
+    // The T positive-map rows and target boxes of this image are read once per query: from global memory every (q, t) step
+    // is one exposed L2 round trip (~250 of them per wave); staged in LDS when they fit.  Same values, same arithmetic.
+    const float* pm_base = pos_map + (size_t)t0 * K;
+    const float* tb_base = tgt_box + (size_t)t0 * 4;
+    if (stage_bytes > 0) {
+        float* stage = reinterpret_cast<float*>(smem + stage_bytes);
+        for (int e = tid; e < T * K; e += MATCH_THREADS) stage[e] = pm_base[e];
+        for (int e = tid; e < T * 4; e += MATCH_THREADS) stage[T * K + e] = tb_base[e];
+        pm_base = stage;
+        tb_base = stage + T * K;
+    }
     if (tid == 0) *bad = 0;
     __syncthreads();
 
@@ -174,18 +188,24 @@ __global__ __launch_bounds__(256) void matcher_kernel(
     const float* lg = logits + ((size_t)(l * B + b) * Q) * K;
     const float* bx = boxes + ((size_t)(l * B + b) * Q) * 4;
     int my_bad = 0;
-    for (int q = wave; q < Q; q += 4) {
-        // softmax over K (exp(x - max) / sum)
+    for (int q = wave; q < Q; q += MATCH_THREADS / 64) {
+        // softmax over K (exp(x - max) / sum); the row is fetched once
         const float* row = lg + (size_t)q * K;
-        float mx = -INFINITY;
-        for (int k = lane; k < K; k += 64) mx = fmaxf(mx, row[k]);
-        mx = wave_max(mx);
         float pr[8];  // K <= 512
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int k = lane + 64 * m;
+            pr[m] = (k < K) ? row[k] : -INFINITY;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) mx = fmaxf(mx, pr[m]);
+        mx = wave_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int k = lane + 64 * m;
-            pr[m] = (k < K) ? expf(row[k] - mx) : 0.f;
+            pr[m] = (k < K) ? expf(pr[m] - mx) : 0.f;
             sum += pr[m];
         }
         sum = wave_sum(sum);
@@ -196,18 +216,26 @@ __global__ __launch_bounds__(256) void matcher_kernel(
         const float ax0 = cx - 0.5f * w, ay0 = cy - 0.5f * h, ax1 = cx + 0.5f * w, ay1 = cy + 0.5f * h;
         const float area_a = (ax1 - ax0) * (ay1 - ay0);
 
-        for (int t = 0; t < T; ++t) {
-            const float* pm = pos_map + (size_t)(t0 + t) * K;
-            float dot = 0.f;
+        // class term: one wave-wide dot product per target; then lane t finishes target t (box L1, GIoU, weighted sum) so the
+        // scalar tail runs once per query instead of once per (query, target)
+        for (int tb0 = 0; tb0 < T; tb0 += 64) {
+            const int tn = min(64, T - tb0);
+            float mydot = 0.f;
+            for (int tt = 0; tt < tn; ++tt) {
+                const float* pm = pm_base + (size_t)(tb0 + tt) * K;
+                float dot = 0.f;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int k = lane + 64 * m;
-                if (k < K) dot += pr[m] * pm[k];
+                for (int m = 0; m < 8; ++m) {
+                    const int k = lane + 64 * m;
+                    if (k < K) dot += pr[m] * pm[k];
+                }
+                dot = wave_sum(dot);
+                if (lane == tt) mydot = dot;
             }
-            dot = wave_sum(dot);
-            if (lane == 0) {
-                const float cost_class = -dot;
-                const float* tb = tgt_box + (size_t)(t0 + t) * 4;
+            if (lane < tn) {
+                const int t = tb0 + lane;
+                const float cost_class = -mydot;
+                const float* tb = tb_base + (size_t)t * 4;
                 const float tcx = tb[0], tcy = tb[1], tw = tb[2], th = tb[3];
                 const float cost_bbox = ((fabsf(cx - tcx) + fabsf(cy - tcy)) + fabsf(w - tw)) + fabsf(h - th);
                 const float bx0 = tcx - 0.5f * tw, by0 = tcy - 0.5f * th, bx1 = tcx + 0.5f * tw, by1 = tcy + 0.5f * th;
@@ -347,15 +375,21 @@ extern "C" int toist_matcher(const float* logits, const float* boxes, const floa
         if (e != hipSuccess) { set_last_error("toist_matcher: memset: %s", hipGetErrorString(e)); return TOIST_EHIP; }
         return TOIST_OK;
     }
-    const size_t lds = matcher_lds_bytes(Q, max_T);
+    size_t lds = matcher_lds_bytes(Q, max_T);
     TOIST_REQUIRE(lds <= 160 * 1024, "toist_matcher: Q=%d max_T=%d needs %zu B of LDS (> 160 KiB)", Q, max_T, lds);
+    const size_t stage = sizeof(float) * (size_t)max_T * ((size_t)K + 4);
+    int stage_off = 0;
+    if (lds + stage <= 64 * 1024) {   // staging is an optimisation: only while the block stays within the default LDS window
+        stage_off = (int)lds;
+        lds += stage;
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)matcher_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_last_error("toist_matcher: set LDS size: %s", hipGetErrorString(e)); return TOIST_EHIP; }
     }
-    hipLaunchKernelGGL(matcher_kernel, dim3(L * B), dim3(256), lds, (hipStream_t)stream, logits, boxes, tgt_boxes,
+    hipLaunchKernelGGL(matcher_kernel, dim3(L * B), dim3(MATCH_THREADS), lds, (hipStream_t)stream, logits, boxes, tgt_boxes,
                        pos_map, tgt_off_dev, match_off_dev, L, B, Q, K, w_class, w_bbox, w_giou,
-                       (long long*)src_idx, (long long*)tgt_idx, status, cost_out);
+                       (long long*)src_idx, (long long*)tgt_idx, status, cost_out, stage_off);
     return check_launch("toist_matcher");
 }
 
