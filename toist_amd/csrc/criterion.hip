@@ -11,13 +11,18 @@
 
 namespace toist {
 
+static constexpr int CRIT_THREADS = 1024;   // 16 waves, one query per wave at a time (the kernel is latency-bound: 48 blocks)
+
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) red[w] = v;
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < CRIT_THREADS / 64; ++i) t += red[i];
+    return t;
 }
 
 struct GiouPair {
@@ -62,7 +67,7 @@ __device__ __forceinline__ GiouPair giou_pair(const float* a, const float* b) {
 
 // MODE 0: forward (losses). MODE 1: backward (dlogits, dboxes from the upstream gradients of the losses).
 template <int MODE>
-__global__ __launch_bounds__(256) void criterion_kernel(
+__global__ __launch_bounds__(CRIT_THREADS) void criterion_kernel(
     const float* __restrict__ logits, const float* __restrict__ boxes, const float* __restrict__ tgt_box,
     const float* __restrict__ pos_map, const int* __restrict__ tgt_off, const int* __restrict__ match_off,
     const long long* __restrict__ src_idx, const long long* __restrict__ tgt_idx, const float* __restrict__ num_boxes,
@@ -71,15 +76,15 @@ __global__ __launch_bounds__(256) void criterion_kernel(
     const float* __restrict__ upstream,     // MODE 1: [L,4] gradient of the total w.r.t. each loss
     float* __restrict__ dlogits, float* __restrict__ dboxes) {
     extern __shared__ int qmap[];           // [Q] global target row matched to query q, or -1
-    __shared__ float red[4];
+    __shared__ float red[CRIT_THREADS / 64];
     const int lb = blockIdx.x, l = lb / B, b = lb % B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Mtot = match_off[B];
     const int m_beg = match_off[b], m_end = match_off[b + 1];
     const int T = tgt_off[b + 1] - tgt_off[b];
-    for (int q = tid; q < Q; q += 256) qmap[q] = -1;
+    for (int q = tid; q < Q; q += CRIT_THREADS) qmap[q] = -1;
     __syncthreads();
-    for (int m = m_beg + tid; m < m_end; m += 256)
+    for (int m = m_beg + tid; m < m_end; m += CRIT_THREADS)
         qmap[(int)src_idx[(size_t)l * Mtot + m]] = tgt_off[b] + (int)tgt_idx[(size_t)l * Mtot + m];
     __syncthreads();
 
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void criterion_kernel(
         g_gi = upstream[l * 4 + 2] * inv_nb;
     }
     float ce_acc = 0.f, l1_acc = 0.f, gi_acc = 0.f, card = 0.f;
-    for (int q = wave; q < Q; q += 4) {
+    for (int q = wave; q < Q; q += CRIT_THREADS / 64) {
         const float* row = lg + (size_t)q * K;
         float x[8];
         float mx = -INFINITY;
@@ -198,7 +203,7 @@ extern "C" int toist_criterion_fwd(const float* logits, const float* boxes, cons
                                    const int32_t* tgt_off, const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx,
                                    const float* num_boxes, int L, int B, int Q, int K, float eos_coef, float* losses, void* stream) {
     if (int rc = criterion_args_ok(L, B, Q, K)) return rc;
-    hipLaunchKernelGGL(criterion_kernel<0>, dim3(L * B), dim3(256), sizeof(int) * Q, (hipStream_t)stream, logits, boxes, tgt_boxes, pos_map,
+    hipLaunchKernelGGL(criterion_kernel<0>, dim3(L * B), dim3(CRIT_THREADS), sizeof(int) * Q, (hipStream_t)stream, logits, boxes, tgt_boxes, pos_map,
                        tgt_off, match_off, (const long long*)src_idx, (const long long*)tgt_idx, num_boxes, L, B, Q, K, eos_coef, losses,
                        (const float*)nullptr, (float*)nullptr, (float*)nullptr);
     return check_launch("toist_criterion_fwd");
@@ -209,7 +214,7 @@ extern "C" int toist_criterion_bwd(const float* logits, const float* boxes, cons
                                    const float* num_boxes, int L, int B, int Q, int K, float eos_coef, const float* upstream,
                                    float* dlogits, float* dboxes, void* stream) {
     if (int rc = criterion_args_ok(L, B, Q, K)) return rc;
-    hipLaunchKernelGGL(criterion_kernel<1>, dim3(L * B), dim3(256), sizeof(int) * Q, (hipStream_t)stream, logits, boxes, tgt_boxes, pos_map,
+    hipLaunchKernelGGL(criterion_kernel<1>, dim3(L * B), dim3(CRIT_THREADS), sizeof(int) * Q, (hipStream_t)stream, logits, boxes, tgt_boxes, pos_map,
                        tgt_off, match_off, (const long long*)src_idx, (const long long*)tgt_idx, num_boxes, L, B, Q, K, eos_coef,
                        (float*)nullptr, upstream, dlogits, dboxes);
     return check_launch("toist_criterion_bwd");
