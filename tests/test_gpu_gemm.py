@@ -237,6 +237,14 @@ def test_rows(dev):
         _close(dx, xr.grad, 1, "ln dx", rtol=2e-2, atol_unit=2e-2)
         _close(dg, gr.grad, rows, "ln dgamma", rtol=1e-2, atol_unit=1e-2)
         _close(db, br.grad, rows, "ln dbeta", rtol=1e-2, atol_unit=1e-2)
+        # fused branch gradient: the same pass also emits dropout(dx) with the (seed, flat index) mask of the standalone kernel
+        dx2, dxd = torch.empty_like(xd), torch.empty_like(xd)
+        k.layernorm_bwd(dy.to(dev), xd, mean, rstd, gamma.to(dev), dx2, None, None, dx_drop=dxd, drop_p=0.25, seed=99)
+        ref = torch.empty_like(xd)
+        k.dropout(dx2, 0.25, 99, ref)
+        assert torch.equal(dx2, dx)
+        assert torch.equal(dxd == 0, ref == 0) and 0.2 < float((dxd == 0).float().mean()) < 0.3
+        assert torch.allclose(dxd.float(), ref.float(), rtol=1e-2, atol=1e-6)        # masked from the unrounded value: <= 1 bf16 ulp apart
     a, b = _rand((64, 256), g), _rand((8, 256), g)
     out = torch.empty(64, 256, dtype=BF, device=dev)
     k.add(a.to(dev), b.to(dev), out, b_period=8 * 256)

@@ -21,12 +21,22 @@ BF16 = torch.bfloat16
 class Var:
     """An activation (bf16, [rows, features] or NHWC) and its gradient slot."""
 
-    __slots__ = ("data", "grad", "needs_grad")
+    __slots__ = ("data", "grad", "needs_grad", "drop", "gdrop")
 
     def __init__(self, data, needs_grad=True):
         self.data = data
         self.grad = None
         self.needs_grad = needs_grad
+        self.drop = None    # (p, seed) when data = residual + dropout(branch): the branch gradient is dropout(grad) with that mask
+        self.gdrop = None   # that masked gradient, when the consumer's backward produced it in the same pass (layernorm)
+
+    def take_branch_grad(self, g):
+        """dropout-masked copy of the gradient g for the `dropout(branch)` term (one extra launch unless the consumer made it)."""
+        gd, self.gdrop = self.gdrop, None
+        if gd is None:
+            gd = torch.empty_like(g)
+            k.dropout(g, self.drop[0], self.drop[1], gd)
+        return gd
 
     def take_grad(self):
         g, self.grad = self.grad, None
@@ -288,6 +298,8 @@ def linear_chain(tape, x, layers, res=None, final_drop=False, out_dtype=BF16, la
         seeds.append(seed)
         cur = y
     out = Var(cur)
+    if final_drop and p > 0:
+        out.drop = (p, seeds[-1])
 
     def bwd():
         g = out.take_grad()
@@ -304,9 +316,7 @@ def linear_chain(tape, x, layers, res=None, final_drop=False, out_dtype=BF16, la
             if last:
                 # g is the gradient w.r.t. the layer output after residual; undo dropout / activation
                 if final_drop and p > 0:
-                    gd = torch.empty_like(g)
-                    k.dropout(g, p, seeds[i], gd)
-                    g = gd
+                    g = out.take_branch_grad(g)
                 if act != k.ACT_NONE and not last_act_external:
                     raise NotImplementedError("activation on the last layer of a chain needs last_act_external")
             # g is now the gradient w.r.t. the pre-activation output of layer i
@@ -351,7 +361,13 @@ def layernorm(tape, x, gamma, beta, eps, y=None):
         if g is None:
             return
         dx = torch.empty_like(g)
-        k.layernorm_bwd(g, x.data, mean, rstd, gamma.f32, dx, gamma.g, beta.g if gamma.g is not None else None)
+        if x.drop is not None and x.grad is None and x.needs_grad:
+            # x = residual + dropout(branch): emit the branch's masked gradient from the same pass over dx
+            x.gdrop = torch.empty_like(g)
+            k.layernorm_bwd(g, x.data, mean, rstd, gamma.f32, dx, gamma.g, beta.g if gamma.g is not None else None, dx_drop=x.gdrop,
+                            drop_p=x.drop[0], seed=x.drop[1])
+        else:
+            k.layernorm_bwd(g, x.data, mean, rstd, gamma.f32, dx, gamma.g, beta.g if gamma.g is not None else None)
         if x.needs_grad:
             accumulate(x, dx)
 
@@ -459,6 +475,8 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
     seed_o = tape.next_seed() if p > 0 else 0
     z = ops.linear(ctx, Wo.w, bo.f32, res=resid.data, drop_where=1 if p > 0 else 0, drop_p=p, drop_seed=seed_o)
     out = Var(z)
+    if p > 0:
+        out.drop = (p, seed_o)
 
     def bwd():
         g = out.take_grad()
@@ -466,11 +484,7 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
             return
         if resid.needs_grad:
             accumulate(resid, g)
-        if p > 0:
-            go = torch.empty_like(g)
-            k.dropout(g, p, seed_o, go)
-        else:
-            go = g
+        go = out.take_branch_grad(g) if p > 0 else g
         if Wo.g is not None:
             ops.linear_wgrad(go, ctx, out=Wo.g, bias_out=bo.g, defer=True)
         dctx = ops.linear_dgrad(go, Wo.w)
