@@ -317,3 +317,56 @@ def test_fused_attention_forward_matches_three_kernel_path(dev, Sq, Sk, drop):
     if drop == 0:
         ref = (pr @ vf).permute(0, 2, 1, 3).reshape(B * Sq, d)
         assert float((c1.float() - ref).abs().max()) <= 3e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("Sq,Sk,drop", [(416, 416, 0.1), (100, 416, 0.1), (100, 100, 0.1), (20, 32, 0.0), (37, 50, 0.1), (130, 250, 0.0), (70, 480, 0.1)])
+def test_fused_attention_backward_matches_five_kernel_path(dev, Sq, Sk, drop):
+    """csrc/attn.hip backward (dQ, dK, dV in one launch) against the four batched GEMMs + softmax backward it replaces, and against
+    fp32 autograd on the same probabilities' inputs (no dropout); packed per-head slices, key-padding mask."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(Sq * 1000 + Sk + 7)
+    B, H, dh = 2, 8, 32
+    d = H * dh
+    q = torch.randn(B * Sq, d, generator=g).to(BF).to(dev)
+    kk = torch.randn(B * Sk, d, generator=g).to(BF).to(dev)
+    v = torch.randn(B * Sk, d, generator=g).to(BF).to(dev)
+    dctx = torch.randn(B * Sq, d, generator=g).to(BF).to(dev)
+    pad = torch.zeros(B, Sk, dtype=torch.uint8)
+    pad[1, Sk - Sk // 3:] = 1
+    pad = pad.to(dev)
+    scale = 1.0 / math.sqrt(dh)
+    k.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+    ld = ops.round8(Sk)
+    prob = torch.zeros(B * H, Sq, ld, dtype=BF, device=dev)
+    pdrop = torch.zeros_like(prob) if drop > 0 else None
+    ctx = torch.empty(B * Sq, d, dtype=BF, device=dev)
+    k.attn_fwd(q, kk, v, pad, B, H, Sq, Sk, dh, scale, prob, pdrop, drop, 4321, ctx)
+    # the five-kernel path
+    dq0, dk0, dv0 = (torch.empty(B * Sq, d, dtype=BF, device=dev), torch.empty(B * Sk, d, dtype=BF, device=dev), torch.empty(B * Sk, d, dtype=BF, device=dev))
+
+    def sm_bwd(dp):
+        ds = torch.empty_like(dp)
+        k.softmax_bwd(prob, dp, B * H * Sq, Sk, ld, ds, drop, 4321)
+        return ds
+    ops.attn_backward(pdrop if pdrop is not None else prob, scale, q, kk, v, dctx, B, H, Sq, Sk, dh, dq0, dk0, dv0, sm_bwd)
+    # fused, written into column slices of wider buffers (as the engine does for the packed q|k gradient)
+    dqk = torch.full((B * Sq, 2 * d), 7.0, dtype=BF, device=dev)
+    dk1, dv1 = torch.empty(B * Sk, d, dtype=BF, device=dev), torch.empty(B * Sk, d, dtype=BF, device=dev)
+    dq1 = dqk[:, d:]
+    k.attn_bwd(q, kk, v, prob, pdrop, ctx, dctx, B, H, Sq, Sk, dh, scale, drop, dq1, dk1, dv1)
+    assert bool((dqk[:, :d] == 7.0).all())
+    for name, a, b in (("dq", dq1, dq0), ("dk", dk1, dk0), ("dv", dv1, dv0)):
+        err = float((a.float() - b.float()).norm() / b.float().norm())
+        assert err < 2e-2, (name, err)
+    assert bool((dk1.view(B, Sk, d)[1, Sk - Sk // 3:] == 0).all()) and bool((dv1.view(B, Sk, d)[1, Sk - Sk // 3:] == 0).all())
+    if drop == 0:
+        qf = q.float().view(B, Sq, H, dh).permute(0, 2, 1, 3).requires_grad_(True)
+        kf = kk.float().view(B, Sk, H, dh).permute(0, 2, 1, 3).requires_grad_(True)
+        vf = v.float().view(B, Sk, H, dh).permute(0, 2, 1, 3).requires_grad_(True)
+        sc = ((qf @ kf.transpose(-1, -2)) * scale).masked_fill(pad.bool()[:, None, None, :], float("-inf"))
+        out = (sc.softmax(-1) @ vf).permute(0, 2, 1, 3).reshape(B * Sq, d)
+        out.backward(dctx.float())
+        for name, a, ref in (("dq", dq1, qf.grad), ("dk", dk1, kf.grad), ("dv", dv1, vf.grad)):
+            ref = ref.permute(0, 2, 1, 3).reshape(a.shape)
+            err = float((a.float() - ref).norm() / ref.norm())
+            assert err < 2e-2, (name, "vs fp32", err)

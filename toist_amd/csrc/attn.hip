@@ -119,6 +119,196 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     }
 }
 
+// Fused attention core, backward: from the saved probabilities, dO and the forward context it produces dQ, dK, dV of one
+// (image, head) in ONE launch -- replaces dV = Pd^T dO, dPd = dO V^T, the softmax backward, dQ = scale dS K and
+// dK = scale dS^T Q (four batched GEMMs + one row kernel, each launch-latency-bound at these sizes).
+//
+// One workgroup of 8 wavefronts per (image, head); queries in tiles of 64.
+//   phase A (wave = a slice of NBW 16-key blocks): dPd = dO V^T comes out of the MFMA with lane (key c16, group g) holding
+//     queries 4g .. 4g+3 of each 16-query block, so dS = P o (dP - D), D = rowsum(dO o O) (no cross-lane reduction), and
+//     dS^T / Pd^T feed dK += dS^T Q and dV += Pd^T dO straight from registers as the B operand (reduction slot 8g' + r <->
+//     query 32c + 4g' + r, slot 8g' + 4 + r <-> query 32c + 16 + 4g' + r); dK, dV accumulate in registers over all tiles.
+//     dS is also written to LDS key-major.
+//   phase B (wave = one 16 x 16 block of the tile's dQ): dQ = dS K with both operands read k-major from LDS.
+template <int NBW>   // 16-key blocks per wave: keys <= 8 * NBW * 16
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ kmat, int ldk,
+                                                       const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ prob,
+                                                       const bf16_t* __restrict__ prob_drop, const bf16_t* __restrict__ ctx, int ldo,
+                                                       const bf16_t* __restrict__ dctx, int lddo, int H, int Sq, int Sk, int ld, float scale,
+                                                       float drop_p, bf16_t* __restrict__ dq, int lddq, bf16_t* __restrict__ dk, int lddk,
+                                                       bf16_t* __restrict__ dv, int lddv) {
+    constexpr int SKP = 8 * NBW * 16, DH = 32, QT = 64, TS = QT + 8;   // TS: row stride of the transposed tiles (bank spread)
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    bf16_t* sV = smem;                       // [SKP][32]
+    bf16_t* sK = sV + SKP * DH;              // [SKP][32]
+    bf16_t* sdST = sK + SKP * DH;            // [SKP][TS]   dS^T of the current tile
+    bf16_t* sdO = sdST + SKP * TS;           // [QT][32]
+    bf16_t* sdOT = sdO + QT * DH;            // [32][TS]
+    bf16_t* sQT = sdOT + DH * TS;            // [32][TS]
+    float* sD = reinterpret_cast<float*>(sQT + DH * TS);   // [QT]
+    typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const float dscale = prob_drop ? 1.f / (1.f - drop_p) : 1.f;
+
+    for (int c = tid; c < SKP * 4; c += 512) {
+        const int key = c >> 2, ch = c & 3;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key < Sk) {
+            kv = *reinterpret_cast<const uint4*>(kmat + ((size_t)b * Sk + key) * ldk + h * DH + ch * 8);
+            vv = *reinterpret_cast<const uint4*>(v + ((size_t)b * Sk + key) * ldv + h * DH + ch * 8);
+        }
+        *reinterpret_cast<uint4*>(sK + key * DH + (ch << 3)) = kv;
+        *reinterpret_cast<uint4*>(sV + key * DH + (ch << 3)) = vv;
+    }
+
+    f32x4_t accK[NBW][2], accV[NBW][2];
+#pragma unroll
+    for (int kb = 0; kb < NBW; ++kb)
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) { accK[kb][eb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accV[kb][eb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+    // The probabilities a lane needs are 2-byte elements of 4 different rows: un-vectorisable, and a global round trip per
+    // key block would be fully exposed with two waves per SIMD.  They are fetched one key block ahead (across tile boundaries).
+    unsigned short pnx[4][4], dnx[4][4];
+    auto fetch = [&](int q0_, int kb_) {
+        const int key = (wave * NBW + kb_) * 16 + c16;
+#pragma unroll
+        for (int xb = 0; xb < 4; ++xb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = q0_ + xb * 16 + 4 * g + r;
+                unsigned short pv = 0, pd = 0;
+                if (key < Sk && qi < Sq) {
+                    const size_t at = ((size_t)bh * Sq + qi) * ld + key;
+                    pv = prob[at];
+                    pd = prob_drop ? prob_drop[at] : pv;
+                }
+                pnx[xb][r] = pv;
+                dnx[xb][r] = pd;
+            }
+    };
+    fetch(0, 0);
+
+    const int n_tiles = (Sq + QT - 1) / QT;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int q0 = t * QT;
+        {   // ---- tile prologue: dO, Q (transposed copies) and D = rowsum(dO o O) ----
+            const int qq = tid >> 3, ch = tid & 7, qi = q0 + qq;             // 64 queries x 8 chunks of 4 features
+            uint2 d2 = make_uint2(0, 0), o2 = make_uint2(0, 0), q2 = make_uint2(0, 0);
+            if (qi < Sq) {
+                d2 = *reinterpret_cast<const uint2*>(dctx + ((size_t)b * Sq + qi) * lddo + h * DH + ch * 4);
+                o2 = *reinterpret_cast<const uint2*>(ctx + ((size_t)b * Sq + qi) * ldo + h * DH + ch * 4);
+                q2 = *reinterpret_cast<const uint2*>(q + ((size_t)b * Sq + qi) * ldq + h * DH + ch * 4);
+            }
+            const bf16_t* dp = reinterpret_cast<const bf16_t*>(&d2);
+            const bf16_t* op = reinterpret_cast<const bf16_t*>(&o2);
+            const bf16_t* qp = reinterpret_cast<const bf16_t*>(&q2);
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part += bf2f(dp[j]) * bf2f(op[j]);
+                sdOT[(ch * 4 + j) * TS + qq] = dp[j];
+                sQT[(ch * 4 + j) * TS + qq] = qp[j];
+            }
+            *reinterpret_cast<uint2*>(sdO + qq * DH + ch * 4) = d2;
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            if (ch == 0) sD[qq] = part;
+        }
+        __syncthreads();
+
+        // ---- phase A ----
+        bf16x8_t dof[4];                       // A operand of dPd: dO[query xb*16 + c16][8g ..]
+#pragma unroll
+        for (int xb = 0; xb < 4; ++xb) dof[xb] = *reinterpret_cast<const bf16x8_t*>(sdO + (xb * 16 + c16) * DH + g * 8);
+#pragma unroll
+        for (int kb = 0; kb < NBW; ++kb) {
+            const int key = (wave * NBW + kb) * 16 + c16;
+            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + key * DH + g * 8);
+            unsigned short pcu[4][4], dcu[4][4];
+#pragma unroll
+            for (int xb = 0; xb < 4; ++xb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pcu[xb][r] = pnx[xb][r]; dcu[xb][r] = dnx[xb][r]; }
+            if (kb + 1 < NBW) fetch(q0, kb + 1);
+            else if (t + 1 < n_tiles) fetch(q0 + QT, 0);
+            unsigned ds_pk[4][2], pd_pk[4][2];
+#pragma unroll
+            for (int xb = 0; xb < 4; ++xb) {
+                const f32x4_t dpd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[xb], vf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const float4 d4 = *reinterpret_cast<const float4*>(sD + xb * 16 + 4 * g);   // D of queries xb*16 + 4g + r
+                const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+                float dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = bf2f(pcu[xb][r]);
+                    const float dp = (prob_drop == nullptr || dcu[xb][r] != 0) ? dpd[r] * dscale : 0.f;
+                    dsv[r] = pv * (dp - dd[r]);
+                }
+                ds_pk[xb][0] = pack2bf(dsv[0], dsv[1]); ds_pk[xb][1] = pack2bf(dsv[2], dsv[3]);
+                pd_pk[xb][0] = (unsigned)dcu[xb][0] | ((unsigned)dcu[xb][1] << 16);
+                pd_pk[xb][1] = (unsigned)dcu[xb][2] | ((unsigned)dcu[xb][3] << 16);
+                *reinterpret_cast<uint2*>(sdST + key * TS + xb * 16 + 4 * g) = make_uint2(ds_pk[xb][0], ds_pk[xb][1]);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                union { unsigned u[4]; bf16x8_t v8; } sb, pb;
+                sb.u[0] = ds_pk[2 * c][0]; sb.u[1] = ds_pk[2 * c][1]; sb.u[2] = ds_pk[2 * c + 1][0]; sb.u[3] = ds_pk[2 * c + 1][1];
+                pb.u[0] = pd_pk[2 * c][0]; pb.u[1] = pd_pk[2 * c][1]; pb.u[2] = pd_pk[2 * c + 1][0]; pb.u[3] = pd_pk[2 * c + 1][1];
+#pragma unroll
+                for (int eb = 0; eb < 2; ++eb) {
+                    // A operands: Q^T, dO^T [feature eb*16 + c16][query slots of chunk c] (re-read per key block: cheaper than 32 VGPRs)
+                    union { uint2 u[2]; bf16x8_t v8; } a, d;
+                    a.u[0] = *reinterpret_cast<const uint2*>(sQT + (eb * 16 + c16) * TS + 32 * c + 4 * g);
+                    a.u[1] = *reinterpret_cast<const uint2*>(sQT + (eb * 16 + c16) * TS + 32 * c + 16 + 4 * g);
+                    d.u[0] = *reinterpret_cast<const uint2*>(sdOT + (eb * 16 + c16) * TS + 32 * c + 4 * g);
+                    d.u[1] = *reinterpret_cast<const uint2*>(sdOT + (eb * 16 + c16) * TS + 32 * c + 16 + 4 * g);
+                    accK[kb][eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v8, sb.v8, accK[kb][eb], 0, 0, 0);
+                    accV[kb][eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d.v8, pb.v8, accV[kb][eb], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: dQ block (queries qb*16 .., features eb*16 ..) = sum over key chunks of 32 ----
+        {
+            const int qb = wave & 3, eb = wave >> 2;
+            f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int c = 0; c < SKP / 32; ++c) {
+                const int k_lo = 32 * c + 4 * g + (c16 >> 2), k_hi = k_lo + 16;
+                const int col4 = (c16 & 3) * 4;
+                union { struct { s16x4_t a, b; } hh; bf16x8_t v8; } kf, sf;
+                kf.hh.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sK + k_lo * DH + eb * 16 + col4));
+                kf.hh.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sK + k_hi * DH + eb * 16 + col4));
+                sf.hh.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sdST + k_lo * TS + qb * 16 + col4));
+                sf.hh.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sdST + k_hi * TS + qb * 16 + col4));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v8, sf.v8, acc, 0, 0, 0);
+            }
+            const int qi = q0 + qb * 16 + c16;
+            if (qi < Sq)
+                *reinterpret_cast<uint2*>(dq + ((size_t)b * Sq + qi) * lddq + h * DH + eb * 16 + g * 4) =
+                    make_uint2(pack2bf(acc[0] * scale, acc[1] * scale), pack2bf(acc[2] * scale, acc[3] * scale));
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kb = 0; kb < NBW; ++kb) {
+        const int key = (wave * NBW + kb) * 16 + c16;
+        if (key < Sk) {
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) {
+                *reinterpret_cast<uint2*>(dk + ((size_t)b * Sk + key) * lddk + h * DH + eb * 16 + g * 4) =
+                    make_uint2(pack2bf(accK[kb][eb][0] * scale, accK[kb][eb][1] * scale), pack2bf(accK[kb][eb][2] * scale, accK[kb][eb][3] * scale));
+                *reinterpret_cast<uint2*>(dv + ((size_t)b * Sk + key) * lddv + h * DH + eb * 16 + g * 4) =
+                    make_uint2(pack2bf(accV[kb][eb][0], accV[kb][eb][1]), pack2bf(accV[kb][eb][2], accV[kb][eb][3]));
+            }
+        }
+    }
+}
+
 }  // namespace toist
 
 using namespace toist;
@@ -142,4 +332,32 @@ extern "C" int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk,
     else TOIST_ATTN(30);
 #undef TOIST_ATTN
     return check_launch("toist_attn_fwd");
+}
+
+extern "C" int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const void* prob, const void* prob_drop,
+                              const void* ctx, int ldo, const void* dctx, int lddo, int B, int H, int Sq, int Sk, int dh, int ld, float scale,
+                              float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, void* stream) {
+    TOIST_REQUIRE(q && kmat && v && prob && ctx && dctx && dq && dk && dv && B > 0 && H > 0 && Sq > 0 && Sk > 0, "toist_attn_bwd: bad args");
+    TOIST_REQUIRE(dh == 32, "toist_attn_bwd: head dim must be 32 (got %d)", dh);
+    TOIST_REQUIRE(Sk <= 512 && ld >= Sk, "toist_attn_bwd: Sk <= 512 and ld >= Sk (got %d, %d)", Sk, ld);
+    TOIST_REQUIRE((ldq % 4) == 0 && (ldk % 8) == 0 && (ldv % 8) == 0 && (ldo % 4) == 0 && (lddo % 4) == 0 && (lddq % 4) == 0 && (lddk % 4) == 0 &&
+                      (lddv % 4) == 0, "toist_attn_bwd: row strides must keep 8-byte (q, ctx, gradients) / 16-byte (k, v) alignment");
+    TOIST_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "toist_attn_bwd: bad dropout p");
+    hipStream_t st = (hipStream_t)stream;
+#define TOIST_ATTN_BWD(NBW)                                                                                                                  \
+    do {                                                                                                                                     \
+        const size_t lds = sizeof(bf16_t) * ((size_t)2 * (8 * NBW * 16) * 32 + (size_t)(8 * NBW * 16) * 72 + 64 * 32 + 2 * 32 * 72) + 64 * 4;  \
+        if (lds > 64 * 1024) {                                                                                                               \
+            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+            if (e != hipSuccess) { set_last_error("toist_attn_bwd: set LDS size: %s", hipGetErrorString(e)); return TOIST_EHIP; }            \
+        }                                                                                                                                    \
+        hipLaunchKernelGGL((attn_bwd_kernel<NBW>), dim3(B * H), dim3(512), lds, st, (const bf16_t*)q, ldq, (const bf16_t*)kmat, ldk,          \
+                           (const bf16_t*)v, ldv, (const bf16_t*)prob, (const bf16_t*)prob_drop, (const bf16_t*)ctx, ldo, (const bf16_t*)dctx,  \
+                           lddo, H, Sq, Sk, ld, scale, drop_p, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);                       \
+    } while (0)
+    if (Sk <= 128) TOIST_ATTN_BWD(1);
+    else if (Sk <= 256) TOIST_ATTN_BWD(2);
+    else TOIST_ATTN_BWD(4);
+#undef TOIST_ATTN_BWD
+    return check_launch("toist_attn_bwd");
 }

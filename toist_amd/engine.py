@@ -455,7 +455,8 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
     vb = ops.linear(v_in.data, Pv[0].w, Pv[1].f32)
     seed_p = tape.next_seed() if p > 0 else 0
     ctx = torch.empty(B * Sq, d, dtype=BF16, device=dev)
-    if FUSED_ATTENTION and dh == 32 and Sk <= 480:
+    fused_core = FUSED_ATTENTION and dh == 32 and Sk <= 480
+    if fused_core:
         # scores -> mask -> softmax -> dropout -> P V in one launch (csrc/attn.hip); the probabilities are kept for backward.
         # Measured (tools/bench_attn_core.py, B=8): 37.2 vs 61.2 us at 416x416, 25.2 vs 30.9 us at 100x416, 9.4 vs 21.2 us at 100x100
         ld = ops.round8(Sk)
@@ -501,7 +502,13 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
             k.softmax_bwd(prob, dp, B * H * Sq, Sk, ld, ds, p, seed_p)
             return ds
 
-        ops.attn_backward(prob_used, scale, qb, kb, vb, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
+        if fused_core and (Sq <= 128 or Sk <= 128):
+            # dV, dP, softmax backward, dQ, dK in one launch (csrc/attn.hip: attn_bwd_kernel).  Measured (tools/bench_attn_core.py,
+            # B=8): 13.4 vs 38.2 us at 100x100, 36.9 vs 44.7 us at 100x416; at 416x416 the five-kernel path wins (81.9 vs 147.9 us:
+            # the probabilities are 2-byte gathers in the layout the fused kernel needs, and only 64 workgroups exist)
+            k.attn_bwd(qb, kb, vb, prob, prob_used if p > 0 else None, ctx, dctx, B, H, Sq, Sk, dh, scale, p, dq, dk, dv)
+        else:
+            ops.attn_backward(prob_used, scale, qb, kb, vb, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
         if fused:
             if packed_qk[0].g is not None:
                 ops.linear_wgrad(dqk, q_in.data, out=packed_qk[0].g, bias_out=packed_qk[1].g, defer=True)

@@ -32,3 +32,15 @@ for Sq, Sk in [(416, 416), (100, 416), (100, 100)]:
 
     fused = lambda: k.attn_fwd(q, kk, v, pad, B, H, Sq, Sk, dh, sc, p0, pu0, 0.1, 7, c)
     print(f"Sq={Sq} Sk={Sk}: three kernels {1000 * timeit(unfused, 30):7.1f} us   fused {1000 * timeit(fused, 30):7.1f} us", flush=True)
+    # backward: fused kernel vs dV / dP GEMMs + softmax backward + dQ / dK GEMMs
+    fused()
+    dctx = torch.randn(B * Sq, d, device=dev).to(BF)
+    dq, dk, dv = torch.empty(B * Sq, d, dtype=BF, device=dev), torch.empty(B * Sk, d, dtype=BF, device=dev), torch.empty(B * Sk, d, dtype=BF, device=dev)
+
+    def sm_bwd(dp):
+        ds = torch.empty_like(dp)
+        k.softmax_bwd(p0, dp, B * H * Sq, Sk, ld, ds, 0.1, 7)
+        return ds
+    unfused_b = lambda: ops.attn_backward(pu0, sc, q, kk, v, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
+    fused_b = lambda: k.attn_bwd(q, kk, v, p0, pu0, c, dctx, B, H, Sq, Sk, dh, sc, 0.1, dq, dk, dv)
+    print(f"Sq={Sq} Sk={Sk}: backward five kernels {1000 * timeit(unfused_b, 30):7.1f} us   fused {1000 * timeit(fused_b, 30):7.1f} us", flush=True)
