@@ -309,6 +309,206 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const bf16_t* __restrict_
     }
 }
 
+// Second backward variant for long query ranges (encoder self-attention, 416 x 416).  attn_bwd_kernel needs the probabilities as
+// 2-byte gathers (lane = key, four query rows), which makes it texture-path bound when the whole score matrix is large.  Here the
+// score-shaped work is done in the FORWARD layout (lane = query, four consecutive keys: 8-byte loads of P / Pd, D is a per-lane
+// scalar, dQ accumulates from registers exactly like P V in the forward kernel), dS and Pd go to LDS query-major, and the key-side
+// products dK += dS^T Q, dV += Pd^T dO read both operands k-major (ds_read_b64_tr_b16) in a second phase.
+//   tile = 32 queries; phase A: wave = (16-query half, quarter of the key blocks); phase B: wave = key blocks w, w + 8, ...
+template <int NB>   // 16-key blocks, multiple of 8: keys <= 16 * NB
+__global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ kmat, int ldk,
+                                                            const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ prob,
+                                                            const bf16_t* __restrict__ prob_drop, const bf16_t* __restrict__ ctx, int ldo,
+                                                            const bf16_t* __restrict__ dctx, int lddo, int H, int Sq, int Sk, int ld,
+                                                            float scale, float drop_p, bf16_t* __restrict__ dq, int lddq,
+                                                            bf16_t* __restrict__ dk, int lddk, bf16_t* __restrict__ dv, int lddv) {
+    constexpr int SKP = NB * 16, DH = 32, QT = 32, LS = SKP + 8, NBQ = NB / 4, NBW = NB / 8;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    bf16_t* sV = smem;                        // [SKP][32]
+    bf16_t* sK = sV + SKP * DH;               // [SKP][32]
+    bf16_t* sdS = sK + SKP * DH;              // [QT][LS]
+    bf16_t* sPd = sdS + QT * LS;              // [QT][LS]
+    bf16_t* sdO = sPd + QT * LS;              // [QT][32]
+    bf16_t* sQ = sdO + QT * DH;               // [QT][32]
+    float* sdQ = reinterpret_cast<float*>(sQ + QT * DH);   // [4][QT][32] partial dQ of the four key quarters
+    float* sD = sdQ + 4 * QT * DH;            // [QT]
+    typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const float dscale = prob_drop ? 1.f / (1.f - drop_p) : 1.f;
+    const int qh = wave & 1, kq = wave >> 1;
+
+    for (int c = tid; c < SKP * 4; c += 512) {
+        const int key = c >> 2, ch = c & 3;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key < Sk) {
+            kv = *reinterpret_cast<const uint4*>(kmat + ((size_t)b * Sk + key) * ldk + h * DH + ch * 8);
+            vv = *reinterpret_cast<const uint4*>(v + ((size_t)b * Sk + key) * ldv + h * DH + ch * 8);
+        }
+        *reinterpret_cast<uint4*>(sK + key * DH + (ch << 3)) = kv;
+        *reinterpret_cast<uint4*>(sV + key * DH + (ch << 3)) = vv;
+    }
+    f32x4_t accK[NBW][2], accV[NBW][2];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) { accK[i][eb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accV[i][eb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+    // probabilities of this lane's query for its key quarter, fetched one tile ahead
+    uint2 pnx[NBQ], dnx[NBQ];
+    auto fetch = [&](int q0_) {
+        const int qi = q0_ + qh * 16 + c16;
+#pragma unroll
+        for (int jj = 0; jj < NBQ; ++jj) {
+            const int k0 = (kq * NBQ + jj) * 16 + 4 * g;
+            uint2 pv = make_uint2(0, 0), pd = make_uint2(0, 0);
+            if (qi < Sq && k0 < ld) {
+                const size_t at = ((size_t)bh * Sq + qi) * ld + k0;
+                pv = *reinterpret_cast<const uint2*>(prob + at);
+                pd = prob_drop ? *reinterpret_cast<const uint2*>(prob_drop + at) : pv;
+            }
+            pnx[jj] = pv;
+            dnx[jj] = pd;
+        }
+    };
+    fetch(0);
+    // rows of dO, O, Q of the next tile (threads 0..255: query tid / 8, features 4 (tid % 8) ..), also fetched one tile ahead
+    uint2 d2n = make_uint2(0, 0), o2n = make_uint2(0, 0), q2n = make_uint2(0, 0);
+    auto fetch_rows = [&](int q0_) {
+        const int qi = q0_ + (tid >> 3), ch = tid & 7;
+        d2n = o2n = q2n = make_uint2(0, 0);
+        if (tid < 256 && qi < Sq) {
+            d2n = *reinterpret_cast<const uint2*>(dctx + ((size_t)b * Sq + qi) * lddo + h * DH + ch * 4);
+            o2n = *reinterpret_cast<const uint2*>(ctx + ((size_t)b * Sq + qi) * ldo + h * DH + ch * 4);
+            q2n = *reinterpret_cast<const uint2*>(q + ((size_t)b * Sq + qi) * ldq + h * DH + ch * 4);
+        }
+    };
+    fetch_rows(0);
+
+    const int n_tiles = (Sq + QT - 1) / QT;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int q0 = t * QT;
+        if (tid < 256) {   // ---- tile prologue: dO, Q rows and D = rowsum(dO o O) ----
+            const int qq = tid >> 3, ch = tid & 7;
+            const uint2 d2 = d2n, o2 = o2n, q2 = q2n;
+            const bf16_t* dp = reinterpret_cast<const bf16_t*>(&d2);
+            const bf16_t* op = reinterpret_cast<const bf16_t*>(&o2);
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part += bf2f(dp[j]) * bf2f(op[j]);
+            *reinterpret_cast<uint2*>(sdO + qq * DH + ch * 4) = d2;
+            *reinterpret_cast<uint2*>(sQ + qq * DH + ch * 4) = q2;
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            if (ch == 0) sD[qq] = part;
+        }
+        __syncthreads();
+
+        {   // ---- phase A: this wave's 16 queries x its quarter of the keys ----
+            const int ql = qh * 16 + c16;                              // query of this lane inside the tile
+            const bf16x8_t dof = *reinterpret_cast<const bf16x8_t*>(sdO + ql * DH + g * 8);
+            const float dsum = sD[ql];
+            uint2 pcu[NBQ], dcu[NBQ];
+#pragma unroll
+            for (int jj = 0; jj < NBQ; ++jj) { pcu[jj] = pnx[jj]; dcu[jj] = dnx[jj]; }
+            if (t + 1 < n_tiles) { fetch(q0 + QT); fetch_rows(q0 + QT); }
+            unsigned ds_pk[NBQ][2];
+#pragma unroll
+            for (int jj = 0; jj < NBQ; ++jj) {
+                const int j = kq * NBQ + jj;
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + (j * 16 + c16) * DH + g * 8);
+                const f32x4_t dpd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const unsigned pw[2] = {pcu[jj].x, pcu[jj].y}, dw[2] = {dcu[jj].x, dcu[jj].y};
+                float dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned short pb = (unsigned short)(pw[r >> 1] >> (16 * (r & 1))), db = (unsigned short)(dw[r >> 1] >> (16 * (r & 1)));
+                    const float dp = (prob_drop == nullptr || db != 0) ? dpd[r] * dscale : 0.f;
+                    dsv[r] = bf2f(pb) * (dp - dsum);
+                }
+                ds_pk[jj][0] = pack2bf(dsv[0], dsv[1]);
+                ds_pk[jj][1] = pack2bf(dsv[2], dsv[3]);
+                *reinterpret_cast<uint2*>(sdS + ql * LS + j * 16 + 4 * g) = make_uint2(ds_pk[jj][0], ds_pk[jj][1]);
+                *reinterpret_cast<uint2*>(sPd + ql * LS + j * 16 + 4 * g) = dcu[jj];
+            }
+            // dQ partial over this key quarter: slot 8g + r <-> key 32c + 4g + r, slot 8g + 4 + r <-> key 32c + 16 + 4g + r
+            f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int cc = 0; cc < NBQ / 2; ++cc) {
+                union { unsigned u[4]; bf16x8_t v8; } sb;
+                sb.u[0] = ds_pk[2 * cc][0]; sb.u[1] = ds_pk[2 * cc][1]; sb.u[2] = ds_pk[2 * cc + 1][0]; sb.u[3] = ds_pk[2 * cc + 1][1];
+                const int c = (kq * NBQ) / 2 + cc;
+                const int k_lo = 32 * c + 4 * g + (c16 >> 2), k_hi = k_lo + 16;
+#pragma unroll
+                for (int eb = 0; eb < 2; ++eb) {
+                    union { struct { s16x4_t a, b; } hh; bf16x8_t v8; } kf;
+                    kf.hh.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sK + k_lo * DH + eb * 16 + (c16 & 3) * 4));
+                    kf.hh.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sK + k_hi * DH + eb * 16 + (c16 & 3) * 4));
+                    acc[eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v8, sb.v8, acc[eb], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb)
+                *reinterpret_cast<float4*>(sdQ + ((size_t)kq * QT + ql) * DH + eb * 16 + 4 * g) = make_float4(acc[eb][0], acc[eb][1], acc[eb][2], acc[eb][3]);
+        }
+        __syncthreads();
+
+        // ---- phase B ----
+        if (tid < 256) {   // dQ of the tile = sum of the four key-quarter partials
+            const int qq = tid >> 3, e4 = (tid & 7) * 4, qi = q0 + qq;
+            float4 a = *reinterpret_cast<const float4*>(sdQ + ((size_t)0 * QT + qq) * DH + e4);
+#pragma unroll
+            for (int kk = 1; kk < 4; ++kk) {
+                const float4 o = *reinterpret_cast<const float4*>(sdQ + ((size_t)kk * QT + qq) * DH + e4);
+                a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+            }
+            if (qi < Sq)
+                *reinterpret_cast<uint2*>(dq + ((size_t)b * Sq + qi) * lddq + h * DH + e4) =
+                    make_uint2(pack2bf(a.x * scale, a.y * scale), pack2bf(a.z * scale, a.w * scale));
+        }
+        {   // dK += dS^T Q, dV += Pd^T dO for this wave's key blocks (reduction over the tile's 32 queries)
+            const int q_lo = 4 * g + (c16 >> 2), q_hi = q_lo + 16, col4 = (c16 & 3) * 4;
+            union { struct { s16x4_t a, b; } hh; bf16x8_t v8; } qf[2], of[2];
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) {
+                qf[eb].hh.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sQ + q_lo * DH + eb * 16 + col4));
+                qf[eb].hh.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sQ + q_hi * DH + eb * 16 + col4));
+                of[eb].hh.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sdO + q_lo * DH + eb * 16 + col4));
+                of[eb].hh.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sdO + q_hi * DH + eb * 16 + col4));
+            }
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                const int jb = wave + 8 * i;
+                union { struct { s16x4_t a, b; } hh; bf16x8_t v8; } sf, pf;
+                sf.hh.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sdS + q_lo * LS + jb * 16 + col4));
+                sf.hh.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sdS + q_hi * LS + jb * 16 + col4));
+                pf.hh.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sPd + q_lo * LS + jb * 16 + col4));
+                pf.hh.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sPd + q_hi * LS + jb * 16 + col4));
+#pragma unroll
+                for (int eb = 0; eb < 2; ++eb) {
+                    accK[i][eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[eb].v8, sf.v8, accK[i][eb], 0, 0, 0);
+                    accV[i][eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of[eb].v8, pf.v8, accV[i][eb], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int key = (wave + 8 * i) * 16 + c16;
+        if (key < Sk) {
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) {
+                *reinterpret_cast<uint2*>(dk + ((size_t)b * Sk + key) * lddk + h * DH + eb * 16 + g * 4) =
+                    make_uint2(pack2bf(accK[i][eb][0] * scale, accK[i][eb][1] * scale), pack2bf(accK[i][eb][2] * scale, accK[i][eb][3] * scale));
+                *reinterpret_cast<uint2*>(dv + ((size_t)b * Sk + key) * lddv + h * DH + eb * 16 + g * 4) =
+                    make_uint2(pack2bf(accV[i][eb][0], accV[i][eb][1]), pack2bf(accV[i][eb][2], accV[i][eb][3]));
+            }
+        }
+    }
+}
+
 }  // namespace toist
 
 using namespace toist;
@@ -336,8 +536,10 @@ extern "C" int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk,
 
 extern "C" int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const void* prob, const void* prob_drop,
                               const void* ctx, int ldo, const void* dctx, int lddo, int B, int H, int Sq, int Sk, int dh, int ld, float scale,
-                              float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, void* stream) {
+                              float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int variant, void* stream) {
     TOIST_REQUIRE(q && kmat && v && prob && ctx && dctx && dq && dk && dv && B > 0 && H > 0 && Sq > 0 && Sk > 0, "toist_attn_bwd: bad args");
+    TOIST_REQUIRE(variant >= 0 && variant <= 2, "toist_attn_bwd: variant 0 (auto), 1 (key-major) or 2 (query-major)");
+    TOIST_REQUIRE((ld % 8) == 0, "toist_attn_bwd: ld must be a multiple of 8");
     TOIST_REQUIRE(dh == 32, "toist_attn_bwd: head dim must be 32 (got %d)", dh);
     TOIST_REQUIRE(Sk <= 512 && ld >= Sk, "toist_attn_bwd: Sk <= 512 and ld >= Sk (got %d, %d)", Sk, ld);
     TOIST_REQUIRE((ldq % 4) == 0 && (ldk % 8) == 0 && (ldv % 8) == 0 && (ldo % 4) == 0 && (lddo % 4) == 0 && (lddq % 4) == 0 && (lddk % 4) == 0 &&
@@ -355,9 +557,28 @@ extern "C" int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk,
                            (const bf16_t*)v, ldv, (const bf16_t*)prob, (const bf16_t*)prob_drop, (const bf16_t*)ctx, ldo, (const bf16_t*)dctx,  \
                            lddo, H, Sq, Sk, ld, scale, drop_p, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);                       \
     } while (0)
-    if (Sk <= 128) TOIST_ATTN_BWD(1);
-    else if (Sk <= 256) TOIST_ATTN_BWD(2);
-    else TOIST_ATTN_BWD(4);
+#define TOIST_ATTN_BWD_ROWS(NB)                                                                                                              \
+    do {                                                                                                                                     \
+        const size_t lds = sizeof(bf16_t) * ((size_t)2 * (NB * 16) * 32 + (size_t)2 * 32 * (NB * 16 + 8) + 2 * 32 * 32) + 4 * (4 * 32 * 32 + 32); \
+        if (lds > 64 * 1024) {                                                                                                               \
+            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_rows_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) { set_last_error("toist_attn_bwd: set LDS size: %s", hipGetErrorString(e)); return TOIST_EHIP; }            \
+        }                                                                                                                                    \
+        hipLaunchKernelGGL((attn_bwd_rows_kernel<NB>), dim3(B * H), dim3(512), lds, st, (const bf16_t*)q, ldq, (const bf16_t*)kmat, ldk,      \
+                           (const bf16_t*)v, ldv, (const bf16_t*)prob, (const bf16_t*)prob_drop, (const bf16_t*)ctx, ldo, (const bf16_t*)dctx,  \
+                           lddo, H, Sq, Sk, ld, scale, drop_p, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);                       \
+    } while (0)
+    if (variant == 0) variant = (Sq > 128 && Sk > 128) ? 2 : 1;
+    if (variant == 2) {
+        if (Sk <= 128) TOIST_ATTN_BWD_ROWS(8);
+        else if (Sk <= 256) TOIST_ATTN_BWD_ROWS(16);
+        else TOIST_ATTN_BWD_ROWS(32);
+    } else {
+        if (Sk <= 128) TOIST_ATTN_BWD(1);
+        else if (Sk <= 256) TOIST_ATTN_BWD(2);
+        else TOIST_ATTN_BWD(4);
+    }
 #undef TOIST_ATTN_BWD
+#undef TOIST_ATTN_BWD_ROWS
     return check_launch("toist_attn_bwd");
 }

@@ -503,10 +503,10 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
             return ds
 
         if fused_core and (Sq <= 128 or Sk <= 128):
-            # dV, dP, softmax backward, dQ, dK in one launch (csrc/attn.hip: attn_bwd_kernel).  Measured (tools/bench_attn_core.py,
-            # B=8): 13.4 vs 38.2 us at 100x100, 36.9 vs 44.7 us at 100x416; at 416x416 the five-kernel path wins (81.9 vs 147.9 us:
-            # the probabilities are 2-byte gathers in the layout the fused kernel needs, and only 64 workgroups exist)
-            k.attn_bwd(qb, kb, vb, prob, prob_used if p > 0 else None, ctx, dctx, B, H, Sq, Sk, dh, scale, p, dq, dk, dv)
+            # dV, dP, softmax backward, dQ, dK in one launch (csrc/attn.hip, query-major variant).  Measured (tools/bench_attn_core.py,
+            # B=8): 12 vs 39 us at 100x100, 32 vs 46 us at 100x416; at 416x416 the five-kernel path still wins (81 vs 113 us: one
+            # workgroup per head walks 13 query tiles serially and only 64 workgroups exist)
+            k.attn_bwd(qb, kb, vb, prob, prob_used if p > 0 else None, ctx, dctx, B, H, Sq, Sk, dh, scale, p, dq, dk, dv, variant=2)
         else:
             ops.attn_backward(prob_used, scale, qb, kb, vb, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
         if fused:

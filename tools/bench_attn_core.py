@@ -42,5 +42,7 @@ for Sq, Sk in [(416, 416), (100, 416), (100, 100)]:
         k.softmax_bwd(p0, dp, B * H * Sq, Sk, ld, ds, 0.1, 7)
         return ds
     unfused_b = lambda: ops.attn_backward(pu0, sc, q, kk, v, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
-    fused_b = lambda: k.attn_bwd(q, kk, v, p0, pu0, c, dctx, B, H, Sq, Sk, dh, sc, 0.1, dq, dk, dv)
-    print(f"Sq={Sq} Sk={Sk}: backward five kernels {1000 * timeit(unfused_b, 30):7.1f} us   fused {1000 * timeit(fused_b, 30):7.1f} us", flush=True)
+    fused_b1 = lambda: k.attn_bwd(q, kk, v, p0, pu0, c, dctx, B, H, Sq, Sk, dh, sc, 0.1, dq, dk, dv, variant=1)
+    fused_b2 = lambda: k.attn_bwd(q, kk, v, p0, pu0, c, dctx, B, H, Sq, Sk, dh, sc, 0.1, dq, dk, dv, variant=2)
+    print(f"Sq={Sq} Sk={Sk}: backward five kernels {1000 * timeit(unfused_b, 30):7.1f} us   fused key-major {1000 * timeit(fused_b1, 30):7.1f} us   "
+          f"fused query-major {1000 * timeit(fused_b2, 30):7.1f} us", flush=True)
