@@ -117,6 +117,12 @@ def test_polygon_rasteriser_properties():
     assert abs(int(tri.sum()) - 600) <= 40
     clipped = C.polygon_to_mask([-5, -5, 20, -5, 20, 50, -5, 50], 16, 12)
     assert clipped.shape == (16, 12) and clipped.all()
+    # the dataset-side helper: one mask per object = union of its polygons; empty input keeps the reference's shape
+    both = C.convert_coco_poly_to_mask([[[2, 1, 7, 1, 7, 5, 2, 5], [0, 6, 3, 6, 3, 8, 0, 8]], [[2, 1, 7, 1, 7, 5, 2, 5]]], 8, 10)
+    want2 = want.copy()
+    want2[6:8, 0:3] = True
+    assert both.shape == (2, 8, 10) and np.array_equal(both[0].numpy(), want2) and np.array_equal(both[1].numpy(), want)
+    assert tuple(C.convert_coco_poly_to_mask([], 8, 10).shape) == (0, 8, 10)
 
 
 def test_accumulate_and_summarize_match_oracle():

@@ -128,6 +128,18 @@ def polygon_to_mask(xy, h, w):
     return counts_to_mask(counts, h, w)
 
 
+def convert_coco_poly_to_mask(segmentations, height, width):
+    """datasets/tdod.py:133-147 (and datasets/coco.py:66-80): one bool mask per object, the union of its polygons
+    (coco_mask.frPyObjects + decode + any(dim=2) in the reference)."""
+    masks = []
+    for polygons in segmentations:
+        m = np.zeros((height, width), dtype=bool)
+        for poly in polygons:
+            m |= polygon_to_mask(poly, height, width)
+        masks.append(torch.from_numpy(m))
+    return torch.stack(masks, dim=0) if masks else torch.zeros((0, height, width), dtype=torch.uint8)
+
+
 # ---- ground truth ----------------------------------------------------------------------------------------------
 class CocoGroundTruth:
     """The slice of pycocotools.coco.COCO the evaluator reads: a COCO-format dict {"images": [{"id","height","width"}],
