@@ -27,16 +27,15 @@ int check_launch(const char* what);  // hipGetLastError -> TOIST_EHIP / TOIST_OK
 // ---- bf16 <-> f32 ------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 
-// round-to-nearest-even, NaN preserved (matches torch's float->bfloat16 cast)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// float -> bfloat16, round-to-nearest-even (torch's cast): gfx950 converts in hardware, two values per
+// v_cvt_pk_bf16_f32 -- the hand-rolled rounding was 5-6 VALU operations per value in every epilogue
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_native_t;
+
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    const bf16x2_native_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
 }
 
 // ---- wave (64-lane) reductions -------------------------------------------------
