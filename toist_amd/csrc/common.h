@@ -53,11 +53,16 @@ __device__ __forceinline__ float wave_max(float v) {
 // counter-based RNG for dropout: one 32-bit hash per (seed, element index).
 // Forward and backward regenerate the same keep-mask from (seed, index).
 __device__ __forceinline__ unsigned hash_u32(unsigned long long seed, unsigned long long idx) {
-    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (unsigned)(z >> 32);
+    // two-round 32-bit mixer (multiply / xor-shift, full avalanche) over the element index, keyed by the 64-bit seed.  The previous
+    // splitmix64 finaliser cost ~25 VALU operations per element in 64-bit multiplies -- visible in every kernel that drops out.
+    unsigned x = (unsigned)idx ^ (unsigned)seed;
+    // the seed enters twice (xor before round 1, a multiplied copy before round 2): masks of different seeds are not index-shifted copies
+    const unsigned key = ((unsigned)(seed >> 32) ^ ((unsigned)seed * 0x9E3779B9u)) + (unsigned)(idx >> 32) * 0x85EBCA6Bu;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= key;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
 }
 // keep with probability 1-p ; thresh = (unsigned)(p * 2^32)
 __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, unsigned thresh) {
