@@ -123,6 +123,18 @@ typedef struct toist_epilogue {
                                       hipGraph draws a fresh mask on every replay */
 } toist_epilogue;
 
+/* Grouped launch: `batch` problems of one shape whose operands are not uniformly strided (the weight gradients of the
+ * identical residual blocks of a ResNet stage: 23 x three GEMMs in layer 3, each too small to fill the chip on its own and
+ * therefore split along K with a fold pass -- grouped, they run as one unsplit launch).  Entry z replaces the strided
+ * batch addressing: A and B start at a / b, C (and res / aux / pre_out) is offset by c_off elements from toist_gemm.c,
+ * epi.rscale by rscale_off elements.  Device memory, `batch` entries; split_k must be 1 and batch_inner 1. */
+typedef struct toist_group {
+    const void* a;
+    const void* b;
+    int64_t c_off;
+    int64_t rscale_off;
+} toist_group;                /* 32 bytes */
+
 typedef struct toist_gemm {
     int32_t M, N, K;
     int32_t a_kind, b_kind;
@@ -142,9 +154,12 @@ typedef struct toist_gemm {
     float* workspace;           /* split_k > 1: f32 scratch of >= split_k * M * N elements (caller-owned) */
     float* a_colsum;            /* optional, A_KROW only: a_colsum[m] += sum_k A[m][k]  (f32 atomics) --
                                    the bias gradient of nn.Linear falls out of the wgrad GEMM's A tiles */
+    const toist_group* group;   /* optional (device memory, `batch` entries): grouped launch, see toist_group */
 } toist_gemm;
 
 int toist_gemm_bf16(const toist_gemm* desc, void* stream);
+/* writes n <= 64 host-side entries into a device table (they travel as kernel arguments: graph-capturable, no staging buffer) */
+int toist_group_fill(const toist_group* rows, int n, toist_group* table, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row kernels (bf16 data, f32 statistics).

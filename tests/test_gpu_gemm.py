@@ -371,3 +371,41 @@ def test_fused_attention_backward_matches_five_kernel_path(dev, Sq, Sk, drop, va
             ref = ref.permute(0, 2, 1, 3).reshape(a.shape)
             err = float((a.float() - ref).norm() / ref.norm())
             assert err < 2e-2, (name, "vs fp32", err)
+
+
+@pytest.mark.parametrize("R,stride", [(1, 1), (3, 1)])
+def test_grouped_conv_wgrad_matches_separate_launches(dev, R, stride):
+    """toist_group: the weight gradients of several same-shape convolutions as ONE unsplit launch (operands at arbitrary
+    addresses, outputs / row scales at element offsets) against one launch per problem (split along K + fold) and fp32 math."""
+    from toist_amd import ops
+    g = torch.Generator().manual_seed(R)
+    n, Nb, H, W, C, Co = 5, 2, 20, 24, 64, 128
+    pad = 1 if R == 3 else 0
+    flat = torch.zeros(n * Co * R * R * C + 64, dtype=torch.float32, device=dev)          # one gradient buffer, like ParamSet.flat
+    scales = (torch.rand(n, Co, generator=g) + 0.5).to(dev)
+    items, refs = [], []
+    for i in range(n):
+        x = torch.randn(Nb, H, W, C, generator=g).to(BF).to(dev)
+        dy = torch.randn(Nb, H, W, Co, generator=g).to(BF).to(dev)
+        out = flat[16 + i * Co * R * R * C: 16 + (i + 1) * Co * R * R * C].view(Co, R, R, C)
+        items.append((dy, x, out, scales[i]))
+        xr = x.float().permute(0, 3, 1, 2).cpu()
+        w = torch.zeros(Co, C, R, R, requires_grad=True)
+        torch.nn.functional.conv2d(xr, w, padding=pad).backward(dy.float().permute(0, 3, 1, 2).cpu())
+        refs.append(w.grad.permute(0, 2, 3, 1) * scales[i].cpu()[:, None, None, None])
+    old = ops.GROUP_MIN_TILES
+    ops.GROUP_MIN_TILES = 1
+    try:
+        ops.conv2d_wgrad_group(items, (Co, R, R, C), stride=stride, pad=pad)
+        from toist_amd import kernels as k
+        k.flush_reductions()
+    finally:
+        ops.GROUP_MIN_TILES = old
+    grouped = [it[2].clone() for it in items]
+    flat.zero_()
+    for dy, x, out, rs in items:
+        ops.conv2d_wgrad(dy, x, (Co, R, R, C), stride=stride, pad=pad, out=out, rscale=rs)
+    assert float(flat[:16].abs().sum()) == 0 and float(flat[-48:].abs().sum()) == 0            # nothing written outside the slices
+    for i in range(n):
+        _close(grouped[i], refs[i], Nb * H * W, f"grouped wgrad {i}", rtol=1e-2, atol_unit=2e-3)
+        assert torch.allclose(grouped[i], items[i][2], rtol=2e-3, atol=2e-2)

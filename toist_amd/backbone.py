@@ -233,7 +233,8 @@ class BackboneBase(nn.Module):
                 finals.append(f)
             return finals, extra
 
-        return functions.run_program(wrapped, named, [images], cache=self._cache, training=self.training, transforms=self._transforms())
+        return functions.run_program(wrapped, named, [images], cache=self._cache, training=self.training, transforms=self._transforms(),
+                                     group_wgrads=True)
 
     # ---- reference-compatible API ------------------------------------------------------------------
     def forward(self, tensor_list: NestedTensor):

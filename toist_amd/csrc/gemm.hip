@@ -159,7 +159,9 @@ __device__ __forceinline__ void epilogue_row8(const toist_gemm& p, float* v, con
                                               const float* xres, const float* xaux, const EpiCols& cols) {
     const toist_epilogue& e = p.epi;
     const int N = p.N, M = p.M, m = r.m, n = r.n, nv = r.nv;
-    const float rs = e.rscale ? e.alpha * e.rscale[m] : e.alpha;
+    const float* rsc = e.rscale;
+    if (rsc && p.group) rsc += p.group[bz].rscale_off;
+    const float rs = rsc ? e.alpha * rsc[m] : e.alpha;
     static_for<8>([&](auto jj) { v[decltype(jj)::value] *= rs; });
     if (e.scale) static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] *= cols.scale[j]; });
     if (e.shift) static_for<8>([&](auto jj) { constexpr int j = decltype(jj)::value; v[j] += cols.shift[j]; });
@@ -484,9 +486,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     const int bz = z / p.split_k, ksl = z - bz * p.split_k;
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
     const toist_operand oa = p.a, ob = p.b;
-    const i32x4_t rsA = make_rsrc((const bf16_t*)oa.ptr + bo * oa.bs_outer + bi * oa.bs_inner);
-    const i32x4_t rsB = make_rsrc((const bf16_t*)ob.ptr + bo * ob.bs_outer + bi * ob.bs_inner);
-    const long long coff = bo * p.cs_outer + bi * p.cs_inner;
+    const bf16_t* a_base = (const bf16_t*)oa.ptr + bo * oa.bs_outer + bi * oa.bs_inner;
+    const bf16_t* b_base = (const bf16_t*)ob.ptr + bo * ob.bs_outer + bi * ob.bs_inner;
+    long long coff_ = bo * p.cs_outer + bi * p.cs_inner;
+    if (p.group) {   // grouped launch: per-problem base pointers from the table (uniform loads)
+        const toist_group gq = p.group[bz];
+        a_base = (const bf16_t*)gq.a;
+        b_base = (const bf16_t*)gq.b;
+        coff_ = gq.c_off;
+    }
+    const i32x4_t rsA = make_rsrc(a_base);
+    const i32x4_t rsB = make_rsrc(b_base);
+    const long long coff = coff_;
     const int lda = oa.ld, ldb = ob.ld;
 
     const int ktiles = (K + BK - 1) / BK;
@@ -1056,6 +1067,26 @@ static int clamp_split(int split_k, int K, int tile) {
 
 }  // namespace toist
 
+namespace toist {
+constexpr int GROUP_MAX = 64;
+struct GroupArgs { toist_group g[GROUP_MAX]; };
+__global__ void group_fill_kernel(const GroupArgs a, int n, toist_group* __restrict__ table) {
+    if ((int)threadIdx.x < n) table[threadIdx.x] = a.g[threadIdx.x];
+}
+}  // namespace toist
+
+// The table travels as kernel arguments (2 KB): no pinned staging buffer to keep alive, and a captured hipGraph replays the
+// same pointers from its kernel node.
+extern "C" int toist_group_fill(const toist_group* rows, int n, toist_group* table, void* stream) {
+    using namespace toist;
+    TOIST_REQUIRE(rows != nullptr && table != nullptr && n > 0 && n <= GROUP_MAX, "toist_group_fill: 1..%d entries (got %d)", GROUP_MAX, n);
+    GroupArgs a;
+    for (int i = 0; i < n; ++i) a.g[i] = rows[i];
+    for (int i = n; i < GROUP_MAX; ++i) a.g[i] = toist_group{nullptr, nullptr, 0, 0};
+    hipLaunchKernelGGL(group_fill_kernel, dim3(1), dim3(GROUP_MAX), 0, (hipStream_t)stream, a, n, table);
+    return check_launch("toist_group_fill");
+}
+
 extern "C" int toist_gemm_effective_split(const toist_gemm* desc) {
     using namespace toist;
     if (desc == nullptr) return 0;
@@ -1117,6 +1148,8 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     if (d.split_k > 1 || d.epi.accumulate)
         TOIST_REQUIRE(d.epi.out_f32, "toist_gemm_bf16: split_k/accumulate needs an f32 output");
     if (d.a_colsum) TOIST_REQUIRE(d.a_kind == TOIST_A_KROW, "toist_gemm_bf16: a_colsum needs a k-major A operand");
+    if (d.group) TOIST_REQUIRE(d.split_k <= 1 && d.batch_inner == 1 && !d.a_colsum && !d.epi.cmap && (d.tile & 255) != 131 && d.a_kind != TOIST_A_CONVT,
+                               "toist_gemm_bf16: a grouped launch takes split_k = 1, batch_inner = 1, no a_colsum / cmap and a generic tile");
     if (d.split_k > 1) {
         TOIST_REQUIRE(!d.epi.scale && !d.epi.shift && !d.epi.res && d.epi.act == TOIST_ACT_NONE && !d.epi.pre_out && d.epi.drop_where == 0 &&
                           !d.epi.cmap && d.batch == 1,

@@ -68,8 +68,12 @@ def overlap_enabled():
     return OVERLAP == "capture" and torch.cuda.is_current_stream_capturing()
 
 
+GROUP_WGRADS = True    # the weight gradients of identical residual blocks run as grouped launches at the end of the program
+
+
 class Tape:
-    def __init__(self, training, drop_p=0.0, seed=0):
+    def __init__(self, training, drop_p=0.0, seed=0, group_wgrads=False):
+        self.groups = {} if (group_wgrads and GROUP_WGRADS) else None   # (shapes, geometry) -> [(dy, x, out, rscale)]
         self.steps = []
         self.training = training
         self.drop_p = drop_p if training else 0.0
@@ -83,10 +87,22 @@ class Tape:
     def record(self, fn):
         self.steps.append(fn)
 
+    def conv_wgrad(self, dy, x, w_shape, out, rscale, stride=1, pad=0):
+        """Weight gradient of a convolution: now, or (programs with group_wgrads) collected with the other convolutions of the same
+        shape and launched grouped when the program's backward ends.  The operands are never written again by this backward."""
+        if self.groups is None:
+            ops.conv2d_wgrad(dy, x, w_shape, stride=stride, pad=pad, out=out, rscale=rscale, defer=True)
+        else:
+            self.groups.setdefault((tuple(dy.shape), tuple(x.shape), tuple(w_shape), stride, pad), []).append((dy, x, out, rscale))
+
     def backward(self):
         for fn in reversed(self.steps):
             fn()
         self.steps = []
+        if self.groups:
+            for (_, _, w_shape, stride, pad), items in self.groups.items():
+                ops.conv2d_wgrad_group(items, w_shape, stride=stride, pad=pad)
+            self.groups = {}
         k.flush_reductions()   # deferred split-K partials of this program -> parameter gradients
 
 
@@ -562,13 +578,13 @@ def bottleneck(tape, x, W, bn, stride, has_down, train):
         g3 = out.take_grad()  # w.r.t. the pre-ReLU sum (masked by the consumer)
         if g3 is None:
             return
-        ops.conv2d_wgrad(g3, a2, w3.shape, out=krsc(W["conv3"].g), rscale=s3, defer=True)
+        tape.conv_wgrad(g3, a2, w3.shape, krsc(W["conv3"].g), s3)
         g2 = ops.conv2d_dgrad(g3, w3, a2.shape[1:3], act=k.ACT_MASK_POS, aux=a2)
-        ops.conv2d_wgrad(g2, a1, w2.shape, stride=stride, pad=1, out=krsc(W["conv2"].g), rscale=s2, defer=True)
+        tape.conv_wgrad(g2, a1, w2.shape, krsc(W["conv2"].g), s2, stride=stride, pad=1)
         g1 = ops.conv2d_dgrad(g2, w2, (H, Wd), stride=stride, pad=1, act=k.ACT_MASK_POS, aux=a1)
-        ops.conv2d_wgrad(g1, x.data, w1.shape, out=krsc(W["conv1"].g), rscale=s1, defer=True)
+        tape.conv_wgrad(g1, x.data, w1.shape, krsc(W["conv1"].g), s1)
         if has_down:
-            ops.conv2d_wgrad(g3, x.data, wd.shape, stride=stride, out=krsc(W["down"].g), rscale=sd, defer=True)
+            tape.conv_wgrad(g3, x.data, wd.shape, krsc(W["down"].g), sd, stride=stride)
         if not x.needs_grad:
             return
         prev = x.take_grad()

@@ -84,10 +84,10 @@ class _TapeFn(torch.autograd.Function):
         return (None, None, None, None, None, *in_grads, *([None] * n_par))
 
 
-def run_program(body, named_params, inputs, cache=None, training=False, drop_p=0.0, seed=0, transforms=None):
+def run_program(body, named_params, inputs, cache=None, training=False, drop_p=0.0, seed=0, transforms=None, group_wgrads=False):
     """body(tape, ps, *input_vars) -> (list_of_output_vars, extra).  Returns (outputs_tuple)."""
     names = tuple(named_params.keys())
     params = tuple(named_params.values())
     need = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (*inputs, *params))
-    tape_kw = dict(training=training, drop_p=drop_p, seed=seed, need_grads=need, transforms=transforms, rejoin=REJOIN)
+    tape_kw = dict(training=training, drop_p=drop_p, seed=seed, need_grads=need, transforms=transforms, rejoin=REJOIN, group_wgrads=group_wgrads)
     return _TapeFn.apply(body, names, cache, len(inputs), tape_kw, *inputs, *params)

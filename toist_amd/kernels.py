@@ -82,6 +82,18 @@ def flush_reductions():
             ent[1] = 0
 
 
+GROUP_MAX = 64
+
+
+def group_table(rows, device):
+    """Device toist_group table from host rows [a_ptr, b_ptr, c_off, rscale_off] (csrc/gemm.hip: the rows travel as kernel arguments)."""
+    n = len(rows)
+    flat = (ctypes.c_int64 * (4 * n))(*[int(v) for r in rows for v in r])
+    dev = torch.empty(n, 4, dtype=torch.int64, device=device)
+    _lib.check(_lib.lib().toist_group_fill(ctypes.cast(flat, ctypes.c_void_p), n, _p(dev), _stream()), "toist_group_fill")
+    return dev
+
+
 def _raw_stream():
     """hipStream_t of torch's current stream as an int.  torch.cuda.current_stream() builds a Stream object through three
     Python layers (~9 us): at ~1500 launches per step that alone was 13 ms of host time; the C accessor takes ~0.3 us."""
@@ -126,7 +138,7 @@ def operand(t, ld=0, bs_outer=0, bs_inner=0, kin=0, tap_stride=0, geom=None):
 def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_outer=0, cs_inner=0, split_k=1, tile=0,
          flags=0, alpha=1.0, scale=None, shift=None, rscale=None, res=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, pre_out=None,
          accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0, flops=0, a_colsum=None, res_bcast=None,
-         defer_reduce=False):
+         defer_reduce=False, group=None):
     """C = epilogue(A @ B^T); see include/toist_hip.h.  `a`/`b` are Operand structs from operand().
     `flops` = algorithmic FLOPs of the call (bench.py's roofline accounting only)."""
     if tile == 0 and FORCE_TILE:
@@ -159,6 +171,7 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
     e.drop_where, e.drop_p, e.drop_seed = drop_where, drop_p, drop_seed
     e.drop_seed_dev = _p(SEED_DEV) if drop_where else None
     d.a_colsum = _p(a_colsum, torch.float32)
+    d.group = _p(group, torch.int64)          # [batch, 4] int64 rows (a pointer, b pointer, c offset, rscale offset): toist_group
     deferred = None
     if split_k > 1:
         eff = int(_lib.lib().toist_gemm_effective_split(ctypes.byref(d))) if defer_reduce else 0

@@ -179,6 +179,41 @@ def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, s
     return out
 
 
+import os as _os
+GROUP_TILE = int(_os.environ.get("TOIST_GROUP_TILE", "0"))   # tile code of grouped weight-gradient launches (0 = the dispatcher's choice)
+GROUP_MIN_TILES = 512   # below this many 64x64 output tiles in total the problems stay separate (they need split-K)
+
+
+def conv2d_wgrad_group(items, w_shape, *, stride=1, pad=0, dil=1):
+    """Weight gradients of several convolutions of ONE shape (the identical residual blocks of a stage) as one grouped GEMM
+    launch: items = [(dy, x, out, rscale)], out f32 [Co,R,S,C] accumulated.  Separately each is 64-144 output tiles with a
+    12800-51200 deep reduction, i.e. split along K plus a fold pass; together they fill the chip unsplit."""
+    dy0, x0, out0, rs0 = items[0]
+    Nb, OH, OW, Co = dy0.shape
+    _, H, W, C = x0.shape
+    Cw, R, S, Cc = w_shape
+    Nn, P = R * S * C, Nb * OH * OW
+    tiles = ((Co + 63) // 64) * ((Nn + 63) // 64) * len(items)
+    if len(items) < 2 or len(items) > k.GROUP_MAX or tiles < GROUP_MIN_TILES or any((it[3] is None) != (rs0 is None) for it in items):
+        for dy, x, out, rs in items:
+            conv2d_wgrad(dy, x, w_shape, stride=stride, pad=pad, dil=dil, out=out, rscale=rs, defer=True)
+        return
+    rows = []
+    for dy, x, out, rs in items:
+        assert dy.shape == dy0.shape and x.shape == x0.shape and dy.is_contiguous() and x.is_contiguous() and out.is_contiguous()
+        c_off, r_off = out.data_ptr() - out0.data_ptr(), (rs.data_ptr() - rs0.data_ptr()) if rs is not None else 0
+        assert c_off % 4 == 0 and r_off % 4 == 0 and out.dtype == torch.float32 and (rs is None or rs.dtype == torch.float32)
+        rows.append([dy.data_ptr(), x.data_ptr(), c_off // 4, r_off // 4])
+    table = k.group_table(rows, dy0.device)
+    a = k.operand(dy0, Co)
+    if R == 1 and S == 1 and stride == 1 and pad == 0:
+        b_kind, b = k.B_KROW, k.operand(x0, C)
+    else:
+        b_kind, b = k.B_CONVX, k.operand(x0, 0, geom=k.ConvGeom(H, W, C, OH, OW, R, S, stride, pad, dil))
+    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out0, Nn, accumulate=True, split_k=1, rscale=rs0, batch=len(items), tile=GROUP_TILE,
+           flops=2 * P * Co * Nn * len(items), group=table)
+
+
 # ------------------------------------------------------------------------------------------ attention
 def round8(n):
     return (n + 7) // 8 * 8
