@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
         for (int col = tid; col < BM; col += 256) {
             float t = 0.f;
             for (int r = 0; r < BK; ++r) t += red[r * BM + col];
-            if (m0 + col < M) atomicAdd(p.a_colsum + m0 + col, t);
+            if (m0 + col < M) atomicAdd(p.a_colsum + (p.group ? p.group[bz].colsum_off : 0) + m0 + col, t);
         }
     }
 
@@ -1068,21 +1068,21 @@ static int clamp_split(int split_k, int K, int tile) {
 }  // namespace toist
 
 namespace toist {
-constexpr int GROUP_MAX = 64;
+constexpr int GROUP_MAX = 64;   // 64 x 48 B = 3 KB of kernel arguments
 struct GroupArgs { toist_group g[GROUP_MAX]; };
 __global__ void group_fill_kernel(const GroupArgs a, int n, toist_group* __restrict__ table) {
     if ((int)threadIdx.x < n) table[threadIdx.x] = a.g[threadIdx.x];
 }
 }  // namespace toist
 
-// The table travels as kernel arguments (2 KB): no pinned staging buffer to keep alive, and a captured hipGraph replays the
+// The table travels as kernel arguments (3 KB): no pinned staging buffer to keep alive, and a captured hipGraph replays the
 // same pointers from its kernel node.
 extern "C" int toist_group_fill(const toist_group* rows, int n, toist_group* table, void* stream) {
     using namespace toist;
     TOIST_REQUIRE(rows != nullptr && table != nullptr && n > 0 && n <= GROUP_MAX, "toist_group_fill: 1..%d entries (got %d)", GROUP_MAX, n);
     GroupArgs a;
     for (int i = 0; i < n; ++i) a.g[i] = rows[i];
-    for (int i = n; i < GROUP_MAX; ++i) a.g[i] = toist_group{nullptr, nullptr, 0, 0};
+    for (int i = n; i < GROUP_MAX; ++i) a.g[i] = toist_group{nullptr, nullptr, 0, 0, 0, 0};
     hipLaunchKernelGGL(group_fill_kernel, dim3(1), dim3(GROUP_MAX), 0, (hipStream_t)stream, a, n, table);
     return check_launch("toist_group_fill");
 }
@@ -1148,8 +1148,8 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     if (d.split_k > 1 || d.epi.accumulate)
         TOIST_REQUIRE(d.epi.out_f32, "toist_gemm_bf16: split_k/accumulate needs an f32 output");
     if (d.a_colsum) TOIST_REQUIRE(d.a_kind == TOIST_A_KROW, "toist_gemm_bf16: a_colsum needs a k-major A operand");
-    if (d.group) TOIST_REQUIRE(d.split_k <= 1 && d.batch_inner == 1 && !d.a_colsum && !d.epi.cmap && (d.tile & 255) != 131 && d.a_kind != TOIST_A_CONVT,
-                               "toist_gemm_bf16: a grouped launch takes split_k = 1, batch_inner = 1, no a_colsum / cmap and a generic tile");
+    if (d.group) TOIST_REQUIRE(d.split_k <= 1 && d.batch_inner == 1 && !d.epi.cmap && (d.tile & 255) != 131 && d.a_kind != TOIST_A_CONVT,
+                               "toist_gemm_bf16: a grouped launch takes split_k = 1, batch_inner = 1, no cmap and a generic tile");
     if (d.split_k > 1) {
         TOIST_REQUIRE(!d.epi.scale && !d.epi.shift && !d.epi.res && d.epi.act == TOIST_ACT_NONE && !d.epi.pre_out && d.epi.drop_where == 0 &&
                           !d.epi.cmap && d.batch == 1,

@@ -95,13 +95,26 @@ class Tape:
         else:
             self.groups.setdefault((tuple(dy.shape), tuple(x.shape), tuple(w_shape), stride, pad), []).append((dy, x, out, rscale))
 
+    def linear_wgrad(self, dy, x, W, b, owned=True):
+        """Weight / bias gradient of an nn.Linear: now, or grouped with the same-shape layers of the program.  `owned` = no later step
+        of this backward writes into dy (a gradient that doubles as a residual's accumulator is not owned and is consumed at once)."""
+        bias_out = b.g if b is not None else None
+        if self.groups is None or not owned:
+            ops.linear_wgrad(dy, x, out=W.g, bias_out=bias_out, defer=True)
+        else:
+            key = ("linear", tuple(dy.shape), dy.stride(0), tuple(x.shape), x.stride(0), W.g.stride(0), bias_out is None)
+            self.groups.setdefault(key, []).append((dy, x, W.g, bias_out))
+
     def backward(self):
         for fn in reversed(self.steps):
             fn()
         self.steps = []
         if self.groups:
-            for (_, _, w_shape, stride, pad), items in self.groups.items():
-                ops.conv2d_wgrad_group(items, w_shape, stride=stride, pad=pad)
+            for key, items in self.groups.items():
+                if key[0] == "linear":
+                    ops.linear_wgrad_group(items)
+                else:
+                    ops.conv2d_wgrad_group(items, key[2], stride=key[3], pad=key[4])
             self.groups = {}
         k.flush_reductions()   # deferred split-K partials of this program -> parameter gradients
 
@@ -337,7 +350,8 @@ def linear_chain(tape, x, layers, res=None, final_drop=False, out_dtype=BF16, la
                     raise NotImplementedError("activation on the last layer of a chain needs last_act_external")
             # g is now the gradient w.r.t. the pre-activation output of layer i
             if W.g is not None:
-                ops.linear_wgrad(g, xin, out=W.g, bias_out=b.g if b is not None else None, defer=True)
+                # the last layer's g doubles as the residual's gradient accumulator unless dropout made a fresh tensor
+                tape.linear_wgrad(g, xin, W, b, owned=not (last and res is not None and res.needs_grad and not (final_drop and p > 0)))
             if i == 0:
                 if x.needs_grad:
                     if in_relu_mask:  # x is a ReLU output whose producer wants d/d(pre-ReLU): mask in the epilogue
@@ -503,7 +517,7 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
             accumulate(resid, g)
         go = out.take_branch_grad(g) if p > 0 else g
         if Wo.g is not None:
-            ops.linear_wgrad(go, ctx, out=Wo.g, bias_out=bo.g, defer=True)
+            tape.linear_wgrad(go, ctx, Wo, bo, owned=(go is not g or not resid.needs_grad))
         dctx = ops.linear_dgrad(go, Wo.w)
         if fused:
             dqk = torch.empty(B * Sq, 2 * d, dtype=BF16, device=dev)
@@ -527,20 +541,20 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
             ops.attn_backward(prob_used, scale, qb, kb, vb, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
         if fused:
             if packed_qk[0].g is not None:
-                ops.linear_wgrad(dqk, q_in.data, out=packed_qk[0].g, bias_out=packed_qk[1].g, defer=True)
+                tape.linear_wgrad(dqk, q_in.data, packed_qk[0], packed_qk[1])
             if q_in.needs_grad:
                 q_in.grad = ops.linear_dgrad(dqk, packed_qk[0].w, res=q_in.grad)
         else:
             if Pq[0].g is not None:
-                ops.linear_wgrad(dq, q_in.data, out=Pq[0].g, bias_out=Pq[1].g, defer=True)
+                tape.linear_wgrad(dq, q_in.data, Pq[0], Pq[1])
             if Pk[0].g is not None:
-                ops.linear_wgrad(dk, k_in.data, out=Pk[0].g, bias_out=Pk[1].g, defer=True)
+                tape.linear_wgrad(dk, k_in.data, Pk[0], Pk[1])
             if q_in.needs_grad:
                 q_in.grad = ops.linear_dgrad(dq, Pq[0].w, res=q_in.grad)
             if k_in.needs_grad:
                 k_in.grad = ops.linear_dgrad(dk, Pk[0].w, res=k_in.grad)
         if Pv[0].g is not None:
-            ops.linear_wgrad(dv, v_in.data, out=Pv[0].g, bias_out=Pv[1].g, defer=True)
+            tape.linear_wgrad(dv, v_in.data, Pv[0], Pv[1])
         if v_in.needs_grad:
             v_in.grad = ops.linear_dgrad(dv, Pv[0].w, res=v_in.grad)
 

@@ -86,10 +86,11 @@ GROUP_MAX = 64
 
 
 def group_table(rows, device):
-    """Device toist_group table from host rows [a_ptr, b_ptr, c_off, rscale_off] (csrc/gemm.hip: the rows travel as kernel arguments)."""
+    """Device toist_group table from host rows [a_ptr, b_ptr, c_off, rscale_off, colsum_off] (csrc/gemm.hip: the rows travel as kernel
+    arguments)."""
     n = len(rows)
-    flat = (ctypes.c_int64 * (4 * n))(*[int(v) for r in rows for v in r])
-    dev = torch.empty(n, 4, dtype=torch.int64, device=device)
+    flat = (ctypes.c_int64 * (6 * n))(*[int(v) for r in rows for v in (list(r) + [0] * (6 - len(r)))])
+    dev = torch.empty(n, 6, dtype=torch.int64, device=device)
     _lib.check(_lib.lib().toist_group_fill(ctypes.cast(flat, ctypes.c_void_p), n, _p(dev), _stream()), "toist_group_fill")
     return dev
 
@@ -171,7 +172,7 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
     e.drop_where, e.drop_p, e.drop_seed = drop_where, drop_p, drop_seed
     e.drop_seed_dev = _p(SEED_DEV) if drop_where else None
     d.a_colsum = _p(a_colsum, torch.float32)
-    d.group = _p(group, torch.int64)          # [batch, 4] int64 rows (a pointer, b pointer, c offset, rscale offset): toist_group
+    d.group = _p(group, torch.int64)          # [batch, 6] int64 rows (a, b pointers; c, rscale, colsum offsets; 0): toist_group
     deferred = None
     if split_k > 1:
         eff = int(_lib.lib().toist_gemm_effective_split(ctypes.byref(d))) if defer_reduce else 0

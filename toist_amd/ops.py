@@ -71,6 +71,27 @@ def linear_wgrad(dy, x, *, out=None, alpha=1.0, flags=0, split_k=None, bias_out=
     return out
 
 
+def linear_wgrad_group(items):
+    """Weight (and bias) gradients of several nn.Linear layers of one shape -- the six layers of an encoder / decoder stack -- as one
+    grouped launch: items = [(dy, x, out, bias_out)].  Separately each is a handful of tiles with a deep reduction (split-K + fold)."""
+    dy0, x0, out0, b0 = items[0]
+    M, N = dy0.shape
+    K = x0.shape[1]
+    if len(items) < 2 or len(items) > k.GROUP_MAX or any((it[3] is None) != (b0 is None) for it in items):
+        for dy, x, out, bo in items:
+            linear_wgrad(dy, x, out=out, bias_out=bo, defer=True)
+        return
+    rows = []
+    for dy, x, out, bo in items:
+        assert dy.shape == dy0.shape and x.shape == x0.shape and _ld(dy) == _ld(dy0) and _ld(x) == _ld(x0) and _ld(out) == _ld(out0)
+        c_off, b_off = out.data_ptr() - out0.data_ptr(), (bo.data_ptr() - b0.data_ptr()) if bo is not None else 0
+        assert c_off % 4 == 0 and b_off % 4 == 0 and out.dtype == torch.float32
+        rows.append([dy.data_ptr(), x.data_ptr(), c_off // 4, 0, b_off // 4])
+    table = k.group_table(rows, dy0.device)
+    k.gemm(N, K, M, k.A_KROW, k.operand(dy0, _ld(dy0)), k.B_KROW, k.operand(x0, _ld(x0)), out0, _ld(out0), accumulate=True, split_k=1,
+           flops=2 * M * N * K * len(items), a_colsum=b0, batch=len(items), group=table)
+
+
 def bias_grad(dy, out=None):
     M, N = dy.shape
     if out is None:
@@ -203,7 +224,7 @@ def conv2d_wgrad_group(items, w_shape, *, stride=1, pad=0, dil=1):
         assert dy.shape == dy0.shape and x.shape == x0.shape and dy.is_contiguous() and x.is_contiguous() and out.is_contiguous()
         c_off, r_off = out.data_ptr() - out0.data_ptr(), (rs.data_ptr() - rs0.data_ptr()) if rs is not None else 0
         assert c_off % 4 == 0 and r_off % 4 == 0 and out.dtype == torch.float32 and (rs is None or rs.dtype == torch.float32)
-        rows.append([dy.data_ptr(), x.data_ptr(), c_off // 4, r_off // 4])
+        rows.append([dy.data_ptr(), x.data_ptr(), c_off // 4, r_off // 4, 0])
     table = k.group_table(rows, dy0.device)
     a = k.operand(dy0, Co)
     if R == 1 and S == 1 and stride == 1 and pad == 0:

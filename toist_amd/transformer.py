@@ -286,7 +286,7 @@ class Transformer(nn.Module):
             return [r], None
 
         (out,) = functions.run_program(prog, named, [], cache=self._cache_text, training=self.training, drop_p=cfg.hidden_dropout_prob,
-                                       seed=self._next_seed())
+                                       seed=self._next_seed(), group_wgrads=True)
         return out, key_pad
 
     # ---- encoder ----------------------------------------------------------------------------------
@@ -312,7 +312,7 @@ class Transformer(nn.Module):
             return [x], None
 
         (out,) = functions.run_program(prog, named, [tokens], cache=self._cache_enc, training=self.training, drop_p=self.dropout,
-                                       seed=self._next_seed())
+                                       seed=self._next_seed(), group_wgrads=True)
         return out
 
     # ---- decoder ----------------------------------------------------------------------------------
@@ -371,7 +371,7 @@ class Transformer(nn.Module):
             return [hs], None
 
         (out,) = functions.run_program(prog, named, [memory, query_embed], cache=self._cache_dec, training=self.training,
-                                       drop_p=self.dropout, seed=self._next_seed())
+                                       drop_p=self.dropout, seed=self._next_seed(), group_wgrads=True)
         return out
 
     # ---- reference-compatible API -------------------------------------------------------------------
