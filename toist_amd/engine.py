@@ -169,7 +169,9 @@ _cast_bf16.elementwise = True
 def compute_copy(t, make, cache, name):
     global COPY_GEN
     ent = cache.get(name) if cache is not None else None
-    if ent is not None and ent.version == t._version and ent.ptr == t.data_ptr() and ent.epoch == WEIGHT_EPOCH and _reg_post_hook is not None:
+    # a frozen tensor (requires_grad False) is outside every optimizer: only its version counter / storage can invalidate the copy
+    if ent is not None and ent.version == t._version and ent.ptr == t.data_ptr() and (ent.epoch == WEIGHT_EPOCH or not t.requires_grad) \
+            and _reg_post_hook is not None:
         return ent.w
     w = make(t)
     if ent is not None and ent.w.shape == w.shape and ent.w.stride() == w.stride():
