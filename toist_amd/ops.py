@@ -231,7 +231,14 @@ def conv2d_wgrad_group(items, w_shape, *, stride=1, pad=0, dil=1):
         b_kind, b = k.B_KROW, k.operand(x0, C)
     else:
         b_kind, b = k.B_CONVX, k.operand(x0, 0, geom=k.ConvGeom(H, W, C, OH, OW, R, S, stride, pad, dil))
-    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out0, Nn, accumulate=True, split_k=1, rscale=rs0, batch=len(items), tile=GROUP_TILE,
+    tile = GROUP_TILE
+    if tile == 0:
+        # measured on the 22 grouped layer-3 problems (K = 12800, tools/run_timeline.sh): 3x3 714 / 562 / 598 us and 1x1 913 / 886 / 818 us
+        # with 64x64 / 128x128 / 128x64 tiles -- deep reductions with enough tiles to fill the chip want the larger tiles
+        big = 129 if R * S > 1 else 130
+        n_big = ((Co + 127) // 128) * ((Nn + (127 if big == 129 else 63)) // (128 if big == 129 else 64)) * len(items)
+        tile = big if n_big >= 256 else 0
+    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out0, Nn, accumulate=True, split_k=1, rscale=rs0, batch=len(items), tile=tile,
            flops=2 * P * Co * Nn * len(items), group=table)
 
 
