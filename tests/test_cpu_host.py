@@ -44,6 +44,12 @@ def test_struct_layouts_match_header(tmp_path):
     from toist_amd import optim
     dt = optim._TENSOR_DT
     assert got == [dt.itemsize, dt.fields["numel"][1], dt.fields["group"][1], 32, 16, ctypes.sizeof(_lib.ReduceDesc)]
+    # the grouped-launch table rows (six int64 per problem, toist_amd/kernels.py: group_table) and the descriptor's group pointer
+    src.write_text('#include "toist_hip.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu %zu\\n", sizeof(toist_group), '
+                   'offsetof(toist_group, c_off), offsetof(toist_group, colsum_off), offsetof(toist_gemm, group));return 0;}\n')
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [48, 16, 32, _lib.Gemm.group.offset]
 
 
 def test_bad_arguments_return_error_codes_without_a_gpu():
