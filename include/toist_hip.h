@@ -127,8 +127,9 @@ typedef struct toist_epilogue {
  * identical residual blocks of a ResNet stage: 23 x three GEMMs in layer 3, each too small to fill the chip on its own and
  * therefore split along K with a fold pass -- grouped, they run as one unsplit launch).  Entry z replaces the strided
  * batch addressing: A and B start at a / b, C (and res / aux / pre_out) is offset by c_off elements from toist_gemm.c,
- * epi.rscale by rscale_off and a_colsum by colsum_off elements.  Device memory, `batch` entries; split_k must be 1 and
- * batch_inner 1. */
+ * epi.rscale by rscale_off and a_colsum by colsum_off elements.  Device memory, `batch` entries; batch_inner must be 1.
+ * With split_k > 1 the workspace is [problem][k-slice][M][N] and the caller folds every problem with
+ * toist_splitk_reduce_batch (TOIST_GEMM_DEFER_REDUCE). */
 typedef struct toist_group {
     const void* a;
     const void* b;

@@ -373,8 +373,9 @@ def test_fused_attention_backward_matches_five_kernel_path(dev, Sq, Sk, drop, va
             assert err < 2e-2, (name, "vs fp32", err)
 
 
+@pytest.mark.parametrize("min_tiles", [1, 1 << 20])      # unsplit group / group that is also split along K
 @pytest.mark.parametrize("R,stride", [(1, 1), (3, 1)])
-def test_grouped_conv_wgrad_matches_separate_launches(dev, R, stride):
+def test_grouped_conv_wgrad_matches_separate_launches(dev, R, stride, min_tiles):
     """toist_group: the weight gradients of several same-shape convolutions as ONE unsplit launch (operands at arbitrary
     addresses, outputs / row scales at element offsets) against one launch per problem (split along K + fold) and fp32 math."""
     from toist_amd import ops
@@ -394,7 +395,7 @@ def test_grouped_conv_wgrad_matches_separate_launches(dev, R, stride):
         torch.nn.functional.conv2d(xr, w, padding=pad).backward(dy.float().permute(0, 3, 1, 2).cpu())
         refs.append(w.grad.permute(0, 2, 3, 1) * scales[i].cpu()[:, None, None, None])
     old = ops.GROUP_MIN_TILES
-    ops.GROUP_MIN_TILES = 1
+    ops.GROUP_MIN_TILES = min_tiles
     try:
         ops.conv2d_wgrad_group(items, (Co, R, R, C), stride=stride, pad=pad)
         from toist_amd import kernels as k

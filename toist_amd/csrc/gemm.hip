@@ -392,7 +392,7 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
     constexpr int CH = (32 * CPR + 255) / 256;       // chunks per thread per band (1 for BN <= 64, 2 for BN = 128)
     static_assert(32 * CPR % 256 == 0 || 32 * CPR < 256, "band chunks must divide over 256 threads");
     const bool partial = p.split_k > 1;              // k-slice partial: raw f32 into the workspace, epilogue in splitk_reduce_kernel
-    float* ws = partial ? p.workspace + (size_t)ksl * M * N : nullptr;
+    float* ws = partial ? p.workspace + ((size_t)bz * p.split_k + ksl) * M * N : nullptr;   // [problem][k-slice][M][N]
     // residual / aux operands of EVERY band are requested up front: one exposed load latency per tile, not one per band
     EpiRow rows_all[FM][CH];
     EpiPre pre_all[FM][CH];
@@ -1148,12 +1148,14 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     if (d.split_k > 1 || d.epi.accumulate)
         TOIST_REQUIRE(d.epi.out_f32, "toist_gemm_bf16: split_k/accumulate needs an f32 output");
     if (d.a_colsum) TOIST_REQUIRE(d.a_kind == TOIST_A_KROW, "toist_gemm_bf16: a_colsum needs a k-major A operand");
-    if (d.group) TOIST_REQUIRE(d.split_k <= 1 && d.batch_inner == 1 && !d.epi.cmap && (d.tile & 255) != 131 && d.a_kind != TOIST_A_CONVT,
-                               "toist_gemm_bf16: a grouped launch takes split_k = 1, batch_inner = 1, no cmap and a generic tile");
+    if (d.group) TOIST_REQUIRE((d.split_k <= 1 || (d.flags & TOIST_GEMM_DEFER_REDUCE)) && d.batch_inner == 1 && !d.epi.cmap && (d.tile & 255) != 131 &&
+                                   d.a_kind != TOIST_A_CONVT,
+                               "toist_gemm_bf16: a grouped launch takes batch_inner = 1, no cmap, a generic tile, and folds its k-slices through "
+                               "toist_splitk_reduce_batch (TOIST_GEMM_DEFER_REDUCE; workspace = [problem][k-slice][M][N])");
     if (d.split_k > 1) {
         TOIST_REQUIRE(!d.epi.scale && !d.epi.shift && !d.epi.res && d.epi.act == TOIST_ACT_NONE && !d.epi.pre_out && d.epi.drop_where == 0 &&
-                          !d.epi.cmap && d.batch == 1,
-                      "toist_gemm_bf16: split_k only supports alpha/rscale/accumulate epilogues on a single batch");
+                          !d.epi.cmap && (d.batch == 1 || d.group != nullptr),
+                      "toist_gemm_bf16: split_k only supports alpha/rscale/accumulate epilogues on a single batch (or a grouped launch)");
         TOIST_REQUIRE(d.workspace != nullptr && (d.N % 4) == 0 && (d.ldc % 4) == 0, "toist_gemm_bf16: split_k needs a workspace and N, ldc %% 4 == 0");
     }
     if (d.epi.act >= TOIST_ACT_MASK_POS) TOIST_REQUIRE(d.epi.aux != nullptr, "toist_gemm_bf16: activation %d needs aux", d.epi.act);

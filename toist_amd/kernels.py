@@ -139,7 +139,7 @@ def operand(t, ld=0, bs_outer=0, bs_inner=0, kin=0, tap_stride=0, geom=None):
 def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_outer=0, cs_inner=0, split_k=1, tile=0,
          flags=0, alpha=1.0, scale=None, shift=None, rscale=None, res=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, pre_out=None,
          accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0, flops=0, a_colsum=None, res_bcast=None,
-         defer_reduce=False, group=None):
+         defer_reduce=False, group=None, group_out=None):
     """C = epilogue(A @ B^T); see include/toist_hip.h.  `a`/`b` are Operand structs from operand().
     `flops` = algorithmic FLOPs of the call (bench.py's roofline accounting only)."""
     if tile == 0 and FORCE_TILE:
@@ -174,7 +174,23 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
     d.a_colsum = _p(a_colsum, torch.float32)
     d.group = _p(group, torch.int64)          # [batch, 6] int64 rows (a, b pointers; c, rscale, colsum offsets; 0): toist_group
     deferred = None
-    if split_k > 1:
+    if split_k > 1 and group is not None:
+        # grouped + split: [problem][k-slice][M][N] partials, one queued fold per problem (group_out = [(c_i, rscale_i)])
+        eff = int(_lib.lib().toist_gemm_effective_split(ctypes.byref(d)))
+        if eff > 1:
+            key = (c.device, _raw_stream())
+            outs = {ci.data_ptr() for ci, _ in group_out}
+            if any(it[0].out in outs for it in _PENDING.get(key, ())):
+                flush_reductions()
+            ws = _arena_take(eff * M * N * batch, c.device)
+            d.workspace = _p(ws, torch.float32)
+            d.flags |= GEMM_DEFER_REDUCE
+            for i, (ci, ri) in enumerate(group_out):
+                rd = _lib.ReduceDesc(ws.data_ptr() + 4 * i * eff * M * N, ci.data_ptr(), _p(ri, torch.float32), eff, M, N, ldc, alpha, 1 if accumulate else 0)
+                _PENDING.setdefault(key, []).append((rd, (ci, ri)))
+        else:
+            d.split_k = 1
+    elif split_k > 1:
         eff = int(_lib.lib().toist_gemm_effective_split(ctypes.byref(d))) if defer_reduce else 0
         if eff > 1:
             # a second deferred reduction into the same output would race with the queued one: fold first

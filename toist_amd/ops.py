@@ -215,10 +215,12 @@ def conv2d_wgrad_group(items, w_shape, *, stride=1, pad=0, dil=1):
     Cw, R, S, Cc = w_shape
     Nn, P = R * S * C, Nb * OH * OW
     tiles = ((Co + 63) // 64) * ((Nn + 63) // 64) * len(items)
-    if len(items) < 2 or len(items) > k.GROUP_MAX or tiles < GROUP_MIN_TILES or any((it[3] is None) != (rs0 is None) for it in items):
+    if len(items) < 2 or len(items) > k.GROUP_MAX or any((it[3] is None) != (rs0 is None) for it in items):
         for dy, x, out, rs in items:
             conv2d_wgrad(dy, x, w_shape, stride=stride, pad=pad, dil=dil, out=out, rscale=rs, defer=True)
         return
+    # too few tiles to fill the chip even together: the group is also split along K (partials folded by the batched reduction)
+    split_k = _split_k_for(tiles, (P + 63) // 64) if tiles < GROUP_MIN_TILES else 1
     rows = []
     for dy, x, out, rs in items:
         assert dy.shape == dy0.shape and x.shape == x0.shape and dy.is_contiguous() and x.is_contiguous() and out.is_contiguous()
@@ -232,14 +234,14 @@ def conv2d_wgrad_group(items, w_shape, *, stride=1, pad=0, dil=1):
     else:
         b_kind, b = k.B_CONVX, k.operand(x0, 0, geom=k.ConvGeom(H, W, C, OH, OW, R, S, stride, pad, dil))
     tile = GROUP_TILE
-    if tile == 0:
+    if tile == 0 and split_k == 1:
         # measured on the 22 grouped layer-3 problems (K = 12800, tools/run_timeline.sh): 3x3 714 / 562 / 598 us and 1x1 913 / 886 / 818 us
         # with 64x64 / 128x128 / 128x64 tiles -- deep reductions with enough tiles to fill the chip want the larger tiles
         big = 129 if R * S > 1 else 130
         n_big = ((Co + 127) // 128) * ((Nn + (127 if big == 129 else 63)) // (128 if big == 129 else 64)) * len(items)
         tile = big if n_big >= 256 else 0
-    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out0, Nn, accumulate=True, split_k=1, rscale=rs0, batch=len(items), tile=tile,
-           flops=2 * P * Co * Nn * len(items), group=table)
+    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out0, Nn, accumulate=True, split_k=split_k, rscale=rs0, batch=len(items), tile=tile,
+           flops=2 * P * Co * Nn * len(items), group=table, group_out=[(it[2], it[3]) for it in items])
 
 
 # ------------------------------------------------------------------------------------------ attention
