@@ -91,8 +91,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
     const unsigned thresh = dx_drop ? (unsigned)(drop_p * 4294967296.0) : 0u;
     const float dscale = dx_drop ? 1.f / (1.f - drop_p) : 1.f;
 
+    // a wave walks its rows serially: the next row's operands are requested before the current row is reduced, and gamma stays in
+    // registers (one exposed load round trip per wave instead of one per row)
+    float gam[LN_MAXCH][8];
+    uint4 nd[LN_MAXCH], nx[LN_MAXCH];
+    float nmu = 0.f, nrs = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+        const int ch = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gam[i][j] = (ch < nch) ? gamma[ch * 8 + j] : 0.f;
+        nd[i] = make_uint4(0, 0, 0, 0);
+        nx[i] = make_uint4(0, 0, 0, 0);
+    }
+    auto fetch = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                nd[i] = *reinterpret_cast<const uint4*>(dy + (size_t)r * D + ch * 8);
+                nx[i] = *reinterpret_cast<const uint4*>(x + (size_t)r * D + ch * 8);
+            }
+        }
+        nmu = mean[r];
+        nrs = rstd[r];
+    };
+    if (wave_global < rows) fetch(wave_global);
     for (int row = wave_global; row < rows; row += nwaves) {
-        const float mu = mean[row], rs = rstd[row];
+        const float mu = nmu, rs = nrs;
+        uint4 cd[LN_MAXCH], cx[LN_MAXCH];
+#pragma unroll
+        for (int i = 0; i < LN_MAXCH; ++i) { cd[i] = nd[i]; cx[i] = nx[i]; }
+        if (row + nwaves < rows) fetch(row + nwaves);
         float g[LN_MAXCH][8], xh[LN_MAXCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -100,12 +130,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
             const int ch = lane + 64 * i;
             if (ch < nch) {
                 float d[8], xv[8];
-                unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)row * D + ch * 8), d);
-                unpack8(*reinterpret_cast<const uint4*>(x + (size_t)row * D + ch * 8), xv);
+                unpack8(cd[i], d);
+                unpack8(cx[i], xv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     xh[i][j] = (xv[j] - mu) * rs;
-                    g[i][j] = d[j] * gamma[ch * 8 + j];
+                    g[i][j] = d[j] * gam[i][j];
                     s1 += g[i][j];
                     s2 += g[i][j] * xh[i][j];
                     ag[i][j] += d[j] * xh[i][j];
