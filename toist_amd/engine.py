@@ -68,7 +68,8 @@ def overlap_enabled():
     return OVERLAP == "capture" and torch.cuda.is_current_stream_capturing()
 
 
-GROUP_WGRADS = True    # the weight gradients of identical residual blocks run as grouped launches at the end of the program
+import os as _os
+GROUP_WGRADS = _os.environ.get("TOIST_GROUP_WGRADS", "1") != "0"   # same-shape weight gradients of a program run as grouped launches at its end
 
 
 class Tape:
