@@ -303,10 +303,13 @@ int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk, const void
  * Pd = prob_drop (or prob when NULL), dP = (dctx v^T) o keep / (1 - drop_p), dS = prob o (dP - rowsum(dctx o ctx)); one launch
  * instead of four batched GEMMs and toist_softmax_bwd.  Layouts as toist_attn_fwd; ctx is the forward context, dctx its
  * gradient; dq / dk / dv are per-head column slices like q / k / v.  variant: 0 = by shape, 1 = key-major kernel (short query
- * ranges), 2 = query-major kernel (long ones). */
+ * ranges), 2 = query-major kernel (long ones).  q_splits > 1 (variant 2, dk / dv slices H*32 wide): that many workgroups share a
+ * head, each a run of query tiles; their dk / dv sums meet in `workspace` (q_splits * 2 * B*Sk * H*32 floats) and a fold
+ * kernel writes dk / dv. */
 int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const void* prob, const void* prob_drop,
                    const void* ctx, int ldo, const void* dctx, int lddo, int B, int H, int Sq, int Sk, int dh, int ld, float scale,
-                   float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int variant, void* stream);
+                   float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int variant, float* workspace, int q_splits,
+                   void* stream);
 
 /* ---- 3x3 / stride 1 / pad 1 convolution with <= 32 channels on either side (mask-head stages at 160x160,
  * segmentation.py:176-241 lay5 / out_lay; HBM-bound): NHWC bf16 in / out, weights [w_co][3][3][w_ci] bf16.

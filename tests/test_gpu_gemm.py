@@ -319,9 +319,9 @@ def test_fused_attention_forward_matches_three_kernel_path(dev, Sq, Sk, drop):
         assert float((c1.float() - ref).abs().max()) <= 3e-2 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant,q_splits", [(1, 1), (2, 1), (2, 4)])      # key-major; query-major; query-major, four workgroups per head
 @pytest.mark.parametrize("Sq,Sk,drop", [(416, 416, 0.1), (100, 416, 0.1), (100, 100, 0.1), (20, 32, 0.0), (37, 50, 0.1), (130, 250, 0.0), (70, 480, 0.1)])
-def test_fused_attention_backward_matches_five_kernel_path(dev, Sq, Sk, drop, variant):
+def test_fused_attention_backward_matches_five_kernel_path(dev, Sq, Sk, drop, variant, q_splits):
     """csrc/attn.hip backward (dQ, dK, dV in one launch) against the four batched GEMMs + softmax backward it replaces (both kernel variants: key-major for short query
     ranges, query-major for long ones), and against fp32 autograd on the same probabilities' inputs (no dropout); packed per-head slices, key-padding mask."""
     from toist_amd import kernels as k, ops
@@ -354,7 +354,7 @@ def test_fused_attention_backward_matches_five_kernel_path(dev, Sq, Sk, drop, va
     dqk = torch.full((B * Sq, 2 * d), 7.0, dtype=BF, device=dev)
     dk1, dv1 = torch.empty(B * Sk, d, dtype=BF, device=dev), torch.empty(B * Sk, d, dtype=BF, device=dev)
     dq1 = dqk[:, d:]
-    k.attn_bwd(q, kk, v, prob, pdrop, ctx, dctx, B, H, Sq, Sk, dh, scale, drop, dq1, dk1, dv1, variant=variant)
+    k.attn_bwd(q, kk, v, prob, pdrop, ctx, dctx, B, H, Sq, Sk, dh, scale, drop, dq1, dk1, dv1, variant=variant, q_splits=q_splits)
     assert bool((dqk[:, :d] == 7.0).all())
     for name, a, b in (("dq", dq1, dq0), ("dk", dk1, dk0), ("dv", dv1, dv0)):
         err = float((a.float() - b.float()).norm() / b.float().norm())

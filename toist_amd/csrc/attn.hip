@@ -321,7 +321,8 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ prob_drop, const bf16_t* __restrict__ ctx, int ldo,
                                                             const bf16_t* __restrict__ dctx, int lddo, int H, int Sq, int Sk, int ld,
                                                             float scale, float drop_p, bf16_t* __restrict__ dq, int lddq,
-                                                            bf16_t* __restrict__ dk, int lddk, bf16_t* __restrict__ dv, int lddv) {
+                                                            bf16_t* __restrict__ dk, int lddk, bf16_t* __restrict__ dv, int lddv,
+                                                            float* __restrict__ part) {
     constexpr int SKP = NB * 16, DH = 32, QT = 32, LS = SKP + 8, NBQ = NB / 4, NBW = NB / 8;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     bf16_t* sV = smem;                        // [SKP][32]
@@ -371,7 +372,13 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
             dnx[jj] = pd;
         }
     };
-    fetch(0);
+    // gridDim.y workgroups share a head: each walks a contiguous run of query tiles (dQ rows are disjoint; their dK / dV sums go
+    // to `part` [split][2][B*Sk][H*32] f32 and attn_bwd_fold_kernel adds them up)
+    const int n_tiles_all = (Sq + QT - 1) / QT;
+    const int per_split = (n_tiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t_beg = (int)blockIdx.y * per_split;
+    const int t_end = (t_beg + per_split < n_tiles_all) ? t_beg + per_split : n_tiles_all;
+    fetch(t_beg * QT);
     // rows of dO, O, Q of the next tile (threads 0..255: query tid / 8, features 4 (tid % 8) ..), also fetched one tile ahead
     uint2 d2n = make_uint2(0, 0), o2n = make_uint2(0, 0), q2n = make_uint2(0, 0);
     auto fetch_rows = [&](int q0_) {
@@ -383,10 +390,10 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
             q2n = *reinterpret_cast<const uint2*>(q + ((size_t)b * Sq + qi) * ldq + h * DH + ch * 4);
         }
     };
-    fetch_rows(0);
+    fetch_rows(t_beg * QT);
 
-    const int n_tiles = (Sq + QT - 1) / QT;
-    for (int t = 0; t < n_tiles; ++t) {
+    const int n_tiles = t_end;
+    for (int t = t_beg; t < n_tiles; ++t) {
         const int q0 = t * QT;
         if (tid < 256) {   // ---- tile prologue: dO, Q rows and D = rowsum(dO o O) ----
             const int qq = tid >> 3, ch = tid & 7;
@@ -500,13 +507,41 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
         if (key < Sk) {
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) {
-                *reinterpret_cast<uint2*>(dk + ((size_t)b * Sk + key) * lddk + h * DH + eb * 16 + g * 4) =
-                    make_uint2(pack2bf(accK[i][eb][0] * scale, accK[i][eb][1] * scale), pack2bf(accK[i][eb][2] * scale, accK[i][eb][3] * scale));
-                *reinterpret_cast<uint2*>(dv + ((size_t)b * Sk + key) * lddv + h * DH + eb * 16 + g * 4) =
-                    make_uint2(pack2bf(accV[i][eb][0], accV[i][eb][1]), pack2bf(accV[i][eb][2], accV[i][eb][3]));
+                if (part != nullptr) {
+                    const size_t plane = (size_t)(gridDim.x / H) * Sk * H * DH;            // B*Sk x H*32
+                    float* pk = part + ((size_t)blockIdx.y * 2 + 0) * plane + ((size_t)b * Sk + key) * (H * DH) + h * DH + eb * 16 + g * 4;
+                    float* pv = part + ((size_t)blockIdx.y * 2 + 1) * plane + ((size_t)b * Sk + key) * (H * DH) + h * DH + eb * 16 + g * 4;
+                    *reinterpret_cast<float4*>(pk) = make_float4(accK[i][eb][0], accK[i][eb][1], accK[i][eb][2], accK[i][eb][3]);
+                    *reinterpret_cast<float4*>(pv) = make_float4(accV[i][eb][0], accV[i][eb][1], accV[i][eb][2], accV[i][eb][3]);
+                } else {
+                    *reinterpret_cast<uint2*>(dk + ((size_t)b * Sk + key) * lddk + h * DH + eb * 16 + g * 4) =
+                        make_uint2(pack2bf(accK[i][eb][0] * scale, accK[i][eb][1] * scale), pack2bf(accK[i][eb][2] * scale, accK[i][eb][3] * scale));
+                    *reinterpret_cast<uint2*>(dv + ((size_t)b * Sk + key) * lddv + h * DH + eb * 16 + g * 4) =
+                        make_uint2(pack2bf(accV[i][eb][0], accV[i][eb][1]), pack2bf(accV[i][eb][2], accV[i][eb][3]));
+                }
             }
         }
     }
+}
+
+// dk = scale * sum_s part[s][0], dv = sum_s part[s][1]: rows = B*Sk, d = H*32 columns, 4 columns per thread
+__global__ __launch_bounds__(256) void attn_bwd_fold_kernel(const float* __restrict__ part, int splits, long long rows, int d, float scale,
+                                                            bf16_t* __restrict__ dk, int lddk, bf16_t* __restrict__ dv, int lddv) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = d >> 2;
+    if (idx >= rows * c4) return;
+    const long long r = idx / c4;
+    const int c = (int)(idx - r * c4) * 4;
+    const size_t plane = (size_t)rows * d;
+    float4 ak = make_float4(0.f, 0.f, 0.f, 0.f), av = ak;
+    for (int sp = 0; sp < splits; ++sp) {
+        const float4 a = *reinterpret_cast<const float4*>(part + ((size_t)sp * 2 + 0) * plane + (size_t)r * d + c);
+        const float4 bq = *reinterpret_cast<const float4*>(part + ((size_t)sp * 2 + 1) * plane + (size_t)r * d + c);
+        ak.x += a.x; ak.y += a.y; ak.z += a.z; ak.w += a.w;
+        av.x += bq.x; av.y += bq.y; av.z += bq.z; av.w += bq.w;
+    }
+    *reinterpret_cast<uint2*>(dk + (size_t)r * lddk + c) = make_uint2(pack2bf(ak.x * scale, ak.y * scale), pack2bf(ak.z * scale, ak.w * scale));
+    *reinterpret_cast<uint2*>(dv + (size_t)r * lddv + c) = make_uint2(pack2bf(av.x, av.y), pack2bf(av.z, av.w));
 }
 
 }  // namespace toist
@@ -536,10 +571,12 @@ extern "C" int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk,
 
 extern "C" int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const void* prob, const void* prob_drop,
                               const void* ctx, int ldo, const void* dctx, int lddo, int B, int H, int Sq, int Sk, int dh, int ld, float scale,
-                              float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int variant, void* stream) {
+                              float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int variant, float* workspace,
+                              int q_splits, void* stream) {
     TOIST_REQUIRE(q && kmat && v && prob && ctx && dctx && dq && dk && dv && B > 0 && H > 0 && Sq > 0 && Sk > 0, "toist_attn_bwd: bad args");
     TOIST_REQUIRE(variant >= 0 && variant <= 2, "toist_attn_bwd: variant 0 (auto), 1 (key-major) or 2 (query-major)");
     TOIST_REQUIRE((ld % 8) == 0, "toist_attn_bwd: ld must be a multiple of 8");
+    TOIST_REQUIRE(q_splits >= 1 && q_splits <= 16 && (q_splits == 1 || workspace != nullptr), "toist_attn_bwd: 1..16 query splits; > 1 needs a workspace");
     TOIST_REQUIRE(dh == 32, "toist_attn_bwd: head dim must be 32 (got %d)", dh);
     TOIST_REQUIRE(Sk <= 512 && ld >= Sk, "toist_attn_bwd: Sk <= 512 and ld >= Sk (got %d, %d)", Sk, ld);
     TOIST_REQUIRE((ldq % 4) == 0 && (ldk % 8) == 0 && (ldv % 8) == 0 && (ldo % 4) == 0 && (lddo % 4) == 0 && (lddq % 4) == 0 && (lddk % 4) == 0 &&
@@ -564,16 +601,25 @@ extern "C" int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk,
             hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_rows_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) { set_last_error("toist_attn_bwd: set LDS size: %s", hipGetErrorString(e)); return TOIST_EHIP; }            \
         }                                                                                                                                    \
-        hipLaunchKernelGGL((attn_bwd_rows_kernel<NB>), dim3(B * H), dim3(512), lds, st, (const bf16_t*)q, ldq, (const bf16_t*)kmat, ldk,      \
-                           (const bf16_t*)v, ldv, (const bf16_t*)prob, (const bf16_t*)prob_drop, (const bf16_t*)ctx, ldo, (const bf16_t*)dctx,  \
-                           lddo, H, Sq, Sk, ld, scale, drop_p, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);                       \
+        hipLaunchKernelGGL((attn_bwd_rows_kernel<NB>), dim3(B * H, q_splits), dim3(512), lds, st, (const bf16_t*)q, ldq, (const bf16_t*)kmat, \
+                           ldk, (const bf16_t*)v, ldv, (const bf16_t*)prob, (const bf16_t*)prob_drop, (const bf16_t*)ctx, ldo,                \
+                           (const bf16_t*)dctx, lddo, H, Sq, Sk, ld, scale, drop_p, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv,  \
+                           q_splits > 1 ? workspace : (float*)nullptr);                                                                     \
     } while (0)
     if (variant == 0) variant = (Sq > 128 && Sk > 128) ? 2 : 1;
     if (variant == 2) {
         if (Sk <= 128) TOIST_ATTN_BWD_ROWS(8);
         else if (Sk <= 256) TOIST_ATTN_BWD_ROWS(16);
         else TOIST_ATTN_BWD_ROWS(32);
+        if (q_splits > 1) {
+            const int rc2 = check_launch("toist_attn_bwd");
+            if (rc2 != TOIST_OK) return rc2;
+            const long long rows = (long long)B * Sk, n4 = rows * (H * 32 / 4);
+            hipLaunchKernelGGL(attn_bwd_fold_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, workspace, q_splits, rows, H * 32, scale,
+                               (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);
+        }
     } else {
+        TOIST_REQUIRE(q_splits == 1, "toist_attn_bwd: query splits need the query-major variant");
         if (Sk <= 128) TOIST_ATTN_BWD(1);
         else if (Sk <= 256) TOIST_ATTN_BWD(2);
         else TOIST_ATTN_BWD(4);

@@ -535,11 +535,12 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
             k.softmax_bwd(prob, dp, B * H * Sq, Sk, ld, ds, p, seed_p)
             return ds
 
-        if fused_core and (Sq <= 128 or Sk <= 128):
-            # dV, dP, softmax backward, dQ, dK in one launch (csrc/attn.hip, query-major variant).  Measured (tools/bench_attn_core.py,
-            # B=8): 12 vs 39 us at 100x100, 32 vs 46 us at 100x416; at 416x416 the five-kernel path still wins (81 vs 113 us: one
-            # workgroup per head walks 13 query tiles serially and only 64 workgroups exist)
-            k.attn_bwd(qb, kb, vb, prob, prob_used if p > 0 else None, ctx, dctx, B, H, Sq, Sk, dh, scale, p, dq, dk, dv, variant=2)
+        if fused_core:
+            # dV, dP, softmax backward, dQ, dK in one launch (csrc/attn.hip, query-major variant; several workgroups per head when the
+            # query range is long, their dK / dV sums folded by a second small kernel).  Measured (tools/bench_attn_core.py, B=8):
+            # 11 vs 35 us at 100x100, 24 vs 41 us at 100x416, 45 vs 70 us at 416x416 (100 us with one workgroup per head)
+            k.attn_bwd(qb, kb, vb, prob, prob_used if p > 0 else None, ctx, dctx, B, H, Sq, Sk, dh, scale, p, dq, dk, dv, variant=2,
+                       q_splits=4 if Sk > 128 else 1)
         else:
             ops.attn_backward(prob_used, scale, qb, kb, vb, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
         if fused:

@@ -449,13 +449,14 @@ def attn_fwd(q, kmat, v, key_pad, B, H, Sq, Sk, dh, scale, prob, prob_drop, drop
                                          _p(ctx, torch.bfloat16), ctx.stride(0), _stream()), "toist_attn_fwd")
 
 
-def attn_bwd(q, kmat, v, prob, prob_drop, ctx, dctx, B, H, Sq, Sk, dh, scale, drop_p, dq, dk, dv, variant=0):
+def attn_bwd(q, kmat, v, prob, prob_drop, ctx, dctx, B, H, Sq, Sk, dh, scale, drop_p, dq, dk, dv, variant=0, q_splits=1):
     """Fused attention core backward (csrc/attn.hip): all operands are column slices of packed [B*S, ld] bf16 buffers."""
+    ws = _workspace(q_splits * 2 * B * Sk * H * dh, q.device) if q_splits > 1 else None
     _lib.check(_lib.lib().toist_attn_bwd(_p(q, torch.bfloat16), q.stride(0), _p(kmat, torch.bfloat16), kmat.stride(0), _p(v, torch.bfloat16), v.stride(0),
                                          _p(prob, torch.bfloat16), _p(prob_drop, torch.bfloat16), _p(ctx, torch.bfloat16), ctx.stride(0),
                                          _p(dctx, torch.bfloat16), dctx.stride(0), B, H, Sq, Sk, dh, prob.shape[-1], scale, drop_p,
                                          _p(dq, torch.bfloat16), dq.stride(0), _p(dk, torch.bfloat16), dk.stride(0), _p(dv, torch.bfloat16), dv.stride(0),
-                                         variant, _stream()), "toist_attn_bwd")
+                                         variant, _p(ws, torch.float32), q_splits, _stream()), "toist_attn_bwd")
 
 
 # ---- evaluation masks (csrc/evalmask.hip): column-major bit planes [n, W, ceil(H/64)] stored in int64 tensors --------------

@@ -44,5 +44,8 @@ for Sq, Sk in [(416, 416), (100, 416), (100, 100)]:
     unfused_b = lambda: ops.attn_backward(pu0, sc, q, kk, v, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
     fused_b1 = lambda: k.attn_bwd(q, kk, v, p0, pu0, c, dctx, B, H, Sq, Sk, dh, sc, 0.1, dq, dk, dv, variant=1)
     fused_b2 = lambda: k.attn_bwd(q, kk, v, p0, pu0, c, dctx, B, H, Sq, Sk, dh, sc, 0.1, dq, dk, dv, variant=2)
+    fused_b4 = lambda: k.attn_bwd(q, kk, v, p0, pu0, c, dctx, B, H, Sq, Sk, dh, sc, 0.1, dq, dk, dv, variant=2, q_splits=4)
+    fused_b2s = lambda: k.attn_bwd(q, kk, v, p0, pu0, c, dctx, B, H, Sq, Sk, dh, sc, 0.1, dq, dk, dv, variant=2, q_splits=2)
     print(f"Sq={Sq} Sk={Sk}: backward five kernels {1000 * timeit(unfused_b, 30):7.1f} us   fused key-major {1000 * timeit(fused_b1, 30):7.1f} us   "
-          f"fused query-major {1000 * timeit(fused_b2, 30):7.1f} us", flush=True)
+          f"fused query-major {1000 * timeit(fused_b2, 30):7.1f} us   x2 splits {1000 * timeit(fused_b2s, 30):7.1f} us   x4 splits "
+          f"{1000 * timeit(fused_b4, 30):7.1f} us", flush=True)
