@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--masks", action="store_true", help="config 3: add the segmentation head and the mask losses")
     ap.add_argument("--no-overlap", action="store_true", help="keep the text branch on the main stream (no parallel graph branch)")
     ap.add_argument("--torch-optimizer", action="store_true", help="diagnostic: torch clip_grad_norm_ + fused AdamW + foreach EMA instead of the HIP tail")
+    ap.add_argument("--defer-ema", action="store_true", help="diagnostic: run the EMA update beside the next forward pass instead of inside the optimizer tail "
+                                                             "(measured slower: 504 vs 514 images/s, the forward pass is HBM-sensitive)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
     ap.add_argument("--split-graph", action="store_true", help="force the multi-GPU structure (graph: fwd+bwd | eager all-reduce | graph: clip+AdamW+EMA) on one GPU")
     return ap.parse_args()
@@ -219,8 +221,11 @@ def main():
     if not a.torch_optimizer:
         # clip_grad_norm_(0.1) + AdamW (3 groups) + EMA + bf16 compute-copy refresh: csrc/optim.hip, 3 launches per step
         from toist_amd.optim import FusedClipAdamWEMA
+        # --defer-ema: the moving average of step i is folded in on a side stream beside the forward pass of step i+1 (same values, one
+        # update per step); off by default -- the extra HBM traffic slows the forward pass by more than the tail gains
         opt = FusedClipAdamWEMA(groups, lr=args.lr, weight_decay=args.weight_decay, max_norm=args.clip_max_norm, ema=list(zip(ema_src, ema)),
-                                ema_decay=0.9998)
+                                ema_decay=0.9998, defer_ema=a.defer_ema)
+    ema_stream = torch.cuda.Stream() if (not a.torch_optimizer and a.defer_ema) else None
 
     samples, tok, targets, pmap = harness.synthetic_batch(a.batch, a.size, a.size, tokens=16, seed=1000 + rank, device=dev, with_masks=a.masks)
     sync = parallel.GradSync()
@@ -231,11 +236,17 @@ def main():
 
     def fwd_bwd():
         kernels.SEED_DEV.add_(1000003)
+        if ema_stream is not None:          # EMA of the previous step's parameters, beside this forward / backward
+            ema_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ema_stream):
+                opt.ema_update()
         mc = model(samples, tok, encode_and_save=True)
         out = model(samples, tok, encode_and_save=False, memory_cache=mc)
         losses = criterion(mc, out, targets, pmap, None)
         total = weighted_total(losses, weight_dict)
         total.backward()                     # with the backbone cut (N > 1): everything but the backbone
+        if ema_stream is not None:
+            torch.cuda.current_stream().wait_stream(ema_stream)     # joined before the optimizer rewrites the parameters
         cut_state["mc"] = mc
         return total
 

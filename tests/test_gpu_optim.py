@@ -107,3 +107,30 @@ def test_torch_optimizer_step_invalidates_compute_copies(dev):
     opt.step()
     w1 = engine.compute_copy(p, engine._cast_bf16, cache, "w")
     assert not torch.equal(w0, w1) and torch.equal(w1, p.detach().to(torch.bfloat16))
+
+
+def test_deferred_ema_is_the_same_average(dev):
+    """defer_ema=True: the moving average leaves step() and runs as ema_update() (beside the next forward pass in bench.py); parameters,
+    moments and -- once the last update is flushed -- the average equal those of the in-step variant bit for bit."""
+    from toist_amd.optim import FusedClipAdamWEMA
+    g = torch.Generator().manual_seed(5)
+    shapes = [(300, 70), (17,), (64, 3, 3, 8), (9000,)]
+
+    def run(defer):
+        params = [torch.nn.Parameter(torch.randn(*s, generator=g.manual_seed(11 + i)).to(dev)) for i, s in enumerate(shapes)]
+        frozen = torch.randn(123, generator=g.manual_seed(99)).to(dev)
+        src = params + [frozen]
+        ema = [p.detach().clone() for p in src]
+        opt = FusedClipAdamWEMA([{"params": params[:2], "lr": 1e-3}, {"params": params[2:], "lr": 3e-4}], weight_decay=1e-2, max_norm=0.5,
+                                ema=list(zip(src, ema)), ema_decay=0.9, defer_ema=defer)
+        for step in range(4):
+            for i, p in enumerate(params):
+                p.grad = torch.randn(p.shape, generator=g.manual_seed(1000 * step + i)).to(dev)
+            if defer and step % 2 == 1:
+                opt.ema_update()                    # explicitly, as the training loop does; other steps rely on step()'s own flush
+            opt.step()
+        opt.ema_update()
+        return [p.detach().clone() for p in params], ema, [m.clone() for m in opt.exp_avg]
+    a, b = run(False), run(True)
+    for x, y in zip(a[0] + a[1] + a[2], b[0] + b[1] + b[2]):
+        assert torch.equal(x, y)
