@@ -46,7 +46,7 @@ class Var:
 # Independent branches of the step are forked onto side HIP streams so that, inside the captured hipGraph,
 # they become parallel branches: the small GEMMs of one branch fill the ramp-up / tail bubbles of the other.
 #   "capture": only while a hipGraph is being captured;  "on": always (tests);  "off": never.
-# Measured on MI355X (B=8, 640x640): text branch || image branch +8.7 % images/s.  Forking the weight-gradient
+# Measured on MI355X (B=8, 640x640): text branch || image branch +8.7 % images/s (+14 % once the rest of the step had shrunk).  Forking the weight-gradient
 # GEMMs from the data-gradient chain was measured too (0 % to -6 %: those kernels already fill the chip and
 # every fork is a cross-stream edge of the graph) and is deliberately not done.
 OVERLAP = "capture"
