@@ -126,7 +126,7 @@ def bench_distillation(a, dev, rank, world):
 
     opts = [tail(model), tail(model_noun)]
     batch = harness.synthetic_distill_batch(a.batch, a.size, a.size, tokens=16, seed=1000 + rank, device=dev)
-    sync = parallel.GradSync()
+    sync = parallel.GradSync([model, model_noun])
 
     def step():
         kernels.SEED_DEV.add_(1000003)
@@ -228,7 +228,7 @@ def main():
     ema_stream = torch.cuda.Stream() if (not a.torch_optimizer and a.defer_ema) else None
 
     samples, tok, targets, pmap = harness.synthetic_batch(a.batch, a.size, a.size, tokens=16, seed=1000 + rank, device=dev, with_masks=a.masks)
-    sync = parallel.GradSync()
+    sync = parallel.GradSync(model)
 
     flats = []  # flat fp32 gradient buffers of the backward programs (filled by the GradSync hook)
 
@@ -302,7 +302,7 @@ def main():
                         optimize()
                 else:
                     # no collective inside a capture: the hook only collects the flat gradient buffers of each segment
-                    functions.GRAD_SYNC = flats.append
+                    functions.GRAD_SYNC = lambda f: flats.append(f) if f is not None else None
                     graph_a = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph_a, stream=side):
                         static_loss = fwd_bwd()

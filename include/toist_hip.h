@@ -221,15 +221,39 @@ int toist_embed_bwd(const void* g, const int64_t* ids, const int64_t* pos_ids, i
  * resident assignment of toist_matcher (same src_idx/tgt_idx/match_off/tgt_off).
  *   num_boxes  device f32[1] (already all-reduced / clamped, mdetr.py:997-1001)
  *   fwd: losses [L,4] f32 += (loss_ce, loss_bbox, loss_giou, cardinality_error) -- caller zeroes it
+ *   match_status  optional int32[L*B] written by toist_matcher: a non-zero entry (NaN / -inf cost block, where SciPy raises
+ *                 ValueError at /root/reference/models/matcher.py:85) poisons that layer's four losses with NaN, so the
+ *                 caller's finite-loss guard (/root/reference/engine.py:82-85) trips without a host sync per call
  *   bwd: upstream [L,4] = d(total)/d(loss); dlogits [L,B,Q,K], dboxes [L,B,Q,4] are fully written
  */
 int toist_criterion_fwd(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
                         const int32_t* tgt_off, const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx,
-                        const float* num_boxes, int L, int B, int Q, int K, float eos_coef, float* losses, void* stream);
+                        const float* num_boxes, int L, int B, int Q, int K, float eos_coef, float* losses,
+                        const int32_t* match_status, void* stream);
 int toist_criterion_bwd(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
                         const int32_t* tgt_off, const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx,
                         const float* num_boxes, int L, int B, int Q, int K, float eos_coef, const float* upstream,
                         float* dlogits, float* dboxes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Contrastive-alignment loss for all decoder layers at once.  Replaces SetCriterion.loss_contrastive_align
+ * (/root/reference/models/mdetr.py:601-666) given the device-resident assignment of toist_matcher.
+ *   proj_queries [L,B,Q,D] f32, proj_tokens [B,T,D] f32: the L2-normalised projections (mdetr.py:429-433)
+ *   tok_mask     uint64 [sum_i T_i, 2]: bit t of row r = token t belongs to a positive span of target r
+ *                (what the reference derives on the host from tokens_positive + char_to_token, :614-643; T <= 128)
+ *   fwd: losses [L] f32 += loss_contrastive_align of layer l (caller zeroes);  temperature = --temperature_NCE
+ *   bwd: upstream [L]; dproj_queries [L,B,Q,D] fully written; dproj_tokens [B,T,D] += (caller zeroes)
+ * toist_l2norm_fwd/bwd: F.normalize(x, p=2, dim=-1) on fp32 rows and its backward (dx from x, dy).
+ */
+int toist_contrastive_fwd(const float* proj_queries, const float* proj_tokens, const uint64_t* tok_mask, const int32_t* tgt_off,
+                          const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx, const float* num_boxes, int L,
+                          int B, int Q, int T, int D, float temperature, float* losses, void* stream);
+int toist_contrastive_bwd(const float* proj_queries, const float* proj_tokens, const uint64_t* tok_mask, const int32_t* tgt_off,
+                          const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx, const float* num_boxes, int L,
+                          int B, int Q, int T, int D, float temperature, const float* upstream, float* dproj_queries,
+                          float* dproj_tokens, void* stream);
+int toist_l2norm_fwd(const float* x, int rows, int D, float* y, void* stream);
+int toist_l2norm_bwd(const float* x, const float* dy, int rows, int D, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Segmentation branch (config 3), /root/reference/models/segmentation.py.

@@ -60,3 +60,107 @@ def test_world_size_two_gloo():
     assert r0["num_boxes_empty"] == 1.0                # clamp(min=1)
     assert r0["flat"] == r1["flat"] == [1.5] * 10      # mean of 1 and 2
     assert r0["w"] == r1["w"]
+
+
+# ---- DistributedDataParallel compatibility (reference main.py:335-337, engine.py:54-101) ------------------------------
+class _Toy(torch.nn.Module):
+    """A module whose `lin` runs through functions.run_program (one autograd node, flat gradient buffer) and whose `plain`
+    is differentiated by torch.autograd itself -- the two ways a parameter of the product receives its gradient.  The
+    program body uses torch ops so the test runs without a GPU; the gradient-delivery machinery under test is the real one."""
+
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(3, 2)
+        self.plain = torch.nn.Linear(2, 1)
+        self.unused = torch.nn.Linear(2, 2)        # find_unused_parameters=True of the reference
+        self._cache = {}
+
+    def forward(self, x):
+        from collections import OrderedDict
+        from toist_amd import engine, functions
+        named = OrderedDict(self.lin.named_parameters())
+
+        def prog(tape, ps, xin):
+            W, b = ps["weight"], ps["bias"]
+            out = engine.Var(xin.data @ W.f32.t() + b.f32)
+
+            def bwd():
+                g = out.take_grad()
+                W.g.add_(g.t() @ xin.data)
+                b.g.add_(g.sum(0))
+
+            tape.record(bwd)
+            return [out], None
+
+        (y,) = functions.run_program(prog, named, [x], cache=self._cache, training=True)
+        return self.plain(y).sum()
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from toist_amd import parallel
+    torch.manual_seed(0)
+    ref = _Toy()
+    xs = [torch.arange(6, dtype=torch.float32).reshape(2, 3) * (r + 1) for r in range(world)]
+    # expected: mean over ranks of the local gradients (what DDP delivers)
+    want = {}
+    for r in range(world):
+        ref.zero_grad(set_to_none=True)
+        ref(xs[r]).backward()
+        for n, p in ref.named_parameters():
+            if p.grad is not None:
+                want[n] = want.get(n, 0) + p.grad.detach().clone() / world
+    res = {}
+
+    def grads(m):
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    def close(a, b):
+        return set(a) == set(b) and all(torch.allclose(a[k], b[k], atol=1e-6) for k in a)
+
+    # 1. torch's own wrapper, exactly as main.py:336 builds it; the engine.py call sequence around it
+    torch.manual_seed(0)
+    m1 = torch.nn.parallel.DistributedDataParallel(_Toy(), find_unused_parameters=True)
+    opt = torch.optim.SGD(m1.parameters(), lr=0.0)
+    opt.zero_grad()
+    m1(xs[rank]).backward()
+    torch.nn.utils.clip_grad_norm_(m1.parameters(), 0.1 * 1e9)
+    opt.step()
+    res["torch_ddp"] = close(grads(m1.module), want)
+    # 2. the flat-buffer wrapper with the same surface
+    torch.manual_seed(0)
+    m2 = parallel.DistributedDataParallel(_Toy(), device_ids=None, find_unused_parameters=True)
+    m2(xs[rank]).backward()
+    res["toist_ddp"] = close(grads(m2.module), want)
+    with m2.no_sync():
+        m2.module.zero_grad(set_to_none=True)
+        m2(xs[rank]).backward()
+    res["no_sync_local"] = not close(grads(m2.module), want)
+    # 3. GradSync(model): flat buffers + the parameters no flat buffer carries
+    torch.manual_seed(0)
+    m3 = _Toy()
+    sync = parallel.GradSync(m3)
+    with sync:
+        m3(xs[rank]).backward()
+        sync.finish()
+    res["gradsync"] = close(grads(m3), want)
+    # 4. gradient accumulation: only the last micro-step is wrapped
+    m3.zero_grad(set_to_none=True)
+    m3(xs[rank]).backward()
+    with sync:
+        m3(xs[rank]).backward()
+        sync.finish()
+    res["accumulate"] = close(grads(m3), {k: 2 * v for k, v in want.items()})
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_wrapping_delivers_averaged_gradients():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ddp_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r] == {"torch_ddp": True, "toist_ddp": True, "no_sync_local": True, "gradsync": True, "accumulate": True}, out[r]

@@ -67,8 +67,12 @@ _SIGNATURES = {
     "toist_sine_position": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_embed_fwd": ([c_void_p] * 5 + [c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_embed_bwd": ([c_void_p] * 3 + [c_int32, c_int32, c_int64] + [c_void_p] * 4, ctypes.c_int),
-    "toist_criterion_fwd": ([c_void_p] * 9 + [c_int32] * 4 + [c_float, c_void_p, c_void_p], ctypes.c_int),
+    "toist_criterion_fwd": ([c_void_p] * 9 + [c_int32] * 4 + [c_float, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_criterion_bwd": ([c_void_p] * 9 + [c_int32] * 4 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_contrastive_fwd": ([c_void_p] * 8 + [c_int32] * 5 + [c_float, c_void_p, c_void_p], ctypes.c_int),
+    "toist_contrastive_bwd": ([c_void_p] * 8 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_l2norm_fwd": ([c_void_p, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "toist_l2norm_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_attnmap_softmax_fwd": ([c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p], ctypes.c_int),
     "toist_attnmap_softmax_bwd": ([c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p, c_void_p], ctypes.c_int),
     "toist_groupnorm_fwd": ([c_void_p] * 3 + [c_int32] * 4 + [c_float, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),

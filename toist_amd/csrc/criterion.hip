@@ -74,7 +74,8 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_kernel(
     int L, int B, int Q, int K, float eos_coef,
     float* __restrict__ losses,             // MODE 0: [L,4] (+=) : ce, bbox, giou, cardinality
     const float* __restrict__ upstream,     // MODE 1: [L,4] gradient of the total w.r.t. each loss
-    float* __restrict__ dlogits, float* __restrict__ dboxes) {
+    float* __restrict__ dlogits, float* __restrict__ dboxes,
+    const int* __restrict__ match_status) { // MODE 0: optional [L*B]; non-zero = invalid cost block -> NaN losses
     extern __shared__ int qmap[];           // [Q] global target row matched to query q, or -1
     __shared__ float red[CRIT_THREADS / 64];
     const int lb = blockIdx.x, l = lb / B, b = lb % B;
@@ -182,6 +183,10 @@ __global__ __launch_bounds__(CRIT_THREADS) void criterion_kernel(
         const float gi = block_sum(gi_acc, red);
         const float cd = block_sum(card, red);
         if (tid == 0) {
+            if (match_status != nullptr && match_status[lb] != 0) {   // SciPy raises here (matcher.py:85): poison instead of a host sync
+                const float nan = __int_as_float(0x7fc00000);
+                for (int c = 0; c < 4; ++c) atomicAdd(losses + l * 4 + c, nan);
+            }
             atomicAdd(losses + l * 4 + 0, ce * inv_nb);
             atomicAdd(losses + l * 4 + 1, l1 * inv_nb);
             atomicAdd(losses + l * 4 + 2, gi * inv_nb);
@@ -201,11 +206,12 @@ static int criterion_args_ok(int L, int B, int Q, int K) {
 
 extern "C" int toist_criterion_fwd(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
                                    const int32_t* tgt_off, const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx,
-                                   const float* num_boxes, int L, int B, int Q, int K, float eos_coef, float* losses, void* stream) {
+                                   const float* num_boxes, int L, int B, int Q, int K, float eos_coef, float* losses,
+                                   const int32_t* match_status, void* stream) {
     if (int rc = criterion_args_ok(L, B, Q, K)) return rc;
     hipLaunchKernelGGL(criterion_kernel<0>, dim3(L * B), dim3(CRIT_THREADS), sizeof(int) * Q, (hipStream_t)stream, logits, boxes, tgt_boxes, pos_map,
                        tgt_off, match_off, (const long long*)src_idx, (const long long*)tgt_idx, num_boxes, L, B, Q, K, eos_coef, losses,
-                       (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const int*)match_status);
     return check_launch("toist_criterion_fwd");
 }
 
@@ -216,6 +222,6 @@ extern "C" int toist_criterion_bwd(const float* logits, const float* boxes, cons
     if (int rc = criterion_args_ok(L, B, Q, K)) return rc;
     hipLaunchKernelGGL(criterion_kernel<1>, dim3(L * B), dim3(CRIT_THREADS), sizeof(int) * Q, (hipStream_t)stream, logits, boxes, tgt_boxes, pos_map,
                        tgt_off, match_off, (const long long*)src_idx, (const long long*)tgt_idx, num_boxes, L, B, Q, K, eos_coef,
-                       (float*)nullptr, upstream, dlogits, dboxes);
+                       (float*)nullptr, upstream, dlogits, dboxes, (const int*)nullptr);
     return check_launch("toist_criterion_bwd");
 }

@@ -2,15 +2,23 @@
 
 `run_program` executes a forward program on the HIP kernels and registers ONE autograd node whose
 backward replays the program's tape.  torch.autograd only carries tensors between these coarse nodes
-(backbone, text encoder, encoder, decoder, heads) and delivers parameter gradients to the optimizer /
-DistributedDataParallel hooks; it never differentiates through individual ops.
+(backbone, text encoder, encoder, decoder, heads); it never differentiates through individual ops.
+
+Parameter gradients leave a program in one of two ways (PARAM_GRADS):
+  "attach"   (default) the views of the program's flat fp32 buffer are attached to `.grad` directly and the
+             GRAD_SYNC hook (toist_amd.parallel.GradSync / parallel.DistributedDataParallel) all-reduces the
+             flat buffer in place -- no AccumulateGrad nodes run, so torch's DDP hooks would NOT fire;
+  "autograd" the node returns them to torch.autograd, AccumulateGrad stores them and every hook registered
+             on a parameter fires: this is what torch.nn.parallel.DistributedDataParallel(model) needs
+             (/root/reference/main.py:335-337).  It is selected automatically while a torch DDP forward is
+             active, so a driver that wraps the model as the reference does gets reduced gradients.
 """
 import torch
 
 from . import engine
 
-# Optional callable(flat_grad_buffer) invoked when a program's backward has produced all of its
-# parameter gradients (set by toist_amd.parallel.GradSync).
+# Optional callable(flat_grad_buffer or None) invoked when a program's backward has produced all of its
+# parameter gradients (set by toist_amd.parallel.GradSync / DistributedDataParallel).
 GRAD_SYNC = None
 
 # Stream the programs launched right now were forked from (set by MDETR.encode around the text branch).
@@ -18,6 +26,18 @@ GRAD_SYNC = None
 # autograd engine does not know it has to join their stream at the end of backward(): each forked
 # program's backward makes REJOIN wait for it instead.
 REJOIN = None
+
+PARAM_GRADS = "auto"     # "auto": "autograd" inside a torch DistributedDataParallel forward, "attach" otherwise
+
+
+def _via_autograd():
+    if PARAM_GRADS != "auto":
+        return PARAM_GRADS == "autograd"
+    try:
+        from torch.nn.parallel import DistributedDataParallel as _DDP
+        return getattr(_DDP, "_active_ddp_module", None) is not None
+    except Exception:  # pragma: no cover
+        return False
 
 
 class _TapeFn(torch.autograd.Function):
@@ -27,6 +47,7 @@ class _TapeFn(torch.autograd.Function):
         params = tensors[n_in:]
         tape_kw = dict(tape_kw)
         ctx.rejoin = tape_kw.pop('rejoin')
+        ctx.via_autograd = tape_kw.pop('via_autograd')
         need = tape_kw.pop('need_grads')  # grad mode is off inside Function.forward: decided by the caller
         transforms = tape_kw.pop('transforms')
         named = dict(zip(names, params))
@@ -64,6 +85,15 @@ class _TapeFn(torch.autograd.Function):
                 in_grads.append(None)
             else:
                 in_grads.append(v.take_grad())
+        n_par = len(ctx.params)
+        if ctx.via_autograd:
+            # torch DistributedDataParallel (or any other per-parameter hook) is listening: hand the gradients to autograd
+            par_grads = [g if (g is not None and p.requires_grad) else None for p, g in zip(ctx.params, ps.grads())]
+            if ctx.rejoin is not None:
+                ctx.rejoin.wait_stream(torch.cuda.current_stream())
+            ctx.tape = ctx.ps = ctx.in_vars = ctx.out_vars = ctx.params = None
+            del tape, ps
+            return (None, None, None, None, None, *in_grads, *par_grads)
         # Parameter gradients live in ONE flat fp32 buffer per program; they are attached to .grad
         # directly (no autograd accumulation copies), so a data-parallel all-reduce can run in place
         # on the flat buffer while the rest of the backward pass proceeds (toist_amd/parallel.py).
@@ -74,12 +104,11 @@ class _TapeFn(torch.autograd.Function):
                 p.grad = g
             else:
                 p.grad.add_(g)
-                ps.flat = None  # accumulated into an older buffer: nothing to reduce in place
-        if GRAD_SYNC is not None and ps.flat is not None:
-            GRAD_SYNC(ps.flat)
+                ps.flat = None  # accumulated into an older buffer: GradSync.finish() reduces those gradients one by one
+        if GRAD_SYNC is not None:
+            GRAD_SYNC(ps.flat)      # None: this program accumulated into older gradients (the hook still learns that a backward ran)
         if ctx.rejoin is not None:
             ctx.rejoin.wait_stream(torch.cuda.current_stream())
-        n_par = len(ctx.params)
         ctx.tape = ctx.ps = ctx.in_vars = ctx.out_vars = ctx.params = None
         return (None, None, None, None, None, *in_grads, *([None] * n_par))
 
@@ -89,5 +118,6 @@ def run_program(body, named_params, inputs, cache=None, training=False, drop_p=0
     names = tuple(named_params.keys())
     params = tuple(named_params.values())
     need = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (*inputs, *params))
-    tape_kw = dict(training=training, drop_p=drop_p, seed=seed, need_grads=need, transforms=transforms, rejoin=REJOIN, group_wgrads=group_wgrads)
+    tape_kw = dict(training=training, drop_p=drop_p, seed=seed, need_grads=need, transforms=transforms, rejoin=REJOIN, group_wgrads=group_wgrads,
+                   via_autograd=need and _via_autograd())
     return _TapeFn.apply(body, names, cache, len(inputs), tape_kw, *inputs, *params)

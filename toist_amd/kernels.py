@@ -324,12 +324,12 @@ def embed_bwd(g, ids, pos_ids, pad_id, dword, dpos, dtype0):
                "toist_embed_bwd")
 
 
-def criterion_fwd(logits, boxes, tgt_boxes, pos_map, tgt_off, match_off, src_idx, tgt_idx, num_boxes, eos_coef, losses):
+def criterion_fwd(logits, boxes, tgt_boxes, pos_map, tgt_off, match_off, src_idx, tgt_idx, num_boxes, eos_coef, losses, status=None):
     L, B, Q, K = logits.shape
     _lib.check(_lib.lib().toist_criterion_fwd(_p(logits, torch.float32), _p(boxes, torch.float32), _p(tgt_boxes, torch.float32),
                                               _p(pos_map, torch.float32), _p(tgt_off, torch.int32), _p(match_off, torch.int32),
                                               _p(src_idx, torch.int64), _p(tgt_idx, torch.int64), _p(num_boxes, torch.float32), L, B, Q, K,
-                                              eos_coef, _p(losses, torch.float32), _stream()), "toist_criterion_fwd")
+                                              eos_coef, _p(losses, torch.float32), _p(status, torch.int32), _stream()), "toist_criterion_fwd")
 
 
 def criterion_bwd(logits, boxes, tgt_boxes, pos_map, tgt_off, match_off, src_idx, tgt_idx, num_boxes, eos_coef, upstream, dlogits, dboxes):
@@ -339,6 +339,32 @@ def criterion_bwd(logits, boxes, tgt_boxes, pos_map, tgt_off, match_off, src_idx
                                               _p(src_idx, torch.int64), _p(tgt_idx, torch.int64), _p(num_boxes, torch.float32), L, B, Q, K,
                                               eos_coef, _p(upstream, torch.float32), _p(dlogits, torch.float32), _p(dboxes, torch.float32),
                                               _stream()), "toist_criterion_bwd")
+
+
+def contrastive_fwd(pq, pt, tok_mask, tgt_off, match_off, src_idx, tgt_idx, num_boxes, temperature, losses):
+    L, B, Q, D = pq.shape
+    _lib.check(_lib.lib().toist_contrastive_fwd(_p(pq, torch.float32), _p(pt, torch.float32), _p(tok_mask, torch.int64), _p(tgt_off, torch.int32),
+                                                _p(match_off, torch.int32), _p(src_idx, torch.int64), _p(tgt_idx, torch.int64),
+                                                _p(num_boxes, torch.float32), L, B, Q, pt.shape[1], D, temperature, _p(losses, torch.float32),
+                                                _stream()), "toist_contrastive_fwd")
+
+
+def contrastive_bwd(pq, pt, tok_mask, tgt_off, match_off, src_idx, tgt_idx, num_boxes, temperature, upstream, dpq, dpt):
+    L, B, Q, D = pq.shape
+    _lib.check(_lib.lib().toist_contrastive_bwd(_p(pq, torch.float32), _p(pt, torch.float32), _p(tok_mask, torch.int64), _p(tgt_off, torch.int32),
+                                                _p(match_off, torch.int32), _p(src_idx, torch.int64), _p(tgt_idx, torch.int64),
+                                                _p(num_boxes, torch.float32), L, B, Q, pt.shape[1], D, temperature, _p(upstream, torch.float32),
+                                                _p(dpq, torch.float32), _p(dpt, torch.float32), _stream()), "toist_contrastive_bwd")
+
+
+def l2norm_fwd(x, y):
+    rows, D = x.numel() // x.shape[-1], x.shape[-1]
+    _lib.check(_lib.lib().toist_l2norm_fwd(_p(x, torch.float32), rows, D, _p(y, torch.float32), _stream()), "toist_l2norm_fwd")
+
+
+def l2norm_bwd(x, dy, dx):
+    rows, D = x.numel() // x.shape[-1], x.shape[-1]
+    _lib.check(_lib.lib().toist_l2norm_bwd(_p(x, torch.float32), _p(dy, torch.float32), rows, D, _p(dx, torch.float32), _stream()), "toist_l2norm_bwd")
 
 
 # ---- segmentation branch ---------------------------------------------------------------------------------

@@ -76,9 +76,20 @@ class MDETR(nn.Module):
         (tok,) = functions.run_program(prog, named, [c5], cache=self._cache_proj, training=self.training)
         return tok
 
-    def _heads(self, stack, B):
-        """class_embed / bbox_embed (+ contrastive image projection) on all decoder layers at once
-        (mdetr.py:420-433).  stack: [L, B*Q, d] bf16 -> logits [L,B,Q,K+1] f32, boxes [L,B,Q,4] f32."""
+    def _text_tokens(self, memory_cache, B):
+        """bf16 [B*Lt, d] text rows of the encoder output (memory_cache["text_memory"], batch-major)."""
+        native = memory_cache.get("_native")
+        tm = memory_cache["text_memory"]
+        Lt = tm.shape[0]
+        if native is not None and native.get("img_memory_ref") is memory_cache.get("img_memory"):
+            mem = native["memory"]
+            return mem.view(B, native["S"], -1)[:, native["S"] - Lt:, :].reshape(B * Lt, -1)
+        return tm.permute(1, 0, 2).to(BF16).reshape(B * Lt, -1)
+
+    def _heads(self, stack, B, text_tok=None):
+        """class_embed / bbox_embed (+ contrastive image and text projections) on all decoder layers at once
+        (mdetr.py:420-433).  stack: [L, B*Q, d] bf16 -> logits [L,B,Q,K+1] f32, boxes [L,B,Q,4] f32
+        (+ raw projections [L,B,Q,h] and [B*Lt,h] f32)."""
         L, BQ, d = stack.shape
         Q = BQ // B
         named = OrderedDict()
@@ -86,9 +97,10 @@ class MDETR(nn.Module):
         named.update(("bbox_embed." + n, p) for n, p in self.bbox_embed.named_parameters())
         if self.contrastive_align_loss:
             named.update(("cimg." + n, p) for n, p in self.contrastive_align_projection_image.named_parameters())
+            named.update(("ctxt." + n, p) for n, p in self.contrastive_align_projection_text.named_parameters())
         want_proj = self.contrastive_align_loss
 
-        def prog(tape, ps, hs):
+        def prog(tape, ps, hs, txt=None):
             x = engine.Var(hs.data.view(L * BQ, d), needs_grad=hs.needs_grad)
 
             def x_bwd():
@@ -147,14 +159,22 @@ class MDETR(nn.Module):
 
                 tape.record(proj_bwd)
                 outs.append(proj)
+                ptxt = engine.linear_chain(tape, txt, [(ps["ctxt.weight"], ps["ctxt.bias"], k.ACT_NONE, False)], out_dtype=torch.float32)
+
+                def ptxt_bwd():
+                    if ptxt.grad is not None:
+                        ptxt.grad = ptxt.grad.to(BF16)
+
+                tape.record(ptxt_bwd)
+                outs.append(ptxt)
             return outs, None
 
-        res = functions.run_program(prog, named, [stack], cache=self._cache_heads, training=self.training)
+        res = functions.run_program(prog, named, [stack] + ([text_tok] if want_proj else []), cache=self._cache_heads, training=self.training)
         K = res[0].shape[-1]
         logits = res[0].view(L, B, Q, K)
         boxes = res[1][:, :4].reshape(L, B, Q, 4)
         proj = res[2].view(L, B, Q, -1) if want_proj else None
-        return logits, boxes, proj
+        return logits, boxes, proj, (res[3] if want_proj else None)
 
     # ---- reference-compatible forward -------------------------------------------------------------------
     def forward(self, samples: NestedTensor, captions, encode_and_save=True, memory_cache=None):
@@ -226,14 +246,15 @@ class MDETR(nn.Module):
         stack = self.transformer.decode_native(memory_cache[key], memory_cache["pos_embed"], memory_cache["mask"],
                                                memory_cache["query_embed"], native=native)
         B = memory_cache["mask"].shape[0]
-        logits, boxes, proj = self._heads(stack, B)
+        text_tok = self._text_tokens(memory_cache, B) if self.contrastive_align_loss else None
+        logits, boxes, proj, proj_text = self._heads(stack, B, text_tok)
         out = {"pred_logits": logits[-1], "pred_boxes": boxes[-1]}
         proj_tokens = None
         if self.contrastive_align_loss:
-            proj_q = F.normalize(proj, p=2, dim=-1)
-            tm = memory_cache["text_memory"]
-            proj_tokens = F.normalize(F.linear(tm, self.contrastive_align_projection_text.weight, self.contrastive_align_projection_text.bias)
-                                      .transpose(0, 1), p=2, dim=-1)
+            # F.normalize(Linear(hs)) / F.normalize(Linear(text_memory).transpose(0, 1)) of mdetr.py:429-433: both projections are
+            # GEMMs of the heads program, the normalisation is the l2norm kernel of csrc/contrastive.hip (fwd + bwd)
+            proj_q = l2_normalize(proj)
+            proj_tokens = l2_normalize(proj_text.view(B, -1, proj_text.shape[-1]))
             out.update({"proj_queries": proj_q[-1], "proj_tokens": proj_tokens, "tokenized": memory_cache["tokenized"]})
         if self.aux_loss:
             aux = []
@@ -244,6 +265,8 @@ class MDETR(nn.Module):
                 aux.append(a)
             out["aux_outputs"] = aux
         out["_stacked"] = {"pred_logits": logits, "pred_boxes": boxes, "hs": stack}
+        if self.contrastive_align_loss:
+            out["_stacked"]["proj_queries"] = proj_q
         return out
 
 
@@ -261,6 +284,8 @@ class SetCriterion(nn.Module):
         self.temperature = temperature
         self.last_match = None
         self._maps, self._nb, self._nb_reduced = {}, {}, {}
+        self._tokmask = None       # (member mask tensors, concatenated [sum T, 2] int64): spans of the last batch, uploaded once
+        self._pending_status = []  # (pinned host copy, event) of matcher status words not yet looked at
 
     # -- helpers ------------------------------------------------------------------------------------------
     def _slot_maps(self, match, device):
@@ -304,11 +329,88 @@ class SetCriterion(nn.Module):
         return red
 
     def _stack(self, outputs):
+        """[L,B,Q,K] logits and [L,B,Q,4] boxes of the layers the reference would visit: the main layer, preceded by the
+        auxiliary ones only when the model emitted 'aux_outputs' (mdetr.py:1009; --no_aux_loss recipes match one layer)."""
         st = outputs.get("_stacked")
         if st is not None:
-            return st["pred_logits"], st["pred_boxes"]
+            lg, bx = st["pred_logits"], st["pred_boxes"]
+            return (lg, bx) if "aux_outputs" in outputs else (lg[-1:], bx[-1:])
         layers = list(outputs.get("aux_outputs", [])) + [outputs]
         return torch.stack([o["pred_logits"] for o in layers]), torch.stack([o["pred_boxes"] for o in layers])
+
+    def _stack_proj(self, outputs, L):
+        st = outputs.get("_stacked")
+        if st is not None and "proj_queries" in st:
+            return st["proj_queries"][-L:]
+        layers = list(outputs.get("aux_outputs", [])) + [outputs]
+        return torch.stack([o["proj_queries"] for o in layers])[-L:]
+
+    # -- matcher status (SciPy raises ValueError on NaN / -inf costs at matcher.py:85) ----------------------------------
+    def _note_status(self, match):
+        """The losses of a layer whose cost block was invalid are NaN already (criterion kernel); additionally stage the status
+        words in pinned host memory without waiting, so the NEXT call (or check_status()) can raise the reference's
+        ValueError -- no host sync on the step's critical path."""
+        st = match.status
+        if not st.is_cuda or torch.cuda.is_current_stream_capturing():
+            return
+        host = torch.empty(st.shape, dtype=st.dtype, pin_memory=True)
+        host.copy_(st, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending_status.append((host, ev))
+
+    def check_status(self, wait=True):
+        """Raise ValueError (as scipy.optimize.linear_sum_assignment does inside the reference matcher) if a cost block of an
+        earlier call held NaN / -inf.  wait=False only looks at copies that have already arrived."""
+        keep = []
+        for host, ev in self._pending_status:
+            if not wait and not ev.query():
+                keep.append((host, ev))
+                continue
+            ev.synchronize()
+            if bool((host == 1).any()):
+                self._pending_status = []
+                raise ValueError("matrix contains invalid numeric entries")
+            if bool((host == 2).any()):
+                self._pending_status = []
+                raise ValueError("cost matrix is infeasible")
+        self._pending_status = keep
+
+    def _token_masks(self, targets, tokenized, device):
+        """int64 [sum T, 2] token bit masks of every target's positive spans (the host part of mdetr.py:614-643, done once per
+        batch instead of once per layer and call: the spans do not depend on the assignment)."""
+        parts = []
+        for i, tgt in enumerate(targets):
+            m = tgt.get("_tok_mask")
+            if m is None or m.device != device:
+                rows = []
+                n = int(tgt["boxes"].shape[0])
+                for t in range(n):
+                    if "token_spans" in tgt:
+                        spans = tgt["token_spans"][t]
+                    else:
+                        spans = []
+                        for beg, end in tgt["tokens_positive" if "tokens_positive" in tgt else "tokens"][t]:
+                            ft = char_span_to_tokens(tokenized, i, beg, end)
+                            if ft is not None:
+                                spans.append(ft)
+                    bits = 0
+                    for bp, ep in spans:
+                        if ep >= 128:
+                            raise ValueError("contrastive_align: token spans beyond position 127 are not supported by the device kernel")
+                        for tkn in range(bp, ep + 1):
+                            bits |= 1 << tkn
+                    lo, hi = bits & ((1 << 64) - 1), bits >> 64
+                    rows.append([lo - (1 << 64) if lo >= (1 << 63) else lo, hi - (1 << 64) if hi >= (1 << 63) else hi])
+                m = torch.tensor(rows, dtype=torch.int64).reshape(n, 2).to(device)
+                tgt["_tok_mask"] = m
+            parts.append(m)
+        ent = self._tokmask
+        if ent is not None and len(ent[0]) == len(parts) and all(a is b for a, b in zip(ent[0], parts)):
+            return ent[1]
+        cat = torch.cat(parts) if parts else torch.zeros(0, 2, dtype=torch.int64, device=device)
+        self._tokmask = (parts, cat)
+        return cat
 
     # -- losses over all layers at once -------------------------------------------------------------------
     def _detection_losses(self, logits, boxes, match, targets, positive_map, num_boxes):
@@ -317,6 +419,7 @@ class SetCriterion(nn.Module):
         L = logits.shape[0]
         vals = _SetLossFn.apply(logits.float().contiguous(), boxes.float().contiguous(), match, positive_map.float().contiguous(),
                                 num_boxes.reshape(1).float().contiguous(), float(self.eos_coef))
+        self._note_status(match)
         out, index = LossDict(), {}
         for l in range(L):
             sfx = "" if l == L - 1 else f"_{l}"
@@ -330,33 +433,27 @@ class SetCriterion(nn.Module):
         out.groups.append((vals, index))
         return out
 
-    def _contrastive_align(self, outputs, match, targets, num_boxes, layer, L):
-        """mdetr.py:601-666; token spans come from `tokens_positive` through tokenized.char_to_token on
-        the host exactly like the reference, or from target['token_spans'] (already token indices)."""
-        pq, pt = outputs["proj_queries"], outputs["proj_tokens"]
-        logits = torch.matmul(pq, pt.transpose(-1, -2)) / self.temperature
-        pm = torch.zeros(logits.shape, dtype=torch.bool)
-        pairs = match.to_list(layer)
-        tokenized = outputs.get("tokenized")
-        for i, ((si, ti), tgt) in enumerate(zip(pairs, targets)):
-            for q, t in zip(si.tolist(), ti.tolist()):
-                if "token_spans" in tgt:
-                    spans = tgt["token_spans"][t]
-                else:
-                    spans = []
-                    for beg, end in tgt["tokens_positive" if "tokens_positive" in tgt else "tokens"][t]:
-                        ft = char_span_to_tokens(tokenized, i, beg, end)
-                        if ft is not None:
-                            spans.append(ft)
-                for bp, ep in spans:
-                    pm[i, q, bp:ep + 1] = True
-        pm = pm.to(logits.device)
-        pos = -logits.masked_fill(~pm, 0)
-        b2t = ((pos.sum(2) / (pm.sum(2) + 1e-6) + logits.logsumexp(2))).masked_fill(~pm.any(2), 0).sum()
-        t2b = ((pos.sum(1) / (pm.sum(1) + 1e-6) + logits.logsumexp(1))).masked_fill(~pm.any(1), 0).sum()
-        return (b2t + t2b) / 2 / num_boxes
+    def _contrastive_align(self, outputs, match, targets, num_boxes, L):
+        """loss_contrastive_align of the L visited layers (mdetr.py:601-666) -> LossDict: one launch of the device kernel
+        (csrc/contrastive.hip) each way; the token spans of the targets are uploaded once per batch."""
+        pq = self._stack_proj(outputs, L)
+        pt = outputs["proj_tokens"]
+        out, index = LossDict(), {}
+        if match.tgt_boxes is None:      # no target in the batch: every term is masked out (mdetr.py:655,662)
+            vals = (pq.sum() * 0 + pt.sum() * 0).expand(L)
+        else:
+            masks = self._token_masks(targets, outputs.get("tokenized"), pq.device)
+            vals = _ContrastiveFn.apply(pq.float().contiguous(), pt.float().contiguous(), match, masks,
+                                        num_boxes.reshape(1).float().contiguous(), float(self.temperature))
+        for l in range(L):
+            key = "loss_contrastive_align" + ("" if l == L - 1 else f"_{l}")
+            out[key], index[key] = vals[l], l
+        if match.tgt_boxes is not None:
+            out.groups.append((vals, index))
+        return out
 
     def forward(self, memory_cache, outputs, targets, positive_map, example_rel=None):
+        self.check_status(wait=False)   # an invalid cost block of an earlier call raises here, like SciPy inside the reference matcher
         if isinstance(outputs, list):
             return self._forward_pair(memory_cache, outputs, targets, positive_map)
         logits, boxes = self._stack(outputs)
@@ -366,10 +463,7 @@ class SetCriterion(nn.Module):
         num_boxes = self._num_boxes(targets, logits.device)
         losses = self._detection_losses(logits, boxes, match, targets, positive_map, num_boxes)
         if "contrastive_align" in self.losses:
-            layers = list(outputs.get("aux_outputs", [])) + [outputs]
-            for l, o in enumerate(layers):
-                sfx = "" if l == L - 1 else f"_{l}"
-                losses["loss_contrastive_align" + sfx] = self._contrastive_align(o, match, targets, num_boxes, l, L)
+            losses.merge(self._contrastive_align(outputs, match, targets, num_boxes, L))
         if "masks" in self.losses:
             from .segmentation import mask_losses
             losses.update(mask_losses(outputs, targets, match, L - 1, num_boxes))
@@ -388,9 +482,7 @@ class SetCriterion(nn.Module):
             num_boxes = self._num_boxes(tgt, logits.device)
             side = self._detection_losses(logits, boxes, match, tgt, pm, num_boxes)
             if "contrastive_align" in self.losses:
-                layers = list(out.get("aux_outputs", [])) + [out]
-                for l, o in enumerate(layers):
-                    side["loss_contrastive_align" + ("" if l == L - 1 else f"_{l}")] = self._contrastive_align(o, match, tgt, num_boxes, l, L)
+                side.merge(self._contrastive_align(out, match, tgt, num_boxes, L))
             if "masks" in self.losses:
                 from .segmentation import mask_losses
                 side.update(mask_losses(out, tgt, match, L - 1, num_boxes))
@@ -587,7 +679,7 @@ class _SetLossFn(torch.autograd.Function):
         L = logits.shape[0]
         losses = torch.zeros(L, 4, dtype=torch.float32, device=logits.device)
         k.criterion_fwd(logits, boxes, match.tgt_boxes, positive_map, match.tgt_off_dev, match.match_off_dev, match.src, match.tgt,
-                        num_boxes, eos_coef, losses)
+                        num_boxes, eos_coef, losses, match.status if match.tgt_boxes is not None else None)
         ctx.save_for_backward(logits, boxes, positive_map, num_boxes)
         ctx.match, ctx.eos = match, eos_coef
         return losses
@@ -600,6 +692,49 @@ class _SetLossFn(torch.autograd.Function):
         k.criterion_bwd(logits, boxes, m.tgt_boxes, positive_map, m.tgt_off_dev, m.match_off_dev, m.src, m.tgt, num_boxes, ctx.eos,
                         g.float().contiguous(), dlogits, dboxes)
         return dlogits, dboxes, None, None, None, None
+
+
+class _ContrastiveFn(torch.autograd.Function):
+    """losses [L] = loss_contrastive_align per visited decoder layer (csrc/contrastive.hip)."""
+
+    @staticmethod
+    def forward(ctx, pq, pt, match, tok_mask, num_boxes, temperature):
+        L = pq.shape[0]
+        losses = torch.zeros(L, dtype=torch.float32, device=pq.device)
+        k.contrastive_fwd(pq, pt, tok_mask, match.tgt_off_dev, match.match_off_dev, match.src[-L:], match.tgt[-L:], num_boxes, temperature, losses)
+        ctx.save_for_backward(pq, pt, tok_mask, num_boxes)
+        ctx.match, ctx.temperature = match, temperature
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        pq, pt, tok_mask, num_boxes = ctx.saved_tensors
+        m, L = ctx.match, pq.shape[0]
+        dpq, dpt = torch.empty_like(pq), torch.zeros_like(pt)
+        k.contrastive_bwd(pq, pt, tok_mask, m.tgt_off_dev, m.match_off_dev, m.src[-L:], m.tgt[-L:], num_boxes, ctx.temperature,
+                          g.float().contiguous(), dpq, dpt)
+        return dpq, dpt, None, None, None, None
+
+
+class _L2NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty_like(x)
+        k.l2norm_fwd(x, y)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        k.l2norm_bwd(x, g.float().contiguous(), dx)
+        return dx
+
+
+def l2_normalize(x):
+    """F.normalize(x, p=2, dim=-1) on fp32 device rows (mdetr.py:429-433), forward and backward on csrc/contrastive.hip."""
+    return _L2NormFn.apply(x.float().contiguous())
 
 
 def _paired_giou(a, b):

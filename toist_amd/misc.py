@@ -117,19 +117,23 @@ class DeviceStager:
             raise RuntimeError("DeviceStager stages into GPU memory: there is no CPU path")
         self.stream = torch.cuda.Stream(device=self.device)
         self._keep = []
+        self._staged = []      # device tensors of the batch in flight (allocated on the copy stream)
 
     def _move(self, t):
         if not torch.is_tensor(t):
             return t
         src = t if t.is_pinned() else t.pin_memory()
         self._keep.append(src)                      # pinned source must outlive the asynchronous copy
-        return src.to(self.device, non_blocking=True)
+        dst = src.to(self.device, non_blocking=True)
+        self._staged.append(dst)
+        return dst
 
     def _move_targets(self, targets):
         return [{k: (v if k in _HOST_KEYS else self._move(v)) for k, v in t.items() if k != "caption"} for t in targets]
 
     def stage(self, batch):
         self._keep = []
+        self._staged = []
         out = dict(batch)
         with torch.cuda.stream(self.stream):
             s = batch["samples"]
@@ -143,4 +147,10 @@ class DeviceStager:
         return out
 
     def wait(self):
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(self.stream)
+        # The blocks were allocated while the copy stream was current: tell the caching allocator that the consumer stream uses them
+        # too, otherwise a dropped batch returns them to the copy stream's pool and a later stage() may overwrite them while kernels
+        # of an earlier step (the host runs ahead of the GPU) are still reading.
+        for t in self._staged:
+            t.record_stream(cur)

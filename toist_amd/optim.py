@@ -86,7 +86,13 @@ class FusedClipAdamWEMA:
         self._groups_dev = torch.zeros(len(self.param_groups), 2, dtype=torch.float32, device=self.device)
         self._chunk = k.opt_chunk_elems()
         n_t = len(params) + len(self._ema_only)
-        self._grads_host = torch.zeros(n_t, dtype=torch.int64).pin_memory()
+        # gradient-pointer table: two pinned host copies used alternately, each guarded by an event recorded behind its upload, so a host
+        # that runs ahead of the GPU never rewrites a table whose asynchronous copy has not been consumed; the upload is skipped
+        # altogether when no pointer changed (REUSE_GRAD_BUFFERS, hipGraph replay)
+        self._grads_host = [torch.zeros(n_t, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self._grads_event = [None, None]
+        self._grads_turn = 0
+        self._grads_last = None
         self._grads_dev = torch.zeros(n_t, dtype=torch.int64, device=self.device)
         self._table = None
         self.defer_ema = bool(defer_ema) and (any(e is not None for e in self._ema_of) or bool(self._ema_only))
@@ -162,7 +168,10 @@ class FusedClipAdamWEMA:
             self.sync_hyperparams()
         if self._ema_pending:
             self.ema_update()       # nobody ran it beside the forward pass: it must see the parameters before they change again
-        gh = self._grads_host.numpy()
+        turn = self._grads_turn
+        if self._grads_event[turn] is not None and not capturing:
+            self._grads_event[turn].synchronize()      # the copy that last read this host table has completed
+        gh = self._grads_host[turn].numpy()
         for i, p in enumerate(self.params):
             g = p.grad
             if g is None:
@@ -171,7 +180,14 @@ class FusedClipAdamWEMA:
             if g.dtype != torch.float32 or g.shape != p.shape or g.stride() != p.stride():
                 raise TypeError("FusedClipAdamWEMA: every gradient must be fp32 with its parameter's shape and strides")
             gh[i] = g.data_ptr()
-        self._grads_dev.copy_(self._grads_host, non_blocking=True)
+        if self._grads_last is None or capturing or not np.array_equal(gh, self._grads_last):
+            self._grads_dev.copy_(self._grads_host[turn], non_blocking=True)
+            if not capturing:
+                ev = self._grads_event[turn] or torch.cuda.Event()
+                ev.record()
+                self._grads_event[turn] = ev
+            self._grads_last = gh.copy()
+            self._grads_turn = turn ^ 1
         k.opt_sqnorm(self._table, self._grads_dev, self._chunks, self._n_chunks, self._partial)
         k.opt_finish_norm(self._partial, self._n_chunks, self.max_norm, self.betas[0], self.betas[1], self.state)
         k.opt_adamw_ema(self._table, self._grads_dev, self._chunks, self._n_chunks, self._groups_dev, self.state, self.betas[0],
@@ -204,17 +220,36 @@ class FusedClipAdamWEMA:
                 "step": int(raw[16:20].view(np.int32)[0])}
 
     def state_dict(self):
-        return {"step": self.device_state()["step"], "exp_avg": [t.clone() for t in self.exp_avg], "exp_avg_sq": [t.clone() for t in self.exp_avg_sq],
-                "param_groups": [{kk: vv for kk, vv in g.items() if kk != "params"} for g in self.param_groups]}
+        """torch.optim.AdamW's layout ({"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [{..., "params": [i, ...]}]}),
+        so the 'optimizer' entry of a reference checkpoint (main.py:511-513, 645) resumes here and vice versa.  The step count is one
+        device counter shared by every parameter (all parameters of the hot path receive a gradient every step)."""
+        step = self.device_state()["step"]
+        state = {i: {"step": torch.tensor(float(step)), "exp_avg": self.exp_avg[i].clone(), "exp_avg_sq": self.exp_avg_sq[i].clone()}
+                 for i in range(len(self.params))} if step > 0 else {}
+        groups, base = [], 0
+        for g in self.param_groups:
+            d = {kk: vv for kk, vv in g.items() if kk != "params"}
+            d.update(betas=self.betas, eps=self.eps, amsgrad=False, maximize=False)
+            d["params"] = list(range(base, base + len(g["params"])))
+            base += len(g["params"])
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        for dst, src in zip(self.exp_avg, sd["exp_avg"]):
-            dst.copy_(src)
-        for dst, src in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
-            dst.copy_(src)
+        if "state" not in sd and "exp_avg" in sd:      # round-1 layout of this class
+            sd = {"state": {i: {"step": sd["step"], "exp_avg": a, "exp_avg_sq": b} for i, (a, b) in enumerate(zip(sd["exp_avg"], sd["exp_avg_sq"]))},
+                  "param_groups": sd.get("param_groups", [])}
+        steps = []
+        for i, st in sd["state"].items():
+            i = int(i)
+            self.exp_avg[i].copy_(st["exp_avg"].reshape(self.exp_avg[i].shape) if st["exp_avg"].shape != self.exp_avg[i].shape else st["exp_avg"])
+            self.exp_avg_sq[i].copy_(st["exp_avg_sq"].reshape(self.exp_avg_sq[i].shape) if st["exp_avg_sq"].shape != self.exp_avg_sq[i].shape else st["exp_avg_sq"])
+            steps.append(int(float(st["step"])))
+        if steps and min(steps) != max(steps):
+            raise ValueError("FusedClipAdamWEMA.load_state_dict: parameters with different step counts (the fused tail keeps one counter)")
         raw = np.zeros(32, dtype=np.uint8)
-        raw[16:20] = np.array([int(sd["step"])], dtype=np.int32).view(np.uint8)
+        raw[16:20] = np.array([steps[0] if steps else 0], dtype=np.int32).view(np.uint8)
         self.state.copy_(torch.from_numpy(raw))
-        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
-            g.update(s)
+        for g, src in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update({kk: vv for kk, vv in src.items() if kk in ("lr", "weight_decay", "initial_lr")})
         self.sync_hyperparams()

@@ -14,9 +14,19 @@ from . import functions
 
 
 class GradSync:
-    def __init__(self, process_group=None):
+    """with GradSync(model): loss.backward(); sync.finish() -- every program's flat gradient buffer is all-reduced (mean) as soon as
+    its backward has finished; finish() joins them and then reduces whatever the flat buffers did not cover: parameters
+    differentiated by plain autograd, and programs that accumulated into gradients kept from an earlier backward (gradient
+    accumulation: wrap only the LAST micro-step, like DDP.no_sync() around the others).  Without `model` only flat buffers are
+    reduced (the round-1 behaviour)."""
+
+    def __init__(self, model=None, process_group=None):
+        if model is not None and not isinstance(model, (torch.nn.Module, list, tuple)):      # GradSync(process_group) of round 1
+            model, process_group = None, model
+        self.models = [] if model is None else (list(model) if isinstance(model, (list, tuple)) else [model])
         self.group = process_group
         self.pending = []
+        self.ranges = []
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
 
     def __enter__(self):
@@ -29,17 +39,32 @@ class GradSync:
         return False
 
     def _launch(self, flat):
+        if flat is None:
+            return
         op = _mean_op(self.group)
         work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
         self.pending.append((work, flat, op))
+        self.ranges.append((flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()))
 
     def finish(self):
-        """Wait for every outstanding all-reduce (call after loss.backward(), before clipping)."""
+        """Wait for every outstanding all-reduce, then reduce the gradients no flat buffer carried (call after loss.backward(),
+        before clipping)."""
         for work, flat, op in self.pending:
             work.wait()
             if op == dist.ReduceOp.SUM:
                 flat.div_(self.world)
-        self.pending = []
+        rest = []
+        if self.world > 1:
+            for p in (q for m in self.models for q in m.parameters()):
+                g = p.grad
+                if g is None or not p.requires_grad:
+                    continue
+                a = g.data_ptr()
+                if not any(lo <= a < hi for lo, hi in self.ranges):
+                    rest.append(g)
+        if rest:
+            all_reduce_mean(rest, self.group)
+        self.pending, self.ranges = [], []
 
 
 def _mean_op(group=None):
@@ -95,3 +120,54 @@ def broadcast_parameters(module, src=0, group=None):
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src, group=group)
+
+
+class DistributedDataParallel(torch.nn.Module):
+    """Constructor / `.module` / forward surface of torch.nn.parallel.DistributedDataParallel (as used at
+    /root/reference/main.py:335-337, 344-346) on top of the flat-buffer gradient exchange: parameters are broadcast from rank 0 at
+    wrap time; during backward every program's flat gradient buffer is all-reduced (mean) asynchronously as soon as the program is
+    done, and a callback queued on the autograd engine joins the collectives (and reduces gradients that did not travel in a flat
+    buffer) before loss.backward() returns -- so clip_grad_norm_ / optimizer.step() see averaged gradients exactly as with torch's
+    DDP.  torch's own DistributedDataParallel(model) also works (functions.PARAM_GRADS, "autograd" path); this class is the faster
+    route: 5 large in-place collectives instead of per-parameter bucket copies.  `find_unused_parameters` is accepted and ignored
+    (unused parameters simply have no gradient); no_sync() skips the exchange for gradient accumulation."""
+
+    def __init__(self, module, device_ids=None, output_device=None, find_unused_parameters=False, process_group=None, broadcast_buffers=True,
+                 **unused):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self.require_backward_grad_sync = True
+        self._sync = GradSync(module, process_group)
+        self._queued = False
+        broadcast_parameters(module, 0, process_group)
+
+    def forward(self, *args, **kwargs):
+        if self.require_backward_grad_sync and self._sync.world > 1 and torch.is_grad_enabled():
+            functions.GRAD_SYNC = self._on_flat
+        return self.module(*args, **kwargs)
+
+    def _on_flat(self, flat):
+        if not self._queued:
+            self._queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+        self._sync._launch(flat)
+
+    def _finish(self):
+        functions.GRAD_SYNC = None
+        self._queued = False
+        self._sync.finish()
+
+    class _NoSync:
+        def __init__(self, ddp):
+            self.ddp = ddp
+
+        def __enter__(self):
+            self.old, self.ddp.require_backward_grad_sync = self.ddp.require_backward_grad_sync, False
+
+        def __exit__(self, *exc):
+            self.ddp.require_backward_grad_sync = self.old
+            return False
+
+    def no_sync(self):
+        return DistributedDataParallel._NoSync(self)
