@@ -112,6 +112,50 @@ def matcher_cases():
         save(f"matcher_{name}.npz", **rec)
 
 
+def matcher_neartie():
+    """Adversarial near-ties decided by the REAL reference: queries 10..13 of every image carry identical logits and boxes that
+    differ by 1-2 ulp in one coordinate, the first two targets of an image are 1 ulp apart and sit on that query cluster, and a
+    second cluster (queries 40..42) has identical boxes and logits that differ by 1 ulp in one class.  The assignment then hinges
+    on the last bits of the fp32 cost block (matcher.py:63-81) and on SciPy's tie rules."""
+    B, Q, K, sizes = 4, 100, 256, [4, 6, 3, 5]
+    logits = formula.tensor("m.nt.logits", (B, Q, K), 6.0)
+    boxes = torch.cat([formula.tensor("m.nt.c", (B, Q, 2), 0.6, 0.5), formula.tensor("m.nt.s", (B, Q, 2), 0.35, 0.225)], -1)
+    up = lambda x, n=1: torch.tensor(np.nextafter(np.float32(x), np.float32(2.0)) if n == 1 else
+                                     np.nextafter(np.nextafter(np.float32(x), np.float32(2.0)), np.float32(2.0)))
+    down = lambda x: torch.tensor(np.nextafter(np.float32(x), np.float32(-2.0)))
+    tgts = []
+    for i, t in enumerate(sizes):
+        for q in (11, 12, 13):
+            logits[i, q] = logits[i, 10]
+            boxes[i, q] = boxes[i, 10]
+        boxes[i, 11, 0] = up(float(boxes[i, 10, 0]))
+        boxes[i, 12, 0] = down(float(boxes[i, 10, 0]))
+        boxes[i, 13, 2] = up(float(boxes[i, 10, 2]), 2)
+        for q in (41, 42):
+            logits[i, q] = logits[i, 40]
+            boxes[i, q] = boxes[i, 40]
+        logits[i, 41, 3] = up(float(logits[i, 40, 3]))
+        logits[i, 42, 200] = down(float(logits[i, 40, 200]))
+        c = formula.tensor(f"m.nt.tc{i}", (t, 2), 0.6, 0.5)
+        s_ = formula.tensor(f"m.nt.ts{i}", (t, 2), 0.35, 0.225)
+        bx = torch.cat([c, s_], -1)
+        bx[0] = boxes[i, 10] + torch.tensor([0.01, -0.01, 0.005, 0.0])
+        bx[1] = bx[0]
+        bx[1, 1] = up(float(bx[0, 1]))
+        bx[2] = boxes[i, 40] + torch.tensor([-0.004, 0.002, 0.0, 0.003])
+        tgts.append(bx)
+    pm = torch.zeros(sum(sizes), K)
+    pm[:, 1:15] = 1.0 / 14.0
+    matcher = HungarianMatcher(cost_class=1.0, cost_bbox=5.0, cost_giou=2.0)
+    out = matcher({"pred_logits": logits, "pred_boxes": boxes}, [{"boxes": b} for b in tgts], pm)
+    rec = {"logits": logits, "boxes": boxes, "pm": pm, "sizes": np.array(sizes)}
+    for i, b in enumerate(tgts):
+        rec[f"tgt{i}"] = b
+    for i, (a, b) in enumerate(out):
+        rec[f"src{i}"], rec[f"dst{i}"] = a, b
+    save("matcher_neartie.npz", **rec)
+
+
 # ------------------------------------------------------------------------------------------ small ops
 def small_ops():
     a = torch.cat([formula.tensor("b.a.c", (7, 2), 0.6, 0.5), formula.tensor("b.a.s", (7, 2), 0.3, 0.2)], -1)
@@ -240,6 +284,10 @@ def whole_model():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "neartie":     # add one fixture without rewriting the others
+        matcher_neartie()
+        sys.exit(0)
     matcher_cases()
+    matcher_neartie()
     small_ops()
     whole_model()

@@ -248,3 +248,37 @@ def test_evaluation_loop_end_to_end(dev):
         assert len(stats[True][name]) == 12 and stats[True][name] == stats[False][name]
         assert all(-1.0 <= v <= 1.0 for v in stats[True][name])
     assert stats[True]["loss"] > 0 and "loss_dice" in stats[True]
+
+
+@pytest.mark.parametrize("case", ["equal", "ragged"])
+def test_postprocess_segm_vs_reference_fixture(dev, case):
+    """The fused PostProcessSegm kernel against masks the REAL reference produced (tests/golden/postprocess_segm.npz, both of its
+    branches).  The kernel composes the two bilinear resizes in one pass, so a pixel whose resized logit is within rounding of 0 may
+    land on the other side of the threshold: at most 1e-4 of the pixels (and never a different shape / dtype)."""
+    import os
+    from toist_amd.postprocessors import PostProcessSegm
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "postprocess_segm.npz"))
+    pred = torch.from_numpy(d["pred_masks"]).to(dev)
+    orig, mx = torch.from_numpy(d[case + "_orig"]).to(dev), torch.from_numpy(d[case + "_max"]).to(dev)
+    res = PostProcessSegm()([{} for _ in range(pred.shape[0])], {"pred_masks": pred}, orig, mx)
+    for i, r in enumerate(res):
+        m = r["masks"]
+        want = np.unpackbits(d[f"{case}_bits{i}"])[:m.numel()].reshape(tuple(m.shape)).astype(bool)
+        assert m.dtype == torch.bool and tuple(m.shape) == want.shape
+        flipped = int((m.numpy() != want).sum())
+        assert flipped <= 1e-4 * want.size + 1, (case, i, flipped, want.size)
+
+
+def test_postprocess_values_vs_reference_fixture(dev):
+    """PostProcess (scores = 1 - p(no object), labels = 1, boxes scaled to the image) against the REAL reference's outputs
+    (tests/golden/postprocess.npz), computed on the device."""
+    import os
+    from toist_amd.postprocessors import PostProcess
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "postprocess.npz"))
+    out = {"pred_logits": torch.from_numpy(d["logits"]).to(dev), "pred_boxes": torch.from_numpy(d["boxes"]).to(dev)}
+    res = PostProcess()(out, torch.from_numpy(d["sizes"]).to(dev))
+    for i, r in enumerate(res):
+        assert r["scores"].is_cuda and r["labels"].dtype == torch.int64
+        assert np.allclose(r["scores"].cpu().numpy(), d["scores"][i], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(r["labels"].cpu().numpy(), d["labels"][i])
+        assert np.allclose(r["boxes"].cpu().numpy(), d["out_boxes"][i], rtol=1e-5, atol=1e-3)

@@ -13,12 +13,121 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _criterion(dev):
+def _criterion(dev, contrastive=False):
     from toist_amd import harness
     from toist_amd.matcher import HungarianMatcher
     from toist_amd.mdetr import SetCriterion
     return SetCriterion(harness.default_args(), 255, matcher=HungarianMatcher(1.0, 5.0, 2.0), eos_coef=0.1,
-                        losses=["labels", "boxes", "cardinality"], temperature=0.07).to(dev)
+                        losses=["labels", "boxes", "cardinality"] + (["contrastive_align"] if contrastive else []), temperature=0.07).to(dev)
+
+
+class _FakeTokenized(dict):
+    """char -> token lookup of the fixture generator (tests/golden/make_golden.py: 3 characters per token, None past the last real token)."""
+
+    def char_to_token(self, i, c=None):
+        if c is None:
+            return None
+        t = c // 3 + 1
+        return t if t < self["n"] - 1 else None
+
+
+def _golden_contrastive_inputs(dev):
+    d = np.load(os.path.join(G, "criterion.npz"))
+    sizes = d["sizes"].tolist()
+    chars = [[(0, 6)], [(3, 9)], [(0, 3), (9, 12)]]
+    targets = [{"boxes": torch.from_numpy(d[f"boxes{i}"]).to(dev), "labels": torch.ones(s, dtype=torch.int64, device=dev), "tokens_positive": chars[:s]}
+               for i, s in enumerate(sizes)]
+    return d, sizes, targets
+
+
+def test_reference_golden_losses_with_contrastive_align(dev):
+    """All 30 losses of the reference's default detection recipe (labels, boxes, cardinality, contrastive_align; 5 aux layers) on the
+    REAL reference's outputs: the contrastive keys come from the device kernel (csrc/contrastive.hip), spans through char_to_token."""
+    d, sizes, targets = _golden_contrastive_inputs(dev)
+    logits, boxes = torch.from_numpy(d["pred_logits"]).to(dev), torch.from_numpy(d["pred_boxes"]).to(dev)
+    pq, pt = torch.from_numpy(d["proj_queries"]).to(dev), torch.from_numpy(d["proj_tokens"]).to(dev)
+    tok = _FakeTokenized(n=pt.shape[1])
+    L = logits.shape[0]
+    out = {"pred_logits": logits[-1], "pred_boxes": boxes[-1], "proj_queries": pq[-1], "proj_tokens": pt, "tokenized": tok,
+           "aux_outputs": [{"pred_logits": logits[i], "pred_boxes": boxes[i], "proj_queries": pq[i], "proj_tokens": pt, "tokenized": tok} for i in range(L - 1)]}
+    crit = _criterion(dev, contrastive=True)
+    losses = crit(None, out, targets, torch.from_numpy(d["pm"]).to(dev), None)
+    ref = dict(zip([str(n) for n in d["names"]], d["values"]))
+    assert set(losses) == set(ref)
+    for k_, v in losses.items():
+        assert abs(float(v) - ref[k_]) <= 1e-4 * abs(ref[k_]) + 1e-5, f"{k_}: {float(v)} vs reference {ref[k_]}"
+    # --no_aux_loss recipes (scripts/train_seg.sh): one layer, un-suffixed keys only, matched with the MAIN layer's outputs
+    out1 = {k_: v for k_, v in out.items() if k_ != "aux_outputs"}
+    out1["_stacked"] = {"pred_logits": logits, "pred_boxes": boxes, "proj_queries": pq}
+    one = _criterion(dev, contrastive=True)(None, out1, targets, torch.from_numpy(d["pm"]).to(dev), None)
+    assert set(one) == {"loss_ce", "loss_bbox", "loss_giou", "cardinality_error", "loss_contrastive_align"}
+    for k_, v in one.items():
+        assert abs(float(v) - ref[k_]) <= 1e-4 * abs(ref[k_]) + 1e-5, f"no-aux {k_}: {float(v)} vs reference {ref[k_]}"
+
+
+def test_contrastive_align_gradients_vs_oracle(dev):
+    """d loss / d proj_queries, d proj_tokens of the device kernel against fp32 autograd through the oracle's restatement
+    (oracle/model_ref.loss_contrastive_align, pinned to the reference by criterion.npz); l2 normalisation forward / backward too."""
+    from oracle import model_ref
+    from toist_amd.mdetr import l2_normalize
+    d, sizes, targets = _golden_contrastive_inputs(dev)
+    logits, boxes = torch.from_numpy(d["pred_logits"]), torch.from_numpy(d["pred_boxes"])
+    g = torch.Generator().manual_seed(5)
+    raw_q = torch.randn(6, 2, 100, 64, generator=g).requires_grad_(True)
+    raw_t = torch.randn(2, 7, 64, generator=g).requires_grad_(True)
+    spans = [[[(1, 2)], [(2, 3)], [(1, 1), (4, 4)]][:s] for s in sizes]
+    pm = torch.from_numpy(d["pm"])
+    w = torch.tensor([0.3, 1.0, 0.7, 1.3, 0.9, 1.1])
+    # oracle
+    pq, pt = torch.nn.functional.normalize(raw_q, dim=-1), torch.nn.functional.normalize(raw_t, dim=-1)
+    tot = 0
+    L = 6
+    for l in range(L):
+        o = {"pred_logits": logits[l], "pred_boxes": boxes[l], "proj_queries": pq[l], "proj_tokens": pt}
+        idx = model_ref.matcher_ref.hungarian_match(logits[l], boxes[l], [torch.from_numpy(d[f"boxes{i}"]) for i in range(len(sizes))], pm)
+        tot = tot + w[l] * model_ref.loss_contrastive_align(o, spans, idx, float(sum(sizes)))["loss_contrastive_align"]
+    tot.backward()
+    # device
+    dq, dt = raw_q.detach().to(dev).requires_grad_(True), raw_t.detach().to(dev).requires_grad_(True)
+    nq, nt = l2_normalize(dq), l2_normalize(dt)
+    assert torch.allclose(nq.detach().cpu(), pq.detach(), atol=1e-6) and torch.allclose(nt.detach().cpu(), pt.detach(), atol=1e-6)
+    tg = [dict(t, token_spans=sp) for t, sp in zip(targets, spans)]
+    for t in tg:
+        t.pop("tokens_positive")
+    lg, bx = logits.to(dev), boxes.to(dev)
+    out = {"pred_logits": lg[-1], "pred_boxes": bx[-1], "proj_queries": nq[-1], "proj_tokens": nt,
+           "aux_outputs": [{"pred_logits": lg[i], "pred_boxes": bx[i], "proj_queries": nq[i], "proj_tokens": nt} for i in range(L - 1)]}
+    losses = _criterion(dev, contrastive=True)(None, out, tg, pm.to(dev), None)
+    order = {**{f"loss_contrastive_align_{l}": l for l in range(L - 1)}, "loss_contrastive_align": L - 1}
+    got = sum(w[l].item() * losses[k_] for k_, l in order.items())
+    assert abs(float(got) - float(tot)) <= 1e-4 * abs(float(tot))
+    got.backward()
+    for a, b, name in [(dq.grad, raw_q.grad, "d proj_queries"), (dt.grad, raw_t.grad, "d proj_tokens")]:
+        err, scale = float((a.cpu() - b).abs().max()), float(b.abs().max())
+        assert err <= 2e-3 * scale + 1e-7, f"{name}: max err {err} (scale {scale})"
+
+
+def test_invalid_costs_poison_the_losses_and_raise(dev):
+    """A NaN logit makes SciPy raise ValueError inside the reference matcher (matcher.py:85).  Here the affected layer's losses turn
+    NaN in the same step (so the finite-loss guard of engine.py:82-85 trips) and check_status() / the next call raise ValueError."""
+    d, sizes, targets = _golden_contrastive_inputs(dev)
+    logits, boxes = torch.from_numpy(d["pred_logits"]).to(dev).clone(), torch.from_numpy(d["pred_boxes"]).to(dev)
+    logits[2, 1, 5, 7] = float("nan")
+    out = {"pred_logits": logits[-1], "pred_boxes": boxes[-1],
+           "aux_outputs": [{"pred_logits": logits[i], "pred_boxes": boxes[i]} for i in range(5)]}
+    crit = _criterion(dev)
+    pm = torch.from_numpy(d["pm"]).to(dev)
+    losses = crit(None, out, targets, pm, None)
+    assert not bool(torch.isfinite(losses["loss_ce_2"])) and bool(torch.isfinite(losses["loss_ce"])) and bool(torch.isfinite(losses["loss_ce_1"]))
+    with pytest.raises(ValueError, match="invalid numeric entries"):
+        crit.check_status()
+    crit(None, out, targets, pm, None)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="invalid numeric entries"):
+        crit(None, out, targets, pm, None)
+    from toist_amd import harness
+    with pytest.raises(SystemExit):
+        harness.finite_or_exit(losses["loss_ce_2"], losses)
 
 
 def test_reference_golden_losses(dev):
@@ -27,7 +136,8 @@ def test_reference_golden_losses(dev):
     sizes = d["sizes"].tolist()
     targets = [{"boxes": torch.from_numpy(d[f"boxes{i}"]).to(dev), "labels": torch.ones(s, dtype=torch.int64, device=dev)} for i, s in enumerate(sizes)]
     logits, boxes = torch.from_numpy(d["pred_logits"]).to(dev), torch.from_numpy(d["pred_boxes"]).to(dev)
-    out = {"pred_logits": logits[-1], "pred_boxes": boxes[-1], "_stacked": {"pred_logits": logits, "pred_boxes": boxes}}
+    out = {"pred_logits": logits[-1], "pred_boxes": boxes[-1], "_stacked": {"pred_logits": logits, "pred_boxes": boxes},
+           "aux_outputs": [{"pred_logits": logits[i], "pred_boxes": boxes[i]} for i in range(logits.shape[0] - 1)]}
     crit = _criterion(dev)
     losses = crit(None, out, targets, torch.from_numpy(d["pm"]).to(dev), None)
     ref = dict(zip([str(n) for n in d["names"]], d["values"]))
@@ -62,7 +172,8 @@ def test_losses_and_gradients_vs_oracle(dev, seed, B, sizes):
     total_of(ref_losses).backward()
 
     lg, bx = logits.detach().to(dev).requires_grad_(True), boxes.detach().to(dev).requires_grad_(True)
-    out = {"pred_logits": lg[-1], "pred_boxes": bx[-1], "_stacked": {"pred_logits": lg, "pred_boxes": bx}}
+    out = {"pred_logits": lg[-1], "pred_boxes": bx[-1], "_stacked": {"pred_logits": lg, "pred_boxes": bx},
+           "aux_outputs": [{"pred_logits": lg[i], "pred_boxes": bx[i]} for i in range(L - 1)]}
     crit = _criterion(dev)
     t_dev = [{k_: v.to(dev) for k_, v in t.items()} for t in targets]
     losses = crit(None, out, t_dev, pmap.to(dev), None)

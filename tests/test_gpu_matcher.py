@@ -80,6 +80,23 @@ def test_indices_bit_exact(dev, seed, B, Q, K, sizes, dup, same_pm):
     assert mism == 0, f"{mism} images with different assignment"
 
 
+@pytest.mark.parametrize("name", ["rand", "dup", "big", "wide", "samepm", "neartie"])
+def test_reference_fixtures_direct(dev, name):
+    """toist_matcher on the inputs the REAL reference's HungarianMatcher was run on (tests/golden/make_golden.py): the index
+    arrays must equal the reference's bit for bit -- including `neartie`, whose assignment hinges on 1-ulp cost differences."""
+    import os
+    import numpy as np
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"matcher_{name}.npz"))
+    sizes = d["sizes"].tolist()
+    tgt = [torch.from_numpy(d[f"tgt{i}"]) for i in range(len(sizes))]
+    src, dst, status, moff, _ = _run_gpu(dev, torch.from_numpy(d["logits"])[None], torch.from_numpy(d["boxes"])[None], tgt, torch.from_numpy(d["pm"]))
+    assert int(status.abs().sum()) == 0
+    bad = [i for i in range(len(sizes))
+           if not (np.array_equal(src[0, int(moff[i]):int(moff[i + 1])].numpy(), d[f"src{i}"]) and
+                   np.array_equal(dst[0, int(moff[i]):int(moff[i + 1])].numpy(), d[f"dst{i}"]))]
+    assert not bad, f"{name}: images {bad} differ from the reference's assignment"
+
+
 def test_invalid_cost_flagged(dev):
     logits, boxes, tgt, pm = _case(9, 2, 100, 256, [3, 2])
     logits[0, 1, 5, 7] = float("nan")
@@ -104,3 +121,18 @@ def test_generic_lsap_matches_oracle(dev):
     bad[1, 2] = float("nan")
     with pytest.raises(ValueError):
         linear_sum_assignment_batch([bad.to(dev)])
+
+
+def test_generic_lsap_committed_known_answers(dev):
+    """toist_lsap against SciPy's own answers (tests/golden/lsap_kat.json: exact ties, duplicated rows / columns, tall, wide,
+    97 x 97, empty) -- one launch for all 40 problems."""
+    import json
+    import os
+    from toist_amd.matcher import linear_sum_assignment_batch
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lsap_kat.json")) as f:
+        kat = json.load(f)
+    cases = [c for c in kat["cases"] if c["rows"] and c["cols"]]
+    costs = [torch.tensor(c["cost"], dtype=torch.float32).reshape(c["rows"], c["cols"]).to(dev) for c in cases]
+    got = linear_sum_assignment_batch(costs)
+    for i, (c, (r, k_)) in enumerate(zip(cases, got)):
+        assert r.cpu().tolist() == c["row_ind"] and k_.cpu().tolist() == c["col_ind"], (i, c["rows"], c["cols"])

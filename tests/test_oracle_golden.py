@@ -21,7 +21,7 @@ def load(name):
     return {k: v for k, v in np.load(os.path.join(G, name), allow_pickle=False).items()}
 
 
-@pytest.mark.parametrize("name", ["rand", "dup", "big", "wide", "samepm"])
+@pytest.mark.parametrize("name", ["rand", "dup", "big", "wide", "samepm", "neartie"])
 def test_matcher_indices_match_reference(name):
     d = load(f"matcher_{name}.npz")
     sizes = d["sizes"].tolist()
@@ -167,3 +167,17 @@ def test_segmentation_branch_matches_reference():
     ref = dict(zip([str(n) for n in d["names"]], d["values"]))
     for k in ("loss_mask", "loss_dice"):
         assert abs(float(ml[k]) - ref[k]) <= 1e-5 + 1e-5 * abs(ref[k]), (k, float(ml[k]), ref[k])
+
+
+@pytest.mark.parametrize("case", ["equal", "ragged"])
+def test_postprocess_segm_matches_reference(case):
+    """oracle/coco_ref.postprocess_segm vs masks produced by the REAL reference's PostProcessSegm (both branches,
+    tests/golden/make_golden_postsegm.py): identical fp32 torch arithmetic -> identical bits."""
+    from oracle import coco_ref
+    d = load("postprocess_segm.npz")
+    pred = torch.from_numpy(d["pred_masks"])
+    orig, mx = torch.from_numpy(d[case + "_orig"]), torch.from_numpy(d[case + "_max"])
+    got = coco_ref.postprocess_segm(pred, orig, mx)
+    for i, m in enumerate(got):
+        want = np.unpackbits(d[f"{case}_bits{i}"])[:m.numel()].reshape(tuple(m.shape)).astype(bool)
+        assert np.array_equal(m.numpy(), want), f"{case} image {i}: {int((m.numpy() != want).sum())} pixels differ"

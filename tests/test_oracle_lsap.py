@@ -67,3 +67,16 @@ def test_matcher_shaped_blocks():
         r, k = lsap.linear_sum_assignment(c)
         assert np.array_equal(a, r) and np.array_equal(b, k)
         assert np.all(np.diff(r) > 0)
+
+
+def test_committed_known_answers():
+    """tests/golden/lsap_kat.json (SciPy's answers, committed: the GPU box need not have SciPy)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lsap_kat.json")) as f:
+        kat = json.load(f)
+    assert len(kat["cases"]) >= 40
+    for i, c in enumerate(kat["cases"]):
+        cost = np.array(c["cost"], dtype=np.float64).reshape(c["rows"], c["cols"])
+        r, k = lsap.linear_sum_assignment(cost)
+        assert r.tolist() == c["row_ind"] and k.tolist() == c["col_ind"], i

@@ -24,6 +24,22 @@ def default_args(**over):
     return SimpleNamespace(**a)
 
 
+def finite_or_exit(loss_value, loss_dict=None, criterion=None):
+    """The NaN / inf guard of the reference loop (engine.py:82-85, 212-215): print the losses and sys.exit(1).  When the criterion is
+    given, an invalid matcher cost block is reported as the ValueError SciPy raises in the reference (matcher.py:85)."""
+    import math
+    import sys
+    v = float(loss_value)
+    if math.isfinite(v):
+        return v
+    if criterion is not None:
+        criterion.check_status()
+    print("Loss is {}, stopping training".format(v))
+    if loss_dict is not None:
+        print({k: float(x) for k, x in loss_dict.items()})
+    sys.exit(1)
+
+
 def synthetic_batch(batch, height=640, width=640, tokens=16, seed=1000, device="cpu", max_targets=10, with_masks=False):
     """Images ~ N(0,1) (already normalised), all-False padding mask; captions = <s> + ids + </s>;
     T_i ~ U{0..max_targets} boxes with cx,cy~U(.2,.8), w,h~U(.05,.4); positive_map rows = 1/(tokens-2)
