@@ -44,18 +44,38 @@ def parse():
     ap.add_argument("--torch-optimizer", action="store_true", help="diagnostic: torch clip_grad_norm_ + fused AdamW + foreach EMA instead of the HIP tail")
     ap.add_argument("--defer-ema", action="store_true", help="diagnostic: run the EMA update beside the next forward pass instead of inside the optimizer tail "
                                                              "(measured slower: 504 vs 514 images/s, the forward pass is HBM-sensitive)")
+    ap.add_argument("--no-contrastive", action="store_true", help="drop loss_contrastive_align (the round-1 configuration; the reference's detection recipe has it on, "
+                    "main.py:179-184)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
     ap.add_argument("--split-graph", action="store_true", help="force the multi-GPU structure (graph: fwd+bwd | eager all-reduce | graph: clip+AdamW+EMA) on one GPU")
     return ap.parse_args()
 
 
-def cpu_baseline_worker(size, threads):
+def cpu_baseline_worker(size, threads, check_path=None):
     """BASELINE.json configs[0]: one 640x640 image + 16-token caption, detection-only forward + one matcher call on the
-    fp32 oracle (a port of the reference CPU path, pinned to the reference by tests/golden).  Prints one JSON line."""
+    fp32 oracle (a port of the reference CPU path, pinned to the reference by tests/golden).  SURVEY.md 8(d): 3 warm-up + 10 timed
+    iterations, median.  With `check_path` (outputs of the GPU step dumped by the parent) it also counts the (layer, image) pairs
+    whose HIP assignment differs from the oracle matcher's on the SAME fp32 logits / boxes.  Prints one JSON line."""
+    import numpy as np
     import toist_amd
-    from oracle import model_ref
+    from oracle import matcher_ref, model_ref
     from toist_amd import harness
     torch.set_num_threads(threads)
+    res = {}
+    if check_path:
+        d = np.load(check_path)
+        logits, boxes, pm = torch.from_numpy(d["logits"]), torch.from_numpy(d["boxes"]), torch.from_numpy(d["pm"])
+        sizes = d["sizes"].tolist()
+        tb = torch.from_numpy(d["tgt_boxes"])
+        tgts = [tb[sum(sizes[:i]):sum(sizes[:i + 1])] for i in range(len(sizes))]
+        moff = np.concatenate([[0], np.cumsum([min(logits.shape[2], s_) for s_ in sizes])])
+        bad = 0
+        for l in range(logits.shape[0]):
+            ref = matcher_ref.hungarian_match(logits[l], boxes[l], tgts, pm)
+            for i, (ri, rj) in enumerate(ref):
+                a, b = d["src"][l, moff[i]:moff[i + 1]], d["tgt"][l, moff[i]:moff[i + 1]]
+                bad += int(not (np.array_equal(a, ri.numpy()) and np.array_equal(b, rj.numpy())))
+        res.update(matcher_mismatch_images=bad, matcher_checked=int(logits.shape[0] * logits.shape[1]))
     args = harness.default_args(device="cpu")
     torch.manual_seed(0)
     model, _, _, _ = toist_amd.build_model(args)
@@ -67,27 +87,30 @@ def cpu_baseline_worker(size, threads):
         with torch.no_grad():
             mc = model_ref.mdetr_encode(sd, samples.tensors, samples.mask, tok["input_ids"], tok["attention_mask"])
             out = model_ref.mdetr_decode(sd, mc)
-            return model_ref.matcher_ref.hungarian_match(out["pred_logits"], out["pred_boxes"], [t["boxes"] for t in targets], pmap)
+            return matcher_ref.hungarian_match(out["pred_logits"], out["pred_boxes"], [t["boxes"] for t in targets], pmap)
 
-    fwd()
-    t0 = time.time()
-    n = 0
-    while n < 3 or (time.time() - t0 < 10 and n < 50):
+    for _ in range(3):
         fwd()
-        n += 1
-    dt = (time.time() - t0) / n
-    print(json.dumps({"value": round(1.0 / dt, 4), "unit": "images/s (forward + matcher, B=1)", "cores": threads, "kind": "port",
-                      "sample": f"configs[0]: oracle fp32 detection forward + Hungarian matcher, 1 image {size}x{size} + 16 tokens, "
-                                f"1 warm-up + {n} timed iterations on {threads} threads"}))
+    times = []
+    for _ in range(10):
+        t0 = time.time()
+        fwd()
+        times.append(time.time() - t0)
+    dt = sorted(times)[len(times) // 2]
+    res.update({"value": round(1.0 / dt, 4), "unit": "images/s (forward + matcher, B=1)", "cores": threads, "kind": "port",
+                "sample": f"configs[0]: oracle fp32 detection forward + Hungarian matcher, 1 image {size}x{size} + 16 tokens, "
+                          f"3 warm-up + 10 timed iterations on {threads} threads, median"})
+    print(json.dumps(res))
 
 
-def cpu_baseline(size):
-    """Runs the CPU baseline in a child process with a hard time limit so a pathological host can never stall the bench."""
+def cpu_baseline(size, check_path=None):
+    """Runs the CPU baseline (and the matcher bit-match check) in a child process with a hard time limit so a pathological host can
+    never stall the bench."""
     import subprocess
     threads = min(os.cpu_count() or 1, 64)
     try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(size), str(threads)], capture_output=True,
-                             text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(size), str(threads)] + ([check_path] if check_path else []),
+                             capture_output=True, text=True, timeout=300, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:  # timeout or failure: report, never block the GPU numbers
@@ -169,7 +192,7 @@ def bench_distillation(a, dev, rank, world):
 
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
-        cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
+        cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
         return
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -191,7 +214,10 @@ def main():
     from toist_amd.mdetr import weighted_total
     if a.distill:
         return bench_distillation(a, dev, rank, world)
-    args = harness.default_args(device="cuda", masks=a.masks, mask_model="smallconv" if a.masks else "none")
+    # the reference's default detection recipe (scripts/train_dete.sh): labels + boxes + cardinality + contrastive_align, 5 aux layers;
+    # the segmentation recipe (scripts/train_seg.sh) passes --no_contrastive_align_loss
+    contrastive = not a.no_contrastive and not a.masks
+    args = harness.default_args(device="cuda", masks=a.masks, mask_model="smallconv" if a.masks else "none", contrastive_align_loss=contrastive)
     torch.manual_seed(0)
     model, criterion, _, weight_dict = toist_amd.build_model(args)
     model.to(dev)
@@ -398,7 +424,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("configs[2] (det + mask head + mask losses): " if a.masks else "") + f"configs[1]: ResNet-101 + RoBERTa-base + 6+6 transformer, 100 queries, batch {a.batch}/GPU {a.size}x{a.size}, "
-                                   "16-token captions, detection loss (labels+boxes+cardinality, 5 aux layers), dropout 0.1, "
+                                   "16-token captions, detection loss (labels+boxes+cardinality" + ("+contrastive_align" if contrastive else "") + ", 5 aux layers), dropout 0.1, "
                                    "clip 0.1 + AdamW + EMA" + (" (torch)" if a.torch_optimizer else " (fused HIP tail)") + "; random-init weights",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4), "launch": ("4 hipGraphs (head | text || backbone | tail), gradient all-reduces under the backbone backward" if split_graph else "hipGraph replay") if use_graph else "eager",
                        "mfma_frac_whole_step": round(ips / world * GFLOP_PER_IMG_TRAIN / 1000.0 / PEAK_BF16_TFLOPS, 5)},
@@ -451,7 +477,30 @@ def main():
                 res["roofline"]["per_variant"] = {k_: {"ms_per_step": round(v[0] / a.steps, 3), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
                                                       "launches_per_step": v[2] // a.steps} for k_, v in per_key.items()}
         if not a.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(a.size)
+            # matcher index bit-match (the second half of the metric): the 6-layer outputs of one more step and the
+            # HIP assignment on them go to the CPU child, which re-matches them with the oracle and counts differing (layer, image) pairs
+            check_path = None
+            try:
+                import tempfile
+                import numpy as np
+                with torch.no_grad():
+                    mc = model(samples, tok, encode_and_save=True)
+                    out = model(samples, tok, encode_and_save=False, memory_cache=mc)
+                    criterion(mc, out, targets, pmap, None)
+                m = criterion.last_match
+                m.check()
+                st = out["_stacked"]
+                check_path = os.path.join(tempfile.mkdtemp(prefix="toist_bench_"), "match.npz")
+                np.savez(check_path, logits=st["pred_logits"].float().cpu().numpy(), boxes=st["pred_boxes"].float().cpu().numpy(), pm=pmap.float().cpu().numpy(),
+                         sizes=np.array(m.sizes), tgt_boxes=(m.tgt_boxes.cpu().numpy() if m.tgt_boxes is not None else np.zeros((0, 4), np.float32)),
+                         src=m.src.cpu().numpy(), tgt=m.tgt.cpu().numpy())
+            except Exception as e:  # the throughput line must survive a failing check; the field then says why
+                res["matcher_mismatch_images"] = f"not checked: {type(e).__name__}: {e}"
+            cb = cpu_baseline(a.size, check_path)
+            if "matcher_mismatch_images" in cb:
+                res["matcher_mismatch_images"] = cb.pop("matcher_mismatch_images")
+                res["matcher_checked_layer_image_pairs"] = cb.pop("matcher_checked")
+            res["cpu_baseline"] = cb
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -1,0 +1,116 @@
+"""Two ranks on ONE GPU (gloo): the reference's DistributedDataParallel wrap (main.py:335-337) and its step sequence
+(engine.py:54-101: encode, decode, criterion, weighted sum, zero_grad, backward, clip, step) run UNCHANGED around the MI355X
+model, and so does toist_amd.parallel.DistributedDataParallel.  After backward every rank must hold the same gradients, equal to
+the mean of the two ranks' local gradients; the num_boxes all-reduce of the criterion (mdetr.py:997-1001) must see both ranks."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+PROBES = ["class_embed.weight", "bbox_embed.layers.2.bias", "transformer.decoder.layers.0.cross_attn_image.in_proj_weight",
+          "transformer.encoder.layers.0.linear1.weight", "transformer.decoder.norm.weight", "transformer.resizer.fc.weight",
+          "transformer.text_encoder.encoder.layer.0.attention.self.query.weight", "input_proj.weight", "backbone.0.body.layer4.2.conv3.weight",
+          "backbone.0.body.layer2.0.conv1.weight", "query_embed.weight"]
+
+
+def _step(model, criterion, weight_dict, batch, dev, clip=True):
+    """engine.py:54-91 verbatim in structure."""
+    samples, tok, targets, pmap = batch
+    memory_cache = model(samples, tok, encode_and_save=True)
+    outputs = model(samples, tok, encode_and_save=False, memory_cache=memory_cache)
+    loss_dict = criterion(memory_cache, outputs, targets, pmap, None)
+    losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+    model.zero_grad(set_to_none=True)
+    losses.backward()
+    if clip:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1e9)
+    return float(losses)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import toist_amd
+    from toist_amd import harness, parallel
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    args = harness.default_args(device="cuda", dropout=0.0, enc_layers=2, dec_layers=2)
+    batches = [harness.synthetic_batch(2, 128, 160, tokens=8, seed=40 + r, device=dev, max_targets=4) for r in range(world)]
+
+    def build():
+        torch.manual_seed(0)
+        model, criterion, _, weight_dict = toist_amd.build_model(args)
+        for n, b in model.named_buffers():
+            if n.endswith("bn3.weight"):
+                b.mul_(0.3)
+        model.to(dev).train()
+        return model, criterion, weight_dict
+
+    def probe(m):
+        named = dict(m.named_parameters())
+        return {n: named[n].grad.detach().float().cpu().clone() for n in PROBES}
+
+    # expected: mean over ranks of the local gradients; num_boxes is all-reduced inside the criterion, so the local runs below are
+    # issued by BOTH ranks in lock-step (rank r feeds batch j when it is j's turn) and rescaled to the two-rank num_boxes
+    model, criterion, weight_dict = build()
+    nb_world = max(sum(len(t["boxes"]) for b in batches for t in b[2]) / world, 1.0)
+    want = None
+    for j in range(world):
+        nb_local = max(float(sum(len(t["boxes"]) for t in batches[j][2])), 1.0)   # both ranks feed batch j: world sum / world = local count
+        _step(model, criterion, weight_dict, batches[j], dev, clip=False)
+        g = {n: v * (nb_local / nb_world) / world for n, v in probe(model).items()}
+        want = g if want is None else {n: want[n] + g[n] for n in g}
+    res = {}
+
+    def compare(got):
+        worst = 1.0
+        for n in PROBES:
+            a, b = got[n].flatten(), want[n].flatten()
+            cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+            ratio = float(a.norm() / (b.norm() + 1e-30))
+            worst = min(worst, cos if 0.97 < ratio < 1.03 else -1.0)
+        return worst
+
+    # 1. torch's own DistributedDataParallel, as the reference wraps the model
+    model, criterion, weight_dict = build()
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True)
+    _step(ddp, criterion, weight_dict, batches[rank], dev)
+    got = probe(ddp.module)
+    res["torch_ddp_cos"] = compare(got)
+    gather = [None] * world
+    dist.all_gather_object(gather, {n: float(v.double().sum()) for n, v in got.items()})
+    res["torch_ddp_same_on_all_ranks"] = all(abs(gather[0][n] - gather[1][n]) <= 1e-6 * (abs(gather[0][n]) + 1e-12) for n in PROBES)
+    del ddp
+    # 2. the flat-buffer wrapper with the same constructor / .module surface
+    model, criterion, weight_dict = build()
+    ddp2 = parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True)
+    _step(ddp2, criterion, weight_dict, batches[rank], dev)
+    res["toist_ddp_cos"] = compare(probe(ddp2.module))
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_ddp_wrap_and_step_sequence(dev):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r]["torch_ddp_same_on_all_ranks"], out[r]
+        assert out[r]["torch_ddp_cos"] > 0.995, out[r]
+        assert out[r]["toist_ddp_cos"] > 0.995, out[r]
