@@ -57,8 +57,8 @@ def _worker(rank, world, port, out):
         for n, b in model.named_buffers():
             if n.endswith("bn3.weight"):
                 b.mul_(0.3)
-        model.to(dev).train()
-        return model, criterion, weight_dict
+        model.to(dev).eval()      # gradients flow as in training; eval() only switches the dropout layers off (RoBERTa's and the resizer's
+        return model, criterion, weight_dict      # are not governed by args.dropout), so the expectation below is deterministic
 
     def probe(m):
         named = dict(m.named_parameters())
@@ -77,13 +77,13 @@ def _worker(rank, world, port, out):
     res = {}
 
     def compare(got):
-        worst = 1.0
+        """(smallest cosine, smallest and largest norm ratio) over the probed tensors"""
+        cos_, rat = [], []
         for n in PROBES:
             a, b = got[n].flatten(), want[n].flatten()
-            cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
-            ratio = float(a.norm() / (b.norm() + 1e-30))
-            worst = min(worst, cos if 0.97 < ratio < 1.03 else -1.0)
-        return worst
+            cos_.append(float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)))
+            rat.append(float(a.norm() / (b.norm() + 1e-30)))
+        return min(cos_), min(rat), max(rat)
 
     # 1. torch's own DistributedDataParallel, as the reference wraps the model
     model, criterion, weight_dict = build()
@@ -112,5 +112,6 @@ def test_reference_ddp_wrap_and_step_sequence(dev):
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     for r in range(world):
         assert out[r]["torch_ddp_same_on_all_ranks"], out[r]
-        assert out[r]["torch_ddp_cos"] > 0.995, out[r]
-        assert out[r]["toist_ddp_cos"] > 0.995, out[r]
+        for key in ("torch_ddp_cos", "toist_ddp_cos"):
+            cos_, lo, hi = out[r][key]
+            assert cos_ > 0.995 and 0.97 < lo and hi < 1.03, out[r]

@@ -373,6 +373,53 @@ def test_fused_attention_backward_matches_five_kernel_path(dev, Sq, Sk, drop, va
             assert err < 2e-2, (name, "vs fp32", err)
 
 
+@pytest.mark.parametrize("q_splits", [1, 4])
+@pytest.mark.parametrize("Sq,Sk,drop", [(416, 416, 0.1), (100, 416, 0.1), (100, 100, 0.1), (37, 50, 0.0), (70, 480, 0.1), (130, 250, 0.0)])
+def test_flash_attention_lse_mode_matches_stored_probabilities(dev, Sq, Sk, drop, q_splits):
+    """Flash-style bookkeeping (csrc/attn.hip): the forward kernel writes only the log-sum-exp of every score row, the backward
+    kernel re-forms P = exp(scale q.k - lse) and the dropout mask from the same (seed, index) hash.  Same context as the path
+    that stores P and dropout(P) (bit for bit: the forward arithmetic is unchanged), same dQ / dK / dV up to the bf16 rounding of
+    the stored probabilities, lse equal to fp32 math."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(Sq * 977 + Sk + 3)
+    B, H, dh = 2, 8, 32
+    d = H * dh
+    q = torch.randn(B * Sq, d, generator=g).to(BF).to(dev)
+    kk = torch.randn(B * Sk, d, generator=g).to(BF).to(dev)
+    v = torch.randn(B * Sk, d, generator=g).to(BF).to(dev)
+    dctx = torch.randn(B * Sq, d, generator=g).to(BF).to(dev)
+    pad = torch.zeros(B, Sk, dtype=torch.uint8)
+    pad[1, Sk - Sk // 3:] = 1
+    pad = pad.to(dev)
+    scale = 1.0 / math.sqrt(dh)
+    k.SEED_DEV = torch.full((1,), 77, dtype=torch.int64, device=dev)
+    ld = ops.round8(Sk)
+    prob = torch.zeros(B * H, Sq, ld, dtype=BF, device=dev)
+    pdrop = torch.zeros_like(prob) if drop > 0 else None
+    ctx0, ctx1 = torch.empty(B * Sq, d, dtype=BF, device=dev), torch.empty(B * Sq, d, dtype=BF, device=dev)
+    lse = torch.empty(B * H, Sq, dtype=torch.float32, device=dev)
+    k.attn_fwd(q, kk, v, pad, B, H, Sq, Sk, dh, scale, prob, pdrop, drop, 4321, ctx0)
+    k.attn_fwd(q, kk, v, pad, B, H, Sq, Sk, dh, scale, None, None, drop, 4321, ctx1, lse=lse)
+    assert torch.equal(ctx0, ctx1)
+    qf = q.float().view(B, Sq, H, dh).permute(0, 2, 1, 3)
+    kf = kk.float().view(B, Sk, H, dh).permute(0, 2, 1, 3)
+    sc = ((qf @ kf.transpose(-1, -2)) * scale).masked_fill(pad.bool()[:, None, None, :], float("-inf"))
+    assert float((lse.view(B, H, Sq) - sc.logsumexp(-1)).abs().max()) <= 2e-3
+    outs = []
+    for mode in (0, 1):
+        dq, dk_, dv = (torch.empty(B * Sq, d, dtype=BF, device=dev), torch.empty(B * Sk, d, dtype=BF, device=dev), torch.empty(B * Sk, d, dtype=BF, device=dev))
+        if mode == 0:
+            k.attn_bwd(q, kk, v, prob, pdrop, ctx0, dctx, B, H, Sq, Sk, dh, scale, drop, dq, dk_, dv, variant=2, q_splits=q_splits)
+        else:
+            k.attn_bwd(q, kk, v, None, None, ctx0, dctx, B, H, Sq, Sk, dh, scale, drop, dq, dk_, dv, variant=2, q_splits=q_splits, lse=lse, key_pad=pad, seed=4321)
+        outs.append((dq, dk_, dv))
+    for name, a, b in zip(("dq", "dk", "dv"), outs[1], outs[0]):
+        err = float((a.float() - b.float()).norm() / b.float().norm())
+        assert err < 1e-2, (name, err)
+    dk1, dv1 = outs[1][1], outs[1][2]
+    assert bool((dk1.view(B, Sk, d)[1, Sk - Sk // 3:] == 0).all()) and bool((dv1.view(B, Sk, d)[1, Sk - Sk // 3:] == 0).all())
+
+
 @pytest.mark.parametrize("min_tiles", [1, 1 << 20])      # unsplit group / group that is also split along K
 @pytest.mark.parametrize("R,stride", [(1, 1), (3, 1)])
 def test_grouped_conv_wgrad_matches_separate_launches(dev, R, stride, min_tiles):

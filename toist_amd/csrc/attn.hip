@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                                                        const bf16_t* __restrict__ v, int ldv, const unsigned char* __restrict__ key_pad, int H,
                                                        int Sq, int Sk, int ld, float scale, bf16_t* __restrict__ prob, bf16_t* __restrict__ prob_drop,
                                                        float drop_p, unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
-                                                       bf16_t* __restrict__ ctx, int ldo) {
+                                                       bf16_t* __restrict__ ctx, int ldo, float* __restrict__ lse) {
     constexpr int SKP = NB * 16, DH = 32;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     bf16_t* sK = smem;               // [SKP][32], 16-byte chunk (key, c) stored in slot c ^ ((key >> 1) & 3)
@@ -74,9 +74,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.f / sum;
-    const unsigned thresh = prob_drop ? (unsigned)(drop_p * 4294967296.0) : 0u;
-    const float dscale = prob_drop ? 1.f / (1.f - drop_p) : 1.f;
+    const bool dropping = drop_p > 0.f;
+    const unsigned thresh = dropping ? (unsigned)(drop_p * 4294967296.0) : 0u;
+    const float dscale = dropping ? 1.f / (1.f - drop_p) : 1.f;
     const size_t row = (size_t)bh * Sq + (qlive ? qi : 0);
+    // flash-style bookkeeping: with `lse` the backward kernel re-forms P = exp(scale q.k - lse) (and the dropout mask from the
+    // same hash) instead of reading two [Sq, Sk] bf16 matrices per head back from HBM; prob / prob_drop may then be NULL
+    if (lse != nullptr && qlive && g == 0) lse[row] = mx + __logf(sum);
     unsigned pk[NB][2];                                          // bf16 pairs of the probabilities that enter P V
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -85,11 +89,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int r = 0; r < 4; ++r) o[r] = s[j][r] * inv;
         const int k0 = j * 16 + g * 4;
         const bool inrow = qlive && k0 < ld;
-        if (inrow) *reinterpret_cast<uint2*>(prob + row * ld + k0) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-        if (prob_drop) {
+        if (inrow && prob != nullptr) *reinterpret_cast<uint2*>(prob + row * ld + k0) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+        if (dropping) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = dropout_keep(seed, (unsigned long long)row * ld + k0 + r, thresh) ? o[r] * dscale : 0.f;
-            if (inrow) *reinterpret_cast<uint2*>(prob_drop + row * ld + k0) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+            if (inrow && prob_drop != nullptr) *reinterpret_cast<uint2*>(prob_drop + row * ld + k0) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
         }
         pk[j][0] = pack2bf(o[0], o[1]);
         pk[j][1] = pack2bf(o[2], o[3]);
@@ -322,7 +326,11 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ dctx, int lddo, int H, int Sq, int Sk, int ld,
                                                             float scale, float drop_p, bf16_t* __restrict__ dq, int lddq,
                                                             bf16_t* __restrict__ dk, int lddk, bf16_t* __restrict__ dv, int lddv,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, const float* __restrict__ lse,
+                                                            const unsigned char* __restrict__ key_pad, unsigned long long seed,
+                                                            const unsigned long long* __restrict__ seed_dev) {
+    // prob == nullptr: flash-style recomputation -- P = exp(scale q.k - lse) per (query, key), the keep mask from the forward
+    // kernel's hash (same seed, same element index row * ld + key); `dropping` then comes from drop_p alone
     constexpr int SKP = NB * 16, DH = 32, QT = 32, LS = SKP + 8, NBQ = NB / 4, NBW = NB / 8;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     bf16_t* sV = smem;                        // [SKP][32]
@@ -333,11 +341,19 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
     bf16_t* sQ = sdO + QT * DH;               // [QT][32]
     float* sdQ = reinterpret_cast<float*>(sQ + QT * DH);   // [4][QT][32] partial dQ of the four key quarters
     float* sD = sdQ + 4 * QT * DH;            // [QT]
+    float* sL = sD + QT;                      // [QT]   log-sum-exp of the tile's queries (recompute mode)
+    unsigned char* sDead = reinterpret_cast<unsigned char*>(sL + QT);   // [SKP] 1 = key masked (recompute mode)
     typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
-    const float dscale = prob_drop ? 1.f / (1.f - drop_p) : 1.f;
+    const bool recompute = prob == nullptr;
+    const bool dropping = recompute ? drop_p > 0.f : prob_drop != nullptr;
+    const float dscale = dropping ? 1.f / (1.f - drop_p) : 1.f;
+    const unsigned thresh = dropping ? (unsigned)(drop_p * 4294967296.0) : 0u;
+    if (seed_dev) seed += *seed_dev;
     const int qh = wave & 1, kq = wave >> 1;
+    if (recompute)
+        for (int kk = tid; kk < SKP; kk += 512) sDead[kk] = (kk >= Sk || (key_pad != nullptr && key_pad[(size_t)b * Sk + kk])) ? 1 : 0;
 
     for (int c = tid; c < SKP * 4; c += 512) {
         const int key = c >> 2, ch = c & 3;
@@ -357,7 +373,10 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
 
     // probabilities of this lane's query for its key quarter, fetched one tile ahead
     uint2 pnx[NBQ], dnx[NBQ];
+#pragma unroll
+    for (int jj = 0; jj < NBQ; ++jj) pnx[jj] = dnx[jj] = make_uint2(0, 0);
     auto fetch = [&](int q0_) {
+        if (recompute) return;
         const int qi = q0_ + qh * 16 + c16;
 #pragma unroll
         for (int jj = 0; jj < NBQ; ++jj) {
@@ -381,9 +400,12 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
     fetch(t_beg * QT);
     // rows of dO, O, Q of the next tile (threads 0..255: query tid / 8, features 4 (tid % 8) ..), also fetched one tile ahead
     uint2 d2n = make_uint2(0, 0), o2n = make_uint2(0, 0), q2n = make_uint2(0, 0);
+    float lsen = 0.f;
     auto fetch_rows = [&](int q0_) {
         const int qi = q0_ + (tid >> 3), ch = tid & 7;
         d2n = o2n = q2n = make_uint2(0, 0);
+        lsen = 0.f;
+        if (recompute && tid < 256 && ch == 0 && qi < Sq) lsen = lse[(size_t)bh * Sq + qi];
         if (tid < 256 && qi < Sq) {
             d2n = *reinterpret_cast<const uint2*>(dctx + ((size_t)b * Sq + qi) * lddo + h * DH + ch * 4);
             o2n = *reinterpret_cast<const uint2*>(ctx + ((size_t)b * Sq + qi) * ldo + h * DH + ch * 4);
@@ -408,7 +430,7 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
             part += __shfl_xor(part, 1, 64);
             part += __shfl_xor(part, 2, 64);
             part += __shfl_xor(part, 4, 64);
-            if (ch == 0) sD[qq] = part;
+            if (ch == 0) { sD[qq] = part; sL[qq] = lsen; }
         }
         __syncthreads();
 
@@ -416,6 +438,11 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
             const int ql = qh * 16 + c16;                              // query of this lane inside the tile
             const bf16x8_t dof = *reinterpret_cast<const bf16x8_t*>(sdO + ql * DH + g * 8);
             const float dsum = sD[ql];
+            const float lse_q = sL[ql];
+            const bool qlive = q0 + ql < Sq;
+            const size_t prow = (size_t)bh * Sq + (qlive ? q0 + ql : 0);
+            bf16x8_t qf = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (recompute) qf = *reinterpret_cast<const bf16x8_t*>(sQ + ql * DH + g * 8);
             uint2 pcu[NBQ], dcu[NBQ];
 #pragma unroll
             for (int jj = 0; jj < NBQ; ++jj) { pcu[jj] = pnx[jj]; dcu[jj] = dnx[jj]; }
@@ -426,13 +453,31 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
                 const int j = kq * NBQ + jj;
                 const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + (j * 16 + c16) * DH + g * 8);
                 const f32x4_t dpd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                const unsigned pw[2] = {pcu[jj].x, pcu[jj].y}, dw[2] = {dcu[jj].x, dcu[jj].y};
                 float dsv[4];
+                if (recompute) {
+                    const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + (j * 16 + c16) * DH + g * 8);
+                    const f32x4_t sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const unsigned dead4 = *reinterpret_cast<const unsigned*>(sDead + j * 16 + g * 4);
+                    const int k0 = j * 16 + 4 * g;
+                    float pdv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned short pb = (unsigned short)(pw[r >> 1] >> (16 * (r & 1))), db = (unsigned short)(dw[r >> 1] >> (16 * (r & 1)));
-                    const float dp = (prob_drop == nullptr || db != 0) ? dpd[r] * dscale : 0.f;
-                    dsv[r] = bf2f(pb) * (dp - dsum);
+                    for (int r = 0; r < 4; ++r) {
+                        const bool dead = ((dead4 >> (8 * r)) & 0xffu) != 0 || !qlive;
+                        const float pv = dead ? 0.f : __expf(sc[r] * scale - lse_q);
+                        const bool keep = !dropping || dropout_keep(seed, (unsigned long long)prow * ld + k0 + r, thresh);
+                        pdv[r] = keep ? pv * dscale : 0.f;
+                        const float dp = keep ? dpd[r] * dscale : 0.f;
+                        dsv[r] = pv * (dp - dsum);
+                    }
+                    dcu[jj] = make_uint2(pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3]));
+                } else {
+                    const unsigned pw[2] = {pcu[jj].x, pcu[jj].y}, dw[2] = {dcu[jj].x, dcu[jj].y};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned short pb = (unsigned short)(pw[r >> 1] >> (16 * (r & 1))), db = (unsigned short)(dw[r >> 1] >> (16 * (r & 1)));
+                        const float dp = (!dropping || db != 0) ? dpd[r] * dscale : 0.f;
+                        dsv[r] = bf2f(pb) * (dp - dsum);
+                    }
                 }
                 ds_pk[jj][0] = pack2bf(dsv[0], dsv[1]);
                 ds_pk[jj][1] = pack2bf(dsv[2], dsv[3]);
@@ -550,8 +595,10 @@ using namespace toist;
 
 extern "C" int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int Sq,
                               int Sk, int dh, int ld, float scale, void* prob, void* prob_drop, float drop_p, uint64_t seed, const uint64_t* seed_dev,
-                              void* ctx, int ldo, void* stream) {
-    TOIST_REQUIRE(q && kmat && v && prob && ctx && B > 0 && H > 0 && Sq > 0 && Sk > 0, "toist_attn_fwd: bad args");
+                              void* ctx, int ldo, float* lse, void* stream) {
+    TOIST_REQUIRE(q && kmat && v && (prob || lse) && ctx && B > 0 && H > 0 && Sq > 0 && Sk > 0, "toist_attn_fwd: bad args (prob or lse must be given)");
+    TOIST_REQUIRE(prob != nullptr || prob_drop == nullptr, "toist_attn_fwd: prob_drop without prob");
+    TOIST_REQUIRE(prob == nullptr || drop_p == 0.f || prob_drop != nullptr, "toist_attn_fwd: with prob and dropout the dropped-out copy prob_drop is required");
     TOIST_REQUIRE(dh == 32, "toist_attn_fwd: head dim must be 32 (got %d)", dh);
     TOIST_REQUIRE(Sk <= 480 && ld >= Sk && (ld % 8) == 0, "toist_attn_fwd: Sk <= 480 (K, V and the mask of a head must fit 64 KB of LDS) and ld = round8(Sk) (got %d, %d)", Sk, ld);
     TOIST_REQUIRE((ldq % 8) == 0 && (ldk % 8) == 0 && (ldv % 8) == 0 && (ldo % 4) == 0, "toist_attn_fwd: row strides must keep 16-byte alignment");
@@ -561,7 +608,7 @@ extern "C" int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk,
 #define TOIST_ATTN(NB)                                                                                                                       \
     hipLaunchKernelGGL((attn_fwd_kernel<NB>), grid, block, 2 * (NB) * 16 * 32 * sizeof(bf16_t) + (NB) * 16, st, (const bf16_t*)q, ldq, (const bf16_t*)kmat, ldk, \
                        (const bf16_t*)v, ldv, key_pad, H, Sq, Sk, ld, scale, (bf16_t*)prob, (bf16_t*)prob_drop, drop_p,                      \
-                       (unsigned long long)seed, (const unsigned long long*)seed_dev, (bf16_t*)ctx, ldo)
+                       (unsigned long long)seed, (const unsigned long long*)seed_dev, (bf16_t*)ctx, ldo, lse)
     if (Sk <= 128) TOIST_ATTN(8);
     else if (Sk <= 416) TOIST_ATTN(26);
     else TOIST_ATTN(30);
@@ -572,8 +619,10 @@ extern "C" int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk,
 extern "C" int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const void* prob, const void* prob_drop,
                               const void* ctx, int ldo, const void* dctx, int lddo, int B, int H, int Sq, int Sk, int dh, int ld, float scale,
                               float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int variant, float* workspace,
-                              int q_splits, void* stream) {
-    TOIST_REQUIRE(q && kmat && v && prob && ctx && dctx && dq && dk && dv && B > 0 && H > 0 && Sq > 0 && Sk > 0, "toist_attn_bwd: bad args");
+                              int q_splits, const float* lse, const uint8_t* key_pad, uint64_t seed, const uint64_t* seed_dev, void* stream) {
+    TOIST_REQUIRE(q && kmat && v && (prob || lse) && ctx && dctx && dq && dk && dv && B > 0 && H > 0 && Sq > 0 && Sk > 0, "toist_attn_bwd: bad args");
+    TOIST_REQUIRE(prob != nullptr || variant != 1, "toist_attn_bwd: the recomputing (lse) mode exists for the query-major variant only");
+    if (prob == nullptr) variant = 2;
     TOIST_REQUIRE(variant >= 0 && variant <= 2, "toist_attn_bwd: variant 0 (auto), 1 (key-major) or 2 (query-major)");
     TOIST_REQUIRE((ld % 8) == 0, "toist_attn_bwd: ld must be a multiple of 8");
     TOIST_REQUIRE(q_splits >= 1 && q_splits <= 16 && (q_splits == 1 || workspace != nullptr), "toist_attn_bwd: 1..16 query splits; > 1 needs a workspace");
@@ -596,7 +645,7 @@ extern "C" int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk,
     } while (0)
 #define TOIST_ATTN_BWD_ROWS(NB)                                                                                                              \
     do {                                                                                                                                     \
-        const size_t lds = sizeof(bf16_t) * ((size_t)2 * (NB * 16) * 32 + (size_t)2 * 32 * (NB * 16 + 8) + 2 * 32 * 32) + 4 * (4 * 32 * 32 + 32); \
+        const size_t lds = sizeof(bf16_t) * ((size_t)2 * (NB * 16) * 32 + (size_t)2 * 32 * (NB * 16 + 8) + 2 * 32 * 32) + 4 * (4 * 32 * 32 + 32 + 32) + (NB) * 16; \
         if (lds > 64 * 1024) {                                                                                                               \
             hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_rows_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) { set_last_error("toist_attn_bwd: set LDS size: %s", hipGetErrorString(e)); return TOIST_EHIP; }            \
@@ -604,7 +653,8 @@ extern "C" int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk,
         hipLaunchKernelGGL((attn_bwd_rows_kernel<NB>), dim3(B * H, q_splits), dim3(512), lds, st, (const bf16_t*)q, ldq, (const bf16_t*)kmat, \
                            ldk, (const bf16_t*)v, ldv, (const bf16_t*)prob, (const bf16_t*)prob_drop, (const bf16_t*)ctx, ldo,                \
                            (const bf16_t*)dctx, lddo, H, Sq, Sk, ld, scale, drop_p, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv,  \
-                           q_splits > 1 ? workspace : (float*)nullptr);                                                                     \
+                           q_splits > 1 ? workspace : (float*)nullptr, lse, key_pad, (unsigned long long)seed,                              \
+                           (const unsigned long long*)seed_dev);                                                                           \
     } while (0)
     if (variant == 0) variant = (Sq > 128 && Sk > 128) ? 2 : 1;
     if (variant == 2) {

@@ -51,6 +51,7 @@ class Var:
 # every fork is a cross-stream edge of the graph) and is deliberately not done.
 OVERLAP = "capture"
 FUSED_ATTENTION = True   # head-dim-32 attention cores run as one fused forward launch (csrc/attn.hip); False = 3 launches
+LSE_ONLY = True          # the fused cores keep only the log-sum-exp of every score row; backward re-forms P and the dropout mask
 _SIDE = {}
 
 
@@ -493,9 +494,16 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
         # scores -> mask -> softmax -> dropout -> P V in one launch (csrc/attn.hip); the probabilities are kept for backward.
         # Measured (tools/bench_attn_core.py, B=8): 37.2 vs 61.2 us at 416x416, 25.2 vs 30.9 us at 100x416, 9.4 vs 21.2 us at 100x100
         ld = ops.round8(Sk)
-        prob = torch.empty(B * H, Sq, ld, dtype=BF16, device=dev)
-        prob_used = torch.empty_like(prob) if p > 0 else None
-        k.attn_fwd(qb, kb, vb, key_pad, B, H, Sq, Sk, dh, scale, prob, prob_used, p, seed_p, ctx)
+        lse = None
+        if LSE_ONLY:
+            # flash-style: nothing score-shaped is written (22 MB of P and 22 MB of dropout(P) per encoder layer at B = 8 otherwise)
+            prob = prob_used = None
+            lse = torch.empty(B * H, Sq, dtype=torch.float32, device=dev)
+            k.attn_fwd(qb, kb, vb, key_pad, B, H, Sq, Sk, dh, scale, None, None, p, seed_p, ctx, lse=lse)
+        else:
+            prob = torch.empty(B * H, Sq, ld, dtype=BF16, device=dev)
+            prob_used = torch.empty_like(prob) if p > 0 else None
+            k.attn_fwd(qb, kb, vb, key_pad, B, H, Sq, Sk, dh, scale, prob, prob_used, p, seed_p, ctx)
     else:
         s = ops.attn_scores(qb, kb, B, H, Sq, Sk, dh, scale)
         ld = s.shape[-1]
@@ -506,6 +514,7 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
         ops.attn_context(prob_used if prob_used is not None else prob, vb, B, H, Sq, Sk, dh, ctx)
     if prob_used is None:
         prob_used = prob
+    lse_only = fused_core and LSE_ONLY
     seed_o = tape.next_seed() if p > 0 else 0
     z = ops.linear(ctx, Wo.w, bo.f32, res=resid.data, drop_where=1 if p > 0 else 0, drop_p=p, drop_seed=seed_o)
     out = Var(z)
@@ -539,8 +548,12 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
             # dV, dP, softmax backward, dQ, dK in one launch (csrc/attn.hip, query-major variant; several workgroups per head when the
             # query range is long, their dK / dV sums folded by a second small kernel).  Measured (tools/bench_attn_core.py, B=8):
             # 11 vs 35 us at 100x100, 24 vs 41 us at 100x416, 45 vs 70 us at 416x416 (100 us with one workgroup per head)
-            k.attn_bwd(qb, kb, vb, prob, prob_used if p > 0 else None, ctx, dctx, B, H, Sq, Sk, dh, scale, p, dq, dk, dv, variant=2,
-                       q_splits=4 if Sk > 128 else 1)
+            if lse_only:
+                k.attn_bwd(qb, kb, vb, None, None, ctx, dctx, B, H, Sq, Sk, dh, scale, p, dq, dk, dv, variant=2, q_splits=4 if Sk > 128 else 1,
+                           lse=lse, key_pad=key_pad, seed=seed_p)
+            else:
+                k.attn_bwd(qb, kb, vb, prob, prob_used if p > 0 else None, ctx, dctx, B, H, Sq, Sk, dh, scale, p, dq, dk, dv, variant=2,
+                           q_splits=4 if Sk > 128 else 1)
         else:
             ops.attn_backward(prob_used, scale, qb, kb, vb, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
         if fused:

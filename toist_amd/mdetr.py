@@ -453,7 +453,8 @@ class SetCriterion(nn.Module):
         return out
 
     def forward(self, memory_cache, outputs, targets, positive_map, example_rel=None):
-        self.check_status(wait=False)   # an invalid cost block of an earlier call raises here, like SciPy inside the reference matcher
+        if self._pending_status and not torch.cuda.is_current_stream_capturing():
+            self.check_status(wait=False)   # an invalid cost block of an earlier call raises here, like SciPy inside the reference matcher
         if isinstance(outputs, list):
             return self._forward_pair(memory_cache, outputs, targets, positive_map)
         logits, boxes = self._stack(outputs)
