@@ -319,7 +319,8 @@ typedef struct toist_opt_state {
  * ctx = prob_drop v, one launch (transformer.py:297,370-400 through nn.MultiheadAttention).  q / k / v / ctx are per-head
  * column slices of [B*S, ld*] buffers (row b*S + s, feature h*32 + e); prob / prob_drop are [B*H, Sq, ld] bf16, ld =
  * round8(Sk), and feed toist_softmax_bwd and the backward GEMMs; prob_drop may be NULL (no dropout: ctx uses prob).
- * Flash-style bookkeeping: with `lse` (f32 [B*H, Sq], log-sum-exp of each score row) given, prob and prob_drop may both be NULL --
+ * Flash-style bookkeeping: with `lse` (f32 [B*H, Sq, 2]: maximum and reciprocal sum of exp(s - max) of each score row -- a split
+ * log-sum-exp, exact for scores of any magnitude) given, prob and prob_drop may both be NULL --
  * nothing score-shaped reaches HBM and toist_attn_bwd re-forms the probabilities (and the dropout mask, from the same
  * (seed, element index) hash) itself. */
 int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int Sq, int Sk,
@@ -332,7 +333,7 @@ int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk, const void
  * gradient; dq / dk / dv are per-head column slices like q / k / v.  variant: 0 = by shape, 1 = key-major kernel (short query
  * ranges), 2 = query-major kernel (long ones).  q_splits > 1 (variant 2, dk / dv slices H*32 wide): that many workgroups share a
  * head, each a run of query tiles; their dk / dv sums meet in `workspace` (q_splits * 2 * B*Sk * H*32 floats) and a fold
- * kernel writes dk / dv.  prob == NULL selects the recomputing mode (query-major kernel): P = exp(scale q k^T - lse) from the
+ * kernel writes dk / dv.  prob == NULL selects the recomputing mode (query-major kernel): P = exp(scale q k^T - max) * rsum from the
  * forward's `lse`, key padding from `key_pad`, the keep mask from (seed + *seed_dev, row * ld + key) as in toist_attn_fwd. */
 int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const void* prob, const void* prob_drop,
                    const void* ctx, int ldo, const void* dctx, int lddo, int B, int H, int Sq, int Sk, int dh, int ld, float scale,

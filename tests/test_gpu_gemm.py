@@ -374,7 +374,8 @@ def test_fused_attention_backward_matches_five_kernel_path(dev, Sq, Sk, drop, va
 
 
 @pytest.mark.parametrize("q_splits", [1, 4])
-@pytest.mark.parametrize("Sq,Sk,drop", [(416, 416, 0.1), (100, 416, 0.1), (100, 100, 0.1), (37, 50, 0.0), (70, 480, 0.1), (130, 250, 0.0)])
+@pytest.mark.parametrize("Sq,Sk,drop", [(416, 416, 0.1), (100, 416, 0.1), (100, 100, 0.1), (37, 50, 0.0), (70, 480, 0.1), (130, 250, 0.0), (20, 20, 0.1), (20, 32, 0.1),
+                                        (32, 32, 0.1), (16, 16, 0.0)])
 def test_flash_attention_lse_mode_matches_stored_probabilities(dev, Sq, Sk, drop, q_splits):
     """Flash-style bookkeeping (csrc/attn.hip): the forward kernel writes only the log-sum-exp of every score row, the backward
     kernel re-forms P = exp(scale q.k - lse) and the dropout mask from the same (seed, index) hash.  Same context as the path
@@ -384,8 +385,9 @@ def test_flash_attention_lse_mode_matches_stored_probabilities(dev, Sq, Sk, drop
     g = torch.Generator().manual_seed(Sq * 977 + Sk + 3)
     B, H, dh = 2, 8, 32
     d = H * dh
-    q = torch.randn(B * Sq, d, generator=g).to(BF).to(dev)
-    kk = torch.randn(B * Sk, d, generator=g).to(BF).to(dev)
+    big = 3e4 if (Sq, Sk) == (32, 32) else 1.0      # scores of ~1e9 (an undamped random-init backbone produces them): the split statistics stay exact
+    q = (torch.randn(B * Sq, d, generator=g) * big).to(BF).to(dev)
+    kk = (torch.randn(B * Sk, d, generator=g) * big).to(BF).to(dev)
     v = torch.randn(B * Sk, d, generator=g).to(BF).to(dev)
     dctx = torch.randn(B * Sq, d, generator=g).to(BF).to(dev)
     pad = torch.zeros(B, Sk, dtype=torch.uint8)
@@ -397,14 +399,15 @@ def test_flash_attention_lse_mode_matches_stored_probabilities(dev, Sq, Sk, drop
     prob = torch.zeros(B * H, Sq, ld, dtype=BF, device=dev)
     pdrop = torch.zeros_like(prob) if drop > 0 else None
     ctx0, ctx1 = torch.empty(B * Sq, d, dtype=BF, device=dev), torch.empty(B * Sq, d, dtype=BF, device=dev)
-    lse = torch.empty(B * H, Sq, dtype=torch.float32, device=dev)
+    lse = torch.empty(B * H, Sq, 2, dtype=torch.float32, device=dev)
     k.attn_fwd(q, kk, v, pad, B, H, Sq, Sk, dh, scale, prob, pdrop, drop, 4321, ctx0)
     k.attn_fwd(q, kk, v, pad, B, H, Sq, Sk, dh, scale, None, None, drop, 4321, ctx1, lse=lse)
     assert torch.equal(ctx0, ctx1)
     qf = q.float().view(B, Sq, H, dh).permute(0, 2, 1, 3)
     kf = kk.float().view(B, Sk, H, dh).permute(0, 2, 1, 3)
     sc = ((qf @ kf.transpose(-1, -2)) * scale).masked_fill(pad.bool()[:, None, None, :], float("-inf"))
-    assert float((lse.view(B, H, Sq) - sc.logsumexp(-1)).abs().max()) <= 2e-3
+    ref_lse = sc.logsumexp(-1)
+    assert float((((lse[..., 0] - lse[..., 1].log()).view(B, H, Sq) - ref_lse).abs() / (1.0 + 1e-3 * ref_lse.abs())).max()) <= 2e-3
     outs = []
     for mode in (0, 1):
         dq, dk_, dv = (torch.empty(B * Sq, d, dtype=BF, device=dev), torch.empty(B * Sk, d, dtype=BF, device=dev), torch.empty(B * Sk, d, dtype=BF, device=dev))

@@ -13,6 +13,15 @@
 
 namespace toist {
 
+// s * scale - m with the product rounded to fp32 before the subtraction (no fma contraction): the forward kernel takes the row
+// maximum of the ROUNDED products, so only this order re-forms exp(s - max) bit for bit; with scores of 1e8 and more (an undamped
+// random-init backbone) a fused multiply-subtract is off by the product's rounding error, i.e. by tens, before the exp
+__device__ __forceinline__ float scaled_minus(float s, float scale, float m) {
+#pragma clang fp contract(off)
+    const float p = s * scale;
+    return p - m;
+}
+
 template <int NB>   // 16-key blocks (Sk <= 16 * NB), NB even
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ kmat, int ldk,
                                                        const bf16_t* __restrict__ v, int ldv, const unsigned char* __restrict__ key_pad, int H,
@@ -59,7 +68,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         const unsigned dead4 = *reinterpret_cast<const unsigned*>(sDead + j * 16 + g * 4);   // this lane's 4 keys
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            a[r] = ((dead4 >> (8 * r)) & 0xffu) ? -INFINITY : a[r] * scale;
+            a[r] = ((dead4 >> (8 * r)) & 0xffu) ? -INFINITY : scaled_minus(a[r], scale, 0.f);
             mx = fmaxf(mx, a[r]);
         }
         s[j] = a;
@@ -80,7 +89,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const size_t row = (size_t)bh * Sq + (qlive ? qi : 0);
     // flash-style bookkeeping: with `lse` the backward kernel re-forms P = exp(scale q.k - lse) (and the dropout mask from the
     // same hash) instead of reading two [Sq, Sk] bf16 matrices per head back from HBM; prob / prob_drop may then be NULL
-    if (lse != nullptr && qlive && g == 0) lse[row] = mx + __logf(sum);
+    // (row maximum, 1 / row sum) rather than one fp32 log-sum-exp: exp(s - max) * rsum re-forms P exactly as it was formed here, whereas
+    // s - lse loses the low bits of s once |s| is large (at |s| ~ 1e8 the fp32 spacing is 8: exp() of that error is unbounded)
+    if (lse != nullptr && qlive && g == 0) *reinterpret_cast<float2*>(lse + 2 * row) = make_float2(mx, inv);
     unsigned pk[NB][2];                                          // bf16 pairs of the probabilities that enter P V
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
                                                             float* __restrict__ part, const float* __restrict__ lse,
                                                             const unsigned char* __restrict__ key_pad, unsigned long long seed,
                                                             const unsigned long long* __restrict__ seed_dev) {
-    // prob == nullptr: flash-style recomputation -- P = exp(scale q.k - lse) per (query, key), the keep mask from the forward
+    // prob == nullptr: flash-style recomputation -- P = exp(scale q.k - max) * rsum per (query, key), the keep mask from the forward
     // kernel's hash (same seed, same element index row * ld + key); `dropping` then comes from drop_p alone
     constexpr int SKP = NB * 16, DH = 32, QT = 32, LS = SKP + 8, NBQ = NB / 4, NBW = NB / 8;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
@@ -341,8 +352,8 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
     bf16_t* sQ = sdO + QT * DH;               // [QT][32]
     float* sdQ = reinterpret_cast<float*>(sQ + QT * DH);   // [4][QT][32] partial dQ of the four key quarters
     float* sD = sdQ + 4 * QT * DH;            // [QT]
-    float* sL = sD + QT;                      // [QT]   log-sum-exp of the tile's queries (recompute mode)
-    unsigned char* sDead = reinterpret_cast<unsigned char*>(sL + QT);   // [SKP] 1 = key masked (recompute mode)
+    float* sL = sD + QT;                      // [QT][2] (row maximum, 1 / row sum) of the tile's queries (recompute mode)
+    unsigned char* sDead = reinterpret_cast<unsigned char*>(sL + 2 * QT);   // [SKP] 1 = key masked (recompute mode)
     typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
@@ -400,12 +411,12 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
     fetch(t_beg * QT);
     // rows of dO, O, Q of the next tile (threads 0..255: query tid / 8, features 4 (tid % 8) ..), also fetched one tile ahead
     uint2 d2n = make_uint2(0, 0), o2n = make_uint2(0, 0), q2n = make_uint2(0, 0);
-    float lsen = 0.f;
+    float2 lsen = make_float2(0.f, 0.f);
     auto fetch_rows = [&](int q0_) {
         const int qi = q0_ + (tid >> 3), ch = tid & 7;
         d2n = o2n = q2n = make_uint2(0, 0);
-        lsen = 0.f;
-        if (recompute && tid < 256 && ch == 0 && qi < Sq) lsen = lse[(size_t)bh * Sq + qi];
+        lsen = make_float2(0.f, 0.f);
+        if (recompute && tid < 256 && ch == 0 && qi < Sq) lsen = *reinterpret_cast<const float2*>(lse + 2 * ((size_t)bh * Sq + qi));
         if (tid < 256 && qi < Sq) {
             d2n = *reinterpret_cast<const uint2*>(dctx + ((size_t)b * Sq + qi) * lddo + h * DH + ch * 4);
             o2n = *reinterpret_cast<const uint2*>(ctx + ((size_t)b * Sq + qi) * ldo + h * DH + ch * 4);
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
             part += __shfl_xor(part, 1, 64);
             part += __shfl_xor(part, 2, 64);
             part += __shfl_xor(part, 4, 64);
-            if (ch == 0) { sD[qq] = part; sL[qq] = lsen; }
+            if (ch == 0) { sD[qq] = part; sL[2 * qq] = lsen.x; sL[2 * qq + 1] = lsen.y; }
         }
         __syncthreads();
 
@@ -438,7 +449,7 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
             const int ql = qh * 16 + c16;                              // query of this lane inside the tile
             const bf16x8_t dof = *reinterpret_cast<const bf16x8_t*>(sdO + ql * DH + g * 8);
             const float dsum = sD[ql];
-            const float lse_q = sL[ql];
+            const float mx_q = sL[2 * ql], rsum_q = sL[2 * ql + 1];
             const bool qlive = q0 + ql < Sq;
             const size_t prow = (size_t)bh * Sq + (qlive ? q0 + ql : 0);
             bf16x8_t qf = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -463,7 +474,7 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool dead = ((dead4 >> (8 * r)) & 0xffu) != 0 || !qlive;
-                        const float pv = dead ? 0.f : __expf(sc[r] * scale - lse_q);
+                        const float pv = dead ? 0.f : __expf(scaled_minus(sc[r], scale, mx_q)) * rsum_q;
                         const bool keep = !dropping || dropout_keep(seed, (unsigned long long)prow * ld + k0 + r, thresh);
                         pdv[r] = keep ? pv * dscale : 0.f;
                         const float dp = keep ? dpd[r] * dscale : 0.f;
@@ -645,7 +656,7 @@ extern "C" int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk,
     } while (0)
 #define TOIST_ATTN_BWD_ROWS(NB)                                                                                                              \
     do {                                                                                                                                     \
-        const size_t lds = sizeof(bf16_t) * ((size_t)2 * (NB * 16) * 32 + (size_t)2 * 32 * (NB * 16 + 8) + 2 * 32 * 32) + 4 * (4 * 32 * 32 + 32 + 32) + (NB) * 16; \
+        const size_t lds = sizeof(bf16_t) * ((size_t)2 * (NB * 16) * 32 + (size_t)2 * 32 * (NB * 16 + 8) + 2 * 32 * 32) + 4 * (4 * 32 * 32 + 32 + 64) + (NB) * 16; \
         if (lds > 64 * 1024) {                                                                                                               \
             hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_rows_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) { set_last_error("toist_attn_bwd: set LDS size: %s", hipGetErrorString(e)); return TOIST_EHIP; }            \

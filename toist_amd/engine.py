@@ -498,7 +498,7 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
         if LSE_ONLY:
             # flash-style: nothing score-shaped is written (22 MB of P and 22 MB of dropout(P) per encoder layer at B = 8 otherwise)
             prob = prob_used = None
-            lse = torch.empty(B * H, Sq, dtype=torch.float32, device=dev)
+            lse = torch.empty(B * H, Sq, 2, dtype=torch.float32, device=dev)   # (row max, 1 / row sum)
             k.attn_fwd(qb, kb, vb, key_pad, B, H, Sq, Sk, dh, scale, None, None, p, seed_p, ctx, lse=lse)
         else:
             prob = torch.empty(B * H, Sq, ld, dtype=BF16, device=dev)

@@ -469,7 +469,7 @@ def wgrad3x3_small(dy, x, out, defer=False):
 
 def attn_fwd(q, kmat, v, key_pad, B, H, Sq, Sk, dh, scale, prob, prob_drop, drop_p, seed, ctx, lse=None):
     """Fused attention core (csrc/attn.hip): q/k/v/ctx are column slices of packed [B*S, ld] bf16 buffers.  With `lse`
-    (f32 [B*H, Sq]) the probabilities need not be stored (prob = prob_drop = None): attn_bwd re-forms them."""
+    (f32 [B*H, Sq, 2]: row maximum, reciprocal row sum) the probabilities need not be stored (prob = prob_drop = None): attn_bwd re-forms them."""
     ld = prob.shape[-1] if prob is not None else (Sk + 7) // 8 * 8
     _lib.check(_lib.lib().toist_attn_fwd(_p(q, torch.bfloat16), q.stride(0), _p(kmat, torch.bfloat16), kmat.stride(0), _p(v, torch.bfloat16), v.stride(0),
                                          _p(key_pad, torch.uint8), B, H, Sq, Sk, dh, ld, scale, _p(prob, torch.bfloat16),
