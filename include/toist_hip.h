@@ -136,7 +136,7 @@ typedef struct toist_group {
     int64_t c_off;
     int64_t rscale_off;
     int64_t colsum_off;
-    int64_t reserved;
+    int64_t shift_off;        /* offset (elements) added to epi.scale / epi.shift: per-problem bias of grouped nn.Linear forwards */
 } toist_group;                /* 48 bytes */
 
 typedef struct toist_gemm {
@@ -159,6 +159,10 @@ typedef struct toist_gemm {
     float* a_colsum;            /* optional, A_KROW only: a_colsum[m] += sum_k A[m][k]  (f32 atomics) --
                                    the bias gradient of nn.Linear falls out of the wgrad GEMM's A tiles */
     const toist_group* group;   /* optional (device memory, `batch` entries): grouped launch, see toist_group */
+    const void* a2;             /* optional, A_ROWK only: output columns n >= a2_from read their A rows from a2 (same ld / batch
+                                   strides) -- nn.MultiheadAttention's packed in_proj applied to two inputs in one launch:
+                                   q, k from x + pos, v from x (transformer.py:293-297, 370-400); a2_from % tile columns == 0 */
+    int32_t a2_from;
 } toist_gemm;
 
 int toist_gemm_bf16(const toist_gemm* desc, void* stream);
@@ -175,7 +179,9 @@ int toist_group_fill(const toist_group* rows, int n, toist_group* table, void* s
  *    p_drop (optional) receives dropout(p) for the PV product.
  */
 int toist_layernorm_fwd(const void* x, const float* gamma, const float* beta, float eps, int rows, int D,
-                        void* y, float* mean, float* rstd, void* stream);
+                        void* y, float* mean, float* rstd, const void* add, void* y2, void* stream);
+/*  optional second output y2 = y + add (both bf16 [rows, D]): the `src + pos` / `tgt + query_pos` that the next attention
+ *  feeds to its q / k projections (transformer.py:293, 366, 386) without a separate elementwise launch */
 int toist_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         int rows, int D, void* dx, float* dgamma, float* dbeta, void* dx_drop, float drop_p,
                         uint64_t seed, const uint64_t* seed_dev, void* stream);

@@ -40,7 +40,7 @@ class Gemm(Structure):
         ("a", Operand), ("b", Operand), ("c", c_void_p), ("ldc", c_int32), ("cs_outer", c_int64),
         ("cs_inner", c_int64), ("batch", c_int32), ("batch_inner", c_int32), ("split_k", c_int32),
         ("tile", c_int32), ("flags", c_int32), ("epi", Epilogue), ("workspace", c_void_p), ("a_colsum", c_void_p),
-        ("group", c_void_p),
+        ("group", c_void_p), ("a2", c_void_p), ("a2_from", c_int32),
     ]
 
 
@@ -55,7 +55,7 @@ _SIGNATURES = {
     "toist_matcher": ([c_void_p] * 6 + [c_int32] * 5 + [c_float] * 3 + [c_void_p] * 5, ctypes.c_int),
     "toist_gemm_bf16": ([POINTER(Gemm), c_void_p], ctypes.c_int),
     "toist_group_fill": ([c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "toist_layernorm_fwd": ([c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_layernorm_fwd": ([c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_layernorm_bwd": ([c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 4 + [c_float, c_uint64, c_void_p, c_void_p], ctypes.c_int),
     "toist_softmax_fwd": ([c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p, c_float, c_uint64, c_void_p, c_void_p], ctypes.c_int),
     "toist_softmax_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_float, c_uint64, c_void_p, c_void_p], ctypes.c_int),

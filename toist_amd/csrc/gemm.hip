@@ -117,12 +117,12 @@ __device__ __forceinline__ void load_cols8(const float* src, const int nv, float
     }
 }
 
-__device__ __forceinline__ void epilogue_cols(const toist_gemm& p, const int n, EpiCols& c) {
+__device__ __forceinline__ void epilogue_cols(const toist_gemm& p, const int n, EpiCols& c, const long long voff) {
     const toist_epilogue& e = p.epi;
     const int nv = (p.N - n < 8) ? (p.N - n) : 8;
     if (nv <= 0) return;
-    if (e.scale) load_cols8(e.scale + n, nv, c.scale, 1.f);
-    if (e.shift) load_cols8(e.shift + n, nv, c.shift, 0.f);
+    if (e.scale) load_cols8(e.scale + voff + n, nv, c.scale, 1.f);
+    if (e.shift) load_cols8(e.shift + voff + n, nv, c.shift, 0.f);
 }
 
 __device__ __forceinline__ bool row8_vec(const bf16_t* rp, const int nv) { return nv == 8 && ((((size_t)rp) & 15) == 0); }
@@ -399,7 +399,7 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
     EpiCols cols[CH];
 #pragma unroll
     for (int q = 0; q < CH; ++q)
-        if (!partial) epilogue_cols(p, n0 + ((tid + 256 * q) % CPR) * 8, cols[q]);
+        if (!partial) epilogue_cols(p, n0 + ((tid + 256 * q) % CPR) * 8, cols[q], p.group ? p.group[bz].shift_off : 0);
     static_for<FM>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
 #pragma unroll
@@ -495,6 +495,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
         b_base = (const bf16_t*)gq.b;
         coff_ = gq.c_off;
     }
+    if (AK == TOIST_A_ROWK && p.a2 != nullptr && n0 >= p.a2_from)      // second A operand for the upper output columns (packed in_proj)
+        a_base = (const bf16_t*)p.a2 + bo * oa.bs_outer + bi * oa.bs_inner;
     const i32x4_t rsA = make_rsrc(a_base);
     const i32x4_t rsB = make_rsrc(b_base);
     const long long coff = coff_;
@@ -1159,6 +1161,8 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
         TOIST_REQUIRE(d.workspace != nullptr && (d.N % 4) == 0 && (d.ldc % 4) == 0, "toist_gemm_bf16: split_k needs a workspace and N, ldc %% 4 == 0");
     }
     if (d.epi.act >= TOIST_ACT_MASK_POS) TOIST_REQUIRE(d.epi.aux != nullptr, "toist_gemm_bf16: activation %d needs aux", d.epi.act);
+    if (d.a2) TOIST_REQUIRE(d.a_kind == TOIST_A_ROWK && aligned16(d.a2) && d.a2_from > 0 && (d.a2_from % 128) == 0 && d.split_k <= 1,
+                            "toist_gemm_bf16: a2 needs a row-major A, 16-byte alignment, a2_from %% 128 == 0 and no split");
     if (d.epi.drop_where) TOIST_REQUIRE(d.epi.drop_p >= 0.f && d.epi.drop_p < 1.f, "toist_gemm_bf16: bad dropout p");
 
     hipStream_t st = (hipStream_t)stream;

@@ -25,7 +25,8 @@ constexpr int LN_MAXCH = 2;  // D <= 1024
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, int rows, int D,
                                                              bf16_t* __restrict__ y, float* __restrict__ mean_out,
-                                                             float* __restrict__ rstd_out) {
+                                                             float* __restrict__ rstd_out, const bf16_t* __restrict__ add,
+                                                             bf16_t* __restrict__ y2) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -59,7 +60,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
-            *reinterpret_cast<uint4*>(y + (size_t)row * D + ch * 8) = pack8(o);
+            const uint4 yo = pack8(o);
+            *reinterpret_cast<uint4*>(y + (size_t)row * D + ch * 8) = yo;
+            if (y2 != nullptr) {   // second output y + add (the positional / query embedding the next attention adds to its q, k input):
+                float a8[8], y8[8];   // bf16(bf16(y) + add), exactly what the separate add kernel computed from the stored y
+                unpack8(*reinterpret_cast<const uint4*>(add + (size_t)row * D + ch * 8), a8);
+                unpack8(yo, y8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y8[j] += a8[j];
+                *reinterpret_cast<uint4*>(y2 + (size_t)row * D + ch * 8) = pack8(y8);
+            }
         }
     }
     if (lane == 0) {
@@ -439,10 +449,11 @@ static inline int grid_for(long long n, int cap = 2048) {
 using namespace toist;
 
 extern "C" int toist_layernorm_fwd(const void* x, const float* gamma, const float* beta, float eps, int rows, int D,
-                                   void* y, float* mean, float* rstd, void* stream) {
+                                   void* y, float* mean, float* rstd, const void* add, void* y2, void* stream) {
     TOIST_REQUIRE(rows > 0 && D > 0 && (D % 8) == 0 && D <= 1024, "toist_layernorm_fwd: rows=%d D=%d (D%%8==0, D<=1024)", rows, D);
+    TOIST_REQUIRE((add == nullptr) == (y2 == nullptr), "toist_layernorm_fwd: add and y2 come together");
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma,
-                       beta, eps, rows, D, (bf16_t*)y, mean, rstd);
+                       beta, eps, rows, D, (bf16_t*)y, mean, rstd, (const bf16_t*)add, (bf16_t*)y2);
     return check_launch("toist_layernorm_fwd");
 }
 

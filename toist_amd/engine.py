@@ -21,12 +21,13 @@ BF16 = torch.bfloat16
 class Var:
     """An activation (bf16, [rows, features] or NHWC) and its gradient slot."""
 
-    __slots__ = ("data", "grad", "needs_grad", "drop", "gdrop")
+    __slots__ = ("data", "grad", "needs_grad", "drop", "gdrop", "plus")
 
     def __init__(self, data, needs_grad=True):
         self.data = data
         self.grad = None
         self.needs_grad = needs_grad
+        self.plus = None    # data + a constant embedding (pos / query_pos), when the producing layernorm emitted it in the same pass
         self.drop = None    # (p, seed) when data = residual + dropout(branch): the branch gradient is dropout(grad) with that mask
         self.gdrop = None   # that masked gradient, when the consumer's backward produced it in the same pass (layernorm)
 
@@ -52,6 +53,7 @@ class Var:
 OVERLAP = "capture"
 FUSED_ATTENTION = True   # head-dim-32 attention cores run as one fused forward launch (csrc/attn.hip); False = 3 launches
 LSE_ONLY = True          # the fused cores keep only the log-sum-exp of every score row; backward re-forms P and the dropout mask
+FUSED_BLOCKS = True      # encoder / decoder layers: packed in_proj in one launch, decoder K/V of all layers grouped, LayerNorm emits y + pos
 _SIDE = {}
 
 
@@ -381,14 +383,17 @@ def linear_chain(tape, x, layers, res=None, final_drop=False, out_dtype=BF16, la
     return out
 
 
-def layernorm(tape, x, gamma, beta, eps, y=None):
+def layernorm(tape, x, gamma, beta, eps, y=None, add=None):
+    """LayerNorm; with `add` (bf16 [rows, D], a constant of the backward pass) the same launch also writes out.plus = y + add."""
     rows, D = x.data.shape
     if y is None:
         y = torch.empty_like(x.data)
     mean = torch.empty(rows, dtype=torch.float32, device=y.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=y.device)
-    k.layernorm_fwd(x.data, gamma.f32, beta.f32, eps, y, mean, rstd)
+    y2 = torch.empty_like(x.data) if add is not None else None
+    k.layernorm_fwd(x.data, gamma.f32, beta.f32, eps, y, mean, rstd, add=add, y2=y2)
     out = Var(y)
+    out.plus = y2
 
     def bwd():
         g = out.take_grad()
@@ -574,6 +579,155 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
             tape.linear_wgrad(dv, v_in.data, Pv[0], Pv[1])
         if v_in.needs_grad:
             v_in.grad = ops.linear_dgrad(dv, Pv[0].w, res=v_in.grad)
+
+    tape.record(bwd)
+    return out
+
+
+# ---- attention blocks with the packed in_proj applied in one launch (FUSED_BLOCKS) -------------------------------------
+# nn.MultiheadAttention(q = k = x + e, v = x) (transformer.py:293-297, 366-372): ONE GEMM forms [q | k | v] -- output columns
+# < 2d read their A rows from xe = x + e, the others from x (toist_gemm.a2) -- and one GEMM carries d[q | k | v] back to x.
+# The gradient w.r.t. a trainable e (the decoder's query embedding) is not formed per layer: every block leaves its dq / dk in a
+# column slice of one [rows, n] buffer (`e_sink`) and the caller multiplies that buffer once by the stacked projection weights.
+def _attn_core(tape, qb, kb, vb, key_pad, B, Sq, Sk, H, ctx, p, seed_p):
+    dh = qb.shape[1] // H
+    scale = 1.0 / math.sqrt(dh)
+    if not (FUSED_ATTENTION and dh == 32 and Sk <= 480):
+        raise NotImplementedError("fused attention blocks need head dim 32 and at most 480 keys")
+    lse = torch.empty(B * H, Sq, 2, dtype=torch.float32, device=qb.device)
+    k.attn_fwd(qb, kb, vb, key_pad, B, H, Sq, Sk, dh, scale, None, None, p, seed_p, ctx, lse=lse)
+
+    def core_bwd(dctx, dq, dk, dv):
+        k.attn_bwd(qb, kb, vb, None, None, ctx, dctx, B, H, Sq, Sk, dh, scale, p, dq, dk, dv, variant=2, q_splits=4 if Sk > 128 else 1,
+                   lse=lse, key_pad=key_pad, seed=seed_p)
+
+    return core_bwd
+
+
+def _out_proj(tape, ctx, Wo, bo, resid, p):
+    """resid + dropout(ctx Wo^T + bo); returns (Var, bwd_head) where bwd_head() -> gradient w.r.t. ctx (or None)."""
+    seed_o = tape.next_seed() if p > 0 else 0
+    z = ops.linear(ctx, Wo.w, bo.f32, res=resid.data, drop_where=1 if p > 0 else 0, drop_p=p, drop_seed=seed_o)
+    out = Var(z)
+    if p > 0:
+        out.drop = (p, seed_o)
+
+    def head():
+        g = out.take_grad()
+        if g is None:
+            return None
+        if resid.needs_grad:
+            accumulate(resid, g)
+        go = out.take_branch_grad(g) if p > 0 else g
+        if Wo.g is not None:
+            tape.linear_wgrad(go, ctx, Wo, bo, owned=(go is not g or not resid.needs_grad))
+        return ops.linear_dgrad(go, Wo.w)
+
+    return out, head
+
+
+def self_attention_block(tape, x, xe, Win, bin_, Wo, bo, key_pad, B, S, H, e_sink=None):
+    """x + dropout(out_proj(MHA(q = k = xe, v = x)));  xe = x + e as a bf16 tensor.  e_sink = (buffer [B*S, n] bf16, column):
+    d q and d k are written at buffer[:, column : column + 2d] (and d v right after, buffer[:, column + 2d : column + 3d])."""
+    d = Wo.w.shape[0]
+    M = B * S
+    dev = x.data.device
+    p = tape.drop_p
+    qkv = torch.empty(M, 3 * d, dtype=BF16, device=dev)
+    k.gemm(M, 3 * d, d, k.A_ROWK, k.operand(xe, xe.stride(0)), k.B_ROWK, k.operand(Win.w, Win.w.stride(0)), qkv, 3 * d, shift=bin_.f32,
+           a2=x.data, a2_from=2 * d, flops=2 * M * 3 * d * d)
+    seed_p = tape.next_seed() if p > 0 else 0
+    ctx = torch.empty(M, d, dtype=BF16, device=dev)
+    core_bwd = _attn_core(tape, qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], key_pad, B, S, S, H, ctx, p, seed_p)
+    out, head = _out_proj(tape, ctx, Wo, bo, x, p)
+
+    def bwd():
+        dctx = head()
+        if dctx is None:
+            return
+        if e_sink is not None:
+            buf, col = e_sink
+            dqkv = buf[:, col:col + 3 * d]
+        else:
+            dqkv = torch.empty(M, 3 * d, dtype=BF16, device=dev)
+        core_bwd(dctx, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:])
+        if Win.g is not None:
+            tape.linear_wgrad(dqkv[:, :2 * d], xe, Win.rows(0, 2 * d), bin_.rows(0, 2 * d))
+            tape.linear_wgrad(dqkv[:, 2 * d:], x.data, Win.rows(2 * d, 3 * d), bin_.rows(2 * d, 3 * d))
+        if x.needs_grad:
+            x.grad = ops.linear_dgrad(dqkv, Win.w, res=x.grad)      # d x = [dq | dk | dv] W_in  (+ residual gradient)
+
+    tape.record(bwd)
+    return out
+
+
+def W0_has_grad(layers):
+    return layers[0][0].g is not None
+
+
+def cross_kv_projections(tape, mem, mem_e, layers):
+    """k_i = mem_e Wk_i^T + bk_i, v_i = mem Wv_i^T + bv_i for every decoder layer i in ONE grouped launch (the inputs are the same
+    for all layers, transformer.py:386-391): layers = [(Win_i, bin_i)] with the packed [3d, d] in_proj of cross_attn_image.
+    Returns (kv [rows, L*2d] bf16 with [k_i | v_i] at columns 2d*i, dkv of the same shape for the blocks' backward to fill)."""
+    L = len(layers)
+    d = layers[0][0].w.shape[1]
+    M = mem.data.shape[0]
+    dev = mem.data.device
+    kv = torch.empty(M, L * 2 * d, dtype=BF16, device=dev)
+    dkv = torch.empty(M, L * 2 * d, dtype=BF16, device=dev) if (mem.needs_grad or W0_has_grad(layers)) else None
+    W0, b0 = layers[0]
+    rows = []
+    for i, (W, b) in enumerate(layers):
+        wkv = W.w[d:]
+        boff = b.f32.data_ptr() - b0.f32.data_ptr()
+        assert boff % 4 == 0
+        rows.append([mem_e.data_ptr(), wkv.data_ptr(), i * 2 * d, 0, 0, boff // 4 + d])
+    table = k.group_table(rows, dev)
+    k.gemm(M, 2 * d, d, k.A_ROWK, k.operand(mem_e, mem_e.stride(0)), k.B_ROWK, k.operand(W0.w[d:], W0.w.stride(0)), kv, L * 2 * d, shift=b0.f32,
+           batch=L, group=table, a2=mem.data, a2_from=d, flops=2 * M * 2 * d * d * L)
+
+    def bwd():
+        if dkv is None:
+            return
+        for i, (W, b) in enumerate(layers):
+            if W.g is not None:
+                tape.linear_wgrad(dkv[:, i * 2 * d:i * 2 * d + d], mem_e, W.rows(d, 2 * d), b.rows(d, 2 * d))
+                tape.linear_wgrad(dkv[:, i * 2 * d + d:(i + 1) * 2 * d], mem.data, W.rows(2 * d, 3 * d), b.rows(2 * d, 3 * d))
+        if mem.needs_grad:
+            wstack = torch.cat([W.w[d:] for W, _ in layers], dim=0)             # [L*2d, d]: d mem = [dk_0 | dv_0 | dk_1 | ...] W_stack
+            mem.grad = ops.linear_dgrad(dkv, wstack, res=mem.grad)
+
+    tape.record(bwd)     # recorded before the decoder layers: runs after all of them have written their slices of dkv
+    return kv, dkv
+
+
+def cross_attention_block(tape, t, te, Wq, bq, kv, dkv, col, Wo, bo, key_pad, B, Sq, Sk, H, e_sink=None):
+    """t + dropout(out_proj(MHA(q = te, k, v precomputed)));  te = t + e (bf16 tensor); k, v = kv[:, col : col + d], kv[:, col + d : col + 2d]
+    from cross_kv_projections, whose backward consumes the dk / dv this block writes into the same columns of dkv."""
+    d = Wo.w.shape[0]
+    M = B * Sq
+    dev = t.data.device
+    p = tape.drop_p
+    qb = ops.linear(te, Wq.w, bq.f32)
+    seed_p = tape.next_seed() if p > 0 else 0
+    ctx = torch.empty(M, d, dtype=BF16, device=dev)
+    core_bwd = _attn_core(tape, qb, kv[:, col:col + d], kv[:, col + d:col + 2 * d], key_pad, B, Sq, Sk, H, ctx, p, seed_p)
+    out, head = _out_proj(tape, ctx, Wo, bo, t, p)
+
+    def bwd():
+        dctx = head()
+        if dctx is None:
+            return
+        if e_sink is not None:
+            buf, c2 = e_sink
+            dq = buf[:, c2:c2 + d]
+        else:
+            dq = torch.empty(M, d, dtype=BF16, device=dev)
+        core_bwd(dctx, dq, dkv[:, col:col + d], dkv[:, col + d:col + 2 * d])
+        if Wq.g is not None:
+            tape.linear_wgrad(dq, te, Wq, bq)
+        if t.needs_grad:
+            t.grad = ops.linear_dgrad(dq, Wq.w, res=t.grad)
 
     tape.record(bwd)
     return out

@@ -139,7 +139,7 @@ def operand(t, ld=0, bs_outer=0, bs_inner=0, kin=0, tap_stride=0, geom=None):
 def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_outer=0, cs_inner=0, split_k=1, tile=0,
          flags=0, alpha=1.0, scale=None, shift=None, rscale=None, res=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, pre_out=None,
          accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0, flops=0, a_colsum=None, res_bcast=None,
-         defer_reduce=False, group=None, group_out=None):
+         defer_reduce=False, group=None, group_out=None, a2=None, a2_from=0):
     """C = epilogue(A @ B^T); see include/toist_hip.h.  `a`/`b` are Operand structs from operand().
     `flops` = algorithmic FLOPs of the call (bench.py's roofline accounting only)."""
     if tile == 0 and FORCE_TILE:
@@ -172,7 +172,9 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
     e.drop_where, e.drop_p, e.drop_seed = drop_where, drop_p, drop_seed
     e.drop_seed_dev = _p(SEED_DEV) if drop_where else None
     d.a_colsum = _p(a_colsum, torch.float32)
-    d.group = _p(group, torch.int64)          # [batch, 6] int64 rows (a, b pointers; c, rscale, colsum offsets; 0): toist_group
+    d.group = _p(group, torch.int64)          # [batch, 6] int64 rows (a, b pointers; c, rscale, colsum, shift offsets): toist_group
+    if a2 is not None:                        # output columns >= a2_from take their A rows from a2 (packed in_proj on two inputs)
+        d.a2, d.a2_from = _p(a2, torch.bfloat16), a2_from
     deferred = None
     if split_k > 1 and group is not None:
         # grouped + split: [problem][k-slice][M][N] partials, one queued fold per problem (group_out = [(c_i, rscale_i)])
@@ -243,11 +245,12 @@ def matcher(logits, boxes, tgt_boxes, pos_map, tgt_off, match_off, max_T, w_clas
                                  _p(status, torch.int32), _p(cost_out, torch.float32), _stream()), "toist_matcher")
 
 
-def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None):
+def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, add=None, y2=None):
     rows, D = x.shape
     _lib.check(
         _lib.lib().toist_layernorm_fwd(_p(x, torch.bfloat16), _p(gamma, torch.float32), _p(beta, torch.float32), eps, rows, D,
-                                       _p(y, torch.bfloat16), _p(mean, torch.float32), _p(rstd, torch.float32), _stream()),
+                                       _p(y, torch.bfloat16), _p(mean, torch.float32), _p(rstd, torch.float32), _p(add, torch.bfloat16),
+                                       _p(y2, torch.bfloat16), _stream()),
         "toist_layernorm_fwd")
 
 

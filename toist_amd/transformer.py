@@ -296,7 +296,26 @@ class Transformer(nn.Module):
         named = engine.named_cache(self, "encoder", lambda: OrderedDict(self.encoder.named_parameters()))
         n_layers = self.encoder.num_layers
 
+        def prog_fused(tape, ps, x):
+            # q = k = src + pos, v = src (transformer.py:293-297): the packed in_proj runs as one launch on both inputs; `src + pos` of
+            # layer i + 1 is a second output of layer i's last LayerNorm
+            xe = torch.empty_like(x.data)
+            k.add(x.data, pos, xe, b_period=pos.numel())
+            for i in range(n_layers):
+                lp = f"layers.{i}."
+                z = engine.self_attention_block(tape, x, xe, ps[lp + "self_attn.in_proj_weight"], ps[lp + "self_attn.in_proj_bias"],
+                                                ps[lp + "self_attn.out_proj.weight"], ps[lp + "self_attn.out_proj.bias"], key_pad, B, S, H)
+                x1 = engine.layernorm(tape, z, ps[lp + "norm1.weight"], ps[lp + "norm1.bias"], 1e-5)
+                z2 = engine.linear_chain(tape, x1, [(ps[lp + "linear1.weight"], ps[lp + "linear1.bias"], k.ACT_RELU, True),
+                                                    (ps[lp + "linear2.weight"], ps[lp + "linear2.bias"], k.ACT_NONE, False)],
+                                         res=x1, final_drop=True)
+                x = engine.layernorm(tape, z2, ps[lp + "norm2.weight"], ps[lp + "norm2.bias"], 1e-5, add=pos if i + 1 < n_layers else None)
+                xe = x.plus
+            return [x], None
+
         def prog(tape, ps, x):
+            if engine.FUSED_BLOCKS and d // H == 32 and S <= 480:
+                return prog_fused(tape, ps, x)
             for i in range(n_layers):
                 lp = f"layers.{i}."
                 Wi, bi = ps[lp + "self_attn.in_proj_weight"], ps[lp + "self_attn.in_proj_bias"]
@@ -324,7 +343,79 @@ class Transformer(nn.Module):
         n_layers = self.decoder.num_layers
         dev = memory.device
 
+        def prog_fused(tape, ps, mem, qe):
+            """Decoder with (a) the packed in_proj of every self-attention as one launch on (tgt + query_pos | tgt), (b) the K / V projections of
+            memory (+ pos) for all layers as ONE grouped launch up front and one dgrad at the end, (c) tgt + query_pos emitted by the
+            LayerNorm that produces tgt, (d) the shared final LayerNorm applied to all layer outputs in one launch, (e) the gradient
+            w.r.t. query_pos formed once: every block leaves its dq / dk in a column slice of one buffer that is multiplied by the stacked
+            projection weights at the end (transformer.py:362-408, 255-262)."""
+            qpos_data = qe.data.to(BF16).unsqueeze(0).expand(B, Q, d).reshape(B * Q, d).contiguous()
+            L = n_layers
+            need = qe.needs_grad or mem.needs_grad or ps["layers.0.self_attn.in_proj_weight"].g is not None
+            sink = torch.empty(B * Q, L * 4 * d, dtype=BF16, device=dev) if need else None    # per layer [dq_s | dk_s | dv_s | dq_c]
+            Wself = [(ps[f"layers.{i}.self_attn.in_proj_weight"], ps[f"layers.{i}.self_attn.in_proj_bias"]) for i in range(L)]
+            Wcross = [(ps[f"layers.{i}.cross_attn_image.in_proj_weight"], ps[f"layers.{i}.cross_attn_image.in_proj_bias"]) for i in range(L)]
+
+            def qpos_bwd():     # recorded first: runs after every layer has written its slice of `sink`
+                if not qe.needs_grad or sink is None:
+                    return
+                zero = torch.zeros(d, d, dtype=BF16, device=dev)
+                wst = torch.cat([t for i in range(L) for t in (Wself[i][0].w[:2 * d], zero, Wcross[i][0].w[:d])], dim=0)     # [L*4d, d]
+                gq = engine.ops.linear_dgrad(sink, wst).view(B, Q, d).float().sum(0)
+                qe.grad = gq if qe.grad is None else qe.grad + gq
+
+            tape.record(qpos_bwd)
+            mem_e = torch.empty_like(mem.data)
+            k.add(mem.data, pos, mem_e, b_period=pos.numel())
+            kv, dkv = engine.cross_kv_projections(tape, mem, mem_e, Wcross)
+            tgt = engine.Var(torch.zeros(B * Q, d, dtype=BF16, device=dev), needs_grad=False)
+            tgt_e = qpos_data
+            tgt_stack = torch.empty(L, B * Q, d, dtype=BF16, device=dev)
+            layer_out = []
+            for i in range(L):
+                lp = f"layers.{i}."
+                Ws, bs = Wself[i]
+                Wc, bc = Wcross[i]
+                z1 = engine.self_attention_block(tape, tgt, tgt_e, Ws, bs, ps[lp + "self_attn.out_proj.weight"], ps[lp + "self_attn.out_proj.bias"],
+                                                 None, B, Q, H, e_sink=(sink, i * 4 * d) if sink is not None else None)
+                t1 = engine.layernorm(tape, z1, ps[lp + "norm1.weight"], ps[lp + "norm1.bias"], 1e-5, add=qpos_data)
+                z3 = engine.cross_attention_block(tape, t1, t1.plus, Wc.rows(0, d), bc.rows(0, d), kv, dkv, i * 2 * d,
+                                                  ps[lp + "cross_attn_image.out_proj.weight"], ps[lp + "cross_attn_image.out_proj.bias"], key_pad, B, Q, S, H,
+                                                  e_sink=(sink, i * 4 * d + 3 * d) if sink is not None else None)
+                t3 = engine.layernorm(tape, z3, ps[lp + "norm3.weight"], ps[lp + "norm3.bias"], 1e-5)
+                z4 = engine.linear_chain(tape, t3, [(ps[lp + "linear1.weight"], ps[lp + "linear1.bias"], k.ACT_RELU, True),
+                                                    (ps[lp + "linear2.weight"], ps[lp + "linear2.bias"], k.ACT_NONE, False)],
+                                         res=t3, final_drop=True)
+                tgt = engine.layernorm(tape, z4, ps[lp + "norm4.weight"], ps[lp + "norm4.bias"], 1e-5, y=tgt_stack[i],
+                                       add=qpos_data if i + 1 < L else None)
+                tgt_e = tgt.plus
+                layer_out.append(tgt)
+            allv = engine.Var(tgt_stack.view(L * B * Q, d))
+
+            def split_bwd():    # gradient of the shared final norm -> the layer outputs (before the layers' own backward steps run)
+                g = allv.take_grad()
+                if g is None:
+                    return
+                g = g.view(L, B * Q, d)
+                for i, v in enumerate(layer_out):
+                    engine.accumulate(v, g[i])
+
+            tape.record(split_bwd)
+            stack = torch.empty(L, B * Q, d, dtype=BF16, device=dev)
+            hs_flat = engine.layernorm(tape, allv, ps["norm.weight"], ps["norm.bias"], 1e-5, y=stack.view(L * B * Q, d))
+            hs = engine.Var(stack)
+
+            def hs_bwd():
+                g = hs.take_grad()
+                if g is not None:
+                    hs_flat.grad = g.reshape(L * B * Q, d)
+
+            tape.record(hs_bwd)
+            return [hs], None
+
         def prog(tape, ps, mem, qe):
+            if engine.FUSED_BLOCKS and d // H == 32 and S <= 480 and Q <= 480:
+                return prog_fused(tape, ps, mem, qe)
             qpos_data = qe.data.to(BF16).unsqueeze(0).expand(B, Q, d).reshape(B * Q, d).contiguous()
             qpos = engine.Var(qpos_data, needs_grad=qe.needs_grad)
 
