@@ -46,6 +46,8 @@ def parse():
                                                              "(measured slower: 504 vs 514 images/s, the forward pass is HBM-sensitive)")
     ap.add_argument("--no-contrastive", action="store_true", help="drop loss_contrastive_align (the round-1 configuration; the reference's detection recipe has it on, "
                     "main.py:179-184)")
+    ap.add_argument("--static-batch", action="store_true", help="replay the step on ONE fixed batch (the round-1 headline); default: every step sees a different "
+                    "batch (images, captions, number of targets per image) through fixed-address input buffers, the same captured graph")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
     ap.add_argument("--split-graph", action="store_true", help="force the multi-GPU structure (graph: fwd+bwd | eager all-reduce | graph: clip+AdamW+EMA) on one GPU")
     return ap.parse_args()
@@ -255,6 +257,33 @@ def main():
 
     samples, tok, targets, pmap = harness.synthetic_batch(a.batch, a.size, a.size, tokens=16, seed=1000 + rank, device=dev, with_masks=a.masks)
     sync = parallel.GradSync(model)
+    # Shape-agnostic step: NBATCH different synthetic batches (images, token ids, 0..10 targets per image) are resident in HBM; before
+    # every step the next one is copied into the fixed-address input buffers the captured graph reads (device copies of images /
+    # ids, one pinned H2D copy of the packed targets: matcher.StaticTargets).  The mask losses (configs[2]) take per-batch target
+    # lists, so --masks keeps one fixed batch.
+    dynamic = not a.static_batch and not a.masks
+    crit_targets, crit_pmap = targets, pmap
+    feed = None
+    if dynamic:
+        from toist_amd.matcher import StaticTargets
+        NBATCH = 4
+        st = StaticTargets(a.batch, 10, args.num_queries, 256, dev)
+        pool = []
+        for i in range(NBATCH):
+            s_i, tok_i, t_i, pm_i = harness.synthetic_batch(a.batch, a.size, a.size, tokens=16, seed=1000 + rank + 7919 * i, max_targets=10)
+            masks_i = criterion.token_masks_host(t_i, None) if contrastive else None
+            pool.append((s_i.tensors.to(dev), tok_i["input_ids"].to(dev), st.pack(t_i, pm_i, masks_i), t_i, pm_i))
+        crit_targets, crit_pmap = st, None
+        state = {"i": 0}
+
+        def feed():
+            img, ids, packed, _, _ = pool[state["i"] % NBATCH]
+            state["i"] += 1
+            samples.tensors.copy_(img)
+            tok["input_ids"].copy_(ids)
+            st.load_packed(packed)
+
+        feed()
 
     flats = []  # flat fp32 gradient buffers of the backward programs (filled by the GradSync hook)
 
@@ -268,7 +297,7 @@ def main():
                 opt.ema_update()
         mc = model(samples, tok, encode_and_save=True)
         out = model(samples, tok, encode_and_save=False, memory_cache=mc)
-        losses = criterion(mc, out, targets, pmap, None)
+        losses = criterion(mc, out, crit_targets, crit_pmap, None)
         total = weighted_total(losses, weight_dict)
         total.backward()                     # with the backbone cut (N > 1): everything but the backbone
         if ema_stream is not None:
@@ -293,6 +322,8 @@ def main():
         """Eager step: every kernel launched from Python; gradient all-reduce overlapped with backward."""
         if zero:
             opt.zero_grad(set_to_none=True)
+        if feed is not None:
+            feed()
         with sync:
             total = fwd_bwd()
             bwd_cut("text")
@@ -357,6 +388,8 @@ def main():
 
         if not split_graph:
             def run_step():
+                if feed is not None:
+                    feed()
                 graph.replay()
                 return static_loss
         else:
@@ -367,6 +400,8 @@ def main():
                 # text stream:                                                  [RoBERTa backward] (beside the backbone)
                 # RCCL stream:               all-reduce(transformer) -> all-reduce(text) ............ all-reduce(backbone)
                 main = torch.cuda.current_stream()
+                if feed is not None:
+                    feed()
                 graph_a.replay()
                 if world > 1:
                     h_head = parallel.all_reduce_mean_async(flats[:n_head])
@@ -425,7 +460,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("configs[2] (det + mask head + mask losses): " if a.masks else "") + f"configs[1]: ResNet-101 + RoBERTa-base + 6+6 transformer, 100 queries, batch {a.batch}/GPU {a.size}x{a.size}, "
                                    "16-token captions, detection loss (labels+boxes+cardinality" + ("+contrastive_align" if contrastive else "") + ", 5 aux layers), dropout 0.1, "
-                                   "clip 0.1 + AdamW + EMA" + (" (torch)" if a.torch_optimizer else " (fused HIP tail)") + "; random-init weights",
+                                   "clip 0.1 + AdamW + EMA" + (" (torch)" if a.torch_optimizer else " (fused HIP tail)") + "; random-init weights; " +
+                                   ("every step a different batch (4 resident batches, 0..10 targets per image) through fixed-address inputs" if dynamic else "one fixed batch"),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4), "launch": ("4 hipGraphs (head | text || backbone | tail), gradient all-reduces under the backbone backward" if split_graph else "hipGraph replay") if use_graph else "eager",
                        "mfma_frac_whole_step": round(ips / world * GFLOP_PER_IMG_TRAIN / 1000.0 / PEAK_BF16_TFLOPS, 5)},
         }

@@ -217,3 +217,80 @@ def test_weighted_total_equals_the_key_by_key_sum(dev):
     # a plain dict (e.g. after reduce_dict) takes the key-by-key route
     plain = {"loss_ce": torch.tensor(2.0, device=dev), "other": torch.tensor(5.0, device=dev)}
     assert float(toist_amd.weighted_total(plain, {"loss_ce": 3.0})) == 6.0
+
+
+def test_static_targets_one_graph_serves_any_batch(dev):
+    """StaticTargets: the criterion step (matcher + labels / boxes / cardinality / contrastive_align, forward and backward) is captured ONCE
+    into a hipGraph and replayed for batches with different numbers of targets per image (incl. none); losses, gradients and the
+    assignment must equal the eager per-batch path (lists of target dicts) on the same inputs."""
+    from toist_amd import harness
+    from toist_amd.matcher import StaticTargets
+    B, Q, K, L, Lt = 4, 100, 256, 3, 12
+    crit_s, crit_e = _criterion(dev, contrastive=True), _criterion(dev, contrastive=True)
+    g = torch.Generator().manual_seed(0)
+    lg = (torch.randn(L, B, Q, K, generator=g) * 2).to(dev).requires_grad_(True)
+    raw = torch.randn(L, B, Q, 4, generator=g)
+    bx = torch.cat([torch.sigmoid(raw[..., :2]) * 0.6 + 0.2, torch.sigmoid(raw[..., 2:]) * 0.35 + 0.05], -1).to(dev).requires_grad_(True)
+    pq = torch.nn.functional.normalize(torch.randn(L, B, Q, 64, generator=g), dim=-1).to(dev).requires_grad_(True)
+    pt = torch.nn.functional.normalize(torch.randn(B, Lt, 64, generator=g), dim=-1).to(dev).requires_grad_(True)
+
+    def outputs():
+        return {"pred_logits": lg[-1], "pred_boxes": bx[-1], "proj_queries": pq[-1], "proj_tokens": pt,
+                "_stacked": {"pred_logits": lg, "pred_boxes": bx, "proj_queries": pq},
+                "aux_outputs": [{"pred_logits": lg[i], "pred_boxes": bx[i], "proj_queries": pq[i], "proj_tokens": pt} for i in range(L - 1)]}
+
+    weights = torch.linspace(0.5, 1.5, 4 * L).tolist()
+
+    def total_of(losses):
+        keys = sorted(k_ for k_ in losses if k_.startswith("loss_"))
+        return sum(losses[k_] * weights[i] for i, k_ in enumerate(keys))
+
+    st = StaticTargets(B, 10, Q, K, dev)
+    batches = []
+    for seed, forced in ((1, None), (2, [0, 0, 0, 0]), (3, [10, 1, 0, 7])):
+        _, _, targets, pmap = harness.synthetic_batch(B, 64, 64, tokens=Lt, seed=seed, max_targets=10)
+        if forced is not None:
+            targets = [{k_: (v[:n] if torch.is_tensor(v) else v[:n]) for k_, v in t.items()} if n <= len(t["boxes"]) else t for t, n in zip(targets, forced)]
+            pmap = torch.cat([t["positive_map"] for t in targets]) if sum(len(t["boxes"]) for t in targets) else torch.zeros(0, K)
+        batches.append((targets, pmap))
+    packs = [st.pack(t, pm, crit_s.token_masks_host(t, None)) for t, pm in batches]
+    # warm-up + capture with the first batch
+    st.load_packed(packs[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            total_of(crit_s(None, outputs(), st, None, None)).backward()
+        for t in (lg, bx, pq, pt):
+            t.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            static_losses = crit_s(None, outputs(), st, None, None)
+            total_of(static_losses).backward()
+    torch.cuda.current_stream().wait_stream(side)
+    static_grads = [t.grad for t in (lg, bx, pq, pt)]
+    for i in (1, 2, 0, 2):
+        targets, pmap = batches[i]
+        st.load_packed(packs[i])
+        graph.replay()
+        torch.cuda.synchronize()
+        got = {k_: float(v) for k_, v in static_losses.items()}
+        got_grads = [g_.clone() for g_ in static_grads]
+        match = st.match_result(L)
+        # eager reference path on the same inputs
+        for t in (lg, bx, pq, pt):
+            t.grad = None
+        t_dev = [{k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in t.items()} for t in targets]
+        ref = crit_e(None, outputs(), t_dev, pmap.to(dev), None)
+        total_of(ref).backward()
+        assert set(got) == set(ref)
+        for k_, v in ref.items():
+            assert abs(got[k_] - float(v)) <= 1e-5 * abs(float(v)) + 1e-6, (i, k_, got[k_], float(v))
+        for a, b in zip(got_grads, (lg.grad, bx.grad, pq.grad, pt.grad)):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-7), (i, float((a - b).abs().max()))
+        for l in range(L):
+            for (gi, gj), (ri, rj) in zip(match.to_list(l), crit_e.last_match.to_list(l)):
+                assert torch.equal(gi, ri) and torch.equal(gj, rj)
+        # restore the graph's gradient tensors as the .grad the captured backward accumulates into
+        for t, g_ in zip((lg, bx, pq, pt), static_grads):
+            t.grad = g_

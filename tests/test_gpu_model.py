@@ -118,6 +118,9 @@ def test_criterion_and_gradients(dev, setup):
     checks = ["class_embed.weight", "bbox_embed.layers.2.weight", "bbox_embed.layers.0.bias", "query_embed.weight",
               "transformer.decoder.layers.5.linear2.weight", "transformer.decoder.layers.0.cross_attn_image.in_proj_weight",
               "transformer.decoder.norm.weight", "transformer.encoder.layers.5.self_attn.in_proj_weight",
+              "transformer.decoder.layers.3.self_attn.in_proj_weight", "transformer.decoder.layers.0.self_attn.in_proj_bias",
+              "transformer.decoder.layers.5.cross_attn_image.in_proj_bias", "transformer.decoder.layers.2.cross_attn_image.out_proj.weight",
+              "transformer.decoder.layers.1.norm1.weight", "transformer.decoder.layers.4.norm4.bias", "transformer.encoder.layers.2.self_attn.in_proj_bias",
               "transformer.encoder.layers.0.linear1.weight", "transformer.encoder.layers.0.norm1.bias", "input_proj.weight",
               "transformer.resizer.fc.weight", "transformer.text_encoder.encoder.layer.11.output.dense.weight",
               "transformer.text_encoder.encoder.layer.0.attention.self.query.weight",

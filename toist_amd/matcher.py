@@ -37,6 +37,101 @@ class MatchResult:
         return [(s[a:b].clone(), t[a:b].clone()) for a, b in zip(self.match_off[:-1], self.match_off[1:])]
 
 
+class StaticTargets:
+    """Fixed-address device image of a batch's targets, so that ONE captured hipGraph of the training step serves every batch: the
+    captured kernels read boxes, positive-map rows, token-span masks, the per-image offsets and num_boxes from these buffers, and
+    `load()` refills them (one pinned staging buffer, one asynchronous H2D copy, no host sync) between replays.  Capacity is
+    batch * max_per_image targets; the number of targets per image may change from step to step.
+
+    Layout of the arena (bytes): boxes f32 [cap,4] | positive_map f32 [cap,K] | token masks i64 [cap,2] | tgt_off i32 [B+1] |
+    match_off i32 [B+1] | num_boxes f32 [1] (local sum of targets; the world mean, clamped to >= 1, is formed on the device)."""
+
+    def __init__(self, batch, max_per_image, num_queries, K=256, device="cuda"):
+        self.B, self.max_per_image, self.Q, self.K = batch, max_per_image, num_queries, K
+        self.cap = cap = batch * max_per_image
+        self.device = torch.device(device)
+        sizes = [cap * 4 * 4, cap * K * 4, cap * 2 * 8, (batch + 1) * 4, (batch + 1) * 4, 4]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 15) // 16 * 16
+        self._host = torch.zeros(total, dtype=torch.uint8).pin_memory()
+        self._dev = torch.zeros(total, dtype=torch.uint8, device=self.device)
+
+        def views(buf):
+            cut = lambda i, dt, shape: buf[offs[i]:offs[i] + sizes[i]].view(dt).view(shape)
+            return (cut(0, torch.float32, (cap, 4)), cut(1, torch.float32, (cap, K)), cut(2, torch.int64, (cap, 2)), cut(3, torch.int32, (batch + 1,)),
+                    cut(4, torch.int32, (batch + 1,)), cut(5, torch.float32, (1,)))
+
+        self._views = views
+        self.boxes, self.positive_map, self.tok_mask, self.tgt_off, self.match_off, self._nb_local = views(self._dev)
+        self.num_boxes = torch.ones(1, dtype=torch.float32, device=self.device)
+        self.sizes = [0] * batch
+        self._out = {}        # L -> (src [L, cap], tgt [L, cap], status [L*B])
+        self._event = None
+
+    def pack(self, targets, positive_map, token_masks=None, out=None):
+        """Host image of one batch (pinned uint8 tensor in the arena layout, + the per-image target counts): build it ahead of time -- in a
+        loader worker -- and hand it to load_packed().  targets: list of dicts with HOST tensors `boxes` [T_i, 4]; positive_map: host
+        [sum T_i, K]; token_masks: host int64 [sum T_i, 2] (SetCriterion.token_masks_host) when the contrastive-alignment loss is on."""
+        sizes = [int(t["boxes"].shape[0]) for t in targets]
+        if len(sizes) != self.B or max(sizes, default=0) > self.max_per_image:
+            raise ValueError(f"StaticTargets holds {self.B} images x <= {self.max_per_image} targets; got sizes {sizes}")
+        host = out if out is not None else torch.zeros(self._host.numel(), dtype=torch.uint8).pin_memory()
+        hb, hp, hm, hto, hmo, hnb = self._views(host)
+        tot = sum(sizes)
+        if tot:
+            hb[:tot] = torch.cat([t["boxes"].float().cpu() for t in targets])
+            hp[:tot] = positive_map.float().cpu()
+            if token_masks is not None:
+                hm[:tot] = token_masks
+        acc_t, acc_m = 0, 0
+        hto[0], hmo[0] = 0, 0
+        for i, sz in enumerate(sizes):
+            acc_t += sz
+            acc_m += min(self.Q, sz)
+            hto[i + 1], hmo[i + 1] = acc_t, acc_m
+        hnb[0] = float(tot)
+        return host, sizes
+
+    def load_packed(self, packed):
+        """One asynchronous H2D copy of a pack()ed batch + the device-side num_boxes (mdetr.py:997-1001: all-reduce, / world, clamp >= 1);
+        no host sync.  Call between replays of the captured step, on the stream that replays it."""
+        host, sizes = packed
+        self.sizes = list(sizes)
+        self._dev.copy_(host, non_blocking=True)
+        self.num_boxes.copy_(self._nb_local)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            torch.distributed.all_reduce(self.num_boxes)
+            self.num_boxes.div_(torch.distributed.get_world_size())
+        self.num_boxes.clamp_(min=1)
+        return self
+
+    def load(self, targets, positive_map, token_masks=None):
+        """pack() into the internal staging buffer + load_packed()."""
+        if self._event is not None:
+            self._event.synchronize()          # the previous upload has left the staging buffer
+        packed = self.pack(targets, positive_map, token_masks, out=self._host)
+        self.load_packed(packed)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        return self
+
+    def outputs(self, L):
+        ent = self._out.get(L)
+        if ent is None:
+            ent = self._out[L] = (torch.zeros(L, self.cap, dtype=torch.int64, device=self.device), torch.zeros(L, self.cap, dtype=torch.int64, device=self.device),
+                                  torch.zeros(L * self.B, dtype=torch.int32, device=self.device))
+        return ent
+
+    def match_result(self, L):
+        """MatchResult of the CURRENT contents (host lists from the last load(), device buffers of the last launch / replay)."""
+        src, tgt, status = self.outputs(L)
+        mtot = sum(min(self.Q, s_) for s_ in self.sizes)
+        flat = lambda t: t.view(-1)[:L * mtot].view(L, mtot)       # the kernels pack the rows with stride match_off[B]
+        return MatchResult(flat(src), flat(tgt), status, self.sizes, self.Q, self.tgt_off, self.match_off, self.boxes)
+
+
 class HungarianMatcher(nn.Module):
     def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1):
         super().__init__()
@@ -75,6 +170,17 @@ class HungarianMatcher(nn.Module):
                       float(self.cost_bbox), float(self.cost_giou), src if mtot else torch.zeros(L, 1, dtype=torch.int64, device=dev),
                       tgt if mtot else torch.zeros(L, 1, dtype=torch.int64, device=dev), status)
         return MatchResult(src, tgt, status, sizes, Q, tgt_off, m_off, tb)
+
+    @torch.no_grad()
+    def match_layers_static(self, logits, boxes, st):
+        """match_layers on a StaticTargets image: every shape and pointer is independent of the batch's target counts, so the launch can
+        be captured once and replayed for any batch (`st.load(...)` in between)."""
+        L, B, Q, K = logits.shape
+        assert B == st.B and Q == st.Q and K == st.K
+        src, tgt, status = st.outputs(L)
+        k.matcher(logits.float().contiguous(), boxes.float().contiguous(), st.boxes, st.positive_map, st.tgt_off, st.match_off, st.max_per_image,
+                  float(self.cost_class), float(self.cost_bbox), float(self.cost_giou), src, tgt, status)
+        return MatchResult(src, tgt, status, st.sizes, Q, st.tgt_off, st.match_off, st.boxes)
 
     @torch.no_grad()
     def forward(self, outputs, targets, positive_map):

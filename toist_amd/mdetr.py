@@ -14,7 +14,7 @@ from torch import nn
 from . import dist, engine, functions
 from . import kernels as k
 from .backbone import build_backbone, nearest_mask
-from .matcher import build_matcher
+from .matcher import StaticTargets, build_matcher
 from .misc import NestedTensor
 from .transformer import build_transformer
 from .distill import ClusterCriterion, char_span_to_tokens, noun_token_features
@@ -376,6 +376,35 @@ class SetCriterion(nn.Module):
                 raise ValueError("cost matrix is infeasible")
         self._pending_status = keep
 
+    def token_masks_host(self, targets, tokenized):
+        """int64 [sum T, 2] host tensor of the targets' token-span bit masks (input of StaticTargets.load)."""
+        rows = []
+        for i, tgt in enumerate(targets):
+            rows += self._span_bits(tgt, i, tokenized)
+        return torch.tensor(rows, dtype=torch.int64).reshape(len(rows), 2)
+
+    @staticmethod
+    def _span_bits(tgt, i, tokenized):
+        rows = []
+        for t in range(int(tgt["boxes"].shape[0])):
+            if "token_spans" in tgt:
+                spans = tgt["token_spans"][t]
+            else:
+                spans = []
+                for beg, end in tgt["tokens_positive" if "tokens_positive" in tgt else "tokens"][t]:
+                    ft = char_span_to_tokens(tokenized, i, beg, end)
+                    if ft is not None:
+                        spans.append(ft)
+            bits = 0
+            for bp, ep in spans:
+                if ep >= 128:
+                    raise ValueError("contrastive_align: token spans beyond position 127 are not supported by the device kernel")
+                for tkn in range(bp, ep + 1):
+                    bits |= 1 << tkn
+            lo, hi = bits & ((1 << 64) - 1), bits >> 64
+            rows.append([lo - (1 << 64) if lo >= (1 << 63) else lo, hi - (1 << 64) if hi >= (1 << 63) else hi])
+        return rows
+
     def _token_masks(self, targets, tokenized, device):
         """int64 [sum T, 2] token bit masks of every target's positive spans (the host part of mdetr.py:614-643, done once per
         batch instead of once per layer and call: the spans do not depend on the assignment)."""
@@ -383,25 +412,8 @@ class SetCriterion(nn.Module):
         for i, tgt in enumerate(targets):
             m = tgt.get("_tok_mask")
             if m is None or m.device != device:
-                rows = []
                 n = int(tgt["boxes"].shape[0])
-                for t in range(n):
-                    if "token_spans" in tgt:
-                        spans = tgt["token_spans"][t]
-                    else:
-                        spans = []
-                        for beg, end in tgt["tokens_positive" if "tokens_positive" in tgt else "tokens"][t]:
-                            ft = char_span_to_tokens(tokenized, i, beg, end)
-                            if ft is not None:
-                                spans.append(ft)
-                    bits = 0
-                    for bp, ep in spans:
-                        if ep >= 128:
-                            raise ValueError("contrastive_align: token spans beyond position 127 are not supported by the device kernel")
-                        for tkn in range(bp, ep + 1):
-                            bits |= 1 << tkn
-                    lo, hi = bits & ((1 << 64) - 1), bits >> 64
-                    rows.append([lo - (1 << 64) if lo >= (1 << 63) else lo, hi - (1 << 64) if hi >= (1 << 63) else hi])
+                rows = self._span_bits(tgt, i, tokenized)
                 m = torch.tensor(rows, dtype=torch.int64).reshape(n, 2).to(device)
                 tgt["_tok_mask"] = m
             parts.append(m)
@@ -459,6 +471,8 @@ class SetCriterion(nn.Module):
             return self._forward_pair(memory_cache, outputs, targets, positive_map)
         logits, boxes = self._stack(outputs)
         L = logits.shape[0]
+        if isinstance(targets, StaticTargets):
+            return self._forward_static(outputs, logits, boxes, targets, L)
         match = self.matcher.match_layers(logits.detach(), boxes.detach(), targets, positive_map)
         self.last_match = match
         num_boxes = self._num_boxes(targets, logits.device)
@@ -470,6 +484,26 @@ class SetCriterion(nn.Module):
             losses.update(mask_losses(outputs, targets, match, L - 1, num_boxes))
         return losses
 
+
+    def _forward_static(self, outputs, logits, boxes, st, L):
+        """Detection losses on a StaticTargets image (matcher.StaticTargets): no shape, pointer or launch parameter depends on the
+        batch's target counts -- the captured step is replayed for any batch after st.load(...).  labels / boxes / cardinality /
+        contrastive_align; the mask losses keep the per-batch path."""
+        if "masks" in self.losses:
+            raise NotImplementedError("StaticTargets covers the detection losses (BASELINE configs[1]); mask losses take lists of target dicts")
+        match = self.matcher.match_layers_static(logits.detach(), boxes.detach(), st)
+        self.last_match = match
+        losses = self._detection_losses(logits, boxes, match, None, st.positive_map, st.num_boxes)
+        if "contrastive_align" in self.losses:
+            pq, pt = self._stack_proj(outputs, L), outputs["proj_tokens"]
+            vals = _ContrastiveFn.apply(pq.float().contiguous(), pt.float().contiguous(), match, st.tok_mask, st.num_boxes, float(self.temperature))
+            out, index = LossDict(), {}
+            for l in range(L):
+                key = "loss_contrastive_align" + ("" if l == L - 1 else f"_{l}")
+                out[key], index[key] = vals[l], l
+            out.groups.append((vals, index))
+            losses.merge(out)
+        return losses
 
     # ---- distillation: [teacher (noun), student (pronoun)] -------------------------------------------------------
     def _forward_pair(self, memory_cache, outputs, targets, positive_map):
