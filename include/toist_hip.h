@@ -346,6 +346,20 @@ int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, const void
                    float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int variant, float* workspace, int q_splits,
                    const float* lse, const uint8_t* key_pad, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
+/* ---- whole-head self-attention for short sequences (S <= 64 keys, head dim <= 64, % 8 == 0): the text encoder's attention
+ * (RoBERTa over a 16-token caption: transformer.py:129-130 via transformers.RobertaSelfAttention) as ONE launch each way instead of
+ * batched 16 x 16 GEMMs + softmax kernels.  q / k / v / ctx / gradients are per-head column slices of [B*S, ld*] bf16 buffers
+ * (row b*S + s, feature h*dh + e); bq / bk / bv (optional, f32 [H*dh]) are the projection biases, added on load so the packed
+ * q | k | v projection needs no epilogue vector; key_pad [B, S] u8 (1 = padding) or NULL; stats f32 [B*H, S, 2] = (row maximum,
+ * 1 / row sum) written by fwd, read by bwd, which re-forms the probabilities and the dropout mask ((seed + *seed_dev, element)). */
+int toist_attn_small_fwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int S,
+                         int dh, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* ctx, int ldo, float* stats,
+                         const float* bq, const float* bk, const float* bv, void* stream);
+int toist_attn_small_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int S,
+                         int dh, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, const float* stats, const void* dctx,
+                         int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, const float* bq, const float* bk,
+                         const float* bv, void* stream);
+
 /* ---- 3x3 / stride 1 / pad 1 convolution with <= 32 channels on either side (mask-head stages at 160x160,
  * segmentation.py:176-241 lay5 / out_lay; HBM-bound): NHWC bf16 in / out, weights [w_co][3][3][w_ci] bf16.
  * dgrad = 0: out[p, co] = shift[co] + sum x[p + tap, ci] w[co, tap, ci] (+ res);  c_src = w_ci, c_out = w_co.

@@ -88,6 +88,10 @@ _SIGNATURES = {
     "toist_attn_bwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32] + [c_int32] * 6 +
                        [c_float, c_float, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_uint64,
                         c_void_p, c_void_p], ctypes.c_int),
+    "toist_attn_small_fwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 4 + [c_float, c_float, c_uint64, c_void_p, c_void_p,
+                             c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_attn_small_bwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 4 + [c_float, c_float, c_uint64, c_void_p, c_void_p,
+                             c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_conv3x3_small": ([c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p], ctypes.c_int),
     "toist_wgrad3x3_small_blocks": ([], ctypes.c_int),
     "toist_wgrad3x3_small": ([c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p], ctypes.c_int),

@@ -733,6 +733,53 @@ def cross_attention_block(tape, t, te, Wq, bq, kv, dkv, col, Wo, bo, key_pad, B,
     return out
 
 
+def packed_cast(view):
+    """compute_copy transform that keeps a parameter's bf16 copy INSIDE a larger buffer (`view` = its rows there): several parameters
+    -- RoBERTa's separate query / key / value matrices -- then form one contiguous GEMM operand, and the optimizer tail keeps
+    refreshing each copy in place through its own pointer."""
+    def make(m):
+        view.copy_(m.detach())
+        return view
+    make.elementwise = True
+    return make
+
+
+def text_attention_block(tape, x, proj, Wpacked, Wo, bo, key_pad, B, L, H):
+    """x + dropout(out_proj(MHA(q = k = v = x))) for the text encoder (HF RobertaSelfAttention + RobertaSelfOutput.dense,
+    transformer.py:129-130): the three projections are ONE GEMM on the packed [3D, D] weight copy (their biases are added when the
+    attention kernel loads q / k / v), the whole head runs in one launch each way (csrc/attn_small.hip), one GEMM carries
+    d[q | k | v] back to x.  proj = [(Wq, bq), (Wk, bk), (Wv, bv)] ParamViews; Wpacked = bf16 [3D, D] holding their copies."""
+    D = Wo.w.shape[0]
+    dh = D // H
+    M = B * L
+    dev = x.data.device
+    p = tape.drop_p
+    scale = 1.0 / math.sqrt(dh)
+    qkv = ops.linear(x.data, Wpacked)
+    seed_p = tape.next_seed() if p > 0 else 0
+    ctx = torch.empty(M, D, dtype=BF16, device=dev)
+    stats = torch.empty(B * H, L, 2, dtype=torch.float32, device=dev)
+    bias = [b.f32 for _, b in proj]
+    k.attn_small_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], key_pad, B, H, L, dh, scale, p, seed_p, ctx, stats, *bias)
+    out, head = _out_proj(tape, ctx, Wo, bo, x, p)
+
+    def bwd():
+        dctx = head()
+        if dctx is None:
+            return
+        dqkv = torch.empty(M, 3 * D, dtype=BF16, device=dev)
+        k.attn_small_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], key_pad, B, H, L, dh, scale, p, seed_p, stats, dctx,
+                         dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], *bias)
+        for i, (W, b) in enumerate(proj):
+            if W.g is not None:
+                tape.linear_wgrad(dqkv[:, i * D:(i + 1) * D], x.data, W, b)
+        if x.needs_grad:
+            x.grad = ops.linear_dgrad(dqkv, Wpacked, res=x.grad)
+
+    tape.record(bwd)
+    return out
+
+
 # ------------------------------------------------------------------------------------------ ResNet blocks
 def bottleneck(tape, x, W, bn, stride, has_down, train):
     """torchvision Bottleneck (v1.5) on NHWC bf16 with FrozenBatchNorm folded: conv weights `W[name].w`

@@ -493,6 +493,22 @@ def attn_bwd(q, kmat, v, prob, prob_drop, ctx, dctx, B, H, Sq, Sk, dh, scale, dr
                                          _p(SEED_DEV) if (prob is None and drop_p > 0) else None, _stream()), "toist_attn_bwd")
 
 
+def attn_small_fwd(q, kmat, v, key_pad, B, H, S, dh, scale, drop_p, seed, ctx, stats, bq=None, bk=None, bv=None):
+    """Whole-head self-attention for S <= 64, dh <= 64 (csrc/attn_small.hip); column slices of packed buffers, optional projection biases."""
+    _lib.check(_lib.lib().toist_attn_small_fwd(_p(q, torch.bfloat16), q.stride(0), _p(kmat, torch.bfloat16), kmat.stride(0), _p(v, torch.bfloat16), v.stride(0),
+                                               _p(key_pad, torch.uint8), B, H, S, dh, scale, drop_p, seed, _p(SEED_DEV) if drop_p > 0 else None,
+                                               _p(ctx, torch.bfloat16), ctx.stride(0), _p(stats, torch.float32), _p(bq, torch.float32), _p(bk, torch.float32),
+                                               _p(bv, torch.float32), _stream()), "toist_attn_small_fwd")
+
+
+def attn_small_bwd(q, kmat, v, key_pad, B, H, S, dh, scale, drop_p, seed, stats, dctx, dq, dk, dv, bq=None, bk=None, bv=None):
+    _lib.check(_lib.lib().toist_attn_small_bwd(_p(q, torch.bfloat16), q.stride(0), _p(kmat, torch.bfloat16), kmat.stride(0), _p(v, torch.bfloat16), v.stride(0),
+                                               _p(key_pad, torch.uint8), B, H, S, dh, scale, drop_p, seed, _p(SEED_DEV) if drop_p > 0 else None,
+                                               _p(stats, torch.float32), _p(dctx, torch.bfloat16), dctx.stride(0), _p(dq, torch.bfloat16), dq.stride(0),
+                                               _p(dk, torch.bfloat16), dk.stride(0), _p(dv, torch.bfloat16), dv.stride(0), _p(bq, torch.float32),
+                                               _p(bk, torch.float32), _p(bv, torch.float32), _stream()), "toist_attn_small_bwd")
+
+
 # ---- evaluation masks (csrc/evalmask.hip): column-major bit planes [n, W, ceil(H/64)] stored in int64 tensors --------------
 def mask_words(h):
     return (h + 63) // 64

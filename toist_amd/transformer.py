@@ -251,6 +251,21 @@ class Transformer(nn.Module):
             return d
         named = engine.named_cache(self, "text", _named)
 
+        small = engine.FUSED_BLOCKS and L <= 64 and cfg.hidden_size // H <= 64 and (cfg.hidden_size // H) % 8 == 0
+        transforms = None
+        if small:
+            # bf16 copies of each layer's query / key / value matrices live side by side in one [3D, D] buffer: one projection GEMM
+            packs = self.__dict__.setdefault("_text_packs", {})
+            key_dev = str(ids.device)
+            if key_dev not in packs:
+                Dh = cfg.hidden_size
+                packs[key_dev] = [torch.zeros(3 * Dh, Dh, dtype=BF16, device=ids.device) for _ in range(cfg.num_hidden_layers)]
+            transforms = {}
+            for i, buf in enumerate(packs[key_dev]):
+                Dh = cfg.hidden_size
+                for j, nm in enumerate(("query", "key", "value")):
+                    transforms[f"text_encoder.encoder.layer.{i}.attention.self.{nm}.weight"] = engine.packed_cast(buf[j * Dh:(j + 1) * Dh])
+
         def prog(tape, ps):
             P = lambda n: ps["text_encoder." + n]
             D = cfg.hidden_size
@@ -270,7 +285,12 @@ class Transformer(nn.Module):
             x = engine.dropout(tape, x)
             for i in range(cfg.num_hidden_layers):
                 lp = f"encoder.layer.{i}."
-                z = engine.attention(
+                if small:
+                    proj = [(P(lp + f"attention.self.{nm}.weight"), P(lp + f"attention.self.{nm}.bias")) for nm in ("query", "key", "value")]
+                    z = engine.text_attention_block(tape, x, proj, self._text_packs[str(ids.device)][i], P(lp + "attention.output.dense.weight"),
+                                                    P(lp + "attention.output.dense.bias"), key_pad, B, L, H)
+                else:
+                  z = engine.attention(
                     tape, x, x, x, (P(lp + "attention.self.query.weight"), P(lp + "attention.self.query.bias")),
                     (P(lp + "attention.self.key.weight"), P(lp + "attention.self.key.bias")),
                     (P(lp + "attention.self.value.weight"), P(lp + "attention.self.value.bias")), P(lp + "attention.output.dense.weight"),
@@ -286,7 +306,7 @@ class Transformer(nn.Module):
             return [r], None
 
         (out,) = functions.run_program(prog, named, [], cache=self._cache_text, training=self.training, drop_p=cfg.hidden_dropout_prob,
-                                       seed=self._next_seed(), group_wgrads=True)
+                                       seed=self._next_seed(), group_wgrads=True, transforms=transforms)
         return out, key_pad
 
     # ---- encoder ----------------------------------------------------------------------------------
