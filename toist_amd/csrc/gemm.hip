@@ -13,6 +13,7 @@
 // NOT the contiguous one (wgrad, PV, dgrad from the forward weight layout) are staged k-major and
 // turned into MFMA fragments by the LDS transpose read ds_read_b64_tr_b16.  The MFMA is issued as
 // D^T = B * A^T so each lane owns 4 consecutive output columns -> 8-byte packed bf16 stores.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -449,8 +450,9 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
     });
 }
 
+// One output tile (tile `tl` of the launch's padded, XCD-striped tile list) of one (batch, k-slice) problem.
 template <int BM, int BN, int BK, int AK, int BKD, int NS>
-__global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
+__device__ __forceinline__ void gemm_tile(const toist_gemm& p, const int tl, bf16_t* const smem) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int ACH = BM * BK / 8 / 256, BCH = BN * BK / 8 / 256;  // 1 KiB DMA pieces per wave per tile
     constexpr bool A_KM = (AK == TOIST_A_KROW);    // A staged k-major
@@ -462,7 +464,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     // is resident at once with as many staged bytes as the 160 KB of LDS allow (see pick_tile below).
     constexpr int CNT = ACH + BCH;
     static_assert(NS >= 2 && NS <= 4, "wait ladder below covers up to 2 younger tiles");
-    __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -477,8 +478,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     const int nt_n = (p.N + BN - 1) / BN;
     const int nt_m = (p.M + BM - 1) / BM;
     const int tiles = nt_m * nt_n;
-    const int tile_id = (int)(blockIdx.x & 7) * ((tiles + 7) >> 3) + (int)(blockIdx.x >> 3);
-    if (tile_id >= tiles) return;            // grid.x is padded to a multiple of 8
+    const int tile_id = (tl & 7) * ((tiles + 7) >> 3) + (tl >> 3);
+    if (tile_id >= tiles) return;            // the tile list is padded to a multiple of 8
     int tile_m, tile_n;
     tile_order(tile_id, nt_m, nt_n, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
         }
     };
 
-    const int ntiles = kt_end - kt_beg;
+    const int ntiles = (p.flags & 256) ? 0 : kt_end - kt_beg;     // flags bit 8 (experiments): skip the reduction loop
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < ntiles) issue(t);
@@ -719,7 +720,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     }
 
     static_assert(32 * (BN + 4) * 4 <= NS * STAGE * 2, "epilogue band must fit the (now idle) ring");
+    if (p.flags & 512) return;                                    // flags bit 9 (experiments): skip the epilogue
     epilogue_tile<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, bz, coff, ksl);
+}
+
+// Persistent launch: the hardware dispatches ~530 workgroups per microsecond chip-wide (measured: a 12800-tile launch whose
+// workgroups return at once takes 24 us, a 3200-tile one 6.9 us), which for the K <= 256 GEMMs of the hot path is as much as their
+// whole reduction loop.  The grid is therefore capped at what the chip holds at once (launch_variant) and every workgroup walks
+// the tile list with stride gridDim.x; a multiple of 8, so a workgroup stays on its XCD's contiguous run of tiles.
+template <int BM, int BN, int BK, int AK, int BKD, int NS>
+__global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
+    constexpr int STAGE = (BM + BN) * BK;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
+    const int tiles8 = ((((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN)) + 7) & ~7;
+    for (int tl = (int)blockIdx.x; tl < tiles8; tl += (int)gridDim.x) {
+        gemm_tile<BM, BN, BK, AK, BKD, NS>(p, tl, smem);
+        if (tl + (int)gridDim.x < tiles8) __syncthreads();       // the next tile's DMA reuses the LDS the epilogue bands lived in
+    }
 }
 
 // ---- 3x3 / stride 1 / pad 1 convolution with a shared halo patch -------------------------------------------------
@@ -1001,11 +1018,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const ReduceBa
     }
 }
 
+// Workgroups of a persistent launch (TOIST_PERSIST_WGS; default 0 = one workgroup per tile).  Measured on MI355X (round 2,
+// tools/dbg/gemm_persist.py, profiles/r02_gemm_persistent_sweep.txt): in a back-to-back microbenchmark 768 workgroups (3 per CU)
+// take 9-16 % off the output-heavy K <= 256 GEMMs (12800x1024x256: 34.0 -> 29.9 us; 204800x256x64: 88.8 -> 76.0 us) by removing
+// most of the dispatch cost, but inside the training step -- cold operands, HBM-bound epilogues -- the same setting is neutral
+// (439 vs 441 images/s on the same box; 1024: -1.4 %, 1536: +0.4 %), so it stays off.
+static long long persist_wgs() {
+    static const long long v = [] {
+        const char* e = getenv("TOIST_PERSIST_WGS");
+        const long long n = e ? atoll(e) : 0;
+        return n <= 0 ? (1LL << 40) : n;
+    }();
+    return v;
+}
+
 template <int BM, int BN, int BK, int AK, int BKD>
 static int launch_variant(const toist_gemm& d, int ring, hipStream_t st) {
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     dim3 grid((tiles + 7) & ~7, 1, d.batch * d.split_k);   // 1-D over tiles (XCD-aware order in the kernel), padded to 8
     constexpr int stage = (BM + BN) * BK * 2;
+    {   // persistent cap: at most ~PERSIST_WGS workgroups over all of x and z (what 256 CUs hold at once), the rest by striding
+        const long long z = (long long)d.batch * d.split_k;
+        long long cap = (persist_wgs() / (z > 0 ? z : 1)) & ~7LL;
+        if (cap < 8) cap = 8;
+        if ((long long)grid.x > cap) grid.x = (unsigned)cap;
+    }
     if (ring == 0) {
         const long long wgs = (long long)tiles * grid.z;
         if (stage <= 8192) ring = 4;

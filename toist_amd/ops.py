@@ -29,7 +29,7 @@ def _split_k_for(tiles, ktiles, target=768, max_split=256):
 
 # ------------------------------------------------------------------------------------------ linear
 def linear(x, w, bias=None, *, out=None, out_dtype=BF16, act=k.ACT_NONE, res=None, alpha=1.0, pre_out=None, scale=None,
-           drop_where=0, drop_p=0.0, drop_seed=0, tile=0):
+           drop_where=0, drop_p=0.0, drop_seed=0, tile=0, flags=0):
     """out[M,N] = act(alpha * x[M,K] @ w[N,K]^T * scale + bias (+dropout) + res)   (nn.Linear forward)."""
     M, K = x.shape
     N = w.shape[0]
@@ -38,7 +38,7 @@ def linear(x, w, bias=None, *, out=None, out_dtype=BF16, act=k.ACT_NONE, res=Non
         out = torch.empty(M, N, dtype=out_dtype, device=x.device)
     k.gemm(M, N, K, k.A_ROWK, k.operand(x, _ld(x)), k.B_ROWK, k.operand(w, _ld(w)), out, _ld(out), alpha=alpha, scale=scale,
            shift=bias, res=res, ldr=_ld(res) if res is not None else 0, act=act, pre_out=pre_out, drop_where=drop_where,
-           drop_p=drop_p, drop_seed=drop_seed, tile=tile, flops=2 * M * N * K)
+           drop_p=drop_p, drop_seed=drop_seed, tile=tile, flags=flags, flops=2 * M * N * K)
     return out
 
 
