@@ -346,6 +346,16 @@ int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, const void
                    float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int variant, float* workspace, int q_splits,
                    const float* lse, const uint8_t* key_pad, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
+/* ---- k-means of the distillation step on the device (models/kmeans.py:21-96 as mdetr.py:213-234 calls it).  One workgroup per
+ * distinct task of the batch: group g covers samples members[group_off[g] .. group_off[g+1]) (batch order), all of task
+ * group_task[g]; for each sample: Lloyd iterations over banks[task] ([N, D] f32, stride bank_stride elements) from
+ * centers[task] ([K, D] f32, stride centers_stride, updated IN PLACE) until (sum_k |shift_k|)^2 < tol (or max_iter), then
+ * pick[sample] = index of the centre nearest to features[sample] ([*, D] f32) and chosen_center[sample] = that centre.
+ * No host synchronisation; iters (optional) receives the iteration count per sample. */
+int toist_kmeans(const float* banks, int64_t bank_stride, float* centers, int64_t centers_stride, const int32_t* group_task,
+                 const int32_t* group_off, const int32_t* members, int n_groups, const float* features, int N, int D, int K, float tol,
+                 int max_iter, int32_t* pick, float* chosen_center, int32_t* iters, void* stream);
+
 /* ---- whole-head self-attention for short sequences (S <= 64 keys, head dim <= 64, % 8 == 0): the text encoder's attention
  * (RoBERTa over a 16-token caption: transformer.py:129-130 via transformers.RobertaSelfAttention) as ONE launch each way instead of
  * batched 16 x 16 GEMMs + softmax kernels.  q / k / v / ctx / gradients are per-head column slices of [B*S, ld*] bf16 buffers

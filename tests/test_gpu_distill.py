@@ -112,3 +112,31 @@ def test_distillation_step_end_to_end(dev):
     g_t = model.transformer.text_encoder.encoder.layer[0].output.dense.weight.grad
     assert g_s is not None and g_n is not None and g_t is not None
     assert float(g_s.abs().sum()) > 0 and float(g_n.abs().sum()) > 0 and float(g_t.abs().sum()) > 0
+
+
+def test_device_kmeans_matches_host_loop(dev):
+    """csrc/kmeans.hip (all samples of a batch in one launch, no host read) against the per-sample Lloyd loop that restates
+    models/kmeans.py (toist_amd.distill.kmeans, itself pinned to the reference's ClusterCriterion by distill.npz): same centres (fp32
+    summation order differs: rtol 1e-4), same picks, same-task samples chained in batch order, banks of other tasks untouched."""
+    from toist_amd import distill
+    args = types.SimpleNamespace(fifo_memory=False)
+    g = torch.Generator().manual_seed(3)
+    cc = distill.ClusterCriterion(feature_dim=256, memory_size=1024, cluster_num=3, task_count=14, args=args)
+    blobs = torch.randn(14, 3, 256, generator=g) * 2
+    cc.feature_bank.copy_(blobs[:, torch.randint(0, 3, (1024,), generator=g)] + 0.3 * torch.randn(14, 1024, 256, generator=g))
+    cc.cluster_centers.copy_(torch.randn(14, 3, 256, generator=g))
+    cc.full_label.fill_(1)
+    cc.to(dev)
+    ref = distill.ClusterCriterion(feature_dim=256, memory_size=1024, cluster_num=3, task_count=14, args=args).to(dev)
+    ref.load_state_dict(cc.state_dict())
+    feats = torch.randn(6, 256, generator=g).to(dev)
+    tasks = [4, None, 9, 4, 0, 9]
+    pick, chosen = cc.cluster_batch(feats, tasks)
+    for i, t in enumerate(tasks):
+        if t is None:
+            continue
+        p_ref, c_ref = ref.memory_cluster(feats[i], t)
+        assert int(pick[i]) == int(p_ref), (i, int(pick[i]), int(p_ref))
+        assert torch.allclose(chosen[i], c_ref, rtol=1e-4, atol=1e-5), (i, float((chosen[i] - c_ref).abs().max()))
+    assert torch.allclose(cc.cluster_centers, ref.cluster_centers, rtol=1e-4, atol=1e-5)
+    assert torch.equal(cc.cluster_centers[1], ref.cluster_centers[1])

@@ -88,6 +88,8 @@ _SIGNATURES = {
     "toist_attn_bwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32] + [c_int32] * 6 +
                        [c_float, c_float, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_uint64,
                         c_void_p, c_void_p], ctypes.c_int),
+    "toist_kmeans": ([c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_float, c_int32,
+                     c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_attn_small_fwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 4 + [c_float, c_float, c_uint64, c_void_p, c_void_p,
                              c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_attn_small_bwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 4 + [c_float, c_float, c_uint64, c_void_p, c_void_p,

@@ -1,0 +1,148 @@
+// Device-resident k-means for the noun-pronoun distillation step (BASELINE configs[4]).
+//
+// Replaces models/kmeans.py:21-96 as ClusterCriterion.memory_cluster calls it (/root/reference/models/mdetr.py:213-234): per
+// sample, Lloyd iterations over the task's memory bank ([1024, 256] fp32) from the task's current centres (K = 3) until
+// (sum_k |c_k' - c_k|)^2 < tol, the centres are stored back, and the centre nearest to the sample's own feature is picked.  The
+// reference (and round 1 here) reads the shift back to the host after EVERY iteration; here the whole loop runs inside one
+// workgroup -- one workgroup per distinct task of the batch, walking that task's samples in batch order so that a later sample
+// starts from the centres the earlier one left, exactly like the sequential reference -- and the host never looks.
+// Work per iteration: two passes over the 1 MB bank (L2-resident) = ~20 us on one CU; neither roofline applies to 1-8 workgroups.
+#include "common.h"
+
+namespace toist {
+
+constexpr int KM_THREADS = 1024, KM_MAXK = 8, KM_MAXD = 256;
+
+__global__ __launch_bounds__(KM_THREADS) void kmeans_kernel(const float* __restrict__ banks, long long bank_stride, float* __restrict__ centers_all,
+                                                            long long centers_stride, const int* __restrict__ group_task,
+                                                            const int* __restrict__ group_off, const int* __restrict__ members,
+                                                            const float* __restrict__ features, int N, int D, int K, float tol, int max_iter,
+                                                            int* __restrict__ pick_out, float* __restrict__ center_out, int* __restrict__ iters_out) {
+    __shared__ float c[KM_MAXK][KM_MAXD];            // current centres
+    __shared__ float part[4][KM_MAXK][KM_MAXD];      // per-quarter member sums
+    __shared__ int cnt_part[4][KM_MAXK];
+    __shared__ float red[KM_THREADS / 64];
+    __shared__ float shift_sh;
+    extern __shared__ unsigned char choice[];        // [N]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, task = group_task[g];
+    const float* X = banks + (long long)task * bank_stride;
+    float* cg = centers_all + (long long)task * centers_stride;
+    for (int i = tid; i < K * D; i += KM_THREADS) c[i / D][i % D] = cg[i];
+    __syncthreads();
+    const int d_of = tid & 255, quarter = tid >> 8;  // update pass: thread = (feature, quarter of the points); needs D <= 256
+    for (int mi = group_off[g]; mi < group_off[g + 1]; ++mi) {
+        const int sample = members[mi];
+        int it = 0;
+        for (; it < max_iter; ++it) {
+            // ---- assignment: one wavefront per point, lanes across the features ----
+            for (int n = wave; n < N; n += KM_THREADS / 64) {
+                float dist[KM_MAXK];
+#pragma unroll
+                for (int kk = 0; kk < KM_MAXK; ++kk) dist[kk] = 0.f;
+                for (int d = lane; d < D; d += 64) {
+                    const float x = X[(long long)n * D + d];
+#pragma unroll
+                    for (int kk = 0; kk < KM_MAXK; ++kk)
+                        if (kk < K) { const float t = x - c[kk][d]; dist[kk] += t * t; }
+                }
+                int best = 0;
+                float bd = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < KM_MAXK; ++kk) {
+                    if (kk < K) {
+                        const float v = wave_sum(dist[kk]);
+                        if (kk == 0 || v < bd) { bd = v; best = kk; }      // first minimum wins, like torch.argmin
+                    }
+                }
+                if (lane == 0) choice[n] = (unsigned char)best;
+            }
+            __syncthreads();
+            // ---- update: member sums per (cluster, feature), four quarters of the points in parallel ----
+            {
+                float s[KM_MAXK];
+                int cn[KM_MAXK];
+#pragma unroll
+                for (int kk = 0; kk < KM_MAXK; ++kk) { s[kk] = 0.f; cn[kk] = 0; }
+                const int per = (N + 3) / 4, n0 = quarter * per, n1 = min(N, n0 + per);
+                if (d_of < D) {
+                    for (int n = n0; n < n1; ++n) {
+                        const int ch = choice[n];
+                        const float x = X[(long long)n * D + d_of];
+#pragma unroll
+                        for (int kk = 0; kk < KM_MAXK; ++kk)
+                            if (kk == ch) { s[kk] += x; ++cn[kk]; }
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < KM_MAXK; ++kk)
+                        if (kk < K) { part[quarter][kk][d_of] = s[kk]; if (d_of == 0) cnt_part[quarter][kk] = cn[kk]; }
+                }
+            }
+            __syncthreads();
+            float my_shift = 0.f;        // this thread's (cluster, feature) contributions to |c' - c|^2, per cluster below
+            // threads 0 .. K*D-1 finish one (cluster, feature) each
+            float diff2 = 0.f;
+            int my_k = -1;
+            if (tid < K * D) {
+                const int kk = tid / D, d = tid - kk * D;
+                my_k = kk;
+                const int count = cnt_part[0][kk] + cnt_part[1][kk] + cnt_part[2][kk] + cnt_part[3][kk];
+                const float old = c[kk][d];
+                float nw = old;                                       // an empty cluster keeps its centre (kmeans.py:72)
+                if (count > 0) nw = (((part[0][kk][d] + part[1][kk][d]) + part[2][kk][d]) + part[3][kk][d]) / (float)count;
+                diff2 = (nw - old) * (nw - old);
+                c[kk][d] = nw;
+            }
+            (void)my_shift;
+            // shift = sum_k sqrt(sum_d diff2): D = 256 features of a cluster are exactly 4 wavefronts
+            float w = wave_sum(diff2);
+            __syncthreads();
+            if (lane == 0) red[wave] = w;
+            __syncthreads();
+            if (tid == 0) {
+                float sh = 0.f;
+                const int waves_per_k = (D + 63) / 64;
+                for (int kk = 0; kk < K; ++kk) {
+                    float t = 0.f;
+                    for (int j = 0; j < waves_per_k; ++j) t += red[kk * waves_per_k + j];
+                    sh += sqrtf(t);
+                }
+                shift_sh = sh;
+            }
+            __syncthreads();
+            (void)my_k;
+            if (shift_sh * shift_sh < tol) { ++it; break; }
+        }
+        // ---- centres back to the task's slot; pick the centre nearest to this sample's feature ----
+        for (int i = tid; i < K * D; i += KM_THREADS) cg[i] = c[i / D][i % D];
+        if (wave == 0) {
+            const float* f = features + (long long)sample * D;
+            int best = 0;
+            float bd = 0.f;
+            for (int kk = 0; kk < K; ++kk) {
+                float t = 0.f;
+                for (int d = lane; d < D; d += 64) { const float u = f[d] - c[kk][d]; t += u * u; }
+                t = wave_sum(t);
+                if (kk == 0 || t < bd) { bd = t; best = kk; }
+            }
+            if (lane == 0) { pick_out[sample] = best; if (iters_out) iters_out[sample] = it; }
+            for (int d = lane; d < D; d += 64) center_out[(long long)sample * D + d] = c[best][d];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace toist
+
+using namespace toist;
+
+extern "C" int toist_kmeans(const float* banks, int64_t bank_stride, float* centers, int64_t centers_stride, const int32_t* group_task,
+                            const int32_t* group_off, const int32_t* members, int n_groups, const float* features, int N, int D, int K, float tol,
+                            int max_iter, int32_t* pick, float* chosen_center, int32_t* iters, void* stream) {
+    TOIST_REQUIRE(banks && centers && group_task && group_off && members && features && pick && chosen_center && n_groups > 0, "toist_kmeans: bad args");
+    TOIST_REQUIRE(N > 0 && N <= 32768 && D > 0 && D <= KM_MAXD && (D % 64) == 0 && K > 0 && K <= KM_MAXK && K * D <= KM_THREADS && max_iter > 0 && tol >= 0.f,
+                  "toist_kmeans: N <= 32768, D <= %d and %% 64 == 0, K <= %d, K * D <= %d (N=%d D=%d K=%d)", KM_MAXD, KM_MAXK, KM_THREADS, N, D, K);
+    hipLaunchKernelGGL(kmeans_kernel, dim3(n_groups), dim3(KM_THREADS), (size_t)((N + 15) & ~15), (hipStream_t)stream, banks, (long long)bank_stride, centers,
+                       (long long)centers_stride, group_task, group_off, members, features, N, D, K, tol, max_iter, pick, chosen_center, iters);
+    return check_launch("toist_kmeans");
+}

@@ -134,20 +134,76 @@ class ClusterCriterion(nn.Module):
             torch.distributed.all_gather(parts, feature_idx)
             feature_idx = torch.cat(parts, 0)
         tasks = feature_idx[:, -1].round().to(torch.int64).tolist()   # one host read per step; the values are small integers
+        full = self._full_host()
+        count = self.__dict__["_count_mirror"]
         for t in sorted(set(tasks) - {-1}):
             new = feature_idx[[i for i, x in enumerate(tasks) if x == t], :-1]
             n = new.shape[0]
             bank = self.feature_bank[t]
-            filling = float(self.full_label[t]) == 0
+            filling = not full[t]
             if filling or self.args.fifo_memory:
                 bank.copy_(torch.cat([bank[n:], new], 0))
                 if filling:
-                    if float(self.update_count[t]) > self.memory_size:
+                    if count[t] > self.memory_size:
                         self.full_label[t] = 1
+                        full[t] = True
                     self.update_count[t] += n
+                    count[t] += n
             else:   # replace the entries closest (L1) to the new features: one LSAP on the device
                 (rows, cols), = linear_sum_assignment_batch([torch.cdist(new, bank, p=1)])
                 bank[cols] = new[rows]
+
+    # ---- device path: every sample of the batch in ONE launch, no host read (csrc/kmeans.hip) -------------------------------
+    _INDEX_TABLES = {}
+
+    def cluster_batch(self, features, tasks):
+        """memory_cluster for all samples of a batch at once.  features [B, d] (device), tasks: host list, one task index per
+        sample or None (sample skipped).  Samples of the same task are processed in batch order by one workgroup (a later sample starts
+        from the centres an earlier one left, as in the sequential reference); the centres are updated in place.  Returns
+        (pick int32 [B], chosen centre [B, d]) on the device, or None when a bank involved is still filling (random initialisation on
+        the host, kmeans.py:8-18: the per-sample host path handles that phase)."""
+        live = [(i, t) for i, t in enumerate(tasks) if t is not None]
+        if not live or not features.is_cuda:
+            return None
+        full = self._full_host()
+        if any(not full[t] for _, t in live):
+            return None
+        key = (tuple(tasks), str(features.device))
+        ent = ClusterCriterion._INDEX_TABLES.get(key)
+        if ent is None:
+            if len(ClusterCriterion._INDEX_TABLES) > 256:
+                ClusterCriterion._INDEX_TABLES.clear()
+            order = sorted(set(t for _, t in live))
+            members, off = [], [0]
+            for t in order:
+                members += [i for i, tt in live if tt == t]
+                off.append(len(members))
+            mk = lambda v: torch.tensor(v, dtype=torch.int32, device=features.device)
+            ent = ClusterCriterion._INDEX_TABLES[key] = (mk(order), mk(off), mk(members))
+        group_task, group_off, members = ent
+        B, d = features.shape
+        pick = torch.zeros(B, dtype=torch.int32, device=features.device)
+        chosen = torch.zeros(B, d, dtype=torch.float32, device=features.device)
+        from . import kernels as k
+        k.kmeans(self.feature_bank, self.cluster_centers, group_task, group_off, members, features.detach().float().contiguous(), 1e-4, 10000, pick, chosen)
+        return pick, chosen
+
+    def _full_host(self):
+        """Host mirror of full_label (one read, then kept in step by update_memory_queue; call sync_host_state() after writing the
+        buffers directly or loading a checkpoint)."""
+        m = self.__dict__.get("_full_mirror")
+        if m is None:
+            m = self.__dict__["_full_mirror"] = [bool(v) for v in self.full_label.detach().cpu().tolist()]
+            self.__dict__["_count_mirror"] = [float(v) for v in self.update_count.detach().cpu().tolist()]
+        return m
+
+    def sync_host_state(self):
+        self.__dict__.pop("_full_mirror", None)
+        self.__dict__.pop("_count_mirror", None)
+
+    def _load_from_state_dict(self, *a, **kw):
+        self.sync_host_state()
+        return super()._load_from_state_dict(*a, **kw)
 
     def memory_cluster(self, feature, t):
         choice, centers = kmeans(self.feature_bank[t], self.cluster_centers[t].clone(), self.cluster_num, full_label=float(self.full_label[t]))
@@ -178,11 +234,17 @@ class ClusterCriterion(nn.Module):
                 rows[i, -1] = task_index(tgt["dataset_name"])
         self.update_memory_queue(rows)
         memory_cache_noun["img_memory_mod"] = memory_cache_noun["img_memory"].clone()
+        tasks = [None if empty[i] else task_index(t["dataset_name"]) for i, t in enumerate(targets_noun)]
+        batch = self.cluster_batch(feats, tasks)
         for i, tgt in enumerate(targets_noun):
             if empty[i]:
                 continue
             spans = [s for box in tgt["noun_tokens_positive"] for s in box]
-            self._substitute(memory_cache_noun, i, span_positions(tokenized, i, spans, L), task_index(tgt["dataset_name"]), feats[i])
+            pos = span_positions(tokenized, i, spans, L)
+            if batch is not None:
+                memory_cache_noun["img_memory_mod"][-L:, i, :][pos.to(text.device)] = batch[1][i]
+            else:
+                self._substitute(memory_cache_noun, i, pos, tasks[i], feats[i])
         memory_cache_noun["full_label"], memory_cache_noun["update_count"] = self.full_label, self.update_count
         return memory_cache_noun
 
@@ -192,13 +254,23 @@ class ClusterCriterion(nn.Module):
         tokenized = memory_cache["tokenized"]
         memory_cache["img_memory_mod"] = memory_cache["img_memory"].clone()
         loss_feature = torch.zeros((), device=text.device)
+        positions, features = [], []
         for i in range(B):
             beg = captions[i].find("something")
             pos = torch.arange(tokenized.char_to_token(i, beg), tokenized.char_to_token(i, beg + len("something") - 1) + 1)
-            feature = text[i][pos.to(text.device)].mean(0)
-            center = self._substitute(memory_cache, i, pos, task_index(names[i]), feature)
+            positions.append(pos)
+            features.append(text[i][pos.to(text.device)].mean(0))
+        tasks = [task_index(n) for n in names]
+        batch = self.cluster_batch(torch.stack(features), tasks) if B else None
+        for i in range(B):
+            if batch is not None:
+                center = batch[1][i]
+                L = len(memory_cache["text_memory"])
+                memory_cache["img_memory_mod"][-L:, i, :][positions[i].to(center.device)] = center
+            else:
+                center = self._substitute(memory_cache, i, positions[i], tasks[i], features[i])
             if with_loss:
-                loss_feature = loss_feature + F.mse_loss(feature, center)
+                loss_feature = loss_feature + F.mse_loss(features[i], center)
         return memory_cache, loss_feature / max(B, 1)
 
     def forward(self, memory_cache_sth, targets_sth, captions_sth):

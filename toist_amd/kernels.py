@@ -493,6 +493,15 @@ def attn_bwd(q, kmat, v, prob, prob_drop, ctx, dctx, B, H, Sq, Sk, dh, scale, dr
                                          _p(SEED_DEV) if (prob is None and drop_p > 0) else None, _stream()), "toist_attn_bwd")
 
 
+def kmeans(banks, centers, group_task, group_off, members, features, tol, max_iter, pick, chosen_center, iters=None):
+    """banks [T, N, D] f32, centers [T, K, D] f32 (updated in place); see toist_kmeans."""
+    T, N, D = banks.shape
+    K = centers.shape[1]
+    _lib.check(_lib.lib().toist_kmeans(_p(banks, torch.float32), banks.stride(0), _p(centers, torch.float32), centers.stride(0), _p(group_task, torch.int32),
+                                       _p(group_off, torch.int32), _p(members, torch.int32), group_task.numel(), _p(features, torch.float32), N, D, K, tol,
+                                       max_iter, _p(pick, torch.int32), _p(chosen_center, torch.float32), _p(iters, torch.int32), _stream()), "toist_kmeans")
+
+
 def attn_small_fwd(q, kmat, v, key_pad, B, H, S, dh, scale, drop_p, seed, ctx, stats, bq=None, bk=None, bv=None):
     """Whole-head self-attention for S <= 64, dh <= 64 (csrc/attn_small.hip); column slices of packed buffers, optional projection biases."""
     _lib.check(_lib.lib().toist_attn_small_fwd(_p(q, torch.bfloat16), q.stride(0), _p(kmat, torch.bfloat16), kmat.stride(0), _p(v, torch.bfloat16), v.stride(0),
