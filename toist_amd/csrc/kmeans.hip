@@ -79,38 +79,32 @@ __global__ __launch_bounds__(KM_THREADS) void kmeans_kernel(const float* __restr
                 }
             }
             __syncthreads();
-            float my_shift = 0.f;        // this thread's (cluster, feature) contributions to |c' - c|^2, per cluster below
-            // threads 0 .. K*D-1 finish one (cluster, feature) each
-            float diff2 = 0.f;
-            int my_k = -1;
+            // threads 0 .. K*D-1 finish one (cluster, feature) each; the squared moves go back to LDS for the per-cluster norms
+            float nw = 0.f, df = 0.f;
+            int fk = 0, fd = 0;
             if (tid < K * D) {
-                const int kk = tid / D, d = tid - kk * D;
-                my_k = kk;
-                const int count = cnt_part[0][kk] + cnt_part[1][kk] + cnt_part[2][kk] + cnt_part[3][kk];
-                const float old = c[kk][d];
-                float nw = old;                                       // an empty cluster keeps its centre (kmeans.py:72)
-                if (count > 0) nw = (((part[0][kk][d] + part[1][kk][d]) + part[2][kk][d]) + part[3][kk][d]) / (float)count;
-                diff2 = (nw - old) * (nw - old);
-                c[kk][d] = nw;
+                fk = tid / D; fd = tid - fk * D;
+                const int count = cnt_part[0][fk] + cnt_part[1][fk] + cnt_part[2][fk] + cnt_part[3][fk];
+                const float old = c[fk][fd];
+                nw = old;                                             // an empty cluster keeps its centre (kmeans.py:72)
+                if (count > 0) nw = (((part[0][fk][fd] + part[1][fk][fd]) + part[2][fk][fd]) + part[3][fk][fd]) / (float)count;
+                df = (nw - old) * (nw - old);
             }
-            (void)my_shift;
-            // shift = sum_k sqrt(sum_d diff2): D = 256 features of a cluster are exactly 4 wavefronts
-            float w = wave_sum(diff2);
+            __syncthreads();                                          // every read of part[] is done
+            if (tid < K * D) { c[fk][fd] = nw; part[0][fk][fd] = df; }
             __syncthreads();
-            if (lane == 0) red[wave] = w;
+            if (tid < K) {                                            // |c_k' - c_k| per cluster (D <= 256 terms)
+                float t = 0.f;
+                for (int d = 0; d < D; ++d) t += part[0][tid][d];
+                red[tid] = sqrtf(t);
+            }
             __syncthreads();
             if (tid == 0) {
                 float sh = 0.f;
-                const int waves_per_k = (D + 63) / 64;
-                for (int kk = 0; kk < K; ++kk) {
-                    float t = 0.f;
-                    for (int j = 0; j < waves_per_k; ++j) t += red[kk * waves_per_k + j];
-                    sh += sqrtf(t);
-                }
+                for (int kk = 0; kk < K; ++kk) sh += red[kk];
                 shift_sh = sh;
             }
             __syncthreads();
-            (void)my_k;
             if (shift_sh * shift_sh < tol) { ++it; break; }
         }
         // ---- centres back to the task's slot; pick the centre nearest to this sample's feature ----
@@ -140,8 +134,8 @@ extern "C" int toist_kmeans(const float* banks, int64_t bank_stride, float* cent
                             const int32_t* group_off, const int32_t* members, int n_groups, const float* features, int N, int D, int K, float tol,
                             int max_iter, int32_t* pick, float* chosen_center, int32_t* iters, void* stream) {
     TOIST_REQUIRE(banks && centers && group_task && group_off && members && features && pick && chosen_center && n_groups > 0, "toist_kmeans: bad args");
-    TOIST_REQUIRE(N > 0 && N <= 32768 && D > 0 && D <= KM_MAXD && (D % 64) == 0 && K > 0 && K <= KM_MAXK && K * D <= KM_THREADS && max_iter > 0 && tol >= 0.f,
-                  "toist_kmeans: N <= 32768, D <= %d and %% 64 == 0, K <= %d, K * D <= %d (N=%d D=%d K=%d)", KM_MAXD, KM_MAXK, KM_THREADS, N, D, K);
+    TOIST_REQUIRE(N > 0 && N <= 32768 && D > 0 && D <= KM_MAXD && D > 0 && K > 0 && K <= KM_MAXK && K * D <= KM_THREADS && max_iter > 0 && tol >= 0.f,
+                  "toist_kmeans: N <= 32768, D <= %d, K <= %d, K * D <= %d (N=%d D=%d K=%d)", KM_MAXD, KM_MAXK, KM_THREADS, N, D, K);
     hipLaunchKernelGGL(kmeans_kernel, dim3(n_groups), dim3(KM_THREADS), (size_t)((N + 15) & ~15), (hipStream_t)stream, banks, (long long)bank_stride, centers,
                        (long long)centers_stride, group_task, group_off, members, features, N, D, K, tol, max_iter, pick, chosen_center, iters);
     return check_launch("toist_kmeans");
