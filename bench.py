@@ -46,6 +46,7 @@ def parse():
                                                              "(measured slower: 504 vs 514 images/s, the forward pass is HBM-sensitive)")
     ap.add_argument("--no-contrastive", action="store_true", help="drop loss_contrastive_align (the round-1 configuration; the reference's detection recipe has it on, "
                     "main.py:179-184)")
+    ap.add_argument("--bf16-grads", action="store_true", help="N > 1: gradients cross the xGMI links as bfloat16 (half the bytes; the reference reduces in fp32)")
     ap.add_argument("--static-batch", action="store_true", help="replay the step on ONE fixed batch (the round-1 headline); default: every step sees a different "
                     "batch (images, captions, number of targets per image) through fixed-address input buffers, the same captured graph")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
@@ -404,15 +405,15 @@ def main():
                     feed()
                 graph_a.replay()
                 if world > 1:
-                    h_head = parallel.all_reduce_mean_async(flats[:n_head])
+                    h_head = parallel.all_reduce_mean_async(flats[:n_head], bf16=a.bf16_grads)
                 text_stream.wait_stream(main)
                 with torch.cuda.stream(text_stream):
                     graph_text.replay()
                     if world > 1:
-                        h_text = parallel.all_reduce_mean_async(flats[n_head:n_text])
+                        h_text = parallel.all_reduce_mean_async(flats[n_head:n_text], bf16=a.bf16_grads)
                 graph_bb.replay()
                 if world > 1:
-                    h_bb = parallel.all_reduce_mean_async(flats[n_text:])
+                    h_bb = parallel.all_reduce_mean_async(flats[n_text:], bf16=a.bf16_grads)
                     h_head.wait()
                     h_text.wait()
                     h_bb.wait()
@@ -451,6 +452,11 @@ def main():
         t = torch.tensor([dt], device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
+    collectives = None
+    if world > 1 and use_graph and split_graph and flats:
+        # the three gradient collectives of the step, each alone on the machine: what the RCCL ring achieves per xGMI link
+        collectives = {name: parallel.measure_all_reduce(fl, bf16=a.bf16_grads) for name, fl in
+                       (("transformer+heads", flats[:n_head]), ("text_encoder", flats[n_head:n_text]), ("backbone", flats[n_text:])) if fl}
 
     if rank == 0:
         ips = a.batch * world * a.steps / dt
@@ -465,6 +471,9 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4), "launch": ("4 hipGraphs (head | text || backbone | tail), gradient all-reduces under the backbone backward" if split_graph else "hipGraph replay") if use_graph else "eager",
                        "mfma_frac_whole_step": round(ips / world * GFLOP_PER_IMG_TRAIN / 1000.0 / PEAK_BF16_TFLOPS, 5)},
         }
+        if collectives is not None:
+            res["collectives"] = collectives
+            res["config"]["gradient_wire_dtype"] = "bf16" if a.bf16_grads else "f32"
         if prof is not None and prof["records"]:
             tot_ms, tot_fl, per_key = 0.0, 0.0, {}
             for e0, e1, fl, key, shape, nbytes in prof["records"]:

@@ -115,3 +115,24 @@ def test_reference_ddp_wrap_and_step_sequence(dev):
         for key in ("torch_ddp_cos", "toist_ddp_cos"):
             cos_, lo, hi = out[r][key]
             assert cos_ > 0.995 and 0.97 < lo and hi < 1.03, out[r]
+
+
+def test_bench_two_ranks_on_one_gpu_gloo(dev):
+    """The N > 1 control flow of bench.py (four hipGraphs: forward + transformer backward | text backward || backbone backward | tail,
+    flat-buffer gradient all-reduces in between, num_boxes all-reduce, max-over-ranks timing) with two ranks sharing this GPU over
+    gloo -- RCCL needs one GPU per rank, which the test box does not have; the launch line is the driver's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TOIST_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, out.stderr[-3000:]
+    res = json.loads(lines[-1])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 16 and res["value"] > 0 and res["scaling"] == "weak"
+    assert "4 hipGraphs" in res["config"]["launch"], res["config"]["launch"]
+    assert set(res["collectives"]) == {"transformer+heads", "text_encoder", "backbone"}
+    assert all(c["busbw_GBps"] > 0 for c in res["collectives"].values())

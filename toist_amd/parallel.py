@@ -73,22 +73,48 @@ def _mean_op(group=None):
 
 
 class _MeanHandle:
-    def __init__(self, works, flats, op, world):
-        self.works, self.flats, self.op, self.world = works, flats, op, world
+    def __init__(self, works, flats, op, world, wire=None):
+        self.works, self.flats, self.op, self.world, self.wire = works, flats, op, world, wire
 
     def wait(self):
         for w in self.works:
             w.wait()
+        if self.wire is not None:                  # bf16 on the wire: back into the fp32 buffers the optimizer reads
+            for f, t in zip(self.flats, self.wire):
+                f.copy_(t)
         if self.op == dist.ReduceOp.SUM:
             for f in self.flats:
                 f.div_(self.world)
 
 
-def all_reduce_mean_async(flats, group=None):
-    """Start the mean all-reduce of a list of flat gradient buffers on the collective stream; .wait() joins."""
+def all_reduce_mean_async(flats, group=None, bf16=False):
+    """Start the mean all-reduce of a list of flat gradient buffers on the collective stream; .wait() joins.  bf16=True halves the
+    bytes on the xGMI links (the per-link-bound ring all-reduce of the 170 MB backbone buffer is the one collective nothing is left
+    to overlap with): the buffers travel as bfloat16 copies and are written back as fp32 (the reference's DDP reduces in fp32, so
+    this is an option, off by default)."""
     op = _mean_op(group)
-    works = [dist.all_reduce(f, op=op, group=group, async_op=True) for f in flats]
-    return _MeanHandle(works, list(flats), op, dist.get_world_size(group))
+    wire = [f.to(torch.bfloat16) for f in flats] if bf16 else None
+    works = [dist.all_reduce(t, op=op, group=group, async_op=True) for t in (wire if bf16 else flats)]
+    return _MeanHandle(works, list(flats), op, dist.get_world_size(group), wire)
+
+
+def measure_all_reduce(flats, group=None, iters=5, bf16=False):
+    """Achieved bandwidth of the mean all-reduce of `flats`, alone on the machine: {"bytes", "ms", "algbw_GBps", "busbw_GBps"} with
+    busbw = algbw * 2 (n - 1) / n (the per-link traffic of a ring), the number to hold against ~153 GB/s per xGMI link."""
+    import time
+    world = dist.get_world_size(group)
+    nbytes = sum(f.numel() * (2 if bf16 else f.element_size()) for f in flats)
+    scratch = [torch.zeros_like(f) for f in flats]
+    all_reduce_mean_async(scratch, group, bf16).wait()
+    torch.cuda.synchronize()
+    dist.barrier(group)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        all_reduce_mean_async(scratch, group, bf16).wait()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    alg = nbytes / dt / 1e9
+    return {"bytes": nbytes, "ms": round(1000 * dt, 3), "algbw_GBps": round(alg, 1), "busbw_GBps": round(alg * 2 * (world - 1) / world, 1)}
 
 
 def all_reduce_mean(flats, group=None):
