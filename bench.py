@@ -215,6 +215,10 @@ def main():
     import toist_amd
     from toist_amd import harness, kernels, parallel
     from toist_amd.mdetr import weighted_total
+    # the roofline kernel = the family that takes most of the step's kernel time (profiles/r02_timeline_*.txt: ~45 %): the 64x64x64
+    # bf16 MFMA GEMM on row-major activations -- every 1x1 convolution of the backbone and every nn.Linear, forward and data gradient
+    global ROOFLINE_KEYS
+    ROOFLINE_KEYS = frozenset({(65, kernels.A_ROWK, kernels.B_ROWK), (65, kernels.A_ROWK, kernels.B_KROW)})
     if a.distill:
         return bench_distillation(a, dev, rank, world)
     # the reference's default detection recipe (scripts/train_dete.sh): labels + boxes + cardinality + contrastive_align, 5 aux layers;
@@ -427,7 +431,7 @@ def main():
         run_step = step
     prof = None
     if rank == 0 and not a.no_roofline and not use_graph:
-        prof = {"key": None if a.profile_all else (65, kernels.A_CONV, kernels.B_ROWK), "records": [], "other": {}}
+        prof = {"key": None if a.profile_all else ROOFLINE_KEYS, "records": [], "other": {}}
     barrier()
     kernels.PROFILE = prof
     t0 = time.perf_counter()
@@ -442,7 +446,7 @@ def main():
         # same K steps once more, eagerly, on the same stream right after the timed region (every rank runs
         # them -- they contain the gradient / num_boxes collectives -- only rank 0 records)
         if rank == 0:
-            prof = {"key": (65, kernels.A_CONV, kernels.B_ROWK), "records": [], "other": {}}
+            prof = {"key": ROOFLINE_KEYS, "records": [], "other": {}}
             kernels.PROFILE = prof
         for _ in range(a.steps):
             step()
@@ -490,18 +494,20 @@ def main():
             if prof["key"] is not None:
                 # HBM bytes per launch of this kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
                 # --pmc WRITE_SIZE in separate runs of this same script, tools/run_gpu_round.sh + tools/pmc_traffic.py)
-                pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+                pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
                 if os.path.exists(pj):
-                    ks = {k_: v for k_, v in json.load(open(pj))["kernels"].items() if "gemm_kernel<64, 64, 64, 2, 0," in k_}
+                    meta = json.load(open(pj))
+                    ks = {k_: v for k_, v in meta["kernels"].items() if "gemm_kernel<64, 64, 64, 0," in k_}
                     disp = sum(v["dispatches"] for v in ks.values())
                     if disp:
                         traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in ks.values()) / disp)
-                        traffic_src = "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction applied)"
+                        traffic_src = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --no-graph` at commit "
+                                       + str(meta.get("commit", "?")) + " (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction applied); not re-measured in this run")
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16_TFLOPS, 5), "traffic": traffic, "traffic_unit": "bytes/launch",
                                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes),
-                               "kernel": "gemm_kernel<64,64,64,A_CONV,B_ROWK> (implicit-GEMM conv forward)" if prof["key"] else "all gemm_kernel launches",
+                               "kernel": "gemm_kernel<64,64,64,A_ROWK,{B_ROWK,B_KROW}> (1x1 convolutions and nn.Linear, forward + data gradient: the largest share of the step's kernel time)" if prof["key"] else "all gemm_kernel launches",
                                "timed": "HIP events around each launch, %d eager steps %s" % (a.steps, "after the graph-replayed timed region" if use_graph else "inside the timed region"),
                                "launches": n, "avg_launch_us": round(1000 * tot_ms / n, 2), "avg_gflop_per_launch": round(tot_fl / n / 1e9, 3)}
             if a.profile_all:

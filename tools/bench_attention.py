@@ -1,8 +1,11 @@
-"""MFMA utilisation of the encoder-decoder attention at batch 8 (BASELINE.json north_star target), measured on the
-product code path: engine.attention forward + backward (projections, QK^T, masked softmax with dropout, PV, output
-projection, residual) captured in a hipGraph and replayed.  GPU only.
+"""MFMA utilisation of the encoder-decoder attention at batch 8 (BASELINE.json north_star target), measured on the product code
+path of round 2: the fused attention blocks of toist_amd.engine (packed in_proj as one launch on two inputs, flash-style core with
+row statistics only, out-proj + dropout + residual, grouped decoder K / V projections, merged data gradients; forward + backward,
+dropout 0.1) captured in a hipGraph and replayed.  GPU only.
 
-FLOP accounting: cores 4*Sq*Sk*d, projections 2*(2*Sq + 2*Sk)*d*d per image, x3 for forward+backward."""
+FLOP accounting: cores 4*Sq*Sk*d, projections 2*(2*Sq + 2*Sk)*d*d per image, x3 for forward + backward.
+Next to every case: the number of kernel launches of the replayed graph, the time the same number of EMPTY launches takes
+(the launch-latency floor of this launch count) and the utilisation that floor alone would allow."""
 import json
 import os
 import sys
@@ -14,37 +17,22 @@ from toist_amd import engine, kernels as k  # noqa: E402
 
 dev = torch.device("cuda")
 BF = torch.bfloat16
-B, d, H = 8, 256, 8
+B, d, H, L = 8, 256, 8, 6
 PEAK = 2500.0
 
 
-def run(name, Sq, Sk, self_attn, reps=50):
+def params(n_layers):
+    """[(Win, bin, Wo, bo)] ParamViews with gradient slots, one set per layer."""
     torch.manual_seed(0)
-    mk = lambda *s: (torch.randn(*s, device=dev) * 0.05)
-    Wi, bi, Wo, bo = mk(3 * d, d), mk(3 * d), mk(d, d), mk(d)
-    views = {}
-    flat = torch.zeros(Wi.numel() + bi.numel() + Wo.numel() + bo.numel(), device=dev)
-    off = 0
-    for n, t in (("Wi", Wi), ("bi", bi), ("Wo", Wo), ("bo", bo)):
-        g = flat[off:off + t.numel()].view(t.shape)
-        off += t.numel()
-        views[n] = engine.ParamView(t.to(BF) if t.dim() == 2 else None, g, t)
-    x = (torch.randn(B * Sq, d, device=dev)).to(BF)
-    mem = x if self_attn else torch.randn(B * Sk, d, device=dev).to(BF)
-    key_pad = torch.zeros(B, Sk, dtype=torch.uint8, device=dev)
-    k.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+    out = []
+    for _ in range(n_layers):
+        mk = lambda *s: (torch.randn(*s, device=dev) * 0.05)
+        ts = [mk(3 * d, d), mk(3 * d), mk(d, d), mk(d)]
+        out.append(tuple(engine.ParamView(t.to(BF) if t.dim() == 2 else None, torch.zeros_like(t), t) for t in ts))
+    return out
 
-    def step():
-        tape = engine.Tape(training=True, drop_p=0.1, seed=1)
-        q = engine.Var(x)
-        kv = q if self_attn else engine.Var(mem)
-        Wv, bv = views["Wi"], views["bi"]
-        out = engine.attention(tape, q, kv, kv, (Wv.rows(0, d), bv.rows(0, d)), (Wv.rows(d, 2 * d), bv.rows(d, 2 * d)),
-                               (Wv.rows(2 * d, 3 * d), bv.rows(2 * d, 3 * d)), views["Wo"], views["bo"], q, key_pad, B, Sq, Sk, H,
-                               packed_qk=(Wv.rows(0, 2 * d), bv.rows(0, 2 * d)) if self_attn else None)
-        out.grad = torch.ones_like(out.data)
-        tape.backward()
 
+def graphed(step, reps=50):
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -62,16 +50,90 @@ def run(name, Sq, Sk, self_attn, reps=50):
         graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    us = 1000.0 * e0.elapsed_time(e1) / reps
+    return 1000.0 * e0.elapsed_time(e1) / reps
+
+
+class Counter:
+    """counts toist kernel launches of one step() by wrapping the ctypes entry points used here"""
+
+    def __init__(self):
+        self.n = 0
+
+    def __enter__(self):
+        from toist_amd import _lib
+        self.lib = _lib.lib()
+        self.saved = {}
+        for name in ("toist_gemm_bf16", "toist_attn_fwd", "toist_attn_bwd", "toist_add_bf16", "toist_splitk_reduce_batch", "toist_group_fill", "toist_layernorm_fwd"):
+            fn = getattr(self.lib, name)
+            self.saved[name] = fn
+
+            def wrap(*a, _fn=fn, _name=name):
+                self.n += 2 if _name == "toist_attn_bwd" else 1      # attn_bwd with query splits = core + fold
+                return _fn(*a)
+
+            setattr(self.lib, name, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.saved.items():
+            setattr(self.lib, name, fn)
+
+
+def empty_launch_us(n):
+    x = torch.zeros(1024, device=dev).to(BF)
+    y = torch.empty_like(x)
+
+    def step():
+        for _ in range(n):
+            k.add(x, x, y)
+
+    return graphed(step)
+
+
+def run(name, Sq, Sk, kind):
+    key_pad = torch.zeros(B, Sk, dtype=torch.uint8, device=dev)
+    k.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+    P = params(L)
+    x = torch.randn(B * Sq, d, device=dev).to(BF)
+    e = torch.randn(B * Sq, d, device=dev).to(BF)
+    mem = torch.randn(B * Sk, d, device=dev).to(BF)
+    pos = torch.randn(B * Sk, d, device=dev).to(BF)
+
+    def step():
+        tape = engine.Tape(training=True, drop_p=0.1, seed=1, group_wgrads=True)
+        outs = []
+        if kind == "cross":
+            m = engine.Var(mem)
+            mem_e = torch.empty_like(mem)
+            k.add(mem, pos, mem_e)
+            kv, dkv = engine.cross_kv_projections(tape, m, mem_e, [(p[0], p[1]) for p in P])
+        for i, (Wi, bi, Wo, bo) in enumerate(P):          # six independent blocks (one per layer), as a step runs them
+            xv = engine.Var(x)
+            xe = torch.empty_like(x)
+            k.add(x, e, xe)                                 # stands for the LayerNorm that emits x + pos in the model
+            if kind == "cross":
+                o = engine.cross_attention_block(tape, xv, xe, Wi.rows(0, d), bi.rows(0, d), kv, dkv, i * 2 * d, Wo, bo, key_pad, B, Sq, Sk, H)
+            else:
+                o = engine.self_attention_block(tape, xv, xe, Wi, bi, Wo, bo, key_pad if kind == "enc" else None, B, Sq, H)
+            o.grad = torch.ones_like(o.data)
+            outs.append(o)
+        tape.backward()
+
+    with Counter() as c:
+        step()
+    launches = c.n
+    us = graphed(step) / L
     flop = 3.0 * B * (4.0 * Sq * Sk * d + 2.0 * (2 * Sq + 2 * Sk) * d * d)
+    floor = empty_launch_us(launches) / L
     return {"case": name, "Sq": Sq, "Sk": Sk, "us_fwd_bwd": round(us, 1), "gflop": round(flop / 1e9, 2), "tflops": round(flop / us / 1e6, 1),
-            "mfma_frac": round(flop / us / 1e6 / PEAK, 4)}
+            "mfma_frac": round(flop / us / 1e6 / PEAK, 4), "launches_per_block": round(launches / L, 1), "empty_launch_floor_us": round(floor, 1),
+            "mfma_frac_if_only_launch_bound": round(flop / floor / 1e6 / PEAK, 4)}
 
 
-rows = [run("encoder self-attention (S=416)", 416, 416, True), run("decoder cross-attention image+text (Q=100, S=416)", 100, 416, False),
-        run("decoder self-attention (Q=100)", 100, 100, True)]
+rows = [run("encoder self-attention (S=416)", 416, 416, "enc"), run("decoder cross-attention image+text (Q=100, S=416)", 100, 416, "cross"),
+        run("decoder self-attention (Q=100)", 100, 100, "dec")]
 tot_us = 6 * sum(r["us_fwd_bwd"] for r in rows)
 tot_fl = 6 * sum(r["gflop"] for r in rows)
-print(json.dumps({"batch": B, "layers": "6+6", "dropout": 0.1, "launch": "hipGraph replay", "cases": rows,
-                  "all_attention_per_step": {"ms": round(tot_us / 1e3, 3), "tflops": round(tot_fl / tot_us * 1e3, 1),
-                                             "mfma_frac": round(tot_fl / tot_us * 1e3 / PEAK, 4)}}, indent=1))
+print(json.dumps({"batch": B, "layers": "6+6", "dropout": 0.1, "launch": "hipGraph replay", "path": "engine.self_attention_block / cross_attention_block / cross_kv_projections",
+                  "cases": rows, "all_attention_per_step": {"ms": round(tot_us / 1e3, 3), "tflops": round(tot_fl / tot_us * 1e3, 1),
+                                                            "mfma_frac": round(tot_fl / tot_us * 1e3 / PEAK, 4)}}, indent=1))

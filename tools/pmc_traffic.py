@@ -24,6 +24,11 @@ for name, (n, f_kib) in fetch.items():
     w_kib = write.get(name, (0, 0.0))[1]
     res[name] = {"dispatches": n, "fetch_kib_raw_mean": round(f_kib, 1), "write_kib_raw_mean": round(w_kib, 1),
                  "hbm_bytes_per_launch": int(2 * f_kib * 1024 + w_kib * 1024)}
-json.dump({"note": "per-launch means over an eager (no-graph) run of bench.py; hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), "
+import subprocess
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    commit = None
+json.dump({"commit": sys.argv[4] if len(sys.argv) > 4 else commit, "note": "per-launch means over an eager (no-graph) run of bench.py; hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), "
                    "FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md", "kernels": res}, open(sys.argv[3], "w"), indent=1)
 print("wrote", sys.argv[3], len(res), "kernels")
