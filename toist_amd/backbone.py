@@ -234,7 +234,7 @@ class BackboneBase(nn.Module):
             return finals, extra
 
         return functions.run_program(wrapped, named, [images], cache=self._cache, training=self.training, transforms=self._transforms(),
-                                     group_wgrads=True)
+                                     group_wgrads=True, store_once=lambda n, t: t.dim() == 4)     # every conv weight: one weight-gradient GEMM each
 
     # ---- reference-compatible API ------------------------------------------------------------------
     def forward(self, tensor_list: NestedTensor):

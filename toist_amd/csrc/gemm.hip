@@ -1018,15 +1018,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const ReduceBa
     }
 }
 
-// Workgroups of a persistent launch (TOIST_PERSIST_WGS; default 0 = one workgroup per tile).  Measured on MI355X (round 2,
-// tools/dbg/gemm_persist.py, profiles/r02_gemm_persistent_sweep.txt): in a back-to-back microbenchmark 768 workgroups (3 per CU)
-// take 9-16 % off the output-heavy K <= 256 GEMMs (12800x1024x256: 34.0 -> 29.9 us; 204800x256x64: 88.8 -> 76.0 us) by removing
-// most of the dispatch cost, but inside the training step -- cold operands, HBM-bound epilogues -- the same setting is neutral
-// (439 vs 441 images/s on the same box; 1024: -1.4 %, 1536: +0.4 %), so it stays off.
+// Workgroups of a persistent launch (TOIST_PERSIST_WGS; 0 = one workgroup per tile everywhere).  Applied (launch_variant) only to the
+// dispatch-bound launches: row-major A, K <= 256, >= 2048 tiles.  Measured on MI355X (round 2, tools/dbg/gemm_persist.py,
+// profiles/r02_gemm_persistent_sweep.txt): 768 workgroups (3 per CU) take 9-16 % off such launches in a back-to-back microbenchmark
+// (12800x1024x256: 34.0 -> 29.9 us; 204800x256x64: 88.8 -> 76.0 us); the whole training step gains 1.3 % (435 -> 441 images/s, same
+// box).  Applied to EVERY launch the same cap is neutral to negative (1024: -1.4 %).
 static long long persist_wgs() {
     static const long long v = [] {
         const char* e = getenv("TOIST_PERSIST_WGS");
-        const long long n = e ? atoll(e) : 0;
+        const long long n = e ? atoll(e) : 768;
         return n <= 0 ? (1LL << 40) : n;
     }();
     return v;
@@ -1037,9 +1037,9 @@ static int launch_variant(const toist_gemm& d, int ring, hipStream_t st) {
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     dim3 grid((tiles + 7) & ~7, 1, d.batch * d.split_k);   // 1-D over tiles (XCD-aware order in the kernel), padded to 8
     constexpr int stage = (BM + BN) * BK * 2;
-    {   // persistent cap: at most ~PERSIST_WGS workgroups over all of x and z (what 256 CUs hold at once), the rest by striding
-        const long long z = (long long)d.batch * d.split_k;
-        long long cap = (persist_wgs() / (z > 0 ? z : 1)) & ~7LL;
+    // persistent cap (experiments, off by default): the dispatch-bound launches only -- row-major A, short reduction, thousands of tiles
+    if (AK == TOIST_A_ROWK && d.K <= 256 && d.batch * d.split_k == 1 && tiles >= 2048) {
+        long long cap = persist_wgs() & ~7LL;
         if (cap < 8) cap = 8;
         if ((long long)grid.x > cap) grid.x = (unsigned)cap;
     }

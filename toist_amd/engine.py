@@ -83,6 +83,7 @@ class Tape:
         self.drop_p = drop_p if training else 0.0
         self._seed = seed * 1000003 + 12345
         self.keep = []  # tensors that must outlive the forward (API outputs etc.)
+        self.fresh_views = []   # ParamViews with store-once gradient slots (ParamSet)
 
     def next_seed(self):
         self._seed += 7919
@@ -91,22 +92,29 @@ class Tape:
     def record(self, fn):
         self.steps.append(fn)
 
-    def conv_wgrad(self, dy, x, w_shape, out, rscale, stride=1, pad=0):
+    def conv_wgrad(self, dy, x, w_shape, out, rscale, stride=1, pad=0, view=None):
         """Weight gradient of a convolution: now, or (programs with group_wgrads) collected with the other convolutions of the same
-        shape and launched grouped when the program's backward ends.  The operands are never written again by this backward."""
+        shape and launched grouped when the program's backward ends.  The operands are never written again by this backward.
+        view = the ParamView whose gradient slot `out` is: a store-once slot (view.fresh) is overwritten, not accumulated into."""
+        store = view is not None and view.fresh and not view.written
+        if view is not None:
+            view.mark_written()
         if self.groups is None:
-            ops.conv2d_wgrad(dy, x, w_shape, stride=stride, pad=pad, out=out, rscale=rscale, defer=True)
+            ops.conv2d_wgrad(dy, x, w_shape, stride=stride, pad=pad, out=out, rscale=rscale, defer=True, accumulate=not store)
         else:
-            self.groups.setdefault((tuple(dy.shape), tuple(x.shape), tuple(w_shape), stride, pad), []).append((dy, x, out, rscale))
+            self.groups.setdefault((tuple(dy.shape), tuple(x.shape), tuple(w_shape), stride, pad, store), []).append((dy, x, out, rscale))
 
     def linear_wgrad(self, dy, x, W, b, owned=True):
         """Weight / bias gradient of an nn.Linear: now, or grouped with the same-shape layers of the program.  `owned` = no later step
-        of this backward writes into dy (a gradient that doubles as a residual's accumulator is not owned and is consumed at once)."""
+        of this backward writes into dy (a gradient that doubles as a residual's accumulator is not owned and is consumed at once).
+        A store-once slot (W.fresh, first launch on it) is overwritten instead of accumulated into; bias slots always accumulate."""
         bias_out = b.g if b is not None else None
+        store = W.fresh and not W.written
+        W.mark_written()
         if self.groups is None or not owned:
-            ops.linear_wgrad(dy, x, out=W.g, bias_out=bias_out, defer=True)
+            ops.linear_wgrad(dy, x, out=W.g, bias_out=bias_out, defer=True, accumulate=not store)
         else:
-            key = ("linear", tuple(dy.shape), dy.stride(0), tuple(x.shape), x.stride(0), W.g.stride(0), bias_out is None)
+            key = ("linear", tuple(dy.shape), dy.stride(0), tuple(x.shape), x.stride(0), W.g.stride(0), bias_out is None, store)
             self.groups.setdefault(key, []).append((dy, x, W.g, bias_out))
 
     def backward(self):
@@ -116,11 +124,14 @@ class Tape:
         if self.groups:
             for key, items in self.groups.items():
                 if key[0] == "linear":
-                    ops.linear_wgrad_group(items)
+                    ops.linear_wgrad_group(items, accumulate=not key[-1])
                 else:
-                    ops.conv2d_wgrad_group(items, key[2], stride=key[3], pad=key[4])
+                    ops.conv2d_wgrad_group(items, key[2], stride=key[3], pad=key[4], accumulate=not key[5])
             self.groups = {}
         k.flush_reductions()   # deferred split-K partials of this program -> parameter gradients
+        for v in self.fresh_views:      # a store-once slot no weight-gradient launch reached (its branch received no gradient): zero, as before
+            if not v.written:
+                v.g.zero_()
 
 
 # ---- bf16 compute copies of the fp32 master weights ------------------------------------------------------------
@@ -209,23 +220,34 @@ def named_cache(owner, key, build):
 class ParamView:
     """bf16 compute copy + fp32 gradient slot of one nn.Parameter (or a row slice of one)."""
 
-    __slots__ = ("w", "g", "f32")
+    __slots__ = ("w", "g", "f32", "fresh", "written", "parent")
 
-    def __init__(self, w_bf16, grad_f32, f32=None):
+    def __init__(self, w_bf16, grad_f32, f32=None, fresh=False, parent=None):
         self.w = w_bf16    # bf16 tensor used by the kernels (None for fp32-only params)
-        self.g = grad_f32  # fp32 gradient accumulator (zero-initialised) or None when frozen
+        self.g = grad_f32  # fp32 gradient slot: zero-initialised accumulator, or (fresh) uninitialised memory a weight-gradient GEMM overwrites
         self.f32 = f32     # fp32 master values for params consumed in fp32 (biases, LN affine)
+        self.fresh = fresh         # store-once gradient (see ParamSet): the first weight-gradient launch stores instead of accumulating
+        self.written = False       # a weight-gradient launch has covered (a row range of) this slot during the current backward
+        self.parent = parent
 
     def rows(self, a, b):
         """Row slice [a:b) of a packed parameter (e.g. the q / k / v blocks of in_proj_weight)."""
         return ParamView(None if self.w is None else self.w[a:b], None if self.g is None else self.g[a:b],
-                         None if self.f32 is None else self.f32[a:b])
+                         None if self.f32 is None else self.f32[a:b], fresh=self.fresh, parent=self)
+
+    def mark_written(self):
+        v = self
+        while v is not None:
+            v.written = True
+            v = v.parent
 
 
 # Opt-in for training loops that never keep a parameter gradient beyond optimizer.zero_grad(): the flat gradient buffer of
 # a program (and its ~600 per-parameter views) is then reused from step to step instead of being re-sliced every forward.
 # Off by default: with it, a gradient tensor stashed by the caller would be overwritten by the next forward pass.
 REUSE_GRAD_BUFFERS = False
+STORE_ONCE = True      # weight gradients of nn.Linear / nn.Conv2d overwrite their (un-zeroed) slots instead of accumulating into zeroed ones
+POISON_FRESH = False   # tests: fill the store-once slots with NaN before every backward
 
 
 class ParamSet:
@@ -234,9 +256,15 @@ class ParamSet:
     `named` is an ordered {name: tensor(fp32 master)}; weights (dim >= 2) get a bf16 copy, vectors
     are used in fp32 directly.  grads() returns gradients in the same order (None for frozen)."""
 
-    def __init__(self, named, trainable, need_grads, bf16_cache=None, transforms=None):
+    def __init__(self, named, trainable, need_grads, bf16_cache=None, transforms=None, store_once=None):
+        """store_once(name, tensor) -> True marks a parameter whose gradient is produced by exactly one weight-gradient GEMM per
+        backward (every nn.Linear / nn.Conv2d weight of the hot path): its slot lives in the tail of the flat buffer, is NOT zeroed
+        -- the GEMM overwrites it (Tape.linear_wgrad / conv_wgrad, accumulate=False) -- which removes 0.74 GB of zero-fill writes and
+        as many read-modify-write reads per step.  Everything else (biases, LayerNorm and embedding gradients: atomics, scatter-adds)
+        sits in the zeroed head of the buffer.  A store-once slot no launch reached is zeroed by Tape.backward."""
         self.names = list(named.keys())
         self.views = {}
+        self.zero_elems = 0
         # The slicing of the flat gradient buffer into ~600 per-parameter views costs ~4 ms of host time per step; with
         # REUSE_GRAD_BUFFERS the layout is memoised in the program's cache and reused (buffer zeroed in place) as long as the
         # parameters are the same objects and no parameter's .grad still aliases the buffer (gradient accumulation gets a
@@ -244,43 +272,67 @@ class ParamSet:
         memo = bf16_cache.get("__layout__") if bf16_cache is not None else None
         params = list(named.values())
         sig = (need_grads, len(params), tuple(trainable.get(n, False) for n in self.names), id(params[0]) if params else 0,
-               params[0].data_ptr() if params else 0, id(params[-1]) if params else 0, params[-1].data_ptr() if params else 0)
+               params[0].data_ptr() if params else 0, id(params[-1]) if params else 0, params[-1].data_ptr() if params else 0,
+               STORE_ONCE and store_once is not None)
         if REUSE_GRAD_BUFFERS and memo is not None and memo["sig"] == sig and need_grads and memo["flat"] is not None:
             lo, hi = memo["flat"].data_ptr(), memo["flat"].data_ptr() + memo["flat"].numel() * 4
             if not any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in params):
                 self.flat = memo["flat"]
-                self.flat.zero_()
+                self.zero_elems = memo["zero_elems"]
+                self._clear()
                 for n, t in named.items():
                     pv = memo["views"][n]
+                    pv.written = False
                     if t.dim() >= 2:
                         pv.w = compute_copy(t, (transforms or {}).get(n) or _cast_bf16, bf16_cache, n)
                     self.views[n] = pv
                 return
+        fresh_names = set()
+        if need_grads and STORE_ONCE and store_once is not None:
+            fresh_names = {n for n in self.names if trainable.get(n, False) and store_once(n, named[n])}
+        pad = lambda t: (t.numel() + 63) // 64 * 64
         total = 0
         if need_grads:
-            for n in self.names:
-                if trainable.get(n, False):
-                    total += (named[n].numel() + 63) // 64 * 64
+            self.zero_elems = sum(pad(named[n]) for n in self.names if trainable.get(n, False) and n not in fresh_names)
+            total = self.zero_elems + sum(pad(named[n]) for n in fresh_names)
         dev = next(iter(named.values())).device if named else None
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev) if total else None
-        off = 0
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev) if total else None
+        self._clear()
+        off_zero, off_fresh = 0, self.zero_elems
         for n in self.names:
             t = named[n]
             g = None
             if need_grads and trainable.get(n, False):
+                off = off_fresh if n in fresh_names else off_zero
                 g = self.flat[off:off + t.numel()].view(t.shape)
                 if t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last):
                     # channels_last conv weights (physically KRSC): the gradient keeps the parameter's layout
                     O, I, R, S = t.shape
                     g = self.flat[off:off + t.numel()].view(O, R, S, I).permute(0, 3, 1, 2)
-                off += (t.numel() + 63) // 64 * 64
+                if n in fresh_names:
+                    off_fresh += pad(t)
+                else:
+                    off_zero += pad(t)
             wb = None
             if t.dim() >= 2:
                 make = (transforms or {}).get(n) or _cast_bf16
                 wb = compute_copy(t, make, bf16_cache, n)
-            self.views[n] = ParamView(wb, g, t.detach())
+            self.views[n] = ParamView(wb, g, t.detach(), fresh=n in fresh_names)
         if REUSE_GRAD_BUFFERS and bf16_cache is not None and need_grads and (memo is None or memo["sig"] != sig):
-            bf16_cache["__layout__"] = {"sig": sig, "flat": self.flat, "views": dict(self.views)}
+            bf16_cache["__layout__"] = {"sig": sig, "flat": self.flat, "views": dict(self.views), "zero_elems": self.zero_elems}
+
+    def _clear(self):
+        """zero the accumulating head of the flat buffer; the store-once tail is left as it is (POISON_FRESH: NaN, so that a slot
+        nothing wrote shows up in the tests)"""
+        if self.flat is None:
+            return
+        if self.zero_elems:
+            self.flat[:self.zero_elems].zero_()
+        if POISON_FRESH and self.zero_elems < self.flat.numel():
+            self.flat[self.zero_elems:].fill_(float("nan"))
+
+    def fresh_views(self):
+        return [v for v in self.views.values() if v.fresh and v.g is not None]
 
     def __getitem__(self, name):
         return self.views[name]
@@ -810,13 +862,13 @@ def bottleneck(tape, x, W, bn, stride, has_down, train):
         g3 = out.take_grad()  # w.r.t. the pre-ReLU sum (masked by the consumer)
         if g3 is None:
             return
-        tape.conv_wgrad(g3, a2, w3.shape, krsc(W["conv3"].g), s3)
+        tape.conv_wgrad(g3, a2, w3.shape, krsc(W["conv3"].g), s3, view=W["conv3"])
         g2 = ops.conv2d_dgrad(g3, w3, a2.shape[1:3], act=k.ACT_MASK_POS, aux=a2)
-        tape.conv_wgrad(g2, a1, w2.shape, krsc(W["conv2"].g), s2, stride=stride, pad=1)
+        tape.conv_wgrad(g2, a1, w2.shape, krsc(W["conv2"].g), s2, stride=stride, pad=1, view=W["conv2"])
         g1 = ops.conv2d_dgrad(g2, w2, (H, Wd), stride=stride, pad=1, act=k.ACT_MASK_POS, aux=a1)
-        tape.conv_wgrad(g1, x.data, w1.shape, krsc(W["conv1"].g), s1)
+        tape.conv_wgrad(g1, x.data, w1.shape, krsc(W["conv1"].g), s1, view=W["conv1"])
         if has_down:
-            tape.conv_wgrad(g3, x.data, wd.shape, krsc(W["down"].g), sd, stride=stride)
+            tape.conv_wgrad(g3, x.data, wd.shape, krsc(W["down"].g), sd, stride=stride, view=W["down"])
         if not x.needs_grad:
             return
         prev = x.take_grad()

@@ -50,10 +50,12 @@ class _TapeFn(torch.autograd.Function):
         ctx.via_autograd = tape_kw.pop('via_autograd')
         need = tape_kw.pop('need_grads')  # grad mode is off inside Function.forward: decided by the caller
         transforms = tape_kw.pop('transforms')
+        store_once = tape_kw.pop('store_once')
         named = dict(zip(names, params))
         trainable = {n: p.requires_grad for n, p in named.items()}
-        ps = engine.ParamSet(named, trainable, need_grads=need, bf16_cache=cache, transforms=transforms)
+        ps = engine.ParamSet(named, trainable, need_grads=need, bf16_cache=cache, transforms=transforms, store_once=store_once)
         tape = engine.Tape(**tape_kw)
+        tape.fresh_views = ps.fresh_views() if need else []
         in_vars = [None if t is None else engine.Var(t, needs_grad=(need and t.requires_grad and t.is_floating_point()))
                    for t in inputs]
         out_vars, extra = body(tape, ps, *in_vars)
@@ -113,11 +115,11 @@ class _TapeFn(torch.autograd.Function):
         return (None, None, None, None, None, *in_grads, *([None] * n_par))
 
 
-def run_program(body, named_params, inputs, cache=None, training=False, drop_p=0.0, seed=0, transforms=None, group_wgrads=False):
+def run_program(body, named_params, inputs, cache=None, training=False, drop_p=0.0, seed=0, transforms=None, group_wgrads=False, store_once=None):
     """body(tape, ps, *input_vars) -> (list_of_output_vars, extra).  Returns (outputs_tuple)."""
     names = tuple(named_params.keys())
     params = tuple(named_params.values())
     need = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (*inputs, *params))
     tape_kw = dict(training=training, drop_p=drop_p, seed=seed, need_grads=need, transforms=transforms, rejoin=REJOIN, group_wgrads=group_wgrads,
-                   via_autograd=need and _via_autograd())
+                   via_autograd=need and _via_autograd(), store_once=store_once)
     return _TapeFn.apply(body, names, cache, len(inputs), tape_kw, *inputs, *params)

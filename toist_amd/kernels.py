@@ -453,7 +453,7 @@ def conv3x3_small(dgrad, src, w, shift, res, out, n_img, H, W, c_src, c_out):
                "toist_conv3x3_small")
 
 
-def wgrad3x3_small(dy, x, out, defer=False):
+def wgrad3x3_small(dy, x, out, defer=False, accumulate=True):
     """out [Co,3,3,C] (f32) += weight gradient of a 3x3 / s1 / p1 convolution with C in {16, 32}, Co in {8, 16} (csrc/smallconv.hip):
     per-workgroup partials into the split-K arena, folded by the batched reduction (queued when defer=True)."""
     n_img, H, W, C = x.shape
@@ -465,7 +465,7 @@ def wgrad3x3_small(dy, x, out, defer=False):
     key = (x.device, _raw_stream())
     if any(it[0].out == out.data_ptr() for it in _PENDING.get(key, ())):
         flush_reductions()
-    rd = _lib.ReduceDesc(ws.data_ptr(), out.data_ptr(), None, blocks, Co, 9 * C, 9 * C, 1.0, 1)
+    rd = _lib.ReduceDesc(ws.data_ptr(), out.data_ptr(), None, blocks, Co, 9 * C, 9 * C, 1.0, 1 if accumulate else 0)
     _PENDING.setdefault(key, []).append((rd, (out,)))
     if not defer:
         flush_reductions()

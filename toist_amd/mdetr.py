@@ -61,7 +61,7 @@ class MDETR(nn.Module):
         def prog(tape, ps, x):
             W, b = ps["weight"], ps["bias"]
             d = W.w.shape[0]
-            Wv = engine.ParamView(W.w.reshape(d, C), None if W.g is None else engine.krsc(W.g).reshape(d, C), None)
+            Wv = engine.ParamView(W.w.reshape(d, C), None if W.g is None else engine.krsc(W.g).reshape(d, C), None, fresh=W.fresh, parent=W)
             xin = engine.Var(x.data.view(B * h * w, C), needs_grad=x.needs_grad)
 
             def bwd():  # recorded first -> runs after the chain's backward
@@ -73,7 +73,7 @@ class MDETR(nn.Module):
             y = engine.linear_chain(tape, xin, [(Wv, b, k.ACT_NONE, False)], in_relu_mask=True)
             return [y], None
 
-        (tok,) = functions.run_program(prog, named, [c5], cache=self._cache_proj, training=self.training)
+        (tok,) = functions.run_program(prog, named, [c5], cache=self._cache_proj, training=self.training, store_once=lambda n, t: t.dim() == 4)
         return tok
 
     def _text_tokens(self, memory_cache, B):
@@ -169,7 +169,9 @@ class MDETR(nn.Module):
                 outs.append(ptxt)
             return outs, None
 
-        res = functions.run_program(prog, named, [stack] + ([text_tok] if want_proj else []), cache=self._cache_heads, training=self.training)
+        once = {"class_embed.weight", "bbox_embed.layers.0.weight", "bbox_embed.layers.1.weight", "cimg.weight", "ctxt.weight"}   # not the padded last box layer
+        res = functions.run_program(prog, named, [stack] + ([text_tok] if want_proj else []), cache=self._cache_heads, training=self.training,
+                                    store_once=lambda n, t: n in once)
         K = res[0].shape[-1]
         logits = res[0].view(L, B, Q, K)
         boxes = res[1][:, :4].reshape(L, B, Q, 4)

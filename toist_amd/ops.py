@@ -55,9 +55,9 @@ def linear_dgrad(dy, w, *, out=None, res=None, act=k.ACT_NONE, aux=None, alpha=1
     return out
 
 
-def linear_wgrad(dy, x, *, out=None, alpha=1.0, flags=0, split_k=None, bias_out=None, defer=False):
-    """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]; `out` must be zero-initialised or hold a running sum.
-    bias_out (f32 [N]) additionally receives += sum_m dy[m, :] from the same kernel."""
+def linear_wgrad(dy, x, *, out=None, alpha=1.0, flags=0, split_k=None, bias_out=None, defer=False, accumulate=True):
+    """dw[N,K] (f32) += dy[M,N]^T @ x[M,K]; `out` must be zero-initialised or hold a running sum -- or, with accumulate=False, is
+    simply overwritten (no zero fill, no read-modify-write).  bias_out (f32 [N]) additionally receives += sum_m dy[m, :]."""
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M
@@ -67,11 +67,11 @@ def linear_wgrad(dy, x, *, out=None, alpha=1.0, flags=0, split_k=None, bias_out=
         tiles = ((N + 63) // 64) * ((K + 63) // 64)
         split_k = _split_k_for(tiles, (M + 63) // 64)
     k.gemm(N, K, M, k.A_KROW, k.operand(dy, _ld(dy)), k.B_KROW, k.operand(x, _ld(x)), out, _ld(out), alpha=alpha,
-           accumulate=True, split_k=split_k, flags=flags, flops=2 * M * N * K, a_colsum=bias_out, defer_reduce=defer)
+           accumulate=accumulate, split_k=split_k, flags=flags, flops=2 * M * N * K, a_colsum=bias_out, defer_reduce=defer)
     return out
 
 
-def linear_wgrad_group(items):
+def linear_wgrad_group(items, accumulate=True):
     """Weight (and bias) gradients of several nn.Linear layers of one shape -- the six layers of an encoder / decoder stack -- as one
     grouped launch: items = [(dy, x, out, bias_out)].  Separately each is a handful of tiles with a deep reduction (split-K + fold)."""
     dy0, x0, out0, b0 = items[0]
@@ -79,7 +79,7 @@ def linear_wgrad_group(items):
     K = x0.shape[1]
     if len(items) < 2 or len(items) > k.GROUP_MAX or any((it[3] is None) != (b0 is None) for it in items):
         for dy, x, out, bo in items:
-            linear_wgrad(dy, x, out=out, bias_out=bo, defer=True)
+            linear_wgrad(dy, x, out=out, bias_out=bo, defer=True, accumulate=accumulate)
         return
     rows = []
     for dy, x, out, bo in items:
@@ -88,7 +88,7 @@ def linear_wgrad_group(items):
         assert c_off % 4 == 0 and b_off % 4 == 0 and out.dtype == torch.float32
         rows.append([dy.data_ptr(), x.data_ptr(), c_off // 4, 0, b_off // 4])
     table = k.group_table(rows, dy0.device)
-    k.gemm(N, K, M, k.A_KROW, k.operand(dy0, _ld(dy0)), k.B_KROW, k.operand(x0, _ld(x0)), out0, _ld(out0), accumulate=True, split_k=1,
+    k.gemm(N, K, M, k.A_KROW, k.operand(dy0, _ld(dy0)), k.B_KROW, k.operand(x0, _ld(x0)), out0, _ld(out0), accumulate=accumulate, split_k=1,
            flops=2 * M * N * K * len(items), a_colsum=b0, batch=len(items), group=table)
 
 
@@ -173,7 +173,7 @@ def conv2d_dgrad(dy, w, in_hw, *, stride=1, pad=0, dil=1, scale=None, res=None, 
     return out
 
 
-def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, split_k=None, rscale=None, defer=False):
+def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, split_k=None, rscale=None, defer=False, accumulate=True):
     """dw [Co,R,S,C] (f32, accumulated) = sum over output pixels of dy (x) gathered x."""
     Nb, OH, OW, Co = dy.shape
     _, H, W, C = x.shape
@@ -183,7 +183,7 @@ def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, s
         out = torch.zeros(Co, R, S, C, dtype=torch.float32, device=dy.device)
     if (OH, OW) == (H, W) and R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and C in (16, 32) and Co in (8, 16) and rscale is None \
             and split_k is None and Nb * H * W >= (1 << 16) and out.is_contiguous():
-        k.wgrad3x3_small(dy, x, out, defer=defer)     # few-channel stage: direct kernel + batched fold
+        k.wgrad3x3_small(dy, x, out, defer=defer, accumulate=accumulate)     # few-channel stage: direct kernel + batched fold
         return out
     P = Nb * OH * OW
     Nn = R * S * C
@@ -195,7 +195,7 @@ def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, s
         b_kind, b = k.B_KROW, k.operand(x, C)
     else:
         b_kind, b = k.B_CONVX, k.operand(x, 0, geom=k.ConvGeom(H, W, C, OH, OW, R, S, stride, pad, dil))
-    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out, Nn, accumulate=True, split_k=split_k, flags=flags, rscale=rscale,
+    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out, Nn, accumulate=accumulate, split_k=split_k, flags=flags, rscale=rscale,
            flops=2 * P * Co * Nn, defer_reduce=defer)
     return out
 
@@ -205,7 +205,7 @@ GROUP_TILE = int(_os.environ.get("TOIST_GROUP_TILE", "0"))   # tile code of grou
 GROUP_MIN_TILES = 512   # below this many 64x64 output tiles in total the problems stay separate (they need split-K)
 
 
-def conv2d_wgrad_group(items, w_shape, *, stride=1, pad=0, dil=1):
+def conv2d_wgrad_group(items, w_shape, *, stride=1, pad=0, dil=1, accumulate=True):
     """Weight gradients of several convolutions of ONE shape (the identical residual blocks of a stage) as one grouped GEMM
     launch: items = [(dy, x, out, rscale)], out f32 [Co,R,S,C] accumulated.  Separately each is 64-144 output tiles with a
     12800-51200 deep reduction, i.e. split along K plus a fold pass; together they fill the chip unsplit."""
@@ -217,7 +217,7 @@ def conv2d_wgrad_group(items, w_shape, *, stride=1, pad=0, dil=1):
     tiles = ((Co + 63) // 64) * ((Nn + 63) // 64) * len(items)
     if len(items) < 2 or len(items) > k.GROUP_MAX or any((it[3] is None) != (rs0 is None) for it in items):
         for dy, x, out, rs in items:
-            conv2d_wgrad(dy, x, w_shape, stride=stride, pad=pad, dil=dil, out=out, rscale=rs, defer=True)
+            conv2d_wgrad(dy, x, w_shape, stride=stride, pad=pad, dil=dil, out=out, rscale=rs, defer=True, accumulate=accumulate)
         return
     # too few tiles to fill the chip even together: the group is also split along K (partials folded by the batched reduction)
     split_k = _split_k_for(tiles, (P + 63) // 64) if tiles < GROUP_MIN_TILES else 1
@@ -240,7 +240,7 @@ def conv2d_wgrad_group(items, w_shape, *, stride=1, pad=0, dil=1):
         big = 129 if R * S > 1 else 130
         n_big = ((Co + 127) // 128) * ((Nn + (127 if big == 129 else 63)) // (128 if big == 129 else 64)) * len(items)
         tile = big if n_big >= 256 else 0
-    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out0, Nn, accumulate=True, split_k=split_k, rscale=rs0, batch=len(items), tile=tile,
+    k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out0, Nn, accumulate=accumulate, split_k=split_k, rscale=rs0, batch=len(items), tile=tile,
            flops=2 * P * Co * Nn * len(items), group=table, group_out=[(it[2], it[3]) for it in items])
 
 

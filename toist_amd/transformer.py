@@ -306,7 +306,8 @@ class Transformer(nn.Module):
             return [r], None
 
         (out,) = functions.run_program(prog, named, [], cache=self._cache_text, training=self.training, drop_p=cfg.hidden_dropout_prob,
-                                       seed=self._next_seed(), group_wgrads=True, transforms=transforms)
+                                       seed=self._next_seed(), group_wgrads=True, transforms=transforms,
+                                       store_once=lambda n, t: t.dim() == 2 and "embeddings" not in n)
         return out, key_pad
 
     # ---- encoder ----------------------------------------------------------------------------------
@@ -351,7 +352,7 @@ class Transformer(nn.Module):
             return [x], None
 
         (out,) = functions.run_program(prog, named, [tokens], cache=self._cache_enc, training=self.training, drop_p=self.dropout,
-                                       seed=self._next_seed(), group_wgrads=True)
+                                       seed=self._next_seed(), group_wgrads=True, store_once=lambda n, t: t.dim() == 2)
         return out
 
     # ---- decoder ----------------------------------------------------------------------------------
@@ -482,7 +483,7 @@ class Transformer(nn.Module):
             return [hs], None
 
         (out,) = functions.run_program(prog, named, [memory, query_embed], cache=self._cache_dec, training=self.training,
-                                       drop_p=self.dropout, seed=self._next_seed(), group_wgrads=True)
+                                       drop_p=self.dropout, seed=self._next_seed(), group_wgrads=True, store_once=lambda n, t: t.dim() == 2)
         return out
 
     # ---- reference-compatible API -------------------------------------------------------------------
