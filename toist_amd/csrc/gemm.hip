@@ -452,7 +452,7 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
 
 // One output tile (tile `tl` of the launch's padded, XCD-striped tile list) of one (batch, k-slice) problem.
 template <int BM, int BN, int BK, int AK, int BKD, int NS>
-__device__ __forceinline__ void gemm_tile(const toist_gemm& p, const int tl, bf16_t* const smem) {
+__device__ __forceinline__ void gemm_tile(const toist_gemm& p, const int tl, bf16_t* const smem, const int z, const bool direct) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int ACH = BM * BK / 8 / 256, BCH = BN * BK / 8 / 256;  // 1 KiB DMA pieces per wave per tile
     constexpr bool A_KM = (AK == TOIST_A_KROW);    // A staged k-major
@@ -478,12 +478,11 @@ __device__ __forceinline__ void gemm_tile(const toist_gemm& p, const int tl, bf1
     const int nt_n = (p.N + BN - 1) / BN;
     const int nt_m = (p.M + BM - 1) / BM;
     const int tiles = nt_m * nt_n;
-    const int tile_id = (tl & 7) * ((tiles + 7) >> 3) + (tl >> 3);
+    const int tile_id = direct ? tl : (tl & 7) * ((tiles + 7) >> 3) + (tl >> 3);
     if (tile_id >= tiles) return;            // the tile list is padded to a multiple of 8
     int tile_m, tile_n;
     tile_order(tile_id, nt_m, nt_n, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int z = blockIdx.z;
     const int bz = z / p.split_k, ksl = z - bz * p.split_k;
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
     const toist_operand oa = p.a, ob = p.b;
@@ -732,9 +731,19 @@ template <int BM, int BN, int BK, int AK, int BKD, int NS>
 __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     constexpr int STAGE = (BM + BN) * BK;
     __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
-    const int tiles8 = ((((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN)) + 7) & ~7;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    if (p.flags & 1024) {
+        // Grouped launch (flag set by launch_variant): whole problems are pinned to XCDs.  Workgroup L runs on XCD L % 8 (dispatch order); XCD x walks the problems
+        // x, x + 8, ... one after the other, all tiles of a problem side by side on that XCD's CUs, so a problem's operands are pulled
+        // into ONE L2.  (Striping every problem's tiles over all eight XCDs, as for a single problem, made each XCD stream every
+        // problem: the 22 grouped layer-3 3x3 weight gradients fetched 9 x their operands -- profiles/r02_pmc_fetch_summary.txt.)
+        const int L = (int)blockIdx.x, q = (L >> 3) / tiles, t = (L >> 3) - q * tiles, z = (L & 7) + 8 * q;
+        if (z < p.batch * p.split_k) gemm_tile<BM, BN, BK, AK, BKD, NS>(p, t, smem, z, true);
+        return;
+    }
+    const int tiles8 = (tiles + 7) & ~7;
     for (int tl = (int)blockIdx.x; tl < tiles8; tl += (int)gridDim.x) {
-        gemm_tile<BM, BN, BK, AK, BKD, NS>(p, tl, smem);
+        gemm_tile<BM, BN, BK, AK, BKD, NS>(p, tl, smem, (int)blockIdx.z, false);
         if (tl + (int)gridDim.x < tiles8) __syncthreads();       // the next tile's DMA reuses the LDS the epilogue bands lived in
     }
 }
@@ -1032,10 +1041,25 @@ static long long persist_wgs() {
     return v;
 }
 
+// Measured and rejected (round 2, off unless TOIST_GROUP_XCD=1): pinning the problems of a grouped launch to XCDs.  FETCH_SIZE shows the
+// grouped layer-3 weight gradients pulling 2-9 x their operand bytes into L2 because every problem's tiles are striped over all eight
+// XCDs -- but those re-reads are served by the 256 MB Infinity Cache, not by HBM, and 22 problems on 8 XCDs leave two XCDs idle a
+// third of the time: 445.6 vs 449.0 images/s on the same box.
+static bool xcd_pinned_groups() {
+    static const bool v = [] { const char* e = getenv("TOIST_GROUP_XCD"); return e != nullptr && atoi(e) != 0; }();
+    return v;
+}
+
 template <int BM, int BN, int BK, int AK, int BKD>
 static int launch_variant(const toist_gemm& d, int ring, hipStream_t st) {
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     dim3 grid((tiles + 7) & ~7, 1, d.batch * d.split_k);   // 1-D over tiles (XCD-aware order in the kernel), padded to 8
+    toist_gemm dd = d;
+    if (d.group != nullptr && xcd_pinned_groups()) {       // grouped: problems pinned to XCDs (gemm_kernel), 8 * ceil(Z / 8) * tiles workgroups
+        const int Z = d.batch * d.split_k;
+        grid = dim3(8u * (unsigned)((Z + 7) / 8) * (unsigned)tiles, 1, 1);
+        dd.flags |= 1024;
+    }
     constexpr int stage = (BM + BN) * BK * 2;
     // persistent cap (experiments, off by default): the dispatch-bound launches only -- row-major A, short reduction, thousands of tiles
     if (AK == TOIST_A_ROWK && d.K <= 256 && d.batch * d.split_k == 1 && tiles >= 2048) {
@@ -1060,11 +1084,11 @@ static int launch_variant(const toist_gemm& d, int ring, hipStream_t st) {
     if (small) ring = 4;
     else if (!t65) ring = 2;
     else if (ring != 2) ring = 3;
-    if constexpr (small) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 4>), grid, dim3(256), 0, st, d);
+    if constexpr (small) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 4>), grid, dim3(256), 0, st, dd);
     else if constexpr (t65) {
-        if (ring == 3) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 3>), grid, dim3(256), 0, st, d);
-        else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 2>), grid, dim3(256), 0, st, d);
-    } else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 2>), grid, dim3(256), 0, st, d);
+        if (ring == 3) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 3>), grid, dim3(256), 0, st, dd);
+        else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 2>), grid, dim3(256), 0, st, dd);
+    } else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 2>), grid, dim3(256), 0, st, dd);
     return TOIST_OK;
 }
 

@@ -246,7 +246,7 @@ class ParamView:
 # a program (and its ~600 per-parameter views) is then reused from step to step instead of being re-sliced every forward.
 # Off by default: with it, a gradient tensor stashed by the caller would be overwritten by the next forward pass.
 REUSE_GRAD_BUFFERS = False
-STORE_ONCE = True      # weight gradients of nn.Linear / nn.Conv2d overwrite their (un-zeroed) slots instead of accumulating into zeroed ones
+STORE_ONCE = __import__('os').environ.get('TOIST_STORE_ONCE', '1') != '0'      # weight gradients of nn.Linear / nn.Conv2d overwrite their (un-zeroed) slots instead of accumulating into zeroed ones
 POISON_FRESH = False   # tests: fill the store-once slots with NaN before every backward
 
 
