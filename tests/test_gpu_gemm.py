@@ -117,6 +117,34 @@ def test_conv_fwd_bwd(dev, C, Co, R, stride, pad, H, W):
         _close(dw, _nhwc(wr.grad), Nb * OH * OW, f"conv wgrad flags={flags}", rtol=3e-3, atol_unit=2e-4)
 
 
+@pytest.mark.parametrize("C,Co,H,W", [(64, 128, 21, 20), (128, 64, 16, 33), (64, 64, 1, 9), (64, 64, 7, 1), (256, 256, 40, 40)])
+def test_conv3x3_stride2_dgrad_parity_classes(dev, C, Co, H, W):
+    """ops._dgrad3x3_s2 (four stride-1 gathers, one per parity of the dx pixel) against autograd and against the generic
+    transposed gather it replaces, with the fused residual + ReLU mask of the bottleneck backward; odd and degenerate planes."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(C + H + W)
+    Nb = 2
+    x = torch.randn(Nb, C, H, W, generator=g).float().requires_grad_(True)
+    w = (torch.randn(Co, C, 3, 3, generator=g) * (1.0 / math.sqrt(C * 9))).to(BF)
+    y = F.conv2d(x, w.float(), stride=2, padding=1)
+    dy = torch.randn(*y.shape, generator=g).to(BF)
+    y.backward(dy.float())
+    aux = torch.randn(Nb, H, W, C, generator=g).to(BF)
+    res = torch.randn(Nb, H, W, C, generator=g).to(BF)
+    ref = torch.where(aux.float() > 0, _nhwc(x.grad) + res.float(), torch.zeros(()))
+    args = (_nhwc(dy).to(dev), _nhwc(w).to(dev), (H, W))
+    kw = dict(stride=2, pad=1, res=res.to(dev), act=k.ACT_MASK_POS, aux=aux.to(dev))
+    assert ops.PARITY_DGRAD
+    got = ops.conv2d_dgrad(*args, **kw)
+    _close(got, ref, Co * 9, "stride-2 dgrad by parity classes")
+    ops.PARITY_DGRAD = False
+    try:
+        old = ops.conv2d_dgrad(*args, **kw)
+    finally:
+        ops.PARITY_DGRAD = True
+    assert float((got.float() - old.float()).abs().max()) <= 2.0 ** -6 * float(old.float().abs().max())
+
+
 def test_conv3_halo_kernel_is_used_and_agrees_with_generic(dev):
     """tile code 131 forces the shared-halo 3x3 kernel (error if it does not apply); it must agree with the generic
     implicit-GEMM tiles to bf16 rounding (fp32 sums in a different order) on a ResNet layer3-shaped problem."""

@@ -1099,6 +1099,7 @@ static int launch_tile(const toist_gemm& d, int ring, hipStream_t st) {
     else if (ak == TOIST_A_ROWK && bk == TOIST_B_KROW) return launch_variant<BM, BN, BK, TOIST_A_ROWK, TOIST_B_KROW>(d, ring, st);
     else if (ak == TOIST_A_CONV && bk == TOIST_B_ROWK) return launch_variant<BM, BN, BK, TOIST_A_CONV, TOIST_B_ROWK>(d, ring, st);
     else if (ak == TOIST_A_CONVT && bk == TOIST_B_KROW) return launch_variant<BM, BN, BK, TOIST_A_CONVT, TOIST_B_KROW>(d, ring, st);
+    else if (ak == TOIST_A_CONV && bk == TOIST_B_KROW) return launch_variant<BM, BN, BK, TOIST_A_CONV, TOIST_B_KROW>(d, ring, st);   // parity classes of a strided dgrad
     else if (ak == TOIST_A_KROW && bk == TOIST_B_KROW) return launch_variant<BM, BN, BK, TOIST_A_KROW, TOIST_B_KROW>(d, ring, st);
     else if (ak == TOIST_A_KROW && bk == TOIST_B_CONVX) return launch_variant<BM, BN, BK, TOIST_A_KROW, TOIST_B_CONVX>(d, ring, st);
     set_last_error("toist_gemm_bf16: unsupported operand kinds a=%d b=%d", ak, bk);
@@ -1115,6 +1116,17 @@ static int auto_tile(const toist_gemm& d) {
     if (t128 >= 1024 && d.K >= 1024) return 129;
     if (d.K > 64 && d.N <= 32 && d.M >= 4096) return 132;   // a 64-wide tile would idle half (or more) of its MFMA columns
     if (d.K > 64 && d.M <= 32 && d.N >= 128) return 133;
+    // Wave quantisation of the 64x64 grid: three workgroups fit a CU (768 slots), so 800 tiles (ResNet layer3 at batch 8: 12800
+    // pixels x 256 channels) run as one full round plus a nearly empty one.  When the last round would be < 1/4 full and there
+    // are at most two full ones, 64x128 tiles (half the workgroups, half the A traffic through LDS) finish in fewer rounds:
+    // measured 28 -> 21 us (1024 -> 256 1x1), 44 -> 34 us (3x3 at 40x40), 42 -> 30 us (13312 x 256 x 2048); at 1.5-1.6 rounds
+    // (1200-1252 tiles) the 64x64 grid stays ahead (29 vs 34 us), as it does below one round (tools/dbg/gemm_tiles.py).
+    const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) * (d.batch > 0 ? d.batch : 1) * (d.split_k > 0 ? d.split_k : 1);
+    const long long rounds = t64 / 768, last = t64 - rounds * 768;
+    static const bool wide = [] { const char* e = std::getenv("TOIST_TILE_64x128"); return !(e && e[0] == '0'); }();
+    if (wide && d.K >= 512 && (d.N % 128) == 0 && rounds >= 1 && rounds <= 2 && last * 4 < 768 &&
+        (d.a_kind == TOIST_A_ROWK || d.a_kind == TOIST_A_CONV) && !d.group)
+        return 134;
     return (d.K > 64) ? 65 : 64;
 }
 
@@ -1239,7 +1251,7 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     if (tile == 0) tile = auto_tile(d);
     d.split_k = clamp_split(d.split_k, d.K, tile);
     // tile codes: 64 = 64x64x32, 65 = 64x64x64, 128 = 128x128x32, 129 = 128x128x64, 130 = 128x64x64, 132 = 128x32x64, 133 = 32x128x64
-    const int bkt = (tile == 64 || tile == 128) ? 32 : 64;
+    const int bkt = (tile == 64 || tile == 128) ? 32 : 64;   // (134 = 64x128x64)
     if (d.b_kind == TOIST_B_KROW && d.b.kin > 0) TOIST_REQUIRE((d.b.kin % 8) == 0, "toist_gemm_bf16: kin %% 8 != 0");
     (void)bkt;
     int rc;
@@ -1251,6 +1263,7 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
         case 130: rc = launch_tile<128, 64, 64>(d, ring, st); break;
         case 132: rc = launch_tile<128, 32, 64>(d, ring, st); break;   // narrow N (<= 32 output columns: mask-head convolutions)
         case 133: rc = launch_tile<32, 128, 64>(d, ring, st); break;   // narrow M (their weight gradients)
+        case 134: rc = launch_tile<64, 128, 64>(d, ring, st); break;   // wide N, short K: half the A re-reads and workgroups of 64x64
         default: set_last_error("toist_gemm_bf16: bad tile code %d", tile); return TOIST_EINVAL;
     }
     if (rc != TOIST_OK) return rc;

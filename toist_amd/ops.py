@@ -5,6 +5,8 @@ Shapes follow the kernels' native layouts (bf16, feature axis innermost): token 
 physical layout of a channels_last OIHW parameter).  Nothing here touches autograd; the modules in
 toist_amd build their forward/backward passes out of these calls.
 """
+import os as _os
+
 import torch
 
 from . import kernels as k
@@ -165,12 +167,49 @@ def conv2d_dgrad(dy, w, in_hw, *, stride=1, pad=0, dil=1, scale=None, res=None, 
         # strided 1x1 (downsample): only rows (n, oy*stride, ox*stride) of dx receive a value
         k.gemm(Nb * OH * OW, C, Co, k.A_ROWK, k.operand(dy, Co), k.B_KROW, k.operand(w.view(Co, C), C), out, C, scale=scale,
                res=res, ldr=ldr, act=act, aux=aux, ldaux=ldaux, cmap=(H, W, OH, OW, stride), flags=flags, flops=fl)
+    elif PARITY_DGRAD and R == 3 and S == 3 and stride == 2 and pad == 1 and dil == 1 and Co % 8 == 0:
+        _dgrad3x3_s2(dy, w, out, scale, res, act, aux, flags, fl)
     else:
         a = k.operand(dy, 0, geom=k.ConvGeom(OH, OW, Co, H, W, R, S, stride, pad, dil))
         b = k.operand(w, R * S * C, kin=Co, tap_stride=C)
         k.gemm(M, C, R * S * Co, k.A_CONVT, a, k.B_KROW, b, out, C, scale=scale, res=res, ldr=ldr, act=act, aux=aux,
                ldaux=ldaux, flags=flags, flops=fl)
     return out
+
+
+PARITY_DGRAD = _os.environ.get("TOIST_PARITY_DGRAD", "1") != "0"
+# taps (r*3 + s) of a 3x3 / stride 2 / pad 1 kernel grouped by the parity (y & 1, x & 1) of the dx pixel they reach, each group in
+# the order a plain stride-1 gather dy[yy + r', xx + s'] visits them:  (0,0): 1 tap | (0,1): 2 | (1,0): 2 | (1,1): 4
+_S2_TAPS = (4, 5, 3, 7, 1, 8, 6, 2, 0)
+_S2_CLASS = ((0, 0, 1, 1, 0), (0, 1, 1, 2, 1), (1, 0, 2, 1, 3), (1, 1, 2, 2, 5))       # (py, px, R', S', first tap)
+_S2_PERM = {}
+
+
+def _dgrad3x3_s2(dy, w, out, scale, res, act, aux, flags, fl):
+    """Data gradient of a 3x3 / stride 2 / pad 1 convolution as four stride-1 gathers, one per parity class of the dx pixel.
+
+    dx[n, y, x] sums dy[n, (y+1-r)/2, (x+1-s)/2] w[:, r, s] over the taps with even y+1-r and x+1-s: a quarter of the nine on
+    average, so the transposed gather over all nine taps (the generic A_CONVT path) streams and multiplies 4x zeros.  Pixels with
+    y = 2yy + py see r = 1 (py = 0) or r in {2, 0} (py = 1) at dy rows yy, yy + 1 -- a 1- or 2-tap stride-1 gather over the dy
+    plane; likewise in x.  Each class is one implicit GEMM (A_CONV gather of dy, k-major weights with the class's taps made
+    adjacent by one permuted copy of w) whose output rows scatter to (2yy + py, 2xx + px) through the epilogue's row map."""
+    Nb, OH, OW, Co = dy.shape
+    _, H, W, C = out.shape
+    perm = _S2_PERM.get(dy.device)
+    if perm is None:
+        perm = _S2_PERM[dy.device] = torch.tensor(_S2_TAPS, dtype=torch.int64, device=dy.device)
+    wp = w.view(Co, 9, C).index_select(1, perm)
+    flat = lambda t, off: None if t is None else t.view(-1, C)[off:]
+    for py, px, Rc, Sc, t0 in _S2_CLASS:
+        PH, PW = (H - py + 1) // 2, (W - px + 1) // 2
+        if PH == 0 or PW == 0:
+            continue
+        off = py * W + px
+        a = k.operand(dy, 0, geom=k.ConvGeom(OH, OW, Co, PH, PW, Rc, Sc, 1, 0, 1))
+        b = k.operand(wp.view(Co, 9 * C)[:, t0 * C:], 9 * C, kin=Co, tap_stride=C)
+        k.gemm(Nb * PH * PW, C, Rc * Sc * Co, k.A_CONV, a, k.B_KROW, b, flat(out, off), C, scale=scale, res=flat(res, off),
+               ldr=C if res is not None else 0, act=act, aux=flat(aux, off), ldaux=C if aux is not None else 0, cmap=(H, W, PH, PW, 2),
+               flags=flags, flops=fl * Rc * Sc // 9)
 
 
 def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, split_k=None, rscale=None, defer=False, accumulate=True):
@@ -200,7 +239,6 @@ def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, s
     return out
 
 
-import os as _os
 GROUP_TILE = int(_os.environ.get("TOIST_GROUP_TILE", "0"))   # tile code of grouped weight-gradient launches (0 = the dispatcher's choice)
 GROUP_MIN_TILES = 512   # below this many 64x64 output tiles in total the problems stay separate (they need split-K)
 
