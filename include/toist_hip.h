@@ -398,6 +398,13 @@ int toist_lsap(const float* cost, const int64_t* offset, const int32_t* rows, co
  * toist_gemm_effective_split tells how many slices the kernel really wrote (k-slices that would own no k-tile are
  * dropped).  `descs` is a HOST array (copied into the kernel arguments); nothing is kept after the call returns. */
 #define TOIST_GEMM_DEFER_REDUCE 2
+/* flags bit2: split_k > 1 with the COMPLETE epilogue.  The k-slices store raw f32 partial tiles to `workspace` ([k-slice][M][N]) as
+ * for any split, and a second kernel adds them in slice order and applies scale / shift / dropout / residual / activation / the
+ * output type exactly as the un-split GEMM would -- for nn.Linear GEMMs with few output tiles and a deep reduction (128 tokens,
+ * K = 3072: 24 tiles on 256 CUs).  batch = 1, no group, no row map; N %% 4 == 0. */
+#define TOIST_GEMM_SPLIT_EPILOGUE 4
+/* tile code the dispatcher would pick for this descriptor (`tile` = 0) */
+int toist_gemm_pick_tile(const toist_gemm* desc);
 typedef struct toist_reduce_desc {
     const float* ws;          /* [splits][M][N] fp32 partials                */
     float* out;               /* [M][ldc] fp32                               */

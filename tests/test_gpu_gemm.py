@@ -76,6 +76,37 @@ def test_linear_dgrad_wgrad(dev, flags):
     _close(db, dy.float().sum(0), M, "bias grad", rtol=3e-3, atol_unit=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 768, 3072), (100, 256, 2048), (700, 260, 2304)])
+def test_split_k_with_the_complete_epilogue(dev, M, N, K):
+    """TOIST_GEMM_SPLIT_EPILOGUE (ops.linear on few tiles / deep K): partial tiles + splitk_epilogue_kernel must give what the un-split
+    launch gives -- bias, dropout (the same mask: it is a function of (seed, row, column)), residual, GELU, bf16 output; run to run
+    bit-identical (the slices are added in slice order)."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bias, res = torch.randn(N, generator=g).to(dev), torch.randn(M, N, generator=g).to(BF).to(dev)
+    k.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+    assert ops._split_for_linear(M, N, K) > 1
+    kw = dict(res=res, act=k.ACT_GELU, drop_where=1, drop_p=0.1, drop_seed=7)
+    one = ops.linear(x, w, bias, split_k=1, **kw).float()
+    for s in (None, 3, 16):
+        got = ops.linear(x, w, bias, split_k=s, **kw).float()
+        again = ops.linear(x, w, bias, split_k=s, **kw).float()
+        assert torch.equal(got, again)
+        assert float((got - one).abs().max()) <= 2.0 ** -6 * float(one.abs().max())
+        assert float(((got == 0) != (one == 0)).float().mean()) < 1e-3          # same dropout mask (up to values rounding to zero)
+    if N % 8:
+        return                                                                  # k-major weights need N % 8 == 0
+    wt = w.t().contiguous()                                                     # data gradient: k-major weights, ReLU mask from aux
+    aux = torch.randn(M, N, generator=g).to(BF).to(dev)
+    one = ops.linear_dgrad(x, wt, res=res, act=k.ACT_MASK_POS, aux=aux, split_k=1).float()
+    got = ops.linear_dgrad(x, wt, res=res, act=k.ACT_MASK_POS, aux=aux).float()
+    assert float((got - one).abs().max()) <= 2.0 ** -6 * float(one.abs().max())
+    ref = torch.where(aux.float() > 0, x.float() @ wt.float() + res.float(), torch.zeros((), device=dev))
+    _close(got.to(BF), ref.cpu(), K, "split dgrad")
+
+
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 

@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtoist_hip.so")
+# TOIST_HIP_LIB: another build of the same library (kernel experiments: A/B two builds inside one GPU session)
+LIB_PATH = os.environ.get("TOIST_HIP_LIB") or os.path.join(_HERE, "libtoist_hip.so")
 
 TOIST_OK = 0
 # operand kinds / activations (mirrors include/toist_hip.h)
@@ -99,6 +100,7 @@ _SIGNATURES = {
     "toist_wgrad3x3_small": ([c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p], ctypes.c_int),
     "toist_lsap": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_gemm_effective_split": ([POINTER(Gemm)], ctypes.c_int),
+    "toist_gemm_pick_tile": ([POINTER(Gemm)], ctypes.c_int),
     "toist_splitk_reduce_batch": ([c_void_p, c_int32, c_void_p], ctypes.c_int),
     "toist_opt_chunk_elems": ([], ctypes.c_int),
     "toist_opt_sqnorm": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),

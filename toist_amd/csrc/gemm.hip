@@ -975,6 +975,37 @@ static int launch_conv3(const toist_gemm& d, hipStream_t st) {
     return TOIST_OK;
 }
 
+// TOIST_GEMM_SPLIT_EPILOGUE: second half of a split-K GEMM that keeps the complete epilogue.  One thread per 8 output columns of a
+// row: the k-slice partials are added in slice order, then the row goes through the same epilogue_row8 as an un-split tile
+// (same dropout stream, residual, activation, output type).
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const toist_gemm p) {
+    const int cpr = (p.N + 7) / 8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.M * cpr) return;
+    const int m = (int)(idx / cpr), n = (int)(idx - (long long)m * cpr) * 8;
+    EpiRow r = epi_row(p, m, n);
+    EpiCols cols;
+    epilogue_cols(p, n, cols, 0);
+    EpiPre pre;
+    epilogue_fetch(p, r, 0, pre);
+    const size_t MN = (size_t)p.M * p.N;
+    const float* q = p.workspace + (size_t)m * p.N + n;
+    const bool two = r.nv > 4;                       // N % 4 == 0: a chunk has 4 or 8 valid columns
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+    for (int s = 0; s < p.split_k; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(q + s * MN);
+        lo.x += a.x; lo.y += a.y; lo.z += a.z; lo.w += a.w;
+        if (two) {
+            const float4 b = *reinterpret_cast<const float4*>(q + s * MN + 4);
+            hi.x += b.x; hi.y += b.y; hi.z += b.z; hi.w += b.w;
+        }
+    }
+    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    float xres[8], xaux[8];
+    epilogue_operands(p, r, 0, pre, xres, xaux);
+    epilogue_row8(p, v, r, 0, 0, xres, xaux, cols);
+}
+
 // C[m][n] (+)= alpha * rscale[m] * sum_s ws[s][m][n]   (second half of a split-K GEMM)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, float alpha,
                                                              const float* __restrict__ rscale, int accumulate, float* __restrict__ c,
@@ -1162,6 +1193,12 @@ extern "C" int toist_group_fill(const toist_group* rows, int n, toist_group* tab
     return check_launch("toist_group_fill");
 }
 
+extern "C" int toist_gemm_pick_tile(const toist_gemm* desc) {
+    using namespace toist;
+    if (desc == nullptr) return 0;
+    return (desc->tile & 255) ? (desc->tile & 255) : auto_tile(*desc);
+}
+
 extern "C" int toist_gemm_effective_split(const toist_gemm* desc) {
     using namespace toist;
     if (desc == nullptr) return 0;
@@ -1220,14 +1257,19 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     // (and discarded), so ld must cover the rounded-up extent.
     if (d.a_kind == TOIST_A_KROW) TOIST_REQUIRE(d.a.ld >= ((d.M + 7) & ~7), "toist_gemm_bf16: A_KROW needs lda >= roundup8(M)");
     if (d.b_kind == TOIST_B_KROW) TOIST_REQUIRE(d.b.ld >= ((d.N + 7) & ~7), "toist_gemm_bf16: B_KROW needs ldb >= roundup8(N)");
-    if (d.split_k > 1 || d.epi.accumulate)
+    const bool split_epi = (d.flags & TOIST_GEMM_SPLIT_EPILOGUE) != 0 && d.split_k > 1;
+    if ((d.split_k > 1 && !split_epi) || d.epi.accumulate)
         TOIST_REQUIRE(d.epi.out_f32, "toist_gemm_bf16: split_k/accumulate needs an f32 output");
+    if (split_epi)
+        TOIST_REQUIRE(d.workspace != nullptr && d.batch == 1 && d.group == nullptr && (d.N % 4) == 0 && !d.epi.cmap && !d.epi.accumulate &&
+                          !(d.flags & TOIST_GEMM_DEFER_REDUCE) && (d.tile & 255) != 131 && !d.a_colsum,
+                      "toist_gemm_bf16: TOIST_GEMM_SPLIT_EPILOGUE needs a workspace, batch = 1, no group / row map / accumulate, N %% 4 == 0");
     if (d.a_colsum) TOIST_REQUIRE(d.a_kind == TOIST_A_KROW, "toist_gemm_bf16: a_colsum needs a k-major A operand");
     if (d.group) TOIST_REQUIRE((d.split_k <= 1 || (d.flags & TOIST_GEMM_DEFER_REDUCE)) && d.batch_inner == 1 && !d.epi.cmap && (d.tile & 255) != 131 &&
                                    d.a_kind != TOIST_A_CONVT,
                                "toist_gemm_bf16: a grouped launch takes batch_inner = 1, no cmap, a generic tile, and folds its k-slices through "
                                "toist_splitk_reduce_batch (TOIST_GEMM_DEFER_REDUCE; workspace = [problem][k-slice][M][N])");
-    if (d.split_k > 1) {
+    if (d.split_k > 1 && !split_epi) {
         TOIST_REQUIRE(!d.epi.scale && !d.epi.shift && !d.epi.res && d.epi.act == TOIST_ACT_NONE && !d.epi.pre_out && d.epi.drop_where == 0 &&
                           !d.epi.cmap && (d.batch == 1 || d.group != nullptr),
                       "toist_gemm_bf16: split_k only supports alpha/rscale/accumulate epilogues on a single batch (or a grouped launch)");
@@ -1269,6 +1311,11 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     if (rc != TOIST_OK) return rc;
     rc = check_launch("toist_gemm_bf16");
     if (rc != TOIST_OK || d.split_k <= 1 || (d.flags & TOIST_GEMM_DEFER_REDUCE)) return rc;
+    if (split_epi) {
+        const long long chunks = (long long)d.M * ((d.N + 7) / 8);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, d);
+        return check_launch("toist_gemm_bf16(splitk epilogue)");
+    }
     const long long total4 = ((long long)d.M * d.N) / 4;
     int grid = (int)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)d.workspace, d.split_k, d.M, d.N, d.epi.alpha,

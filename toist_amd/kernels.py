@@ -50,6 +50,7 @@ def _workspace(elems, device):
 # queued, and flush_reductions() folds everything queued on the current stream with one launch per 48 GEMMs.
 # The queue must be flushed before anything reads those outputs: engine.Tape.backward() does it at program end.
 GEMM_DEFER_REDUCE = 2
+GEMM_SPLIT_EPILOGUE = 4
 _ARENA = {}     # (device, stream) -> [buffer, used elements]
 _PENDING = {}   # (device, stream) -> list of (ReduceDesc, keep-alive tensors)
 
@@ -139,7 +140,7 @@ def operand(t, ld=0, bs_outer=0, bs_inner=0, kin=0, tap_stride=0, geom=None):
 def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_outer=0, cs_inner=0, split_k=1, tile=0,
          flags=0, alpha=1.0, scale=None, shift=None, rscale=None, res=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, pre_out=None,
          accumulate=False, cmap=None, drop_where=0, drop_p=0.0, drop_seed=0, flops=0, a_colsum=None, res_bcast=None,
-         defer_reduce=False, group=None, group_out=None, a2=None, a2_from=0):
+         defer_reduce=False, group=None, group_out=None, a2=None, a2_from=0, split_epilogue=False):
     """C = epilogue(A @ B^T); see include/toist_hip.h.  `a`/`b` are Operand structs from operand().
     `flops` = algorithmic FLOPs of the call (bench.py's roofline accounting only)."""
     if tile == 0 and FORCE_TILE:
@@ -176,7 +177,11 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
     if a2 is not None:                        # output columns >= a2_from take their A rows from a2 (packed in_proj on two inputs)
         d.a2, d.a2_from = _p(a2, torch.bfloat16), a2_from
     deferred = None
-    if split_k > 1 and group is not None:
+    if split_k > 1 and split_epilogue:
+        # k-slices folded by a second kernel that applies the complete epilogue (any output type): csrc/gemm.hip splitk_epilogue_kernel
+        d.workspace = _p(_workspace(split_k * M * N, c.device), torch.float32)
+        d.flags |= GEMM_SPLIT_EPILOGUE
+    elif split_k > 1 and group is not None:
         # grouped + split: [problem][k-slice][M][N] partials, one queued fold per problem (group_out = [(c_i, rscale_i)])
         eff = int(_lib.lib().toist_gemm_effective_split(ctypes.byref(d)))
         if eff > 1:
@@ -214,10 +219,7 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
         return
     if not flops:
         flops = 2 * M * N * K * max(batch, 1)
-    t = tile
-    if t == 0:
-        t128 = ((M + 127) // 128) * ((N + 127) // 128) * max(batch, 1) * max(split_k, 1)
-        t = 129 if (t128 >= 1024 and K >= 1024) else (65 if K > 64 else 64)
+    t = int(_lib.lib().toist_gemm_pick_tile(ctypes.byref(d)))
     key = (t, a_kind, b_kind)
     want = prof["key"]
     if want is not None and key != want and not (isinstance(want, (set, frozenset)) and key in want):

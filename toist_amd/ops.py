@@ -30,30 +30,51 @@ def _split_k_for(tiles, ktiles, target=768, max_split=256):
 
 
 # ------------------------------------------------------------------------------------------ linear
+SPLIT_LINEAR = _os.environ.get("TOIST_SPLIT_LINEAR", "1") != "0"
+SPLIT_MAX_TILES, SPLIT_MIN_KTILES, SPLIT_KTILES_PER_SLICE, SPLIT_TARGET_WGS = 64, 32, 8, 384
+
+
+def _split_for_linear(M, N, K):
+    """k-slices for an nn.Linear GEMM with few 64x64 output tiles and a deep reduction (RoBERTa's FFN2 on 8 x 16 tokens: 24 tiles on
+    256 CUs, each workgroup walking 48 k-tiles alone; the decoder's FFN2 on 800 queries: 52 tiles).  The slices are folded by
+    csrc/gemm.hip splitk_epilogue_kernel, which applies the complete epilogue.  Measured (tools/dbg/gemm_splitk.py, us per launch,
+    1 slice -> best): 128x768x3072 21.2 -> 11.8 (6 slices), its data gradient 26.3 -> 12.7; 128x768x2304 17.4 -> 11.1 (4);
+    800x256x2048 15.9 -> 11.7 (4); K = 768 gains < 1 us and 208 tiles (3328x256x2048) gain nothing: left alone."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    ktiles = (K + 63) // 64
+    if not SPLIT_LINEAR or tiles > SPLIT_MAX_TILES or ktiles < SPLIT_MIN_KTILES or N % 4:
+        return 1
+    return max(1, min(ktiles // SPLIT_KTILES_PER_SLICE, SPLIT_TARGET_WGS // tiles))
+
+
 def linear(x, w, bias=None, *, out=None, out_dtype=BF16, act=k.ACT_NONE, res=None, alpha=1.0, pre_out=None, scale=None,
-           drop_where=0, drop_p=0.0, drop_seed=0, tile=0, flags=0):
+           drop_where=0, drop_p=0.0, drop_seed=0, tile=0, flags=0, split_k=None):
     """out[M,N] = act(alpha * x[M,K] @ w[N,K]^T * scale + bias (+dropout) + res)   (nn.Linear forward)."""
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    if split_k is None:
+        split_k = _split_for_linear(M, N, K)
     k.gemm(M, N, K, k.A_ROWK, k.operand(x, _ld(x)), k.B_ROWK, k.operand(w, _ld(w)), out, _ld(out), alpha=alpha, scale=scale,
            shift=bias, res=res, ldr=_ld(res) if res is not None else 0, act=act, pre_out=pre_out, drop_where=drop_where,
-           drop_p=drop_p, drop_seed=drop_seed, tile=tile, flags=flags, flops=2 * M * N * K)
+           drop_p=drop_p, drop_seed=drop_seed, tile=tile, flags=flags, flops=2 * M * N * K, split_k=split_k, split_epilogue=split_k > 1)
     return out
 
 
-def linear_dgrad(dy, w, *, out=None, res=None, act=k.ACT_NONE, aux=None, alpha=1.0, scale=None, flags=0):
+def linear_dgrad(dy, w, *, out=None, res=None, act=k.ACT_NONE, aux=None, alpha=1.0, scale=None, flags=0, split_k=None):
     """dx[M,K] = (dy[M,N] @ w[N,K]) (+res) ; w is read k-major (no transposed copy)."""
     M, N = dy.shape
     K = w.shape[1]
     assert w.shape[0] == N
     if out is None:
         out = torch.empty(M, K, dtype=BF16, device=dy.device)
+    if split_k is None:
+        split_k = _split_for_linear(M, K, N)
     k.gemm(M, K, N, k.A_ROWK, k.operand(dy, _ld(dy)), k.B_KROW, k.operand(w, _ld(w)), out, _ld(out), alpha=alpha, scale=scale,
            res=res, ldr=_ld(res) if res is not None else 0, act=act, aux=aux, ldaux=_ld(aux) if aux is not None else 0,
-           flags=flags, flops=2 * M * N * K)
+           flags=flags, flops=2 * M * N * K, split_k=split_k, split_epilogue=split_k > 1)
     return out
 
 

@@ -1,0 +1,5 @@
+# usage: ab_lib.sh OTHER.so [script args...] -- bench with the in-tree library and with OTHER.so, interleaved, on the same box
+for i in 1 2; do
+for lib in "" "$1"; do
+echo "lib=${lib:-default}"; TOIST_HIP_LIB=$lib python bench.py --no-cpu-baseline --no-roofline 2>&1 | grep '^{"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+done; done

@@ -44,14 +44,6 @@ def conv(Nb, H, C, Co, stride=1):
     dy = torch.randn(Nb, OH, OH, Co, device=dev).to(BF)
     sweep(f"conv3 dgrad {Nb}x{H}x{H} {C}->{Co} s{stride}", lambda: ops.conv2d_dgrad(dy, w, (H, H), stride=stride, pad=1))
 
-TILES = (0, 65, 134)
-for s in ((12800, 256, 1024), (12800, 512, 1024), (3200, 1024, 2048), (3200, 2048, 1024), (3200, 512, 2048), (51200, 128, 1024), (6400, 256, 1024), (9600, 256, 2048),
-          (20000, 256, 1024), (12800, 128, 1024), (12800, 384, 1024), (3328, 2048, 256), (3328, 256, 2048), (6656, 256, 2048), (13312, 256, 2048), (13312, 2048, 256)):
+TILES = (65, 65 | (3 << 8), 64)
+for s in ((12800, 1024, 256), (51200, 512, 128), (204800, 256, 64), (204800, 64, 256), (3328, 2048, 256), (800, 2048, 256), (12800, 256, 256), (3328, 256, 256), (800, 256, 256), (3328, 768, 256)):
     lin(*s)
-conv(8, 40, 256, 256)
-conv(8, 80, 128, 128)
-conv(8, 20, 512, 512)
-conv(8, 80, 256, 256, 2)
-conv(8, 40, 512, 512, 2)
-conv(4, 40, 256, 256)
-conv(16, 40, 256, 256)
