@@ -81,9 +81,18 @@ __device__ __forceinline__ void load_row8(const bf16_t* rp, const int nv, float*
     }
 }
 
+#ifndef EPI_NT_STORE
+#define EPI_NT_STORE 0
+#endif
 __device__ __forceinline__ void store_row8_bf16(bf16_t* cp, const int nv, const float* v) {
     if (nv == 8 && ((((size_t)cp) & 15) == 0)) {
+#if EPI_NT_STORE
+        typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+        const u4 val = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        __builtin_nontemporal_store(val, reinterpret_cast<u4*>(cp));
+#else
         *reinterpret_cast<uint4*>(cp) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+#endif
     } else {
         static_for<8>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
@@ -377,30 +386,22 @@ __device__ __forceinline__ void tile_order(int L, int nt_m, int nt_n, int& tile_
 }
 
 // ---- epilogue of one workgroup tile -----------------------------------------------------------------------
-// After the MFMAs a lane owns output row c16 and 4 consecutive columns 4*g .. 4*g+3 of each 16x16 fragment:
-// stored directly, a wavefront store would touch 16 rows x 32 bytes.  Instead the tile goes through LDS in
-// bands of 32 rows (fragment row i of both wave rows), and every thread finishes 8 consecutive columns of
-// one row: 16-byte bf16 accesses, whole 128-byte row segments per 8 lanes, for C, res, aux and pre_out alike.
-// 256 threads = 2x2 waves of WM x WN; `band` = at least 32 x (BN + 4) floats of idle LDS.
-template <int BN, int WM, int WN, int FM, int FN>
-__device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc)[FM][FN], float* band, const int m0, const int n0,
-                                              const int bz, const long long coff, const int ksl) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c16 = lane & 15;
-    const int M = p.M, N = p.N;
-    constexpr int LDT = BN + 4;                      // f32 band pitch: +4 keeps the float4 writes conflict-free
-    constexpr int CPR = BN / 8;                      // 8-column chunks per band row
-    constexpr int CH = (32 * CPR + 255) / 256;       // chunks per thread per band (1 for BN <= 64, 2 for BN = 128)
+template <int BN, int FM>
+struct EpiTile {            // rows and pre-requested residual / aux chunks of one thread for every band of a tile
+    static constexpr int CPR = BN / 8;                      // 8-column chunks per band row
+    static constexpr int CH = (32 * CPR + 255) / 256;       // chunks per thread per band (1 for BN <= 64, 2 for BN = 128)
     static_assert(32 * CPR % 256 == 0 || 32 * CPR < 256, "band chunks must divide over 256 threads");
-    const bool partial = p.split_k > 1;              // k-slice partial: raw f32 into the workspace, epilogue in splitk_reduce_kernel
-    float* ws = partial ? p.workspace + ((size_t)bz * p.split_k + ksl) * M * N : nullptr;   // [problem][k-slice][M][N]
-    // residual / aux operands of EVERY band are requested up front: one exposed load latency per tile, not one per band
-    EpiRow rows_all[FM][CH];
-    EpiPre pre_all[FM][CH];
-    EpiCols cols[CH];
-#pragma unroll
-    for (int q = 0; q < CH; ++q)
-        if (!partial) epilogue_cols(p, n0 + ((tid + 256 * q) % CPR) * 8, cols[q], p.group ? p.group[bz].shift_off : 0);
+    EpiRow rows[FM][CH];
+    EpiPre pre[FM][CH];
+};
+
+// first half: resolve this thread's rows of tile (m0, n0) and request the residual / aux operands of EVERY band up front (one
+// exposed load latency per tile, not one per band; the panel kernel issues it a whole tile ahead)
+template <int BN, int WM, int FM>
+__device__ __forceinline__ void epilogue_request(const toist_gemm& p, const int m0, const int n0, const long long coff, const bool partial,
+                                                 EpiTile<BN, FM>& t) {
+    constexpr int CPR = EpiTile<BN, FM>::CPR, CH = EpiTile<BN, FM>::CH;
+    const int tid = threadIdx.x, M = p.M;
     static_for<FM>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
 #pragma unroll
@@ -408,20 +409,39 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
             const int c = tid + 256 * q;
             const int br = c / CPR, c8 = c - br * CPR;
             const int m = (c < 32 * CPR) ? m0 + (br >> 4) * WM + i * 16 + (br & 15) : M;   // narrow tiles: the upper threads idle
-            rows_all[i][q] = epi_row(p, m < M ? m : 0, n0 + c8 * 8);
-            rows_all[i][q].m = m;
-            if (!partial && m < M && rows_all[i][q].nv > 0) epilogue_fetch(p, rows_all[i][q], coff, pre_all[i][q]);
+            t.rows[i][q] = epi_row(p, m < M ? m : 0, n0 + c8 * 8);
+            t.rows[i][q].m = m;
+            if (!partial && m < M && t.rows[i][q].nv > 0) epilogue_fetch(p, t.rows[i][q], coff, t.pre[i][q]);
         }
     });
+}
+
+// second half: the accumulators go through LDS band by band and every thread finishes 8 consecutive columns of one row
+// Barrier between the LDS writes and reads of the epilogue bands.  NOT __syncthreads(): that is a workgroup-scope fence, and hipcc
+// drains vmcnt in front of it -- every band then waited for the previous band's GLOBAL stores to be acknowledged (a 1-2 us round
+// trip under load, four times per 64x64 tile), which is what kept the store phase of the 1x1-convolution GEMMs at 2.2 TB/s while the
+// same tile pattern written without barriers runs at 4.3 (tools/probe/store_pattern.hip).  Only the LDS traffic has to be ordered.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int BN, int WM, int WN, int FM, int FN>
+__device__ __forceinline__ void epilogue_finish(const toist_gemm& p, f32x4_t (&acc)[FM][FN], float* band, EpiTile<BN, FM>& t,
+                                                const EpiCols (&cols)[EpiTile<BN, FM>::CH], const int bz, const long long coff, const int ksl,
+                                                const bool partial) {
+    constexpr int CPR = EpiTile<BN, FM>::CPR, CH = EpiTile<BN, FM>::CH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c16 = lane & 15;
+    const int M = p.M, N = p.N;
+    constexpr int LDT = BN + 4;                      // f32 band pitch: +4 keeps the float4 writes conflict-free
+    float* ws = partial ? p.workspace + ((size_t)bz * p.split_k + ksl) * M * N : nullptr;   // [problem][k-slice][M][N]
     static_for<FM>([&](auto ii) {
         constexpr int i = decltype(ii)::value;
-        EpiRow (&rows)[CH] = rows_all[i];
-        __syncthreads();                             // previous band (or the last k-tile / the colsum scratch) is consumed
+        EpiRow (&rows)[CH] = t.rows[i];
+        lds_barrier();                               // previous band (or the last k-tile / the colsum scratch) is consumed
         static_for<FN>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
             *reinterpret_cast<f32x4_t*>(band + (wm * 16 + c16) * LDT + wn * WN + j * 16 + g * 4) = acc[i][j];
         });
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int q = 0; q < CH; ++q) {
             const int c = tid + 256 * q;
@@ -442,12 +462,32 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
                     }
                 } else {
                     float xres[8], xaux[8];
-                    epilogue_operands(p, r, coff, pre_all[i][q], xres, xaux);
+                    epilogue_operands(p, r, coff, t.pre[i][q], xres, xaux);
                     epilogue_row8(p, v, r, bz, coff, xres, xaux, cols[q]);
                 }
             }
         }
     });
+}
+
+// After the MFMAs a lane owns output row c16 and 4 consecutive columns 4*g .. 4*g+3 of each 16x16 fragment:
+// stored directly, a wavefront store would touch 16 rows x 32 bytes.  Instead the tile goes through LDS in
+// bands of 32 rows (fragment row i of both wave rows), and every thread finishes 8 consecutive columns of
+// one row: 16-byte bf16 accesses, whole 128-byte row segments per 8 lanes, for C, res, aux and pre_out alike.
+// 256 threads = 2x2 waves of WM x WN; `band` = at least 32 x (BN + 4) floats of idle LDS.
+template <int BN, int WM, int WN, int FM, int FN>
+__device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc)[FM][FN], float* band, const int m0, const int n0,
+                                              const int bz, const long long coff, const int ksl) {
+    constexpr int CPR = EpiTile<BN, FM>::CPR, CH = EpiTile<BN, FM>::CH;
+    // k-slice partial: raw f32 into the workspace, epilogue in splitk_reduce_kernel / splitk_epilogue_kernel
+    const bool partial = p.split_k > 1;
+    EpiCols cols[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q)
+        if (!partial) epilogue_cols(p, n0 + (((int)threadIdx.x + 256 * q) % CPR) * 8, cols[q], p.group ? p.group[bz].shift_off : 0);
+    EpiTile<BN, FM> t;
+    epilogue_request<BN, WM, FM>(p, m0, n0, coff, partial, t);
+    epilogue_finish<BN, WM, WN, FM, FN>(p, acc, band, t, cols, bz, coff, ksl, partial);
 }
 
 // One output tile (tile `tl` of the launch's padded, XCD-striped tile list) of one (batch, k-slice) problem.
@@ -942,6 +982,253 @@ __global__ __launch_bounds__(256) void conv3_kernel(const toist_gemm p) {
     epilogue_tile<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, 0, 0, 0);
 }
 
+
+// ---- short reductions (K <= 256): one resident weight panel per workgroup ------------------------------------------------
+// The 1x1 convolutions of ResNet layers 1-3 and their data gradients are GEMMs with K = 64 .. 256 and tens of thousands of rows
+// (12800 x 1024 x 256 at batch 8: 45 launches per step).  Through the generic tiles every 64x64 output tile stages 64 KB of
+// operands for 4 k-steps of MFMAs and then a 3-stream epilogue (residual, ReLU mask, store): the launch is bound by the LDS-DMA
+// rate in its reduction loops, by HBM in its epilogues, and the two phases did not overlap (tools/dbg/gemm_attr.py: 26.7 us =
+// 6.9 dispatch + 8.9 reduction + 10.9 epilogue).  Here a workgroup keeps ONE 64-column panel of B for its whole life -- as MFMA
+// fragments in registers (64 VGPRs for K = 256) -- and walks down the rows: per output tile only the 64 x K block of A travels
+// (half the staged bytes), whole-K at once into one of two 32 KB LDS slots, and the block of the NEXT tile is in flight while
+// this tile's epilogue reads its residual / mask rows and stores.  Workgroups are dealt to XCDs (blockIdx % 8) so that the
+// N / 64 workgroups sharing an A block sit on one L2; 64 KB of LDS = two workgroups per CU.
+template <int BKD, int ACT>
+__global__ __launch_bounds__(256, 2) void panel_kernel(const toist_gemm p) {
+    constexpr int BM = 64, BN = 64, BK = 64, WM = 32, WN = 32, FM = 2, FN = 2, KT = 4, KS = 8;
+    constexpr int SUB = BM * BK;                 // one k-tile of an A block (8 KiB)
+    constexpr int SLOT = SUB * KT;               // whole-K A block (32 KiB)
+    constexpr int LDT = BN + 4;                  // f32 band pitch
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c16 = lane & 15;
+    const int M = p.M, N = p.N, K = p.K;
+    const int nt_m = (M + BM - 1) / BM, nt_n = (N + BN - 1) / BN;
+    const int kt = (K + BK - 1) / BK, nks = (K + 31) / 32;
+    // blockIdx = 8 * slot + xcd: XCD x owns the contiguous row tiles [x * m_per, ...); inside it workgroup `slot` = (row group, column panel)
+    const int xcd = (int)blockIdx.x & 7, slot_id = (int)blockIdx.x >> 3;
+    const int groups = ((int)gridDim.x >> 3) / nt_n;
+    const int tile_n = slot_id % nt_n, rr = slot_id / nt_n;
+    const int m_per = (nt_m + 7) >> 3;
+    const int m_beg = xcd * m_per, m_end = (m_beg + m_per < nt_m) ? m_beg + m_per : nt_m;
+    if (rr >= groups || m_beg + rr >= m_end) return;
+    const int n0 = tile_n * BN;
+    const i32x4_t rsA = make_rsrc(p.a.ptr), rsB = make_rsrc(p.b.ptr);
+    const int lda = p.a.ld, ldb = p.b.ld;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // ---- the B panel as MFMA fragments: bq[ks][j] = 8 consecutive k (32 ks + 8 g ..) of column n0 + wn*32 + 16 j + c16 ----
+    bf16x8_t bq[KS][FN];
+    if (BKD == TOIST_B_ROWK) {
+        const bf16_t* B = (const bf16_t*)p.b.ptr;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + c16, k = ks * 32 + g * 8;
+                const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                bq[ks][j] = (n < N && k < K) ? *reinterpret_cast<const bf16x8_t*>(B + (size_t)n * ldb + k) : zero;
+            }
+    } else {
+        // k-major weights [K][N]: staged once through LDS in the k-major tile layout, transposed into fragments by ds_read_b64_tr_b16
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int pch = (it * 4 + wave) * 64 + lane;
+                const int krow = pch / (BN / 8), rc = swz_m<BN>(krow, pch % (BN / 8));
+                const int nn = n0 + rc * 8, k = t * BK + krow;
+                if (t < kt) dma16(lds0 + (unsigned)(t * SUB * 2) + (unsigned)(it * 4 + wave) * 1024u, rsB, nn + k * ldb, nn < N && k < K);
+            }
+        wait_vm<0>();
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                bq[ks][j] = (ks < nks) ? fragment<true, BN, BK>(smem + (ks >> 1) * SUB, wn * WN + j * 16, ks & 1, g, c16) : zero;
+            }
+        __syncthreads();
+    }
+
+    // ---- A blocks: k-tile t of a block is a [64][64] k-contiguous tile (2 pieces per thread) ----
+    int a_off[2];                                 // row * lda + swizzled k-chunk of this thread's two pieces
+    int a_row[2], a_col[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int pch = (it * 4 + wave) * 64 + lane;
+        a_row[it] = pch / (BK / 8);
+        a_col[it] = swz_k<BK>(a_row[it], pch % (BK / 8)) * 8;
+        a_off[it] = a_row[it] * lda + a_col[it];
+    }
+    auto issue_a = [&](int slot, int tile_m) {
+        const int m0 = tile_m * BM;
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+                if (t < kt) dma16(lds0 + (unsigned)((slot * SLOT + t * SUB) * 2) + (unsigned)(it * 4 + wave) * 1024u, rsA, m0 * lda + a_off[it] + t * BK,
+                                  m0 + a_row[it] < M && t * BK + a_col[it] < K);
+    };
+
+    // ---- lean epilogue (panel_applies admits only what it covers): bf16 rows of 8 columns, 16-byte accesses, optional per-column scale /
+    // shift, optional residual, ACT in {none, ReLU, mask by aux > 0}.  A thread finishes chunk c8 of band row `brow` of both bands; the
+    // residual / mask chunks of a tile are requested one tile ahead. ----
+    const int c8 = tid & 7, brow = tid >> 3;
+    const int ncol = n0 + c8 * 8;
+    const bool col_ok = ncol < N;                 // N % 8 == 0: a chunk is whole or absent
+    const int rloc = (brow >> 4) * WM + (brow & 15);            // + 16 i: tile row of this thread in band i
+    const bf16_t* const resp = (const bf16_t*)p.epi.res;
+    const bf16_t* const auxp = (const bf16_t*)p.epi.aux;
+    bf16_t* const outp = (bf16_t*)p.c;
+    const int ldc = p.ldc, ldr = p.epi.ldr, ldaux = p.epi.ldaux;
+    const float alpha = p.epi.alpha;
+    float csc[8], csh[8];
+    const bool has_scale = p.epi.scale != nullptr, has_shift = p.epi.shift != nullptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { csc[j] = 1.f; csh[j] = 0.f; }
+    if (col_ok) {
+        if (has_scale) load_cols8(p.epi.scale + ncol, 8, csc, 1.f);
+        if (has_shift) load_cols8(p.epi.shift + ncol, 8, csh, 0.f);
+    }
+    struct Rows { uint4 res[FM], aux[FM]; };
+    auto request = [&](const int tile_m, Rows& q) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = tile_m * BM + rloc + 16 * i;
+            if (col_ok && m < M) {
+                if (resp) q.res[i] = *reinterpret_cast<const uint4*>(resp + (size_t)((unsigned)(m * ldr + ncol)));
+                if (ACT == TOIST_ACT_MASK_POS) q.aux[i] = *reinterpret_cast<const uint4*>(auxp + (size_t)((unsigned)(m * ldaux + ncol)));
+            }
+        }
+    };
+
+    Rows q0, q1;
+    int tm = m_beg + rr;
+    issue_a(0, tm);
+    request(tm, q0);
+    // one tile: block in `slot`, rows in `cur`; the next tile's block / rows go to the other slot / `nxt` (two copies of the body, so
+    // that the row state stays in registers)
+    auto tile = [&](const int slot, Rows& cur, Rows& nxt) {
+        wait_vm<0>();                     // this tile's block and residual / mask rows landed (and the previous stores drained)
+        __builtin_amdgcn_s_barrier();     // ... for every wave; everyone is done with the other slot (previous tile's band)
+        if (tm + groups < m_end) {        // both fly during the MFMAs and the epilogue below
+            issue_a(slot ^ 1, tm + groups);
+            request(tm + groups, nxt);
+        }
+        f32x4_t acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const bf16_t* sA = smem + slot * SLOT;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks < nks) {
+                bf16x8_t af[FM];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) af[i] = fragment<false, BM, BK>(sA + (ks >> 1) * SUB, wm * WM + i * 16, ks & 1, g, c16);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][j], af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        // bands of 32 rows through the (consumed) A slot: fragment row i of both wave rows, then one 8-column chunk per thread
+        float* const band = reinterpret_cast<float*>(smem + slot * SLOT);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            lds_barrier();                // the MFMA reads of this slot / the previous band's reads are done
+#pragma unroll
+            for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4_t*>(band + (wm * 16 + c16) * LDT + wn * WN + j * 16 + g * 4) = acc[i][j];
+            lds_barrier();
+            const int m = tm * BM + rloc + 16 * i;
+            if (col_ok && m < M) {
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(band + brow * LDT + c8 * 8);
+                const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(band + brow * LDT + c8 * 8 + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] * (alpha * csc[j]) + csh[j];
+                if (resp) {
+                    float x[8];
+                    unpack8(cur.res[i], x);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += x[j];
+                }
+                if (ACT == TOIST_ACT_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                if (ACT == TOIST_ACT_MASK_POS) {
+                    float x[8];
+                    unpack8(cur.aux[i], x);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = x[j] > 0.f ? v[j] : 0.f;
+                }
+                *reinterpret_cast<uint4*>(outp + (size_t)((unsigned)(m * ldc + ncol))) =
+                    make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            }
+        }
+    };
+    while (tm < m_end) {
+        tile(0, q0, q1);
+        tm += groups;
+        if (tm >= m_end) break;
+        tile(1, q1, q0);
+        tm += groups;
+    }
+}
+
+static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
+
+// Tile code 135, or picked by the dispatcher (panel_min_tiles) when the call qualifies.
+static bool panel_applies(const toist_gemm& d) {
+    if (d.a_kind != TOIST_A_ROWK || (d.b_kind != TOIST_B_ROWK && d.b_kind != TOIST_B_KROW)) return false;
+    if (d.b_kind == TOIST_B_KROW && d.b.kin > 0) return false;
+    if (d.K > 256 || (d.K % 8) != 0 || (d.a.ld % 8) != 0 || (d.b.ld % 8) != 0) return false;
+    if (d.batch != 1 || d.split_k != 1 || d.group != nullptr || d.a2 != nullptr || d.a_colsum != nullptr || (d.flags & 1)) return false;
+    if ((d.N + 63) / 64 > 64 || (d.M + 63) / 64 < 16) return false;      // row tiles are dealt to 8 XCDs: too few would leave XCDs idle
+    if ((long long)d.M * d.a.ld >= (1ll << 30) || (long long)d.K * d.b.ld >= (1ll << 30) || (long long)d.N * d.b.ld >= (1ll << 30)) return false;   // 32-bit element offsets
+    // the kernel's lean epilogue: bf16 rows in whole 16-byte chunks, per-column scale / shift, residual, {none, ReLU, aux > 0 mask}
+    const toist_epilogue& e = d.epi;
+    if (e.out_f32 || e.accumulate || e.rscale || e.pre_out || e.drop_where || e.cmap || e.res_div > 0) return false;
+    if (e.act != TOIST_ACT_NONE && e.act != TOIST_ACT_RELU && e.act != TOIST_ACT_MASK_POS) return false;
+    if ((d.N % 8) != 0 || (d.ldc % 8) != 0 || !aligned16(d.c) || (long long)d.M * d.ldc >= (1ll << 31)) return false;
+    if (e.res && ((e.ldr % 8) != 0 || !aligned16(e.res) || (long long)d.M * e.ldr >= (1ll << 31))) return false;
+    if (e.act == TOIST_ACT_MASK_POS && ((e.ldaux % 8) != 0 || !aligned16(e.aux) || (long long)d.M * e.ldaux >= (1ll << 31))) return false;
+    if ((e.scale && (((size_t)e.scale) & 15)) || (e.shift && (((size_t)e.shift) & 15))) return false;
+    return true;
+}
+
+static long long panel_min_tiles() {
+    static const long long v = [] { const char* e = getenv("TOIST_PANEL_MIN_TILES"); return e ? atoll(e) : 128LL; }();
+    return v;
+}
+
+static int launch_panel(const toist_gemm& d, hipStream_t st) {
+    const int nt_m = (d.M + 63) / 64, nt_n = (d.N + 63) / 64;
+    const int m_per = (nt_m + 7) / 8;
+    int groups = 64 / nt_n;                       // two workgroups per CU, 32 CUs per XCD
+    if (groups > m_per) groups = m_per;
+    if (groups < 1) groups = 1;
+    dim3 grid(8u * (unsigned)(groups * nt_n), 1, 1);
+    const bool rowk = d.b_kind == TOIST_B_ROWK;
+#define TOIST_PANEL(ACT)                                                                                             \
+    do {                                                                                                             \
+        if (rowk) hipLaunchKernelGGL((panel_kernel<TOIST_B_ROWK, ACT>), grid, dim3(256), 0, st, d);                  \
+        else hipLaunchKernelGGL((panel_kernel<TOIST_B_KROW, ACT>), grid, dim3(256), 0, st, d);                       \
+    } while (0)
+    switch (d.epi.act) {
+        case TOIST_ACT_RELU: TOIST_PANEL(TOIST_ACT_RELU); break;
+        case TOIST_ACT_MASK_POS: TOIST_PANEL(TOIST_ACT_MASK_POS); break;
+        default: TOIST_PANEL(TOIST_ACT_NONE); break;
+    }
+#undef TOIST_PANEL
+    return TOIST_OK;
+}
+
 // true when the halo kernel covers this call (the dispatcher then never looks at the tile code)
 static bool conv3_applies(const toist_gemm& d) {
     const bool fwd = d.a_kind == TOIST_A_CONV && d.b_kind == TOIST_B_ROWK;
@@ -1137,7 +1424,6 @@ static int launch_tile(const toist_gemm& d, int ring, hipStream_t st) {
     return TOIST_EINVAL;
 }
 
-static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
 
 // tile code the dispatcher picks for tile == 0
 static int auto_tile(const toist_gemm& d) {
@@ -1196,7 +1482,12 @@ extern "C" int toist_group_fill(const toist_group* rows, int n, toist_group* tab
 extern "C" int toist_gemm_pick_tile(const toist_gemm* desc) {
     using namespace toist;
     if (desc == nullptr) return 0;
-    return (desc->tile & 255) ? (desc->tile & 255) : auto_tile(*desc);
+    if (desc->tile & 255) return desc->tile & 255;
+    toist_gemm d = *desc;
+    if (d.batch <= 0) d.batch = 1;
+    if (d.split_k <= 0) d.split_k = 1;
+    if ((long long)((d.M + 63) / 64) * ((d.N + 63) / 64) >= panel_min_tiles() && panel_applies(d)) return 135;
+    return auto_tile(d);
 }
 
 extern "C" int toist_gemm_effective_split(const toist_gemm* desc) {
@@ -1288,6 +1579,13 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
         return rc3 != TOIST_OK ? rc3 : check_launch("toist_gemm_bf16(conv3)");
     }
     TOIST_REQUIRE(d.tile != 131, "toist_gemm_bf16: the 3x3 halo kernel does not cover this call");
+    if (d.tile == 135 || (d.tile == 0 && (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) >= panel_min_tiles())) {
+        if (panel_applies(d)) {
+            const int rcp = launch_panel(d, st);
+            return rcp != TOIST_OK ? rcp : check_launch("toist_gemm_bf16(panel)");
+        }
+        TOIST_REQUIRE(d.tile != 135, "toist_gemm_bf16: the short-K panel kernel does not cover this call");
+    }
     int tile = d.tile & 255;
     const int ring = d.tile >> 8;   // 0 = pick; else slots of the DMA ring (2..4)
     if (tile == 0) tile = auto_tile(d);
