@@ -490,8 +490,97 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
     epilogue_finish<BN, WM, WN, FM, FN>(p, acc, band, t, cols, bz, coff, ksl, partial);
 }
 
+// ---- lean epilogue -------------------------------------------------------------------------------------------------------
+// epilogue_tile above serves every option of toist_epilogue, and the hot-path GEMMs were bound by ITS instruction stream: ~1000 VALU
+// instructions per 64x64 tile per wave (64-bit row maps, per-option branches, spilled descriptor words read back lane by lane), 4
+// cycles each on a wave64 -- 8400 cycles per tile measured inside the short-K kernel against ~500 of MFMA work.  The convolutions
+// of the backbone need a fraction of it: bf16 rows in whole 16-byte chunks, per-column scale / shift, a residual, ReLU or a mask.
+// lean_epilogue_ok() admits exactly that; everything else keeps the general path.
+template <int BN, int WM, int WN, int FM, int FN>
+__device__ __forceinline__ void epilogue_lean(const toist_gemm& p, f32x4_t (&acc)[FM][FN], float* band, const int m0, const int n0, const long long coff) {
+    constexpr int CPR = BN / 8, CH = (32 * CPR + 255) / 256, LDT = BN + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c16 = lane & 15;
+    const int M = p.M, N = p.N;
+    const toist_epilogue& e = p.epi;
+    bf16_t* const outp = (bf16_t*)p.c + coff;
+    const bf16_t* const resp = e.res ? (const bf16_t*)e.res + coff : nullptr;
+    const bf16_t* const auxp = (e.act == TOIST_ACT_MASK_POS) ? (const bf16_t*)e.aux + coff : nullptr;
+    const int ldc = p.ldc, ldr = e.ldr, ldaux = e.ldaux, act = e.act;
+    const float alpha = e.alpha;
+    int rloc[CH], ncol[CH], brow[CH], c8[CH];
+    bool col_ok[CH];
+    float mul[CH][8], add[CH][8];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+        const int c = tid + 256 * q;
+        brow[q] = c / CPR; c8[q] = c - brow[q] * CPR;
+        rloc[q] = (brow[q] >> 4) * WM + (brow[q] & 15);
+        ncol[q] = n0 + c8[q] * 8;
+        col_ok[q] = c < 32 * CPR && ncol[q] < N;            // N % 8 == 0: a chunk is whole or absent
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mul[q][j] = alpha; add[q][j] = 0.f; }
+        if (col_ok[q]) {
+            if (e.scale) {
+                float t[8];
+                load_cols8(e.scale + ncol[q], 8, t, 1.f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mul[q][j] = alpha * t[j];
+            }
+            if (e.shift) load_cols8(e.shift + ncol[q], 8, add[q], 0.f);
+        }
+    }
+    // residual / mask chunks of every band are requested up front
+    uint4 rres[FM][CH], raux[FM][CH];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int m = m0 + rloc[q] + 16 * i;
+            if (col_ok[q] && m < M) {
+                if (resp) rres[i][q] = *reinterpret_cast<const uint4*>(resp + (long long)m * ldr + ncol[q]);
+                if (auxp) raux[i][q] = *reinterpret_cast<const uint4*>(auxp + (long long)m * ldaux + ncol[q]);
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        lds_barrier();                // the last k-tile / the previous band is consumed
+#pragma unroll
+        for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4_t*>(band + (wm * 16 + c16) * LDT + wn * WN + j * 16 + g * 4) = acc[i][j];
+        lds_barrier();
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int m = m0 + rloc[q] + 16 * i;
+            if (col_ok[q] && m < M) {
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(band + brow[q] * LDT + c8[q] * 8);
+                const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(band + brow[q] * LDT + c8[q] * 8 + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] * mul[q][j] + add[q][j];
+                if (resp) {
+                    float x[8];
+                    unpack8(rres[i][q], x);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += x[j];
+                }
+                if (act == TOIST_ACT_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                } else if (act == TOIST_ACT_MASK_POS) {
+                    float x[8];
+                    unpack8(raux[i][q], x);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = x[j] > 0.f ? v[j] : 0.f;
+                }
+                *reinterpret_cast<uint4*>(outp + (long long)m * ldc + ncol[q]) =
+                    make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            }
+        }
+    }
+}
+
 // One output tile (tile `tl` of the launch's padded, XCD-striped tile list) of one (batch, k-slice) problem.
-template <int BM, int BN, int BK, int AK, int BKD, int NS>
+template <int BM, int BN, int BK, int AK, int BKD, int NS, bool LEAN>
 __device__ __forceinline__ void gemm_tile(const toist_gemm& p, const int tl, bf16_t* const smem, const int z, const bool direct) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int ACH = BM * BK / 8 / 256, BCH = BN * BK / 8 / 256;  // 1 KiB DMA pieces per wave per tile
@@ -760,14 +849,15 @@ __device__ __forceinline__ void gemm_tile(const toist_gemm& p, const int tl, bf1
 
     static_assert(32 * (BN + 4) * 4 <= NS * STAGE * 2, "epilogue band must fit the (now idle) ring");
     if (p.flags & 512) return;                                    // flags bit 9 (experiments): skip the epilogue
-    epilogue_tile<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, bz, coff, ksl);
+    if constexpr (LEAN) epilogue_lean<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, coff);
+    else epilogue_tile<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, bz, coff, ksl);
 }
 
 // Persistent launch: the hardware dispatches ~530 workgroups per microsecond chip-wide (measured: a 12800-tile launch whose
 // workgroups return at once takes 24 us, a 3200-tile one 6.9 us), which for the K <= 256 GEMMs of the hot path is as much as their
 // whole reduction loop.  The grid is therefore capped at what the chip holds at once (launch_variant) and every workgroup walks
 // the tile list with stride gridDim.x; a multiple of 8, so a workgroup stays on its XCD's contiguous run of tiles.
-template <int BM, int BN, int BK, int AK, int BKD, int NS>
+template <int BM, int BN, int BK, int AK, int BKD, int NS, bool LEAN = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
     constexpr int STAGE = (BM + BN) * BK;
     __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
@@ -778,12 +868,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
         // into ONE L2.  (Striping every problem's tiles over all eight XCDs, as for a single problem, made each XCD stream every
         // problem: the 22 grouped layer-3 3x3 weight gradients fetched 9 x their operands -- profiles/r02_pmc_fetch_summary.txt.)
         const int L = (int)blockIdx.x, q = (L >> 3) / tiles, t = (L >> 3) - q * tiles, z = (L & 7) + 8 * q;
-        if (z < p.batch * p.split_k) gemm_tile<BM, BN, BK, AK, BKD, NS>(p, t, smem, z, true);
+        if (z < p.batch * p.split_k) gemm_tile<BM, BN, BK, AK, BKD, NS, LEAN>(p, t, smem, z, true);
         return;
     }
     const int tiles8 = (tiles + 7) & ~7;
     for (int tl = (int)blockIdx.x; tl < tiles8; tl += (int)gridDim.x) {
-        gemm_tile<BM, BN, BK, AK, BKD, NS>(p, tl, smem, (int)blockIdx.z, false);
+        gemm_tile<BM, BN, BK, AK, BKD, NS, LEAN>(p, tl, smem, (int)blockIdx.z, false);
         if (tl + (int)gridDim.x < tiles8) __syncthreads();       // the next tile's DMA reuses the LDS the epilogue bands lived in
     }
 }
@@ -804,7 +894,7 @@ constexpr int C3_PATCH = C3_NP * 512;                 // elements per patch buff
 constexpr int C3_BT = C3_BN * C3_BK;                  // elements per weight tile (8 KiB)
 constexpr int C3_LDS = (2 * C3_PATCH + C3_NB * C3_BT) * 2;   // 80 KiB: two workgroups per CU
 
-template <bool DGRAD>
+template <bool DGRAD, bool LEAN>
 __global__ __launch_bounds__(256) void conv3_kernel(const toist_gemm p) {
     constexpr int BM = C3_BM, BN = C3_BN, BK = C3_BK, WM = 64, WN = 32, FM = 4, FN = 2;
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
@@ -979,9 +1069,26 @@ __global__ __launch_bounds__(256) void conv3_kernel(const toist_gemm p) {
         if (++slot == C3_NB) slot = 0;
     }
     wait_vm<0>();
-    epilogue_tile<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, 0, 0, 0);
+    if constexpr (LEAN) epilogue_lean<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, 0);
+    else epilogue_tile<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, 0, 0, 0);
 }
 
+
+static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
+
+// what epilogue_lean (and the panel kernel's epilogue) covers
+static bool lean_epilogue_ok(const toist_gemm& d) {
+    static const bool on = [] { const char* v = getenv("TOIST_LEAN_EPILOGUE"); return !(v && v[0] == '0'); }();
+    const toist_epilogue& e = d.epi;
+    if (!on || d.split_k > 1 || d.group != nullptr || d.a_colsum != nullptr) return false;
+    if (e.out_f32 || e.accumulate || e.rscale || e.pre_out || e.drop_where || e.cmap || e.res_div > 0) return false;
+    if (e.act != TOIST_ACT_NONE && e.act != TOIST_ACT_RELU && e.act != TOIST_ACT_MASK_POS) return false;
+    if ((d.N % 8) != 0 || (d.ldc % 8) != 0 || !aligned16(d.c) || (d.cs_outer % 8) != 0 || (d.cs_inner % 8) != 0) return false;
+    if (e.res && ((e.ldr % 8) != 0 || !aligned16(e.res))) return false;
+    if (e.act == TOIST_ACT_MASK_POS && (e.aux == nullptr || (e.ldaux % 8) != 0 || !aligned16(e.aux))) return false;
+    if ((e.scale && (((size_t)e.scale) & 15)) || (e.shift && (((size_t)e.shift) & 15))) return false;
+    return true;
+}
 
 // ---- short reductions (K <= 256): one resident weight panel per workgroup ------------------------------------------------
 // The 1x1 convolutions of ResNet layers 1-3 and their data gradients are GEMMs with K = 64 .. 256 and tens of thousands of rows
@@ -1181,8 +1288,6 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const toist_gemm p) {
     }
 }
 
-static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
-
 // Tile code 135, or picked by the dispatcher (panel_min_tiles) when the call qualifies.
 static bool panel_applies(const toist_gemm& d) {
     if (d.a_kind != TOIST_A_ROWK || (d.b_kind != TOIST_B_ROWK && d.b_kind != TOIST_B_KROW)) return false;
@@ -1248,8 +1353,10 @@ static bool conv3_applies(const toist_gemm& d) {
 static int launch_conv3(const toist_gemm& d, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS has to be enabled per kernel (idempotent, not a mutable result)
-        if (hipFuncSetAttribute((const void*)conv3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)conv3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess) {
             set_last_error("toist_gemm_bf16: cannot enable %d bytes of LDS for the 3x3 kernel", C3_LDS);
             return TOIST_EHIP;
         }
@@ -1257,8 +1364,14 @@ static int launch_conv3(const toist_gemm& d, hipStream_t st) {
     }
     const int tiles = ((d.M + C3_BM - 1) / C3_BM) * ((d.N + C3_BN - 1) / C3_BN);
     dim3 grid((tiles + 7) & ~7, 1, 1);
-    if (d.a_kind == TOIST_A_CONVT) hipLaunchKernelGGL(conv3_kernel<true>, grid, dim3(256), C3_LDS, st, d);
-    else hipLaunchKernelGGL(conv3_kernel<false>, grid, dim3(256), C3_LDS, st, d);
+    const bool lean = lean_epilogue_ok(d);
+    if (d.a_kind == TOIST_A_CONVT) {
+        if (lean) hipLaunchKernelGGL((conv3_kernel<true, true>), grid, dim3(256), C3_LDS, st, d);
+        else hipLaunchKernelGGL((conv3_kernel<true, false>), grid, dim3(256), C3_LDS, st, d);
+    } else {
+        if (lean) hipLaunchKernelGGL((conv3_kernel<false, true>), grid, dim3(256), C3_LDS, st, d);
+        else hipLaunchKernelGGL((conv3_kernel<false, false>), grid, dim3(256), C3_LDS, st, d);
+    }
     return TOIST_OK;
 }
 
@@ -1402,6 +1515,17 @@ static int launch_variant(const toist_gemm& d, int ring, hipStream_t st) {
     if (small) ring = 4;
     else if (!t65) ring = 2;
     else if (ring != 2) ring = 3;
+    // lean epilogue (epilogue_lean): instantiated for the tiles and operand kinds of the backbone's convolutions
+    constexpr bool lean_inst = BK == 64 && ((BM == 64 && BN == 64) || (BM == 64 && BN == 128) || (BM == 128 && BN == 64)) && AK != TOIST_A_KROW;
+    if constexpr (lean_inst) {
+        if (lean_epilogue_ok(dd)) {
+            if constexpr (t65) {
+                if (ring == 3) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 3, true>), grid, dim3(256), 0, st, dd);
+                else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 2, true>), grid, dim3(256), 0, st, dd);
+            } else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 2, true>), grid, dim3(256), 0, st, dd);
+            return TOIST_OK;
+        }
+    }
     if constexpr (small) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 4>), grid, dim3(256), 0, st, dd);
     else if constexpr (t65) {
         if (ring == 3) hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, AK, BKD, 3>), grid, dim3(256), 0, st, dd);
