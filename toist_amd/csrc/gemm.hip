@@ -497,17 +497,24 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
 // of the backbone need a fraction of it: bf16 rows in whole 16-byte chunks, per-column scale / shift, a residual, ReLU or a mask.
 // lean_epilogue_ok() admits exactly that; everything else keeps the general path.
 template <int BN, int WM, int WN, int FM, int FN>
-__device__ __forceinline__ void epilogue_lean(const toist_gemm& p, f32x4_t (&acc)[FM][FN], float* band, const int m0, const int n0, const long long coff) {
+__device__ __forceinline__ void epilogue_lean(const toist_gemm& p, f32x4_t (&acc)[FM][FN], float* band, const int m0, const int n0, const int bz,
+                                              const long long coff) {
     constexpr int CPR = BN / 8, CH = (32 * CPR + 255) / 256, LDT = BN + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c16 = lane & 15;
     const int M = p.M, N = p.N;
     const toist_epilogue& e = p.epi;
     bf16_t* const outp = (bf16_t*)p.c + coff;
+    const int act = e.act;
+    const bool masked = act >= TOIST_ACT_MASK_POS;         // activations that read aux
     const bf16_t* const resp = e.res ? (const bf16_t*)e.res + coff : nullptr;
-    const bf16_t* const auxp = (e.act == TOIST_ACT_MASK_POS) ? (const bf16_t*)e.aux + coff : nullptr;
-    const int ldc = p.ldc, ldr = e.ldr, ldaux = e.ldaux, act = e.act;
+    const bf16_t* const auxp = masked ? (const bf16_t*)e.aux + coff : nullptr;
+    const int ldc = p.ldc, ldr = e.ldr, ldaux = e.ldaux;
     const float alpha = e.alpha;
+    const int drop = e.drop_where;
+    const unsigned long long dseed = drop ? e.drop_seed + (e.drop_seed_dev ? *e.drop_seed_dev : 0ull) : 0ull;
+    const unsigned dth = (unsigned)(e.drop_p * 4294967296.0);
+    const float dsc = 1.f / (1.f - e.drop_p);
     int rloc[CH], ncol[CH], brow[CH], c8[CH];
     bool col_ok[CH];
     float mul[CH][8], add[CH][8];
@@ -530,16 +537,24 @@ __device__ __forceinline__ void epilogue_lean(const toist_gemm& p, f32x4_t (&acc
             if (e.shift) load_cols8(e.shift + ncol[q], 8, add[q], 0.f);
         }
     }
-    // residual / mask chunks of every band are requested up front
+    // output row of GEMM row m (the optional scatter map of a strided data gradient); residual / mask chunks of every band requested up front
+    long long crow[FM][CH];
     uint4 rres[FM][CH], raux[FM][CH];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int q = 0; q < CH; ++q) {
             const int m = m0 + rloc[q] + 16 * i;
+            crow[i][q] = m;
             if (col_ok[q] && m < M) {
-                if (resp) rres[i][q] = *reinterpret_cast<const uint4*>(resp + (long long)m * ldr + ncol[q]);
-                if (auxp) raux[i][q] = *reinterpret_cast<const uint4*>(auxp + (long long)m * ldaux + ncol[q]);
+                if (e.cmap) {
+                    const int plane = e.cOH * e.cOW;
+                    const int n_img = m / plane, rem = m - n_img * plane;
+                    const int oy = rem / e.cOW, ox = rem - oy * e.cOW;
+                    crow[i][q] = ((long long)n_img * e.cH + (long long)oy * e.cst) * e.cW + (long long)ox * e.cst;
+                }
+                if (resp) rres[i][q] = *reinterpret_cast<const uint4*>(resp + crow[i][q] * ldr + ncol[q]);
+                if (auxp) raux[i][q] = *reinterpret_cast<const uint4*>(auxp + crow[i][q] * ldaux + ncol[q]);
             }
         }
 #pragma unroll
@@ -557,6 +572,11 @@ __device__ __forceinline__ void epilogue_lean(const toist_gemm& p, f32x4_t (&acc
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = v[j] * mul[q][j] + add[q][j];
+                const unsigned long long didx = ((unsigned long long)bz * M + m) * N + ncol[q];     // same element index as epilogue_row8
+                if (drop == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = dropout_keep(dseed, didx + j, dth) ? v[j] * dsc : 0.f;
+                }
                 if (resp) {
                     float x[8];
                     unpack8(rres[i][q], x);
@@ -566,13 +586,28 @@ __device__ __forceinline__ void epilogue_lean(const toist_gemm& p, f32x4_t (&acc
                 if (act == TOIST_ACT_RELU) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-                } else if (act == TOIST_ACT_MASK_POS) {
+                } else if (act == TOIST_ACT_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+                } else if (masked) {
                     float x[8];
                     unpack8(raux[i][q], x);
+                    if (act == TOIST_ACT_MASK_POS) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = x[j] > 0.f ? v[j] : 0.f;
+                        for (int j = 0; j < 8; ++j) v[j] = x[j] > 0.f ? v[j] : 0.f;
+                    } else if (act == TOIST_ACT_GELU_BWD) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(x[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= x[j] * (1.f - x[j]);
+                    }
                 }
-                *reinterpret_cast<uint4*>(outp + (long long)m * ldc + ncol[q]) =
+                if (drop == 2) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = dropout_keep(dseed, didx + j, dth) ? v[j] * dsc : 0.f;
+                }
+                *reinterpret_cast<uint4*>(outp + crow[i][q] * ldc + ncol[q]) =
                     make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
             }
         }
@@ -849,7 +884,7 @@ __device__ __forceinline__ void gemm_tile(const toist_gemm& p, const int tl, bf1
 
     static_assert(32 * (BN + 4) * 4 <= NS * STAGE * 2, "epilogue band must fit the (now idle) ring");
     if (p.flags & 512) return;                                    // flags bit 9 (experiments): skip the epilogue
-    if constexpr (LEAN) epilogue_lean<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, coff);
+    if constexpr (LEAN) epilogue_lean<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, bz, coff);
     else epilogue_tile<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, bz, coff, ksl);
 }
 
@@ -1069,7 +1104,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(const toist_gemm p) {
         if (++slot == C3_NB) slot = 0;
     }
     wait_vm<0>();
-    if constexpr (LEAN) epilogue_lean<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, 0);
+    if constexpr (LEAN) epilogue_lean<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, 0, 0);
     else epilogue_tile<BN, WM, WN, FM, FN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, 0, 0, 0);
 }
 
@@ -1078,14 +1113,16 @@ static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
 
 // what epilogue_lean (and the panel kernel's epilogue) covers
 static bool lean_epilogue_ok(const toist_gemm& d) {
-    static const bool on = [] { const char* v = getenv("TOIST_LEAN_EPILOGUE"); return !(v && v[0] == '0'); }();
+    // TOIST_LEAN_EPILOGUE: 0 = never, 1 = only scale / shift / residual / ReLU / mask, 2 (default) = also dropout, GELU, aux-based gradients, row map
+    static const int level = [] { const char* v = getenv("TOIST_LEAN_EPILOGUE"); return v ? atoi(v) : 2; }();
     const toist_epilogue& e = d.epi;
-    if (!on || d.split_k > 1 || d.group != nullptr || d.a_colsum != nullptr) return false;
-    if (e.out_f32 || e.accumulate || e.rscale || e.pre_out || e.drop_where || e.cmap || e.res_div > 0) return false;
-    if (e.act != TOIST_ACT_NONE && e.act != TOIST_ACT_RELU && e.act != TOIST_ACT_MASK_POS) return false;
+    if (level == 1 && (e.drop_where || e.cmap || (e.act != TOIST_ACT_NONE && e.act != TOIST_ACT_RELU && e.act != TOIST_ACT_MASK_POS))) return false;
+    if (level <= 0 || d.split_k > 1 || d.group != nullptr || d.a_colsum != nullptr) return false;
+    if (e.out_f32 || e.accumulate || e.rscale || e.pre_out || e.res_div > 0) return false;
+    if (e.act == TOIST_ACT_SIGMOID) return false;
     if ((d.N % 8) != 0 || (d.ldc % 8) != 0 || !aligned16(d.c) || (d.cs_outer % 8) != 0 || (d.cs_inner % 8) != 0) return false;
     if (e.res && ((e.ldr % 8) != 0 || !aligned16(e.res))) return false;
-    if (e.act == TOIST_ACT_MASK_POS && (e.aux == nullptr || (e.ldaux % 8) != 0 || !aligned16(e.aux))) return false;
+    if (e.act >= TOIST_ACT_MASK_POS && (e.aux == nullptr || (e.ldaux % 8) != 0 || !aligned16(e.aux))) return false;
     if ((e.scale && (((size_t)e.scale) & 15)) || (e.shift && (((size_t)e.shift) & 15))) return false;
     return true;
 }
