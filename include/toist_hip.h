@@ -184,7 +184,11 @@ int toist_layernorm_fwd(const void* x, const float* gamma, const float* beta, fl
  *  feeds to its q / k projections (transformer.py:293, 366, 386) without a separate elementwise launch */
 int toist_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         int rows, int D, void* dx, float* dgamma, float* dbeta, void* dx_drop, float drop_p,
-                        uint64_t seed, const uint64_t* seed_dev, void* stream);
+                        uint64_t seed, const uint64_t* seed_dev, float* partials, int partial_blocks, void* stream);
+/* `partials` (optional, instead of dgamma / dbeta): f32 [2][partial_blocks][D] per-block sums of dy*xhat and dy, written with plain
+ * stores (no contended atomics) for the caller to fold -- toist_splitk_reduce_batch with splits = partial_blocks, M = 1, N = D.
+ * partial_blocks = toist_layernorm_bwd_blocks(rows). */
+int toist_layernorm_bwd_blocks(int rows);
 int toist_softmax_fwd(const void* scores, const uint8_t* key_pad, int nbatch, int H, int Sq, int Sk, int ld,
                       void* p, void* p_drop, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 int toist_softmax_bwd(const void* p, const void* dp, int rows, int Sk, int ld, void* ds, float drop_p,

@@ -57,7 +57,8 @@ _SIGNATURES = {
     "toist_gemm_bf16": ([POINTER(Gemm), c_void_p], ctypes.c_int),
     "toist_group_fill": ([c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_layernorm_fwd": ([c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "toist_layernorm_bwd": ([c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 4 + [c_float, c_uint64, c_void_p, c_void_p], ctypes.c_int),
+    "toist_layernorm_bwd": ([c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 4 + [c_float, c_uint64, c_void_p, c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "toist_layernorm_bwd_blocks": ([c_int32], ctypes.c_int),
     "toist_softmax_fwd": ([c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p, c_float, c_uint64, c_void_p, c_void_p], ctypes.c_int),
     "toist_softmax_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_float, c_uint64, c_void_p, c_void_p], ctypes.c_int),
     "toist_colsum": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),

@@ -1495,6 +1495,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const ReduceBa
     }
 }
 
+// the same for TALL stacks (many slices of a small output: the per-block partial sums of a LayerNorm backward, 416 slices of 256 floats):
+// a block folds 64 consecutive elements, 16 threads per float4 column walking the slices 16 apart, then a 16-way sum through LDS
+constexpr int RT_ELEMS = 64;
+__global__ __launch_bounds__(256) void splitk_reduce_tall_kernel(const ReduceBatch a) {
+    __shared__ float4 red[16][16];
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.blk_end[i]) ++i;
+    const toist_reduce_desc d = a.d[i];
+    const int b0 = (i == 0) ? 0 : a.blk_end[i - 1];
+    const long long total = (long long)d.M * d.N;
+    const int sl = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const long long e = (long long)(blockIdx.x - b0) * RT_ELEMS + c * 4;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < total)
+        for (int k = sl; k < d.splits; k += 16) {
+            const float4 t = *reinterpret_cast<const float4*>(d.ws + (size_t)k * total + e);
+            s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w;
+        }
+    red[sl][c] = s4;
+    __syncthreads();
+    if (sl == 0 && e < total) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 t = red[k][c]; s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w; }
+        const int m = (int)(e / d.N), n = (int)(e - (long long)m * d.N);
+        const float f = d.rscale ? d.alpha * d.rscale[m] : d.alpha;
+        float* cp = d.out + (long long)m * d.ldc + n;
+        if (d.accumulate) { cp[0] += s4.x * f; cp[1] += s4.y * f; cp[2] += s4.z * f; cp[3] += s4.w * f; }
+        else { cp[0] = s4.x * f; cp[1] = s4.y * f; cp[2] = s4.z * f; cp[3] = s4.w * f; }
+    }
+}
+
 // Workgroups of a persistent launch (TOIST_PERSIST_WGS; 0 = one workgroup per tile everywhere).  Applied (launch_variant) only to the
 // dispatch-bound launches: row-major A, K <= 256, >= 2048 tiles.  Measured on MI355X (round 2, tools/dbg/gemm_persist.py,
 // profiles/r02_gemm_persistent_sweep.txt): 768 workgroups (3 per CU) take 9-16 % off such launches in a back-to-back microbenchmark
@@ -1661,21 +1692,36 @@ extern "C" int toist_gemm_effective_split(const toist_gemm* desc) {
 extern "C" int toist_splitk_reduce_batch(const toist_reduce_desc* descs, int n, void* stream) {
     using namespace toist;
     TOIST_REQUIRE(descs != nullptr && n > 0, "toist_splitk_reduce_batch: no descriptors");
-    for (int base = 0; base < n; base += RB_MAX) {
+    // two passes over the descriptors: ordinary stacks (a thread walks all slices of its 4 elements) and tall ones (> 32 slices of <= 4096 elements)
+    for (int tall = 0; tall < 2; ++tall) {
         ReduceBatch a;
-        a.n = (n - base < RB_MAX) ? n - base : RB_MAX;
+        a.n = 0;
         int blocks = 0;
-        for (int i = 0; i < a.n; ++i) {
-            const toist_reduce_desc& d = descs[base + i];
+        auto launch = [&]() -> int {
+            if (a.n == 0) return TOIST_OK;
+            if (tall) hipLaunchKernelGGL(splitk_reduce_tall_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+            a.n = 0;
+            blocks = 0;
+            return check_launch("toist_splitk_reduce_batch");
+        };
+        for (int i = 0; i < n; ++i) {
+            const toist_reduce_desc& d = descs[i];
             TOIST_REQUIRE(d.ws && d.out && d.splits >= 1 && d.M > 0 && d.N > 0 && (d.N % 4) == 0 && (d.ldc % 4) == 0 &&
                               ((((size_t)d.ws) | ((size_t)d.out)) & 15) == 0,
-                          "toist_splitk_reduce_batch: descriptor %d is malformed", base + i);
-            a.d[i] = d;
-            blocks += (int)(((long long)d.M * d.N + RB_ELEMS - 1) / RB_ELEMS);
-            a.blk_end[i] = blocks;
+                          "toist_splitk_reduce_batch: descriptor %d is malformed", i);
+            const long long total = (long long)d.M * d.N;
+            const bool is_tall = d.splits > 32 && total <= 4096;
+            if ((int)is_tall != tall) continue;
+            a.d[a.n] = d;
+            blocks += (int)((total + (tall ? RT_ELEMS : RB_ELEMS) - 1) / (tall ? RT_ELEMS : RB_ELEMS));
+            a.blk_end[a.n] = blocks;
+            if (++a.n == RB_MAX) {
+                const int rc = launch();
+                if (rc != TOIST_OK) return rc;
+            }
         }
-        hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-        const int rc = check_launch("toist_splitk_reduce_batch");
+        const int rc = launch();
         if (rc != TOIST_OK) return rc;
     }
     return TOIST_OK;

@@ -456,9 +456,9 @@ def layernorm(tape, x, gamma, beta, eps, y=None, add=None):
             # x = residual + dropout(branch): emit the branch's masked gradient from the same pass over dx
             x.gdrop = torch.empty_like(g)
             k.layernorm_bwd(g, x.data, mean, rstd, gamma.f32, dx, gamma.g, beta.g if gamma.g is not None else None, dx_drop=x.gdrop,
-                            drop_p=x.drop[0], seed=x.drop[1])
+                            drop_p=x.drop[0], seed=x.drop[1], defer=True)
         else:
-            k.layernorm_bwd(g, x.data, mean, rstd, gamma.f32, dx, gamma.g, beta.g if gamma.g is not None else None)
+            k.layernorm_bwd(g, x.data, mean, rstd, gamma.f32, dx, gamma.g, beta.g if gamma.g is not None else None, defer=True)
         if x.needs_grad:
             accumulate(x, dx)
 

@@ -6,6 +6,8 @@ memory and streams only.  There is no fallback: a CPU tensor or a missing librar
 """
 import ctypes
 
+import os as _os
+
 import torch
 
 from . import _lib
@@ -257,13 +259,29 @@ def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, add=None, y2=Non
         "toist_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma=None, dbeta=None, dx_drop=None, drop_p=0.0, seed=0):
+LN_DEFER = _os.environ.get("TOIST_LN_DEFER", "1") != "0"
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma=None, dbeta=None, dx_drop=None, drop_p=0.0, seed=0, defer=False):
+    """defer=True: dgamma / dbeta (f32, accumulated) are not updated by contended atomics inside the kernel -- every block writes its
+    partial sums to the split-K arena and the fold is queued for flush_reductions() (engine.Tape.backward ends with it)."""
     rows, D = x.shape
+    partials, blocks = None, 0
+    if defer and LN_DEFER and dgamma is not None:
+        key = (x.device, _raw_stream())
+        if any(it[0].out in (dgamma.data_ptr(), dbeta.data_ptr()) for it in _PENDING.get(key, ())):
+            flush_reductions()          # two queued folds into one output would race
+        blocks = int(_lib.lib().toist_layernorm_bwd_blocks(rows))
+        partials = _arena_take(2 * blocks * D, x.device)
+        for i, out in enumerate((dgamma, dbeta)):
+            rd = _lib.ReduceDesc(partials.data_ptr() + 4 * i * blocks * D, out.data_ptr(), None, blocks, 1, D, D, 1.0, 1)
+            _PENDING.setdefault(key, []).append((rd, (out, partials)))
     _lib.check(
         _lib.lib().toist_layernorm_bwd(_p(dy, torch.bfloat16), _p(x, torch.bfloat16), _p(mean, torch.float32),
                                        _p(rstd, torch.float32), _p(gamma, torch.float32), rows, D, _p(dx, torch.bfloat16),
-                                       _p(dgamma, torch.float32), _p(dbeta, torch.float32), _p(dx_drop, torch.bfloat16),
-                                       drop_p, seed, _p(SEED_DEV), _stream()), "toist_layernorm_bwd")
+                                       None if partials is not None else _p(dgamma, torch.float32),
+                                       None if partials is not None else _p(dbeta, torch.float32), _p(dx_drop, torch.bfloat16),
+                                       drop_p, seed, _p(SEED_DEV), _p(partials, torch.float32), blocks, _stream()), "toist_layernorm_bwd")
 
 
 def softmax_fwd(scores, key_pad, nbatch, H, Sq, Sk, ld, p, p_drop=None, drop_p=0.0, seed=0):
