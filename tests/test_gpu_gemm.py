@@ -519,3 +519,37 @@ def test_grouped_conv_wgrad_matches_separate_launches(dev, R, stride, min_tiles)
     for i in range(n):
         _close(grouped[i], refs[i], Nb * H * W, f"grouped wgrad {i}", rtol=1e-2, atol_unit=2e-3)
         assert torch.allclose(grouped[i], items[i][2], rtol=2e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("B,H,S,dh", [(8, 12, 16, 64), (3, 4, 11, 32), (2, 2, 40, 64), (1, 3, 64, 16)])
+def test_small_attention_against_autograd(dev, B, H, S, dh):
+    """csrc/attn_small.hip (whole-head attention of the text encoder: S <= 64, head dim <= 64) forward and backward against fp32
+    autograd, with key padding and the three projection biases added on load; dropout off (the mask is a hash, covered by the model tests)."""
+    from toist_amd import kernels as k
+    g = torch.Generator().manual_seed(S * dh)
+    d = H * dh
+    qkv = torch.randn(B * S, 3 * d, generator=g).to(BF)
+    bias = [torch.randn(d, generator=g) * 0.3 for _ in range(3)]
+    pad = torch.zeros(B, S, dtype=torch.uint8)
+    for b in range(B):
+        pad[b, S - (b % 3):] = 1 if b % 3 else 0
+    dctx = torch.randn(B * S, d, generator=g).to(BF)
+    scale = dh ** -0.5
+    leaves = [(qkv[:, i * d:(i + 1) * d].float() + bias[i]).view(B, S, H, dh).transpose(1, 2).requires_grad_(True) for i in range(3)]
+    sc = (leaves[0] @ leaves[1].transpose(-1, -2)) * scale
+    sc = sc.masked_fill(pad.bool()[:, None, None, :], float("-inf"))
+    ctx_ref = (sc.softmax(-1) @ leaves[2]).transpose(1, 2).reshape(B * S, d)
+    ctx_ref.backward(dctx.float())
+    ref_grads = [t.grad.transpose(1, 2).reshape(B * S, d) for t in leaves]
+    qkv_d = qkv.to(dev)
+    q, kk, v = (qkv_d[:, i * d:(i + 1) * d] for i in range(3))
+    bd = [t.to(dev) for t in bias]
+    ctx = torch.empty(B * S, d, dtype=BF, device=dev)
+    stats = torch.empty(B * H * S * 2, dtype=torch.float32, device=dev)
+    k.attn_small_fwd(q, kk, v, pad.to(dev), B, H, S, dh, scale, 0.0, 0, ctx, stats, *bd)
+    _close(ctx, ctx_ref.detach(), S, "small attention forward", rtol=2e-2, atol_unit=3e-3)
+    dqkv = torch.empty(B * S, 3 * d, dtype=BF, device=dev)
+    dq, dk, dv = (dqkv[:, i * d:(i + 1) * d] for i in range(3))
+    k.attn_small_bwd(q, kk, v, pad.to(dev), B, H, S, dh, scale, 0.0, 0, stats, dctx.to(dev), dq, dk, dv, *bd)
+    for name, got, ref in zip("qkv", (dq, dk, dv), ref_grads):
+        _close(got, ref, S * 4, f"small attention d{name}", rtol=3e-2, atol_unit=3e-3)

@@ -13,32 +13,47 @@ namespace toist {
 
 constexpr int AS_MAXS = 64, AS_MAXD = 64, AS_THREADS = 256;
 
+constexpr int AS_LD = AS_MAXD + 4;       // fp32 row pitch: 16-byte aligned rows (float4 reads), consecutive rows 4 banks apart
 struct AsShared {
-    float q[AS_MAXS][AS_MAXD + 1];
-    float k[AS_MAXS][AS_MAXD + 1];
-    float v[AS_MAXS][AS_MAXD + 1];
+    float q[AS_MAXS][AS_LD];
+    float k[AS_MAXS][AS_LD];
+    float v[AS_MAXS][AS_LD];
     float p[AS_MAXS][AS_MAXS + 1];      // scores -> probabilities (-> dS in backward)
     float pd[AS_MAXS][AS_MAXS + 1];     // dropped-out probabilities (backward: also dP)
-    float g[AS_MAXS][AS_MAXD + 1];      // backward: dO
+    float g[AS_MAXS][AS_LD];            // backward: dO
     float rowdot[AS_MAXS];
     unsigned char dead[AS_MAXS];
 };
 
 // rows of one head -> LDS as fp32; `bias` (optional, fp32 [H * dh]) is the projection bias, added here so that the packed q | k | v
 // projection can run as one plain GEMM without an epilogue vector (the three biases are separate parameters)
-__device__ __forceinline__ void as_load(float (*dst)[AS_MAXD + 1], const bf16_t* src, int ld, int b, int h, int S, int dh, const float* bias) {
+__device__ __forceinline__ void as_load(float (*dst)[AS_LD], const bf16_t* src, int ld, int b, int h, int S, int dh, const float* bias) {
     const int per = dh >> 3;                                    // 16-byte chunks per row
     for (int c = threadIdx.x; c < S * per; c += AS_THREADS) {
         const int i = c / per, ch = c - i * per;
         const uint4 u = *reinterpret_cast<const uint4*>(src + ((size_t)b * S + i) * ld + h * dh + ch * 8);
         const unsigned w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float b0 = bias ? bias[h * dh + ch * 8 + 2 * j] : 0.f, b1 = bias ? bias[h * dh + ch * 8 + 2 * j + 1] : 0.f;
-            dst[i][ch * 8 + 2 * j] = __uint_as_float(w[j] << 16) + b0;
-            dst[i][ch * 8 + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u) + b1;
+        float4 blo = make_float4(0.f, 0.f, 0.f, 0.f), bhi = blo;
+        if (bias) {
+            blo = *reinterpret_cast<const float4*>(bias + h * dh + ch * 8);
+            bhi = *reinterpret_cast<const float4*>(bias + h * dh + ch * 8 + 4);
         }
+        *reinterpret_cast<float4*>(&dst[i][ch * 8]) = make_float4(__uint_as_float(w[0] << 16) + blo.x, __uint_as_float(w[0] & 0xffff0000u) + blo.y,
+                                                                  __uint_as_float(w[1] << 16) + blo.z, __uint_as_float(w[1] & 0xffff0000u) + blo.w);
+        *reinterpret_cast<float4*>(&dst[i][ch * 8 + 4]) = make_float4(__uint_as_float(w[2] << 16) + bhi.x, __uint_as_float(w[2] & 0xffff0000u) + bhi.y,
+                                                                      __uint_as_float(w[3] << 16) + bhi.z, __uint_as_float(w[3] & 0xffff0000u) + bhi.w);
     }
+}
+
+// sum_c a[c] * b[c] over dh (a multiple of 8) features of two LDS rows, four at a time
+__device__ __forceinline__ float as_dot(const float* a, const float* b, int dh) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int c = 0; c < dh; c += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(a + c), y = *reinterpret_cast<const float4*>(b + c);
+        acc.x += x.x * y.x; acc.y += x.y * y.y; acc.z += x.z * y.z; acc.w += x.w * y.w;
+    }
+    return (acc.x + acc.y) + (acc.z + acc.w);
 }
 
 // scores, masked softmax and dropout of one head into sh.p (probabilities) and sh.pd (dropped-out, rescaled); FWD also stores
@@ -50,32 +65,37 @@ __device__ __forceinline__ void as_probabilities(AsShared& sh, const unsigned ch
     __syncthreads();
     for (int e = threadIdx.x; e < S * S; e += AS_THREADS) {
         const int i = e / S, j = e - i * S;
-        float acc = 0.f;
-        for (int c = 0; c < dh; ++c) acc += sh.q[i][c] * sh.k[j][c];
+        const float acc = as_dot(sh.q[i], sh.k[j], dh);
         sh.p[i][j] = sh.dead[j] ? -INFINITY : acc * scale;
     }
     __syncthreads();
     const unsigned thresh = drop_p > 0.f ? (unsigned)(drop_p * 4294967296.0) : 0u;
     const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    for (int i = threadIdx.x; i < S; i += AS_THREADS) {
+    // a row of scores is spread over G = 16 / 32 / 64 lanes of one wavefront (one element per lane; row statistics by xor-shuffles)
+    const int G = S <= 16 ? 16 : (S <= 32 ? 32 : 64);
+    const int jl = threadIdx.x & (G - 1);
+    for (int i = threadIdx.x / G; i < S; i += AS_THREADS / G) {
+        const float sc = jl < S ? sh.p[i][jl] : -INFINITY;
         float mx, rs;
         if (FWD) {
-            mx = -INFINITY;
-            for (int j = 0; j < S; ++j) mx = fmaxf(mx, sh.p[i][j]);
-            float sum = 0.f;
-            for (int j = 0; j < S; ++j) sum += __expf(sh.p[i][j] - mx);
+            mx = sc;
+            for (int o = G >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float sum = jl < S ? __expf(sc - mx) : 0.f;
+            for (int o = G >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
             rs = 1.f / sum;
-            stats[2 * ((size_t)bh * S + i)] = mx;
-            stats[2 * ((size_t)bh * S + i) + 1] = rs;
+            if (jl == 0) {
+                stats[2 * ((size_t)bh * S + i)] = mx;
+                stats[2 * ((size_t)bh * S + i) + 1] = rs;
+            }
         } else {
             mx = stats[2 * ((size_t)bh * S + i)];
             rs = stats[2 * ((size_t)bh * S + i) + 1];
         }
-        for (int j = 0; j < S; ++j) {
-            const float pv = __expf(sh.p[i][j] - mx) * rs;
-            const bool keep = drop_p <= 0.f || dropout_keep(seed, ((unsigned long long)bh * S + i) * S + j, thresh);
-            sh.p[i][j] = pv;
-            sh.pd[i][j] = keep ? pv * dscale : 0.f;
+        if (jl < S) {
+            const float pv = __expf(sc - mx) * rs;
+            const bool keep = drop_p <= 0.f || dropout_keep(seed, ((unsigned long long)bh * S + i) * S + jl, thresh);
+            sh.p[i][jl] = pv;
+            sh.pd[i][jl] = keep ? pv * dscale : 0.f;
         }
     }
     __syncthreads();
@@ -96,11 +116,16 @@ __global__ __launch_bounds__(AS_THREADS) void attn_small_fwd_kernel(const bf16_t
     as_load(sh.v, v, ldv, b, h, S, dh, bv);
     __syncthreads();
     as_probabilities<true>(sh, key_pad, b, bh, S, dh, scale, drop_p, seed, stats);
-    for (int e = threadIdx.x; e < S * (dh >> 1); e += AS_THREADS) {
-        const int i = e / (dh >> 1), c = (e - i * (dh >> 1)) * 2;
-        float a0 = 0.f, a1 = 0.f;
-        for (int j = 0; j < S; ++j) { a0 += sh.pd[i][j] * sh.v[j][c]; a1 += sh.pd[i][j] * sh.v[j][c + 1]; }
-        *reinterpret_cast<unsigned*>(ctx + ((size_t)b * S + i) * ldo + h * dh + c) = pack2bf(a0, a1);
+    const int quarter = dh >> 2;
+    for (int e = threadIdx.x; e < S * quarter; e += AS_THREADS) {      // four features of one query row per thread
+        const int i = e / quarter, c = (e - i * quarter) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < S; ++j) {
+            const float w = sh.pd[i][j];
+            const float4 x = *reinterpret_cast<const float4*>(&sh.v[j][c]);
+            a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w;
+        }
+        *reinterpret_cast<uint2*>(ctx + ((size_t)b * S + i) * ldo + h * dh + c) = make_uint2(pack2bf(a.x, a.y), pack2bf(a.z, a.w));
     }
 }
 
@@ -122,29 +147,35 @@ __global__ __launch_bounds__(AS_THREADS) void attn_small_bwd_kernel(const bf16_t
     as_load(sh.g, dctx, lddo, b, h, S, dh, nullptr);
     __syncthreads();
     as_probabilities<false>(sh, key_pad, b, bh, S, dh, scale, drop_p, seed, const_cast<float*>(stats));
-    const int half = dh >> 1;
-    // dV[j] = sum_i pd[i][j] dO[i]
-    for (int e = threadIdx.x; e < S * half; e += AS_THREADS) {
-        const int j = e / half, c = (e - j * half) * 2;
-        float a0 = 0.f, a1 = 0.f;
-        for (int i = 0; i < S; ++i) { a0 += sh.pd[i][j] * sh.g[i][c]; a1 += sh.pd[i][j] * sh.g[i][c + 1]; }
-        *reinterpret_cast<unsigned*>(dv + ((size_t)b * S + j) * lddv + h * dh + c) = pack2bf(a0, a1);
+    const int quarter = dh >> 2;
+    // dV[j] = sum_i pd[i][j] dO[i]: four features per thread
+    for (int e = threadIdx.x; e < S * quarter; e += AS_THREADS) {
+        const int j = e / quarter, c = (e - j * quarter) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < S; ++i) {
+            const float w = sh.pd[i][j];
+            const float4 x = *reinterpret_cast<const float4*>(&sh.g[i][c]);
+            a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w;
+        }
+        *reinterpret_cast<uint2*>(dv + ((size_t)b * S + j) * lddv + h * dh + c) = make_uint2(pack2bf(a.x, a.y), pack2bf(a.z, a.w));
     }
     __syncthreads();
     // dP (w.r.t. the dropped-out probabilities) masked and rescaled: keep <=> pd != 0 or p == 0
     const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     for (int e = threadIdx.x; e < S * S; e += AS_THREADS) {
         const int i = e / S, j = e - i * S;
-        float acc = 0.f;
-        for (int c = 0; c < dh; ++c) acc += sh.g[i][c] * sh.v[j][c];
+        const float acc = as_dot(sh.g[i], sh.v[j], dh);
         const bool keep = drop_p <= 0.f || sh.pd[i][j] != 0.f;
         sh.pd[i][j] = keep ? acc * dscale : 0.f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < S; i += AS_THREADS) {
-        float t = 0.f;
-        for (int j = 0; j < S; ++j) t += sh.p[i][j] * sh.pd[i][j];
-        sh.rowdot[i] = t;
+    {
+        const int G = S <= 16 ? 16 : (S <= 32 ? 32 : 64), jl = threadIdx.x & (G - 1);
+        for (int i = threadIdx.x / G; i < S; i += AS_THREADS / G) {
+            float t = jl < S ? sh.p[i][jl] * sh.pd[i][jl] : 0.f;
+            for (int o = G >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (jl == 0) sh.rowdot[i] = t;
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < S * S; e += AS_THREADS) {
@@ -152,15 +183,19 @@ __global__ __launch_bounds__(AS_THREADS) void attn_small_bwd_kernel(const bf16_t
         sh.p[i][j] = sh.p[i][j] * (sh.pd[i][j] - sh.rowdot[i]) * scale;      // dS, with the score scale folded in
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < S * half; e += AS_THREADS) {
-        const int i = e / half, c = (e - i * half) * 2;
-        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    // dQ[i] = sum_j dS[i][j] k[j] (threads 0 .. S*dh/4) and dK[i] = sum_j dS[j][i] q[j] (the next S*dh/4): four features per thread
+    for (int e = threadIdx.x; e < 2 * S * quarter; e += AS_THREADS) {
+        const bool is_k = e >= S * quarter;
+        const int r = is_k ? e - S * quarter : e;
+        const int i = r / quarter, c = (r - i * quarter) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = 0; j < S; ++j) {
-            a0 += sh.p[i][j] * sh.k[j][c]; a1 += sh.p[i][j] * sh.k[j][c + 1];       // dQ[i] = sum_j dS[i][j] k[j]
-            b0 += sh.p[j][i] * sh.q[j][c]; b1 += sh.p[j][i] * sh.q[j][c + 1];       // dK[i] = sum_j dS[j][i] q[j]
+            const float w = is_k ? sh.p[j][i] : sh.p[i][j];
+            const float4 x = *reinterpret_cast<const float4*>(is_k ? &sh.q[j][c] : &sh.k[j][c]);
+            a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w;
         }
-        *reinterpret_cast<unsigned*>(dq + ((size_t)b * S + i) * lddq + h * dh + c) = pack2bf(a0, a1);
-        *reinterpret_cast<unsigned*>(dk + ((size_t)b * S + i) * lddk + h * dh + c) = pack2bf(b0, b1);
+        bf16_t* const out = is_k ? dk + ((size_t)b * S + i) * lddk : dq + ((size_t)b * S + i) * lddq;
+        *reinterpret_cast<uint2*>(out + h * dh + c) = make_uint2(pack2bf(a.x, a.y), pack2bf(a.z, a.w));
     }
 }
 
@@ -187,7 +222,7 @@ extern "C" int toist_attn_small_fwd(const void* q, int ldq, const void* kmat, in
                                     int dh, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* ctx, int ldo, float* stats,
                                     const float* bq, const float* bk, const float* bv, void* stream) {
     if (int rc = attn_small_ok("toist_attn_small_fwd", B, H, S, dh, drop_p)) return rc;
-    TOIST_REQUIRE(q && kmat && v && ctx && stats && (ldq % 8) == 0 && (ldk % 8) == 0 && (ldv % 8) == 0 && (ldo % 2) == 0, "toist_attn_small_fwd: bad args");
+    TOIST_REQUIRE(q && kmat && v && ctx && stats && (ldq % 8) == 0 && (ldk % 8) == 0 && (ldv % 8) == 0 && (ldo % 4) == 0, "toist_attn_small_fwd: bad args");
     static const int once = attn_small_lds((const void*)attn_small_fwd_kernel);
     if (once != TOIST_OK) return once;
     hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(B * H), dim3(AS_THREADS), sizeof(AsShared), (hipStream_t)stream, (const bf16_t*)q, ldq, (const bf16_t*)kmat,
@@ -202,7 +237,7 @@ extern "C" int toist_attn_small_bwd(const void* q, int ldq, const void* kmat, in
                                     const float* bv, void* stream) {
     if (int rc = attn_small_ok("toist_attn_small_bwd", B, H, S, dh, drop_p)) return rc;
     TOIST_REQUIRE(q && kmat && v && stats && dctx && dq && dk && dv && (ldq % 8) == 0 && (ldk % 8) == 0 && (ldv % 8) == 0 && (lddo % 8) == 0 &&
-                      (lddq % 2) == 0 && (lddk % 2) == 0 && (lddv % 2) == 0, "toist_attn_small_bwd: bad args");
+                      (lddq % 4) == 0 && (lddk % 4) == 0 && (lddv % 4) == 0, "toist_attn_small_bwd: bad args");
     static const int once = attn_small_lds((const void*)attn_small_bwd_kernel);
     if (once != TOIST_OK) return once;
     hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * H), dim3(AS_THREADS), sizeof(AsShared), (hipStream_t)stream, (const bf16_t*)q, ldq, (const bf16_t*)kmat,
