@@ -261,6 +261,9 @@ def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, s
 
 
 GROUP_TILE = int(_os.environ.get("TOIST_GROUP_TILE", "0"))   # tile code of grouped weight-gradient launches (0 = the dispatcher's choice)
+GROUP_TILE_3X3 = int(_os.environ.get("TOIST_GROUP_TILE_3X3", "130"))
+GROUP_TILE_1X1 = int(_os.environ.get("TOIST_GROUP_TILE_1X1", "134"))
+GROUP_SPLIT_TILE = int(_os.environ.get("TOIST_GROUP_SPLIT_TILE", "130"))   # grouped AND split along K: 128x64 tiles with twice the slices (+0.7% step over 64x64)
 GROUP_MIN_TILES = 512   # below this many 64x64 output tiles in total the problems stay separate (they need split-K)
 
 
@@ -295,10 +298,14 @@ def conv2d_wgrad_group(items, w_shape, *, stride=1, pad=0, dil=1, accumulate=Tru
     tile = GROUP_TILE
     if tile == 0 and split_k == 1:
         # measured on the 22 grouped layer-3 problems (K = 12800, tools/run_timeline.sh): 3x3 714 / 562 / 598 us and 1x1 913 / 886 / 818 us
-        # with 64x64 / 128x128 / 128x64 tiles -- deep reductions with enough tiles to fill the chip want the larger tiles
-        big = 129 if R * S > 1 else 130
-        n_big = ((Co + 127) // 128) * ((Nn + (127 if big == 129 else 63)) // (128 if big == 129 else 64)) * len(items)
+        # with 64x64 / 128x128 / 128x64 tiles -- deep reductions with enough tiles to fill the chip want the larger tiles.  Re-measured with the
+        # 64x128 tile (code 134) on whole steps, same box: (3x3, 1x1) = (129, 130) 517-519 images/s, (134, 134) 522-526, (130, 134) 523-527
+        big = GROUP_TILE_3X3 if R * S > 1 else GROUP_TILE_1X1
+        n_big = ((Co + (63 if big == 134 else 127)) // (64 if big == 134 else 128)) * ((Nn + (63 if big == 130 else 127)) // (64 if big == 130 else 128)) * len(items)
         tile = big if n_big >= 256 else 0
+    elif tile == 0 and GROUP_SPLIT_TILE:
+        tile = GROUP_SPLIT_TILE
+        split_k = min(2 * split_k, max(1, (P + 63) // 64 // 4))
     k.gemm(Co, Nn, P, k.A_KROW, a, b_kind, b, out0, Nn, accumulate=accumulate, split_k=split_k, rscale=rs0, batch=len(items), tile=tile,
            flops=2 * P * Co * Nn * len(items), group=table, group_out=[(it[2], it[3]) for it in items])
 
