@@ -1622,7 +1622,10 @@ static int auto_tile(const toist_gemm& d) {
     // measured on MI355X (tools/sweep_gemm.py): 128x128x64 only pays once >= ~4 tiles per CU exist and K
     // is deep; below that 64x64x64 tiles keep more workgroups (and DMA) in flight.
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.batch > 0 ? d.batch : 1) * (d.split_k > 0 ? d.split_k : 1);
-    if (t128 >= 1024 && d.K >= 1024) return 129;
+    // (round 2: the 128x64 tile beats 128x128 on every large problem measured -- 4096^3: 675 vs 555 TFLOP/s, 8192 x 8192 x 2048: 708 vs 443;
+    // 128x128 needs 231-247 VGPRs, two waves per SIMD)
+    static const int big_tile = [] { const char* e = getenv("TOIST_BIG_TILE"); return e ? atoi(e) : 130; }();
+    if (t128 >= 1024 && d.K >= 1024) return big_tile;
     if (d.K > 64 && d.N <= 32 && d.M >= 4096) return 132;   // a 64-wide tile would idle half (or more) of its MFMA columns
     if (d.K > 64 && d.M <= 32 && d.N >= 128) return 133;
     // Wave quantisation of the 64x64 grid: three workgroups fit a CU (768 slots), so 800 tiles (ResNet layer3 at batch 8: 12800
