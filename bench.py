@@ -23,6 +23,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 GFLOP_PER_IMG_TRAIN = 397.7  # detection train step, stem + layer1 frozen
 
@@ -215,10 +216,11 @@ def main():
     import toist_amd
     from toist_amd import harness, kernels, parallel
     from toist_amd.mdetr import weighted_total
-    # the roofline kernel = the family that takes most of the step's kernel time (profiles/r02_timeline_*.txt: ~45 %): the 64x64x64
-    # bf16 MFMA GEMM on row-major activations -- every 1x1 convolution of the backbone and every nn.Linear, forward and data gradient
+    # the roofline kernel = the kernel with the largest share of the step's kernel time (profiles/r02_timeline_graph_step.txt): the
+    # short-K panel kernel (csrc/gemm.hip panel_kernel, dispatcher tile code 135) -- the 1x1 convolutions of the backbone with K <= 256 and
+    # their data gradients, 81 launches per step.  ~100 flop per algorithmic byte, below the ridge (2500 TFLOP/s / 8 TB/s = 312): HBM-bound.
     global ROOFLINE_KEYS
-    ROOFLINE_KEYS = frozenset({(65, kernels.A_ROWK, kernels.B_ROWK), (65, kernels.A_ROWK, kernels.B_KROW)})
+    ROOFLINE_KEYS = frozenset({(135, kernels.A_ROWK, kernels.B_ROWK), (135, kernels.A_ROWK, kernels.B_KROW)})
     if a.distill:
         return bench_distillation(a, dev, rank, world)
     # the reference's default detection recipe (scripts/train_dete.sh): labels + boxes + cardinality + contrastive_align, 5 aux layers;
@@ -497,19 +499,25 @@ def main():
                 pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
                 if os.path.exists(pj):
                     meta = json.load(open(pj))
-                    ks = {k_: v for k_, v in meta["kernels"].items() if "gemm_kernel<64, 64, 64, 0," in k_}
+                    ks = {k_: v for k_, v in meta["kernels"].items() if "panel_kernel" in k_}
                     disp = sum(v["dispatches"] for v in ks.values())
                     if disp:
                         traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in ks.values()) / disp)
                         traffic_src = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --no-graph` at commit "
                                        + str(meta.get("commit", "?")) + " (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction applied); not re-measured in this run")
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 5), "traffic": traffic, "traffic_unit": "bytes/launch",
+            gbs = sum(r[5] for r in prof["records"]) / (tot_ms * 1e-3) / 1e9
+            if prof["key"] is not None:
+                res["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 5),
+                                   "kernel": "panel_kernel<{B_ROWK,B_KROW},act> (1x1 convolutions with K <= 256 and their data gradients: the largest single share of the step's kernel time)",
+                                   "tflops": round(ach, 2), "mfma_frac": round(ach / PEAK_BF16_TFLOPS, 5)}
+            else:
+                res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5),
+                                   "kernel": "all gemm launches"}
+            res["roofline"].update({"traffic": traffic, "traffic_unit": "bytes/launch",
                                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes),
-                               "kernel": "gemm_kernel<64,64,64,A_ROWK,{B_ROWK,B_KROW}> (1x1 convolutions and nn.Linear, forward + data gradient: the largest share of the step's kernel time)" if prof["key"] else "all gemm_kernel launches",
                                "timed": "HIP events around each launch, %d eager steps %s" % (a.steps, "after the graph-replayed timed region" if use_graph else "inside the timed region"),
-                               "launches": n, "avg_launch_us": round(1000 * tot_ms / n, 2), "avg_gflop_per_launch": round(tot_fl / n / 1e9, 3)}
+                               "launches": n, "avg_launch_us": round(1000 * tot_ms / n, 2), "avg_gflop_per_launch": round(tot_fl / n / 1e9, 3)})
             if a.profile_all:
                 shapes = {}
                 for e0, e1, fl, key, shape, nbytes in prof["records"]:
