@@ -553,3 +553,25 @@ def test_small_attention_against_autograd(dev, B, H, S, dh):
     k.attn_small_bwd(q, kk, v, pad.to(dev), B, H, S, dh, scale, 0.0, 0, stats, dctx.to(dev), dq, dk, dv, *bd)
     for name, got, ref in zip("qkv", (dq, dk, dv), ref_grads):
         _close(got, ref, S * 4, f"small attention d{name}", rtol=3e-2, atol_unit=3e-3)
+
+
+@pytest.mark.parametrize("M,N,K,drop_where,act", [(3328, 2048, 256, 2, 1), (3328, 256, 256, 1, 0), (800, 512, 128, 1, 1), (12800, 1024, 256, 0, 1), (1000, 264, 72, 2, 0)])
+def test_short_k_panel_kernel_matches_generic_tiles(dev, M, N, K, drop_where, act):
+    """csrc/gemm.hip panel_kernel (tile code 135: K <= 256, weight panel resident in registers, lean epilogue incl. the transformer's
+    dropout) must reproduce the generic 64x64 tiles bit for bit -- same MFMA order along K, same epilogue arithmetic, same dropout hash."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bias, res = torch.randn(N, generator=g).to(dev), torch.randn(M, N, generator=g).to(BF).to(dev)
+    k.SEED_DEV = torch.full((1,), 12345, dtype=torch.int64, device=dev)
+    kw = dict(res=res, act=k.ACT_RELU if act else k.ACT_NONE, drop_where=drop_where, drop_p=0.1 if drop_where else 0.0, drop_seed=99)
+    a = ops.linear(x, w, bias, tile=65, **kw)
+    b = ops.linear(x, w, bias, tile=135, **kw)
+    assert torch.equal(a, b)
+    wt = w.t().contiguous()
+    aux = torch.randn(M, N, generator=g).to(BF).to(dev)
+    da = ops.linear_dgrad(x, wt, res=res, act=k.ACT_MASK_POS, aux=aux, split_k=1)
+    out = torch.empty_like(da)
+    k.gemm(M, N, K, k.A_ROWK, k.operand(x, K), k.B_KROW, k.operand(wt, N), out, N, res=res, ldr=N, act=k.ACT_MASK_POS, aux=aux, ldaux=N, tile=135)
+    assert torch.equal(da, out)

@@ -1228,6 +1228,10 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const toist_gemm p) {
     bf16_t* const outp = (bf16_t*)p.c;
     const int ldc = p.ldc, ldr = p.epi.ldr, ldaux = p.epi.ldaux;
     const float alpha = p.epi.alpha;
+    const int drop = p.epi.drop_where;            // nn.Linear + dropout of the transformer layers (same element index and hash as epilogue_row8)
+    const unsigned long long dseed = drop ? p.epi.drop_seed + (p.epi.drop_seed_dev ? *p.epi.drop_seed_dev : 0ull) : 0ull;
+    const unsigned dth = (unsigned)(p.epi.drop_p * 4294967296.0);
+    const float dsc = 1.f / (1.f - p.epi.drop_p);
     float csc[8], csh[8];
     const bool has_scale = p.epi.scale != nullptr, has_shift = p.epi.shift != nullptr;
 #pragma unroll
@@ -1295,6 +1299,11 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const toist_gemm p) {
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = v[j] * (alpha * csc[j]) + csh[j];
+                const unsigned long long didx = (unsigned long long)m * N + ncol;
+                if (drop == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = dropout_keep(dseed, didx + j, dth) ? v[j] * dsc : 0.f;
+                }
                 if (resp) {
                     float x[8];
                     unpack8(cur.res[i], x);
@@ -1310,6 +1319,10 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const toist_gemm p) {
                     unpack8(cur.aux[i], x);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = x[j] > 0.f ? v[j] : 0.f;
+                }
+                if (drop == 2) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = dropout_keep(dseed, didx + j, dth) ? v[j] * dsc : 0.f;
                 }
                 *reinterpret_cast<uint4*>(outp + (size_t)((unsigned)(m * ldc + ncol))) =
                     make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
@@ -1331,11 +1344,12 @@ static bool panel_applies(const toist_gemm& d) {
     if (d.b_kind == TOIST_B_KROW && d.b.kin > 0) return false;
     if (d.K > 256 || (d.K % 8) != 0 || (d.a.ld % 8) != 0 || (d.b.ld % 8) != 0) return false;
     if (d.batch != 1 || d.split_k != 1 || d.group != nullptr || d.a2 != nullptr || d.a_colsum != nullptr || (d.flags & 1)) return false;
-    if ((d.N + 63) / 64 > 64 || (d.M + 63) / 64 < 16) return false;      // row tiles are dealt to 8 XCDs: too few would leave XCDs idle
+    if ((d.N + 63) / 64 > 64 || (d.M + 63) / 64 < 8) return false;      // row tiles are dealt to 8 XCDs: too few would leave XCDs idle
     if ((long long)d.M * d.a.ld >= (1ll << 30) || (long long)d.K * d.b.ld >= (1ll << 30) || (long long)d.N * d.b.ld >= (1ll << 30)) return false;   // 32-bit element offsets
     // the kernel's lean epilogue: bf16 rows in whole 16-byte chunks, per-column scale / shift, residual, {none, ReLU, aux > 0 mask}
     const toist_epilogue& e = d.epi;
-    if (e.out_f32 || e.accumulate || e.rscale || e.pre_out || e.drop_where || e.cmap || e.res_div > 0) return false;
+    if (e.out_f32 || e.accumulate || e.rscale || e.pre_out || e.cmap || e.res_div > 0) return false;
+    if (e.drop_where && !(e.drop_p >= 0.f && e.drop_p < 1.f)) return false;
     if (e.act != TOIST_ACT_NONE && e.act != TOIST_ACT_RELU && e.act != TOIST_ACT_MASK_POS) return false;
     if ((d.N % 8) != 0 || (d.ldc % 8) != 0 || !aligned16(d.c) || (long long)d.M * d.ldc >= (1ll << 31)) return false;
     if (e.res && ((e.ldr % 8) != 0 || !aligned16(e.res) || (long long)d.M * e.ldr >= (1ll << 31))) return false;
