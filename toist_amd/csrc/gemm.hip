@@ -892,8 +892,20 @@ __device__ __forceinline__ void gemm_tile(const toist_gemm& p, const int tl, bf1
 // workgroups return at once takes 24 us, a 3200-tile one 6.9 us), which for the K <= 256 GEMMs of the hot path is as much as their
 // whole reduction loop.  The grid is therefore capped at what the chip holds at once (launch_variant) and every workgroup walks
 // the tile list with stride gridDim.x; a multiple of 8, so a workgroup stays on its XCD's contiguous run of tiles.
+// Waves per SIMD asked of the register allocator.  Round 2's descriptor options (second A operand, groups, the persistent loop, the
+// up-front residual requests) had grown the 64x64 kernels from 97 + 16 to 128 + 16 registers and the 128x64 / 64x128 ones from 125 + 32
+// to 158-186 + 32: one occupancy step lost each (round-1 build, same box: 4096^3 on 128x64 tiles 726 TFLOP/s, now 672).
+#ifndef GEMM_WAVES_64
+#define GEMM_WAVES_64 4
+#endif
+#ifndef GEMM_WAVES_128
+#define GEMM_WAVES_128 3
+#endif
+template <int BM, int BN, int NS>
+constexpr int gemm_min_waves() { return (BM * BN <= 4096 && NS == 2) ? GEMM_WAVES_64 : (BM * BN == 8192 ? GEMM_WAVES_128 : 1); }
+
 template <int BM, int BN, int BK, int AK, int BKD, int NS, bool LEAN = false>
-__global__ __launch_bounds__(256) void gemm_kernel(const toist_gemm p) {
+__global__ __launch_bounds__(256, (gemm_min_waves<BM, BN, NS>())) void gemm_kernel(const toist_gemm p) {
     constexpr int STAGE = (BM + BN) * BK;
     __shared__ __attribute__((aligned(16))) bf16_t smem[NS * STAGE];
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
