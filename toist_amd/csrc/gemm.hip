@@ -1654,15 +1654,15 @@ static int auto_tile(const toist_gemm& d) {
     if (t128 >= 1024 && d.K >= 1024) return big_tile;
     if (d.K > 64 && d.N <= 32 && d.M >= 4096) return 132;   // a 64-wide tile would idle half (or more) of its MFMA columns
     if (d.K > 64 && d.M <= 32 && d.N >= 128) return 133;
-    // Wave quantisation of the 64x64 grid: three workgroups fit a CU (768 slots), so 800 tiles (ResNet layer3 at batch 8: 12800
-    // pixels x 256 channels) run as one full round plus a nearly empty one.  When the last round would be < 1/4 full and there
-    // are at most two full ones, 64x128 tiles (half the workgroups, half the A traffic through LDS) finish in fewer rounds:
-    // measured 28 -> 21 us (1024 -> 256 1x1), 44 -> 34 us (3x3 at 40x40), 42 -> 30 us (13312 x 256 x 2048); at 1.5-1.6 rounds
-    // (1200-1252 tiles) the 64x64 grid stays ahead (29 vs 34 us), as it does below one round (tools/dbg/gemm_tiles.py).
+    // Wave quantisation of the 64x64 grid: four two-slot workgroups fit a CU (1024 slots; three before the occupancy hint of gemm_kernel,
+    // when 800 tiles -- ResNet layer3 at batch 8 -- were a full round plus a 4 % one and this rule bought 28 -> 21 us).  When the last
+    // round would be < 1/4 full and there are at most two full ones, 64x128 tiles (half the workgroups, half the A traffic through LDS)
+    // finish in fewer rounds: 17000 x 256 x 1024 25.8 -> 21.2 us, 20000 x 256 x 1024 26.6 -> 22.1, 12800 x 384 x 1024 25.9 -> 22.1; at
+    // 1.5-1.6 rounds (12800 x 512 x 1024) the 64x64 grid stays ahead (29.3 vs 31.0), as it does below one round (tools/dbg/gemm_tiles.py).
     const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) * (d.batch > 0 ? d.batch : 1) * (d.split_k > 0 ? d.split_k : 1);
-    const long long rounds = t64 / 768, last = t64 - rounds * 768;
+    const long long rounds = t64 / 1024, last = t64 - rounds * 1024;
     static const bool wide = [] { const char* e = std::getenv("TOIST_TILE_64x128"); return !(e && e[0] == '0'); }();
-    if (wide && d.K >= 512 && (d.N % 128) == 0 && rounds >= 1 && rounds <= 2 && last * 4 < 768 &&
+    if (wide && d.K >= 512 && (d.N % 128) == 0 && rounds >= 1 && rounds <= 2 && last * 4 < 1024 &&
         (d.a_kind == TOIST_A_ROWK || d.a_kind == TOIST_A_CONV) && !d.group)
         return 134;
     return (d.K > 64) ? 65 : 64;
