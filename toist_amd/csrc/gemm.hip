@@ -1665,12 +1665,7 @@ static int auto_tile(const toist_gemm& d) {
     if (wide && d.K >= 512 && (d.N % 128) == 0 && rounds >= 1 && rounds <= 2 && last * 4 < 1024 &&
         (d.a_kind == TOIST_A_ROWK || d.a_kind == TOIST_A_CONV) && !d.group)
         return 134;
-    // (experiment) a nearly full single round: TOIST_TILE_NEARLY_FULL = smallest 64x64 tile count that takes 64x128 tiles, TOIST_TILE_NEARLY_KINDS = 1 conv gathers only, 2 also row-major A
-    static const int nearly = [] { const char* e = std::getenv("TOIST_TILE_NEARLY_FULL"); return e ? atoi(e) : 0; }();
-    static const int nearly_kinds = [] { const char* e = std::getenv("TOIST_TILE_NEARLY_KINDS"); return e ? atoi(e) : 1; }();
-    if (wide && nearly > 0 && d.K >= 1024 && (d.N % 128) == 0 && rounds == 0 && t64 >= nearly && !d.group &&
-        (d.a_kind == TOIST_A_CONV || (nearly_kinds >= 2 && d.a_kind == TOIST_A_ROWK)))
-        return 134;
+    // (a nearly full single round -- 800 tiles of 1024 -- stays on 64x64: 64x128 there measured 552 vs 556 images/s for the conv gathers, 546 with row-major A too)
     return (d.K > 64) ? 65 : 64;
 }
 
