@@ -1610,7 +1610,7 @@ static int launch_variant(const toist_gemm& d, int ring, hipStream_t st) {
     else if (!t65) ring = 2;
     else if (ring != 2) ring = 3;
     // lean epilogue (epilogue_lean): instantiated for the tiles and operand kinds of the backbone's convolutions
-    constexpr bool lean_inst = BK == 64 && ((BM == 64 && BN == 64) || (BM == 64 && BN == 128) || (BM == 128 && BN == 64)) && AK != TOIST_A_KROW;
+    constexpr bool lean_inst = BK == 64 && ((BM == 64 && BN == 64) || (BM == 64 && BN == 128) || (BM == 128 && BN == 64) || (BM == 128 && BN == 32)) && AK != TOIST_A_KROW;
     if constexpr (lean_inst) {
         if (lean_epilogue_ok(dd)) {
             if constexpr (t65) {
