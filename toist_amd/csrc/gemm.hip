@@ -1438,6 +1438,7 @@ static int launch_conv3(const toist_gemm& d, hipStream_t st) {
     return TOIST_OK;
 }
 
+#ifndef GEMM_UNIT   // plain (non-template) kernels live in the main translation unit only
 // TOIST_GEMM_SPLIT_EPILOGUE: second half of a split-K GEMM that keeps the complete epilogue.  One thread per 8 output columns of a
 // row: the k-slice partials are added in slice order, then the row goes through the same epilogue_row8 as an un-split tile
 // (same dropout stream, residual, activation, output type).
@@ -1552,6 +1553,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_tall_kernel(const ReduceBat
     }
 }
 
+#endif  // GEMM_UNIT
+
 // Workgroups of a persistent launch (TOIST_PERSIST_WGS; 0 = one workgroup per tile everywhere).  Applied (launch_variant) only to the
 // dispatch-bound launches: row-major A, K <= 256, >= 2048 tiles.  Measured on MI355X (round 2, tools/dbg/gemm_persist.py,
 // profiles/r02_gemm_persistent_sweep.txt): 768 workgroups (3 per CU) take 9-16 % off such launches in a back-to-back microbenchmark
@@ -1643,6 +1646,35 @@ static int launch_tile(const toist_gemm& d, int ring, hipStream_t st) {
 }
 
 
+// ---- translation units ---------------------------------------------------------------------------------------------------
+// hipcc needs ~5 minutes for every tile family in one unit.  gemm_tiles_b.hip and gemm_tiles_c.hip include this file with GEMM_UNIT = 1 / 2
+// and compile one launch_tiles_*() each (make -j builds the three side by side); everything below this block -- dispatcher, plain kernels,
+// the extern "C" entry points -- belongs to the main unit.
+int launch_tiles_a(int tile, const toist_gemm& d, int ring, hipStream_t st);   // 64x64x32, 128x128x{32,64}, 128x32x64, 32x128x64
+int launch_tiles_b(int tile, const toist_gemm& d, int ring, hipStream_t st);   // 64x64x64
+int launch_tiles_c(int tile, const toist_gemm& d, int ring, hipStream_t st);   // 128x64x64, 64x128x64
+#if !defined(GEMM_UNIT)
+int launch_tiles_a(int tile, const toist_gemm& d, int ring, hipStream_t st) {
+    switch (tile) {
+        case 64: return launch_tile<64, 64, 32>(d, ring, st);
+        case 128: return launch_tile<128, 128, 32>(d, ring, st);
+        case 129: return launch_tile<128, 128, 64>(d, ring, st);
+        case 132: return launch_tile<128, 32, 64>(d, ring, st);   // narrow N (<= 32 output columns: mask-head convolutions)
+        case 133: return launch_tile<32, 128, 64>(d, ring, st);   // narrow M (their weight gradients)
+        default: set_last_error("toist_gemm_bf16: bad tile code %d", tile); return TOIST_EINVAL;
+    }
+}
+#elif GEMM_UNIT == 1
+int launch_tiles_b(int tile, const toist_gemm& d, int ring, hipStream_t st) { (void)tile; return launch_tile<64, 64, 64>(d, ring, st); }
+#elif GEMM_UNIT == 2
+int launch_tiles_c(int tile, const toist_gemm& d, int ring, hipStream_t st) {
+    if (tile == 130) return launch_tile<128, 64, 64>(d, ring, st);
+    return launch_tile<64, 128, 64>(d, ring, st);                  // 134: wide N
+}
+#endif
+
+#ifndef GEMM_UNIT
+
 // tile code the dispatcher picks for tile == 0
 static int auto_tile(const toist_gemm& d) {
     // measured on MI355X (tools/sweep_gemm.py): 128x128x64 only pays once >= ~4 tiles per CU exist and K
@@ -1679,8 +1711,11 @@ static int clamp_split(int split_k, int K, int tile) {
     return (ktiles + kper - 1) / kper;
 }
 
+#endif  // GEMM_UNIT (dispatcher helpers)
+
 }  // namespace toist
 
+#ifndef GEMM_UNIT
 namespace toist {
 constexpr int GROUP_MAX = 64;   // 64 x 48 B = 3 KB of kernel arguments
 struct GroupArgs { toist_group g[GROUP_MAX]; };
@@ -1832,16 +1867,10 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     if (d.b_kind == TOIST_B_KROW && d.b.kin > 0) TOIST_REQUIRE((d.b.kin % 8) == 0, "toist_gemm_bf16: kin %% 8 != 0");
     (void)bkt;
     int rc;
-    switch (tile) {
-        case 64: rc = launch_tile<64, 64, 32>(d, ring, st); break;
-        case 65: rc = launch_tile<64, 64, 64>(d, ring, st); break;
-        case 128: rc = launch_tile<128, 128, 32>(d, ring, st); break;
-        case 129: rc = launch_tile<128, 128, 64>(d, ring, st); break;
-        case 130: rc = launch_tile<128, 64, 64>(d, ring, st); break;
-        case 132: rc = launch_tile<128, 32, 64>(d, ring, st); break;   // narrow N (<= 32 output columns: mask-head convolutions)
-        case 133: rc = launch_tile<32, 128, 64>(d, ring, st); break;   // narrow M (their weight gradients)
-        case 134: rc = launch_tile<64, 128, 64>(d, ring, st); break;   // wide N, short K: half the A re-reads and workgroups of 64x64
-        default: set_last_error("toist_gemm_bf16: bad tile code %d", tile); return TOIST_EINVAL;
+    switch (tile) {       // tile families by translation unit
+        case 65: rc = launch_tiles_b(tile, d, ring, st); break;
+        case 130: case 134: rc = launch_tiles_c(tile, d, ring, st); break;
+        default: rc = launch_tiles_a(tile, d, ring, st); break;
     }
     if (rc != TOIST_OK) return rc;
     rc = check_launch("toist_gemm_bf16");
@@ -1857,3 +1886,4 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
                        d.epi.rscale, d.epi.accumulate, (float*)d.c, d.ldc);
     return check_launch("toist_gemm_bf16(splitk reduce)");
 }
+#endif  // GEMM_UNIT (main unit)
