@@ -575,3 +575,30 @@ def test_short_k_panel_kernel_matches_generic_tiles(dev, M, N, K, drop_where, ac
     out = torch.empty_like(da)
     k.gemm(M, N, K, k.A_ROWK, k.operand(x, K), k.B_KROW, k.operand(wt, N), out, N, res=res, ldr=N, act=k.ACT_MASK_POS, aux=aux, ldaux=N, tile=135)
     assert torch.equal(da, out)
+
+
+@pytest.mark.parametrize("tile", [65, 134, 130, 132, 129])
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 192), (333, 136, 1024)])
+def test_lean_epilogue_equals_the_general_one(dev, tile, M, N, K):
+    """epilogue_lean (bf16 output, picked by lean_epilogue_ok) against the general epilogue_tile, which the same GEMM takes when it
+    stores f32: identical arithmetic, so rounding the f32 result to bf16 must give the lean result bit for bit -- bias, dropout
+    (before the residual and after the activation), residual, ReLU / GELU / mask, on every tile with a lean instantiation (129 has none)."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(tile + M)
+    x = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bias, res = torch.randn(N, generator=g).to(dev), torch.randn(M, N, generator=g).to(BF).to(dev)
+    aux = torch.randn(M, N, generator=g).to(BF).to(dev)
+    k.SEED_DEV = torch.full((1,), 777, dtype=torch.int64, device=dev)
+    for act, dw in ((k.ACT_RELU, 1), (k.ACT_GELU, 2), (k.ACT_NONE, 0)):
+        kw = dict(res=res, act=act, drop_where=dw, drop_p=0.1 if dw else 0.0, drop_seed=5, tile=tile, split_k=1)
+        lean = ops.linear(x, w, bias, **kw)
+        full = ops.linear(x, w, bias, out_dtype=torch.float32, **kw)
+        assert torch.equal(lean, full.to(BF)), f"act {act} dropout {dw}"
+    wt = w.t().contiguous()
+    ldn = wt.stride(0)
+    out_b = torch.empty(M, N, dtype=BF, device=dev)
+    out_f = torch.empty(M, N, dtype=torch.float32, device=dev)
+    for out in (out_b, out_f):
+        k.gemm(M, N, K, k.A_ROWK, k.operand(x, K), k.B_KROW, k.operand(wt, ldn), out, N, res=res, ldr=N, act=k.ACT_MASK_POS, aux=aux, ldaux=N, tile=tile)
+    assert torch.equal(out_b, out_f.to(BF))
