@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--bf16-grads", action="store_true", help="N > 1: gradients cross the xGMI links as bfloat16 (half the bytes; the reference reduces in fp32)")
     ap.add_argument("--static-batch", action="store_true", help="replay the step on ONE fixed batch (the round-1 headline); default: every step sees a different "
                     "batch (images, captions, number of targets per image) through fixed-address input buffers, the same captured graph")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 PMC passes that measure the roofline kernel's HBM traffic (the committed passes are quoted instead)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
     ap.add_argument("--split-graph", action="store_true", help="force the multi-GPU structure (graph: fwd+bwd | eager all-reduce | graph: clip+AdamW+EMA) on one GPU")
     return ap.parse_args()
@@ -119,6 +120,43 @@ def cpu_baseline(size, check_path=None):
         return json.loads(line)
     except Exception as e:  # timeout or failure: report, never block the GPU numbers
         return {"value": None, "unit": "images/s (forward + matcher, B=1)", "cores": threads, "kind": "port", "sample": f"not measured: {type(e).__name__}"}
+
+
+def pmc_traffic_live(kernel_substr, timeout=300):
+    """HBM bytes per launch of the roofline kernel, measured now: two rocprofv3 PMC passes over a short eager run of this script
+    (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, counters only with --kernel-trace, from /tmp), units and corrections as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes (both counters in KiB; FETCH_SIZE doubled on gfx950 for 16-byte-per-lane loads).
+    Returns (bytes_per_launch, dispatches, note) or (None, 0, reason)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, 0, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="toist_pmc_", dir="/tmp")
+    kib, disp = {}, 0
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--no-cpu-baseline", "--no-graph", "--no-roofline", "--steps", "2", "--warmup", "1"]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=timeout)
+            path = os.path.join(out, "p_counter_collection.csv")
+            tot, n = 0.0, 0
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if row.get("Counter_Name") == ctr and kernel_substr in row.get("Kernel_Name", ""):
+                        tot += float(row["Counter_Value"])
+                        n += 1
+            if n == 0:
+                return None, 0, f"no {kernel_substr} dispatch in the {ctr} pass"
+            kib[ctr], disp = tot / n, n
+        return int(2 * kib["FETCH_SIZE"] * 1024 + kib["WRITE_SIZE"] * 1024), disp, None
+    except Exception as e:  # profiler missing / timed out / unreadable output: the committed passes are quoted instead
+        return None, 0, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def bench_distillation(a, dev, rank, world):
@@ -493,9 +531,16 @@ def main():
             n = len(prof["records"])
             alg_bytes = sum(r[5] for r in prof["records"]) / n
             traffic, traffic_src = None, None
-            if prof["key"] is not None:
-                # HBM bytes per launch of this kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-                # --pmc WRITE_SIZE in separate runs of this same script, tools/run_gpu_round.sh + tools/pmc_traffic.py)
+            if prof["key"] is not None and world == 1 and not a.no_pmc:
+                traffic, n_disp, why = pmc_traffic_live("panel_kernel")
+                if traffic is not None:
+                    traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `bench.py --no-graph --steps 2`, "
+                                   "%d panel_kernel dispatches per pass, 2*FETCH_SIZE + WRITE_SIZE per launch (KiB units, gfx950 FETCH correction)" % n_disp)
+                else:
+                    traffic_src = "live PMC passes failed (" + str(why) + ")"
+            if prof["key"] is not None and traffic is None:
+                # fallback: HBM bytes per launch of this kernel from the committed PMC passes (tools/run_gpu_round.sh + tools/pmc_traffic.py)
+                why_live = traffic_src
                 pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
                 if os.path.exists(pj):
                     meta = json.load(open(pj))
@@ -504,7 +549,8 @@ def main():
                     if disp:
                         traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in ks.values()) / disp)
                         traffic_src = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --no-graph` at commit "
-                                       + str(meta.get("commit", "?")) + " (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction applied); not re-measured in this run")
+                                       + str(meta.get("commit", "?")) + " (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction applied); not re-measured in this run"
+                                       + ("" if not why_live else " -- " + why_live))
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             gbs = sum(r[5] for r in prof["records"]) / (tot_ms * 1e-3) / 1e9
             if prof["key"] is not None:
