@@ -1573,6 +1573,12 @@ static long long persist_wgs() {
 // grouped layer-3 weight gradients pulling 2-9 x their operand bytes into L2 because every problem's tiles are striped over all eight
 // XCDs -- but those re-reads are served by the 256 MB Infinity Cache, not by HBM, and 22 problems on 8 XCDs leave two XCDs idle a
 // third of the time: 445.6 vs 449.0 images/s on the same box.
+// 64x64x64 launches with at most this many workgroups take the 3-slot ring (TOIST_RING3_MAX_WGS)
+static long long ring3_max_wgs() {
+    static const long long v = [] { const char* e = getenv("TOIST_RING3_MAX_WGS"); return e ? atoll(e) : 512LL; }();
+    return v;
+}
+
 static bool xcd_pinned_groups() {
     static const bool v = [] { const char* e = getenv("TOIST_GROUP_XCD"); return e != nullptr && atoi(e) != 0; }();
     return v;
@@ -1598,7 +1604,7 @@ static int launch_variant(const toist_gemm& d, int ring, hipStream_t st) {
     if (ring == 0) {
         const long long wgs = (long long)tiles * grid.z;
         if (stage <= 8192) ring = 4;
-        else if (BM == 64 && BN == 64) ring = wgs <= 512 ? 3 : 2;
+        else if (BM == 64 && BN == 64) ring = wgs <= ring3_max_wgs() ? 3 : 2;
         else ring = 2;
     }
     if (ring * stage > 160 * 1024) {

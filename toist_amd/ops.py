@@ -20,9 +20,13 @@ def _ld(t):
     return t.stride(0)
 
 
-def _split_k_for(tiles, ktiles, target=768, max_split=256):
+SPLIT_TARGET = int(_os.environ.get("TOIST_SPLIT_TARGET", "768"))
+
+
+def _split_k_for(tiles, ktiles, target=None, max_split=256):
     """k-slices for a reduction-heavy GEMM with few output tiles (wgrad): fill ~3 workgroups per CU
     while leaving every slice at least 4 k-tiles."""
+    target = target or SPLIT_TARGET
     if tiles >= target or ktiles <= 8:
         return 1
     s = min(max_split, max(1, target // max(tiles, 1)), max(1, ktiles // 4))
