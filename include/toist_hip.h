@@ -150,8 +150,9 @@ typedef struct toist_gemm {
     int32_t split_k;            /* >= 1; > 1 needs out_f32 and `workspace`: every k-slice stores its raw f32
                                    partial tile there and a second kernel reduces them into C */
     int32_t tile;               /* 0 = auto; 64 = 64x64x32, 65 = 64x64x64, 128 = 128x128x32, 129 = 128x128x64,
-                                   130 = 128x64x64, 132 = 128x32x64, 133 = 32x128x64 (BM x BN x BK);
-                                   131 = shared-halo 3x3 kernel; + 256 * ring slots (optional) */
+                                   130 = 128x64x64, 132 = 128x32x64, 133 = 32x128x64, 134 = 64x128x64 (BM x BN x BK);
+                                   131 = shared-halo 3x3 kernel, 135 = short-K panel kernel (K <= 256, row-major A; error
+                                   if the call does not qualify); + 256 * ring slots (optional) */
     int32_t flags;              /* bit0: build K-strided fragments with ds_write_b16 instead of
                                    ds_read_b64_tr_b16 (validation fallback) */
     toist_epilogue epi;
