@@ -100,7 +100,7 @@ def run(name, Sq, Sk, kind):
     pos = torch.randn(B * Sk, d, device=dev).to(BF)
 
     def step():
-        tape = engine.Tape(training=True, drop_p=0.1, seed=1, group_wgrads=True)
+        tape = engine.Tape(training=True, drop_p=float(os.environ.get("TOIST_BENCH_ATTN_DROP", "0.1")), seed=1, group_wgrads=True)
         outs = []
         if kind == "cross":
             m = engine.Var(mem)
