@@ -1370,8 +1370,8 @@ static bool panel_applies(const toist_gemm& d) {
     return true;
 }
 
-static long long panel_min_tiles() {   // 128 -> 32 (the 800-query decoder linears, 52 tiles): 559.8 -> 563.8 images/s over two rounds
-    static const long long v = [] { const char* e = getenv("TOIST_PANEL_MIN_TILES"); return e ? atoll(e) : 32LL; }();
+static long long panel_min_tiles() {   // (32 -- the 800-query decoder linears, 52 tiles -- measured 559.8 -> 563.8 images/s over two noisy rounds: not taken)
+    static const long long v = [] { const char* e = getenv("TOIST_PANEL_MIN_TILES"); return e ? atoll(e) : 128LL; }();
     return v;
 }
 
