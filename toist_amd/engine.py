@@ -7,6 +7,7 @@ them in reverse.  Activations are bf16, statistics / parameter gradients fp32.  
 and FrozenBN backward steps are folded into the epilogue of the GEMM that produces the gradient.
 """
 import math
+import os as _os_early
 
 import weakref
 
@@ -50,18 +51,19 @@ class Var:
 # Measured on MI355X (B=8, 640x640): text branch || image branch +8.7 % images/s (+14 % once the rest of the step had shrunk).  Forking the weight-gradient
 # GEMMs from the data-gradient chain was measured too (0 % to -6 %: those kernels already fill the chip and
 # every fork is a cross-stream edge of the graph) and is deliberately not done.
-OVERLAP = "capture"
+OVERLAP = _os_early.environ.get("TOIST_OVERLAP", "capture")   # "capture": fork the text branch inside captured graphs only; "on" / "off"
 FUSED_ATTENTION = True   # head-dim-32 attention cores run as one fused forward launch (csrc/attn.hip); False = 3 launches
 LSE_ONLY = True          # the fused cores keep only the log-sum-exp of every score row; backward re-forms P and the dropout mask
 FUSED_BLOCKS = True      # encoder / decoder layers: packed in_proj in one launch, decoder K/V of all layers grouped, LayerNorm emits y + pos
 _SIDE = {}
+SIDE_PRIORITY = int(_os_early.environ.get("TOIST_SIDE_PRIORITY", "0"))   # -1 = high: the small kernels of a side branch get free CU slots first
 
 
 def side_stream(device, name):
     key = (device.index, name)
     s = _SIDE.get(key)
     if s is None:
-        s = _SIDE[key] = torch.cuda.Stream(device=device)
+        s = _SIDE[key] = torch.cuda.Stream(device=device, priority=SIDE_PRIORITY)
     return s
 
 
