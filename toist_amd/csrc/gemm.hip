@@ -1350,6 +1350,286 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const toist_gemm p) {
     }
 }
 
+// ---- panel kernel, second generation (round 3) ------------------------------------------------------------------------------
+// What bounded panel_kernel above (profiles/r02: 2.5-2.8 TB/s of algorithmic bytes = 31-36 % of the HBM peak, traffic 1.06 x): every
+// tile opened with `s_waitcnt vmcnt(0)`, which on gfx9 also drains the STORES the wave issued a few hundred cycles earlier (stores and
+// loads share the counter) -- a full write round trip per tile -- and the residual / mask rows were compiler-visible register loads
+// requested ONE tile ahead, so a workgroup had 8-16 KB of HBM reads in flight against the ~49 KB per CU that 5 TB/s x 2.5 us asks for.
+// Here nothing the compiler can see touches memory inside the tile loop:
+//   * the residual and mask tiles of a row block travel by LDS-DMA into the same ring stage as its A block (no VGPRs held by loads in
+//     flight, any prefetch distance);
+//   * the output rows leave through `buffer_store_dwordx4` in inline asm (out-of-range lanes use an offset beyond num_records: the
+//     instruction is issued by every wave of every tile, which makes the per-tile operation count exact);
+//   * the tile-top wait is `vmcnt(n)` with n = everything this wave issued AFTER the loads of the tile it is about to read
+//     (memory operations of one wave retire from the counter in issue order): the stores of the last D tiles and the loads of the next
+//     D - 1 stay in flight across the barrier.
+// ns ring stages (prefetch distance D = ns - 1 tiles) of [A block BM x K | residual BM x 64 | mask BM x 64]; BM = 64 or 32 rows.
+__device__ __forceinline__ void wait_vm_n(const int n) {   // wave-uniform n; a smaller immediate (waiting for more) is always safe
+#define TOIST_W(i) case i: wait_vm<i>(); break;
+    switch (n) {
+        TOIST_W(0) TOIST_W(1) TOIST_W(2) TOIST_W(3) TOIST_W(4) TOIST_W(5) TOIST_W(6) TOIST_W(7) TOIST_W(8) TOIST_W(9) TOIST_W(10) TOIST_W(11)
+        TOIST_W(12) TOIST_W(13) TOIST_W(14) TOIST_W(15) TOIST_W(16) TOIST_W(17) TOIST_W(18) TOIST_W(19) TOIST_W(20) TOIST_W(21) TOIST_W(22)
+        TOIST_W(23) TOIST_W(24) TOIST_W(25) TOIST_W(26) TOIST_W(27) TOIST_W(28) TOIST_W(29) TOIST_W(30) TOIST_W(31) TOIST_W(32) TOIST_W(33)
+        TOIST_W(34) TOIST_W(35) TOIST_W(36) TOIST_W(37) TOIST_W(38) TOIST_W(39) TOIST_W(40) TOIST_W(41) TOIST_W(42) TOIST_W(43) TOIST_W(44)
+        default: wait_vm<45>(); break;
+    }
+#undef TOIST_W
+}
+
+// 16 bytes of every lane to (descriptor base + byte offset); an offset >= num_records drops the lane's store.  The trailing s_nop keeps
+// hipcc's next instruction off the data registers until the store has read them (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void store16_asm(const i32x4_t& r, const int byte_off, const u32x4_t& v) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(byte_off), "s"(r) : "memory");
+}
+
+constexpr int P2_BAND = 32 * (64 + 4) * 4;            // bytes of the f32 epilogue band (32 rows x 64 columns, pitch 68)
+constexpr int P2_HEAD = (P2_BAND + 1023) & ~1023;     // ring stages start here
+
+__device__ __forceinline__ unsigned long long cyc_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+// PROF (experiments, flags bit 11 + a workspace): wave 0 of every workgroup adds up the shader cycles of its four tile phases
+template <int BKD, int ACT, int BM, bool PROF = false>
+__global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, const int ns) {
+    constexpr int BN = 64, BK = 64, WM = BM / 2, WN = 32, FM = WM / 16, FN = 2, KS = 8;
+    constexpr int SUB = BM * BK;                  // one k-tile of an A block (elements)
+    constexpr int PW = BM / 32;                   // 1 KiB pieces per wave: per A k-tile, per residual tile, per mask tile
+    constexpr int LDT = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* const smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c16 = lane & 15;
+    const int M = p.M, N = p.N, K = p.K;
+    const int nt_m = (M + BM - 1) / BM, nt_n = (N + BN - 1) / BN;
+    const int kt = (K + BK - 1) / BK, nks = (K + 31) / 32;
+    const int xcd = (int)blockIdx.x & 7, slot_id = (int)blockIdx.x >> 3;
+    const int groups = ((int)gridDim.x >> 3) / nt_n;
+    const int tile_n = slot_id % nt_n, rr = slot_id / nt_n;
+    const int m_per = (nt_m + 7) >> 3;
+    const int m_beg = xcd * m_per, m_end = (m_beg + m_per < nt_m) ? m_beg + m_per : nt_m;
+    if (rr >= groups || m_beg + rr >= m_end) return;
+    const int T = (m_end - (m_beg + rr) + groups - 1) / groups;      // tiles of this workgroup: m_beg + rr + j * groups
+    const int n0 = tile_n * BN;
+    const bf16_t* const resp = (const bf16_t*)p.epi.res;
+    const bf16_t* const auxp = (const bf16_t*)p.epi.aux;
+    const bool has_res = resp != nullptr;
+    constexpr bool has_aux = ACT == TOIST_ACT_MASK_POS;
+    const i32x4_t rsA = make_rsrc(p.a.ptr), rsB = make_rsrc(p.b.ptr), rsC = make_rsrc(p.c);
+    const i32x4_t rsR = make_rsrc(has_res ? (const void*)resp : p.a.ptr), rsX = make_rsrc(has_aux ? (const void*)auxp : p.a.ptr);
+    const int lda = p.a.ld, ldb = p.b.ld;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    // stage layout (elements): [kt k-tiles of A][residual tile][mask tile]
+    const int res_off = kt * SUB, aux_off = res_off + (has_res ? BM * BN : 0), stage = aux_off + (has_aux ? BM * BN : 0);
+    bf16_t* const ring = smem + P2_HEAD / 2;
+    const unsigned ring0 = lds0 + P2_HEAD;
+
+    // ---- the B panel as MFMA fragments (as in panel_kernel) ----
+    bf16x8_t bq[KS][FN];
+    if (BKD == TOIST_B_ROWK) {
+        const bf16_t* B = (const bf16_t*)p.b.ptr;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + c16, k = ks * 32 + g * 8;
+                const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                bq[ks][j] = (n < N && k < K) ? *reinterpret_cast<const bf16x8_t*>(B + (size_t)n * ldb + k) : zero;
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int pch = (it * 4 + wave) * 64 + lane;
+                const int krow = pch / (BN / 8), rc = swz_m<BN>(krow, pch % (BN / 8));
+                const int nn = n0 + rc * 8, k = t * BK + krow;
+                if (t < kt) dma16(lds0 + (unsigned)(t * 64 * BK * 2) + (unsigned)(it * 4 + wave) * 1024u, rsB, nn + k * ldb, nn < N && k < K);
+            }
+        wait_vm<0>();
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                bq[ks][j] = (ks < nks) ? fragment<true, BN, BK>(smem + (ks >> 1) * 64 * BK, wn * WN + j * 16, ks & 1, g, c16) : zero;
+            }
+        __syncthreads();
+    }
+
+    // ---- per-lane invariants of the DMA pieces ----
+    int a_off[PW], a_row[PW], a_col[PW];          // A k-tile: [BM][64] k-contiguous, swizzled
+    int r_off[PW], x_off[PW], r_row[PW];          // residual / mask tile: [BM][64] row-major, lane-linear
+    bool r_colok[PW];
+#pragma unroll
+    for (int it = 0; it < PW; ++it) {
+        const int pch = (it * 4 + wave) * 64 + lane;
+        a_row[it] = pch / (BK / 8);
+        a_col[it] = swz_k<BK>(a_row[it], pch % (BK / 8)) * 8;
+        a_off[it] = a_row[it] * lda + a_col[it];
+        r_row[it] = pch >> 3;
+        const int cc = n0 + (pch & 7) * 8;
+        r_colok[it] = cc < N;
+        r_off[it] = r_row[it] * p.epi.ldr + cc;
+        x_off[it] = r_row[it] * p.epi.ldaux + cc;
+    }
+    const int P = PW * (kt + (has_res ? 1 : 0) + (has_aux ? 1 : 0));    // DMA instructions per wave per tile
+    constexpr int S = FM;                                               // store instructions per wave per tile
+    auto issue = [&](const int slot, const int tile_m) {
+        const int m0 = tile_m * BM;
+        const unsigned sb = ring0 + (unsigned)(slot * stage) * 2u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int it = 0; it < PW; ++it)
+                if (t < kt) dma16(sb + (unsigned)(t * SUB * 2) + (unsigned)(it * 4 + wave) * 1024u, rsA, m0 * lda + a_off[it] + t * BK,
+                                  m0 + a_row[it] < M && t * BK + a_col[it] < K);
+        if (has_res) {
+#pragma unroll
+            for (int it = 0; it < PW; ++it)
+                dma16(sb + (unsigned)(res_off * 2) + (unsigned)(it * 4 + wave) * 1024u, rsR, m0 * p.epi.ldr + r_off[it], m0 + r_row[it] < M && r_colok[it]);
+        }
+        if (has_aux) {
+#pragma unroll
+            for (int it = 0; it < PW; ++it)
+                dma16(sb + (unsigned)(aux_off * 2) + (unsigned)(it * 4 + wave) * 1024u, rsX, m0 * p.epi.ldaux + x_off[it], m0 + r_row[it] < M && r_colok[it]);
+        }
+    };
+
+    // ---- epilogue invariants (the arithmetic of panel_kernel / epilogue_lean, bit for bit) ----
+    const int c8 = tid & 7, brow = tid >> 3;
+    const int ncol = n0 + c8 * 8;
+    const bool col_ok = ncol < N;
+    const int rloc = (brow >> 4) * WM + (brow & 15);
+    const int ldc = p.ldc;
+    const float alpha = p.epi.alpha;
+    const int drop = p.epi.drop_where;
+    const unsigned long long dseed = drop ? p.epi.drop_seed + (p.epi.drop_seed_dev ? *p.epi.drop_seed_dev : 0ull) : 0ull;
+    const unsigned dth = (unsigned)(p.epi.drop_p * 4294967296.0);
+    const float dsc = 1.f / (1.f - p.epi.drop_p);
+    float csc[8], csh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { csc[j] = 1.f; csh[j] = 0.f; }
+    if (col_ok) {
+        if (p.epi.scale != nullptr) load_cols8(p.epi.scale + ncol, 8, csc, 1.f);
+        if (p.epi.shift != nullptr) load_cols8(p.epi.shift + ncol, 8, csh, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) csc[j] *= alpha;
+    float* const band = reinterpret_cast<float*>(smem);
+    // The prologue's own (compiler-visible) loads end here: naming their registers as asm operands makes hipcc place ITS wait for them in
+    // front of this statement instead of at their first use inside the tile loop, where it would be a vmcnt(0) per tile.  From here on
+    // the wave's counter holds only what `issue` and the stores put there.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int jj = 0; jj < FN; ++jj) asm volatile("" : "+v"(bq[ks][jj]));
+#pragma unroll
+    for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(csc[q]), "+v"(csh[q]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const int D = ns - 1;
+#pragma unroll 1
+    for (int j = 0; j < D && j < T; ++j) issue(j, m_beg + rr + j * groups);
+    int slot = 0;
+    unsigned long long pc[4] = {0, 0, 0, 0}, t0 = 0, t1 = 0;
+    if (PROF) t0 = cyc_now();
+#pragma unroll 1
+    for (int j = 0; j < T; ++j) {
+        const int tm = m_beg + rr + j * groups;
+        // operations this wave issued after the loads of tile j: the stores of the last min(j, D) tiles, the loads of the next min(D - 1, T - 1 - j)
+        const int st_young = (j < D ? j : D) * S, ld_young = (T - 1 - j < D - 1 ? T - 1 - j : D - 1) * P;
+        wait_vm_n(st_young + ld_young);
+        asm volatile("s_barrier" ::: "memory");           // ... landed for every wave; everyone is done with the stage tile j - 1 was read from
+        if (PROF) { t1 = cyc_now(); pc[0] += t1 - t0; t0 = t1; }
+        if (j + D < T) {
+            int s2 = slot + D;
+            if (s2 >= ns) s2 -= ns;
+            issue(s2, tm + D * groups);
+        }
+        if (PROF) { t1 = cyc_now(); pc[1] += t1 - t0; t0 = t1; }
+        f32x4_t acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < FN; ++jj) acc[i][jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const bf16_t* sA = ring + slot * stage;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks < nks) {
+                bf16x8_t af[FM];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) af[i] = fragment<false, BM, BK>(sA + (ks >> 1) * SUB, wm * WM + i * 16, ks & 1, g, c16);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < FN; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][jj], af[i], acc[i][jj], 0, 0, 0);
+            }
+        }
+        const bf16_t* sR = sA + res_off;
+        const bf16_t* sX = sA + aux_off;
+        if (PROF) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < FN; ++jj) asm volatile("" : "+v"(acc[i][jj]));
+            t1 = cyc_now(); pc[2] += t1 - t0; t0 = t1;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            if (i > 0) lds_barrier();         // the previous band has been read (band 0: the tile-top barrier did that)
+#pragma unroll
+            for (int jj = 0; jj < FN; ++jj) *reinterpret_cast<f32x4_t*>(band + (wm * 16 + c16) * LDT + wn * WN + jj * 16 + g * 4) = acc[i][jj];
+            lds_barrier();
+            const int rt = rloc + 16 * i, m = tm * BM + rt;
+            const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(band + brow * LDT + c8 * 8);
+            const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(band + brow * LDT + c8 * 8 + 4);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = v[q] * csc[q] + csh[q];
+            const unsigned long long didx = (unsigned long long)m * N + ncol;
+            if (drop == 1) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = dropout_keep(dseed, didx + q, dth) ? v[q] * dsc : 0.f;
+            }
+            if (has_res) {
+                float x[8];
+                unpack8(*reinterpret_cast<const uint4*>(sR + rt * BN + c8 * 8), x);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += x[q];
+            }
+            if (ACT == TOIST_ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            if (has_aux) {
+                float x[8];
+                unpack8(*reinterpret_cast<const uint4*>(sX + rt * BN + c8 * 8), x);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = x[q] > 0.f ? v[q] : 0.f;
+            }
+            if (drop == 2) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = dropout_keep(dseed, didx + q, dth) ? v[q] * dsc : 0.f;
+            }
+            const u32x4_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+            store16_asm(rsC, (col_ok && m < M) ? (m * ldc + ncol) * 2 : OOB, o);
+        }
+        if (PROF) { t1 = cyc_now(); pc[3] += t1 - t0; t0 = t1; }
+        if (++slot == ns) slot = 0;
+    }
+    if (PROF && tid == 0 && p.workspace != nullptr) {
+        float* o = p.workspace + (size_t)blockIdx.x * 8;
+        o[0] = (float)pc[0]; o[1] = (float)pc[1]; o[2] = (float)pc[2]; o[3] = (float)pc[3]; o[4] = (float)T;
+    }
+}
+
 // Tile code 135, or picked by the dispatcher (panel_min_tiles) when the call qualifies.
 static bool panel_applies(const toist_gemm& d) {
     if (d.a_kind != TOIST_A_ROWK || (d.b_kind != TOIST_B_ROWK && d.b_kind != TOIST_B_KROW)) return false;
@@ -1394,6 +1674,76 @@ static int launch_panel(const toist_gemm& d, hipStream_t st) {
         default: TOIST_PANEL(TOIST_ACT_NONE); break;
     }
 #undef TOIST_PANEL
+    return TOIST_OK;
+}
+
+// panel2_kernel: what panel_applies admits, with byte offsets that fit the 2 GiB buffer descriptors of the DMA / store path
+static bool panel2_applies(const toist_gemm& d) {
+    if (!panel_applies(d)) return false;
+    const long long lim = 1ll << 30;
+    if ((long long)d.M * d.ldc >= lim) return false;
+    if (d.epi.res && (long long)d.M * d.epi.ldr >= lim) return false;
+    if (d.epi.act == TOIST_ACT_MASK_POS && (long long)d.M * d.epi.ldaux >= lim) return false;
+    return true;
+}
+
+// variant = ring code of the tile word (tile >> 8): low nibble = ring stages (2..4; 0 = pick), bit 4 = 32-row blocks
+static int launch_panel2(const toist_gemm& d, int variant, hipStream_t st) {
+    int ns = variant & 15;
+    int bm = (variant & 16) ? 32 : 64;
+    const int kt = (d.K + 63) / 64;
+    const bool has_res = d.epi.res != nullptr, has_aux = d.epi.act == TOIST_ACT_MASK_POS;
+    if (ns == 0) { ns = 3; bm = 64; }
+    if (ns < 2 || ns > 4) { set_last_error("toist_gemm_bf16: panel ring of %d stages (2..4)", ns); return TOIST_EINVAL; }
+    const int stage = bm * 64 * 2 * (kt + (has_res ? 1 : 0) + (has_aux ? 1 : 0));
+    int lds = P2_HEAD + ns * stage;
+    if (lds < 32768) lds = 32768;                 // the k-major weight panel is staged through 32 KB once
+    if (lds > 160 * 1024) { set_last_error("toist_gemm_bf16: panel ring of %d x %d bytes exceeds the LDS", ns, stage); return TOIST_EINVAL; }
+    const int nt_m = (d.M + bm - 1) / bm, nt_n = (d.N + 63) / 64;
+    const int m_per = (nt_m + 7) / 8;
+    int per_cu = (160 * 1024) / lds;              // workgroups a CU holds (LDS); registers allow 2 waves per SIMD
+    static const int max_per_cu = [] { const char* e = getenv("TOIST_PANEL_PER_CU"); return e ? atoi(e) : 2; }();
+    if (per_cu > max_per_cu) per_cu = max_per_cu;
+    int groups = (32 * per_cu) / nt_n;
+    if (groups > m_per) groups = m_per;
+    if (groups < 1) groups = 1;
+    dim3 grid(8u * (unsigned)(groups * nt_n), 1, 1);
+    const bool rowk = d.b_kind == TOIST_B_ROWK;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+#define TOIST_PANEL2_ONE(BKD, ACT, BM_)                                                                                                   \
+    do {                                                                                                                                  \
+        static bool attr[64] = {};                                                                                                        \
+        const int di = dev & 63;                                                                                                          \
+        if (!attr[di]) {   /* idempotent; a race sets the same value twice */                                                             \
+            if (hipFuncSetAttribute((const void*)panel2_kernel<BKD, ACT, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { \
+                set_last_error("toist_gemm_bf16: cannot enable 160 KB of LDS for the panel kernel");                                      \
+                return TOIST_EHIP;                                                                                                        \
+            }                                                                                                                             \
+            attr[di] = true;                                                                                                              \
+        }                                                                                                                                 \
+        hipLaunchKernelGGL((panel2_kernel<BKD, ACT, BM_>), grid, dim3(256), lds, st, d, ns);                                              \
+    } while (0)
+#define TOIST_PANEL2(ACT)                                                                                             \
+    do {                                                                                                              \
+        if (rowk) { if (bm == 64) TOIST_PANEL2_ONE(TOIST_B_ROWK, ACT, 64); else TOIST_PANEL2_ONE(TOIST_B_ROWK, ACT, 32); } \
+        else { if (bm == 64) TOIST_PANEL2_ONE(TOIST_B_KROW, ACT, 64); else TOIST_PANEL2_ONE(TOIST_B_KROW, ACT, 32); }      \
+    } while (0)
+    if ((d.flags & 2048) && d.workspace != nullptr && rowk && d.epi.act == TOIST_ACT_RELU) {      // experiments: per-phase cycle counters
+        if (hipFuncSetAttribute((const void*)panel2_kernel<TOIST_B_ROWK, TOIST_ACT_RELU, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)panel2_kernel<TOIST_B_ROWK, TOIST_ACT_RELU, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return TOIST_EHIP;
+        if (bm == 64) hipLaunchKernelGGL((panel2_kernel<TOIST_B_ROWK, TOIST_ACT_RELU, 64, true>), grid, dim3(256), lds, st, d, ns);
+        else hipLaunchKernelGGL((panel2_kernel<TOIST_B_ROWK, TOIST_ACT_RELU, 32, true>), grid, dim3(256), lds, st, d, ns);
+        return TOIST_OK;
+    }
+    switch (d.epi.act) {
+        case TOIST_ACT_RELU: TOIST_PANEL2(TOIST_ACT_RELU); break;
+        case TOIST_ACT_MASK_POS: TOIST_PANEL2(TOIST_ACT_MASK_POS); break;
+        default: TOIST_PANEL2(TOIST_ACT_NONE); break;
+    }
+#undef TOIST_PANEL2
+#undef TOIST_PANEL2_ONE
     return TOIST_OK;
 }
 
@@ -1857,12 +2207,15 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
         return rc3 != TOIST_OK ? rc3 : check_launch("toist_gemm_bf16(conv3)");
     }
     TOIST_REQUIRE(d.tile != 131, "toist_gemm_bf16: the 3x3 halo kernel does not cover this call");
-    if (d.tile == 135 || (d.tile == 0 && (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) >= panel_min_tiles())) {
+    if ((d.tile & 255) == 135 || (d.tile == 0 && (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) >= panel_min_tiles())) {
         if (panel_applies(d)) {
-            const int rcp = launch_panel(d, st);
+            // tile word 135 | variant << 8: variant 1 = the round-2 kernel, otherwise panel2_kernel (see launch_panel2)
+            static const int def_variant = [] { const char* e = getenv("TOIST_PANEL_VARIANT"); return e ? atoi(e) : 1; }();
+            const int variant = (d.tile >> 8) ? (d.tile >> 8) : def_variant;
+            const int rcp = (variant == 1 || !panel2_applies(d)) ? launch_panel(d, st) : launch_panel2(d, variant, st);
             return rcp != TOIST_OK ? rcp : check_launch("toist_gemm_bf16(panel)");
         }
-        TOIST_REQUIRE(d.tile != 135, "toist_gemm_bf16: the short-K panel kernel does not cover this call");
+        TOIST_REQUIRE((d.tile & 255) != 135, "toist_gemm_bf16: the short-K panel kernel does not cover this call");
     }
     int tile = d.tile & 255;
     const int ring = d.tile >> 8;   // 0 = pick; else slots of the DMA ring (2..4)

@@ -191,7 +191,12 @@ def compute_copy(t, make, cache, name):
             and _reg_post_hook is not None:
         return ent.w
     w = make(t)
-    if ent is not None and ent.w.shape == w.shape and ent.w.stride() == w.stride():
+    pinned = bool(getattr(make, "pinned", False))     # the transform owns the copy's storage (packed_cast): the entry must BE that view
+    if ent is not None and pinned and ent.w.data_ptr() != w.data_ptr():
+        ent = None                                    # a copy built by another transform of the same parameter: rebuild around the view
+    if ent is not None and pinned:
+        pass                                          # make() has refreshed the view in place
+    elif ent is not None and ent.w.shape == w.shape and ent.w.stride() == w.stride():
         ent.w.copy_(w)
     else:
         ent = ComputeCopy()
@@ -795,6 +800,7 @@ def packed_cast(view):
         view.copy_(m.detach())
         return view
     make.elementwise = True
+    make.pinned = True
     return make
 
 

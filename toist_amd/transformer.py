@@ -252,19 +252,20 @@ class Transformer(nn.Module):
         named = engine.named_cache(self, "text", _named)
 
         small = engine.FUSED_BLOCKS and L <= 64 and cfg.hidden_size // H <= 64 and (cfg.hidden_size // H) % 8 == 0
-        transforms = None
-        if small:
-            # bf16 copies of each layer's query / key / value matrices live side by side in one [3D, D] buffer: one projection GEMM
-            packs = self.__dict__.setdefault("_text_packs", {})
-            key_dev = str(ids.device)
-            if key_dev not in packs:
-                Dh = cfg.hidden_size
-                packs[key_dev] = [torch.zeros(3 * Dh, Dh, dtype=BF16, device=ids.device) for _ in range(cfg.num_hidden_layers)]
-            transforms = {}
-            for i, buf in enumerate(packs[key_dev]):
-                Dh = cfg.hidden_size
+        # bf16 copies of each layer's query / key / value matrices ALWAYS live side by side in one [3D, D] buffer (one projection GEMM on
+        # the short-caption path; plain row slices of it on the long-caption path): the transform of a parameter never changes between
+        # batches, so the compute-copy cache (engine.compute_copy) cannot hand a stand-alone copy to the packed path or vice versa.
+        packs = self.__dict__.setdefault("_text_packs", {})
+        key_dev = str(ids.device)
+        if key_dev not in packs or packs[key_dev][2] != id(self):     # id: a deepcopy of the module must get its own buffers and closures
+            Dh = cfg.hidden_size
+            bufs = [torch.zeros(3 * Dh, Dh, dtype=BF16, device=ids.device) for _ in range(cfg.num_hidden_layers)]
+            tr = {}
+            for i, buf in enumerate(bufs):
                 for j, nm in enumerate(("query", "key", "value")):
-                    transforms[f"text_encoder.encoder.layer.{i}.attention.self.{nm}.weight"] = engine.packed_cast(buf[j * Dh:(j + 1) * Dh])
+                    tr[f"text_encoder.encoder.layer.{i}.attention.self.{nm}.weight"] = engine.packed_cast(buf[j * Dh:(j + 1) * Dh])
+            packs[key_dev] = (bufs, tr, id(self))
+        pack_bufs, transforms = packs[key_dev][:2]
 
         def prog(tape, ps):
             P = lambda n: ps["text_encoder." + n]
@@ -287,7 +288,7 @@ class Transformer(nn.Module):
                 lp = f"encoder.layer.{i}."
                 if small:
                     proj = [(P(lp + f"attention.self.{nm}.weight"), P(lp + f"attention.self.{nm}.bias")) for nm in ("query", "key", "value")]
-                    z = engine.text_attention_block(tape, x, proj, self._text_packs[str(ids.device)][i], P(lp + "attention.output.dense.weight"),
+                    z = engine.text_attention_block(tape, x, proj, pack_bufs[i], P(lp + "attention.output.dense.weight"),
                                                     P(lp + "attention.output.dense.bias"), key_pad, B, L, H)
                 else:
                   z = engine.attention(
