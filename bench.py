@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 GFLOP_PER_IMG_TRAIN = 397.7  # detection train step, stem + layer1 frozen
+GFLOP_PER_IMG_TRAIN_MASKS = 839.9         # with the mask head, everything trainable (3 x 288.5 - 25.6)
+GFLOP_PER_IMG_TRAIN_MASKS_FROZEN = 583.5  # frozen-detector recipe: full forward (288.5) + backward of attention map / mask head / adapters only (2 x 147.5)
 
 
 def parse():
@@ -41,6 +43,13 @@ def parse():
     ap.add_argument("--distill", action="store_true", help="config 5 on this GPU: teacher + student forward, cluster criterion, paired criterion "
                     "(eager launch: the k-means loop reads the device); use with --batch 4")
     ap.add_argument("--masks", action="store_true", help="config 3: add the segmentation head and the mask losses")
+    ap.add_argument("--frozen", action="store_true", help="with --masks: the reference's segmentation recipe (scripts/train_seg.sh:5-12): --frozen_weights (detector frozen, "
+                    "models/segmentation.py:22-24), --no_aux_loss, --no_contrastive_align_loss -- only bbox_attention.* / mask_head.* train")
+    ap.add_argument("--mixed-sizes", action="store_true", help="configs[1] on a stream of batches of three padded image sizes (640x640, 576x704, 512x768) through "
+                    "toist_amd.harness.CapturedTrainStep: one cached hipGraph per shape bucket, the library's replayed step with variable-size inputs")
+    ap.add_argument("--no-secondary", action="store_true", help="do not run the short configs[2] / configs[2]-frozen / configs[4] legs (child processes) that the default N = 1 run appends as `secondary`")
+    ap.add_argument("--repeats", type=int, default=3, help="hipGraph replay: the K-step timed region is run this many times (value = the FIRST region; min / median reported beside it)")
+    ap.add_argument("--allow-eager-fallback", action="store_true", help="N > 1: if hipGraph capture fails, run eager instead of aborting (a different launch protocol: labelled in config.launch)")
     ap.add_argument("--no-overlap", action="store_true", help="keep the text branch on the main stream (no parallel graph branch)")
     ap.add_argument("--torch-optimizer", action="store_true", help="diagnostic: torch clip_grad_norm_ + fused AdamW + foreach EMA instead of the HIP tail")
     ap.add_argument("--defer-ema", action="store_true", help="diagnostic: run the EMA update beside the next forward pass instead of inside the optimizer tail "
@@ -69,18 +78,20 @@ def cpu_baseline_worker(size, threads, check_path=None):
     res = {}
     if check_path:
         d = np.load(check_path)
-        logits, boxes, pm = torch.from_numpy(d["logits"]), torch.from_numpy(d["boxes"]), torch.from_numpy(d["pm"])
-        sizes = d["sizes"].tolist()
-        tb = torch.from_numpy(d["tgt_boxes"])
-        tgts = [tb[sum(sizes[:i]):sum(sizes[:i + 1])] for i in range(len(sizes))]
-        moff = np.concatenate([[0], np.cumsum([min(logits.shape[2], s_) for s_ in sizes])])
-        bad = 0
-        for l in range(logits.shape[0]):
-            ref = matcher_ref.hungarian_match(logits[l], boxes[l], tgts, pm)
-            for i, (ri, rj) in enumerate(ref):
-                a, b = d["src"][l, moff[i]:moff[i + 1]], d["tgt"][l, moff[i]:moff[i + 1]]
-                bad += int(not (np.array_equal(a, ri.numpy()) and np.array_equal(b, rj.numpy())))
-        res.update(matcher_mismatch_images=bad, matcher_checked=int(logits.shape[0] * logits.shape[1]))
+        bad = checked = 0
+        for bi in range(int(d["nb"])):
+            logits, boxes, pm = torch.from_numpy(d[f"logits{bi}"]), torch.from_numpy(d[f"boxes{bi}"]), torch.from_numpy(d[f"pm{bi}"])
+            sizes = d[f"sizes{bi}"].tolist()
+            tb = torch.from_numpy(d[f"tgt_boxes{bi}"])
+            tgts = [tb[sum(sizes[:i]):sum(sizes[:i + 1])] for i in range(len(sizes))]
+            moff = np.concatenate([[0], np.cumsum([min(logits.shape[2], s_) for s_ in sizes])])
+            for l in range(logits.shape[0]):
+                ref = matcher_ref.hungarian_match(logits[l], boxes[l], tgts, pm)
+                for i, (ri, rj) in enumerate(ref):
+                    a, b = d[f"src{bi}"][l, moff[i]:moff[i + 1]], d[f"tgt{bi}"][l, moff[i]:moff[i + 1]]
+                    bad += int(not (np.array_equal(a, ri.numpy()) and np.array_equal(b, rj.numpy())))
+            checked += int(logits.shape[0] * logits.shape[1])
+        res.update(matcher_mismatch_images=bad, matcher_checked=checked)
     args = harness.default_args(device="cpu")
     torch.manual_seed(0)
     model, _, _, _ = toist_amd.build_model(args)
@@ -122,6 +133,26 @@ def cpu_baseline(size, check_path=None):
         return {"value": None, "unit": "images/s (forward + matcher, B=1)", "cores": threads, "kind": "port", "sample": f"not measured: {type(e).__name__}"}
 
 
+def secondary_legs():
+    """configs[2] (mask head, everything trainable), configs[2] with the reference's frozen-detector recipe and configs[4] (distillation,
+    batch 4 pairs) as child runs of this script: {name: {value, unit, ms_per_step, steps, launch, workload} | {error}}."""
+    import subprocess
+    legs = (("configs[2]", ["--masks"]), ("configs[2] frozen recipe", ["--masks", "--frozen"]), ("configs[4]", ["--distill", "--batch", "4"]),
+            ("configs[1] mixed image sizes (library CapturedTrainStep)", ["--mixed-sizes", "--steps", "12"]))
+    out = {}
+    for name, flags in legs:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-roofline", "--no-secondary", "--repeats", "1", "--steps", "10",
+                                "--warmup", "3"] + flags, capture_output=True, text=True, timeout=420)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]
+            d = json.loads(line)
+            out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "launch": d["config"].get("launch"),
+                         "mfma_frac_whole_step": d["config"].get("mfma_frac_whole_step"), "workload": d["config"]["workload"]}
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    return out
+
+
 def pmc_traffic_live(kernel_substr, timeout=300):
     """HBM bytes per launch of the roofline kernel, measured now: two rocprofv3 PMC passes over a short eager run of this script
     (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, counters only with --kernel-trace, from /tmp), units and corrections as
@@ -146,7 +177,7 @@ def pmc_traffic_live(kernel_substr, timeout=300):
             tot, n = 0.0, 0
             with open(path) as f:
                 for row in csv.DictReader(f):
-                    if row.get("Counter_Name") == ctr and kernel_substr in row.get("Kernel_Name", ""):
+                    if row.get("Counter_Name") == ctr and any(k_ in row.get("Kernel_Name", "") for k_ in kernel_substr):
                         tot += float(row["Counter_Value"])
                         n += 1
             if n == 0:
@@ -232,6 +263,53 @@ def bench_distillation(a, dev, rank, world):
         torch.distributed.destroy_process_group()
 
 
+def bench_mixed_sizes(a, dev):
+    """configs[1] through toist_amd.harness.CapturedTrainStep on a stream that alternates three image sizes (the reference resizes to
+    480..800 x <= 1333, datasets/tdod.py:305-319): every bucket's graph is captured on first use, then the timed region replays them."""
+    import toist_amd
+    from toist_amd import harness, kernels
+    from toist_amd.optim import FusedClipAdamWEMA
+    args = harness.default_args(device="cuda", contrastive_align_loss=True)
+    torch.manual_seed(0)
+    model, criterion, _, weight_dict = toist_amd.build_model(args)
+    model.to(dev).train()
+    criterion.train()
+    kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    groups = [{"params": [p for n, p in named if "backbone" not in n and "text_encoder" not in n]},
+              {"params": [p for n, p in named if "backbone" in n], "lr": args.lr_backbone},
+              {"params": [p for n, p in named if "text_encoder" in n], "lr": args.text_encoder_lr}]
+    src = [v for v in model.state_dict().values() if v.is_floating_point()]
+    opt = FusedClipAdamWEMA(groups, lr=args.lr, weight_decay=args.weight_decay, max_norm=args.clip_max_norm, ema=list(zip(src, [v.detach().clone() for v in src])),
+                            ema_decay=0.9998)
+    cap = harness.CapturedTrainStep(model, criterion, opt, weight_dict, batch=a.batch, max_targets_per_image=10, pad_hw=64, pad_tokens=8, max_graphs=4)
+    sizes = ((640, 640), (576, 704), (512, 768))
+    from toist_amd.matcher import StaticTargets
+    packer = StaticTargets(a.batch, 10, args.num_queries, 256, dev)      # same arena layout as the buckets' own (batch, capacity, queries, K)
+    pool = []
+    for i in range(6):
+        h, w = sizes[i % 3]
+        s_i, tok_i, t_i, pm_i = harness.synthetic_batch(a.batch, h, w, tokens=16, seed=1000 + 7919 * i, max_targets=10)
+        packed = packer.pack(t_i, pm_i, criterion.token_masks_host(t_i, None))
+        pool.append((s_i.to(dev), tok_i.to(dev), t_i, pm_i, packed))
+    for i in range(max(a.warmup, 6)):      # first pass: one eager step + capture per bucket
+        s_i, tok_i, t_i, pm_i, packed = pool[i % 6]
+        cap.step(s_i, tok_i, t_i, pm_i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        s_i, tok_i, t_i, pm_i, packed = pool[i % 6]
+        last = cap.step(s_i, tok_i, packed=packed)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "train images/sec/node (640x640, bs=8/GPU) + matcher index bit-match", "value": round(a.batch * a.steps / dt, 3), "unit": "images/s", "n_gpus": 1,
+                      "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "bf16", "data": "synthetic",
+                      "config": {"workload": f"configs[1] recipe on a stream alternating three image sizes {sizes} (equal pixel counts within 4 %), batch {a.batch}, 16-token captions, 0..10 targets "
+                                             "per image, through toist_amd.harness.CapturedTrainStep (one cached hipGraph per padded shape bucket)",
+                                 "global_batch": a.batch, "parallelism": "dp1", "final_loss": round(float(last), 4), "launch": f"hipGraph replay, {cap.captures} cached graphs, {cap.replays} replays"}}))
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
         cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
@@ -261,10 +339,17 @@ def main():
     ROOFLINE_KEYS = frozenset({(135, kernels.A_ROWK, kernels.B_ROWK), (135, kernels.A_ROWK, kernels.B_KROW)})
     if a.distill:
         return bench_distillation(a, dev, rank, world)
+    if a.mixed_sizes:
+        if world > 1:
+            raise SystemExit("--mixed-sizes is a single-GPU leg")
+        return bench_mixed_sizes(a, dev)
     # the reference's default detection recipe (scripts/train_dete.sh): labels + boxes + cardinality + contrastive_align, 5 aux layers;
     # the segmentation recipe (scripts/train_seg.sh) passes --no_contrastive_align_loss
     contrastive = not a.no_contrastive and not a.masks
-    args = harness.default_args(device="cuda", masks=a.masks, mask_model="smallconv" if a.masks else "none", contrastive_align_loss=contrastive)
+    if a.frozen and not a.masks:
+        raise SystemExit("--frozen is the segmentation recipe: use it with --masks")
+    args = harness.default_args(device="cuda", masks=a.masks, mask_model="smallconv" if a.masks else "none", contrastive_align_loss=contrastive,
+                                frozen_weights="detector_checkpoint.pth" if a.frozen else None, aux_loss=not a.frozen)
     torch.manual_seed(0)
     model, criterion, _, weight_dict = toist_amd.build_model(args)
     model.to(dev)
@@ -420,8 +505,8 @@ def main():
                     graph_b = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph_b, stream=side):
                         optimize()
-        except Exception as e:   # a distributed job must still produce a number: fall back to eager launches with overlapped all-reduces
-            if world == 1:
+        except Exception as e:   # N > 1 with --allow-eager-fallback: eager launches with overlapped all-reduces (a different protocol, labelled in config.launch)
+            if world == 1 or not a.allow_eager_fallback:
                 raise
             print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             functions.GRAD_SYNC = None
@@ -481,6 +566,17 @@ def main():
     dt = time.perf_counter() - t0
     kernels.PROFILE = None
     loss_val = float(last)
+    # the same K-step region again (replayed graphs only: nothing is instrumented there): boxes of the pool differ by +- 8 % and one
+    # 0.3 s region is one sample -- `value` stays the FIRST region, the spread is reported beside it
+    region_ms = [1000 * dt / a.steps]
+    if use_graph and prof is None:
+        for _ in range(max(a.repeats, 1) - 1):
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                run_step()
+            barrier()
+            region_ms.append(1000 * (time.perf_counter() - t1) / a.steps)
     if not a.no_roofline and use_graph:
         # kernel-level timing needs per-launch HIP events, which a replayed graph cannot carry: time the
         # same K steps once more, eagerly, on the same stream right after the timed region (every rank runs
@@ -504,17 +600,24 @@ def main():
 
     if rank == 0:
         ips = a.batch * world * a.steps / dt
+        gflop_img = (GFLOP_PER_IMG_TRAIN_MASKS_FROZEN if a.frozen else GFLOP_PER_IMG_TRAIN_MASKS) if a.masks else GFLOP_PER_IMG_TRAIN
         res = {
             "metric": "train images/sec/node (640x640, bs=8/GPU) + matcher index bit-match", "value": round(ips, 3), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("configs[2] (det + mask head + mask losses): " if a.masks else "") + f"configs[1]: ResNet-101 + RoBERTa-base + 6+6 transformer, 100 queries, batch {a.batch}/GPU {a.size}x{a.size}, "
-                                   "16-token captions, detection loss (labels+boxes+cardinality" + ("+contrastive_align" if contrastive else "") + ", 5 aux layers), dropout 0.1, "
+            "config": {"workload": (("configs[2], the reference's FROZEN-detector segmentation recipe (scripts/train_seg.sh: --frozen_weights --no_aux_loss --no_contrastive_align_loss; only bbox_attention / mask_head train): " if a.frozen else "configs[2] (det + mask head + mask losses, everything trainable): ") if a.masks else "") + f"configs[1]: ResNet-101 + RoBERTa-base + 6+6 transformer, 100 queries, batch {a.batch}/GPU {a.size}x{a.size}, "
+                                   "16-token captions, detection loss (labels+boxes+cardinality" + ("+contrastive_align" if contrastive else "") + (", no aux layers" if a.frozen else ", 5 aux layers") + "), dropout 0.1, "
                                    "clip 0.1 + AdamW + EMA" + (" (torch)" if a.torch_optimizer else " (fused HIP tail)") + "; random-init weights; " +
                                    ("every step a different batch (4 resident batches, 0..10 targets per image) through fixed-address inputs" if dynamic else "one fixed batch"),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4), "launch": ("4 hipGraphs (head | text || backbone | tail), gradient all-reduces under the backbone backward" if split_graph else "hipGraph replay") if use_graph else "eager",
-                       "mfma_frac_whole_step": round(ips / world * GFLOP_PER_IMG_TRAIN / 1000.0 / PEAK_BF16_TFLOPS, 5)},
+                       "gflop_per_image": gflop_img,
+                       "mfma_frac_whole_step": round(ips / world * gflop_img / 1000.0 / PEAK_BF16_TFLOPS, 5)},
         }
+        if len(region_ms) > 1:
+            srt = sorted(region_ms)
+            res["repeats"] = {"ms_per_step": [round(v, 3) for v in region_ms], "min": round(srt[0], 3), "median": round(srt[len(srt) // 2], 3),
+                              "images_per_s_median": round(a.batch * world / (srt[len(srt) // 2] * 1e-3), 1),
+                              "note": "the K-step timed region run %d times back to back; `value` / `ms_per_step` are the first" % len(region_ms)}
         if collectives is not None:
             res["collectives"] = collectives
             res["config"]["gradient_wire_dtype"] = "bf16" if a.bf16_grads else "f32"
@@ -532,10 +635,10 @@ def main():
             alg_bytes = sum(r[5] for r in prof["records"]) / n
             traffic, traffic_src = None, None
             if prof["key"] is not None and world == 1 and not a.no_pmc:
-                traffic, n_disp, why = pmc_traffic_live("panel_kernel")
+                traffic, n_disp, why = pmc_traffic_live(("panel_kernel", "panel2_kernel"))
                 if traffic is not None:
                     traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `bench.py --no-graph --steps 2`, "
-                                   "%d panel_kernel dispatches per pass, 2*FETCH_SIZE + WRITE_SIZE per launch (KiB units, gfx950 FETCH correction)" % n_disp)
+                                   "%d panel kernel dispatches per pass, 2*FETCH_SIZE + WRITE_SIZE per launch (KiB units, gfx950 FETCH correction)" % n_disp)
                 else:
                     traffic_src = "live PMC passes failed (" + str(why) + ")"
             if prof["key"] is not None and traffic is None:
@@ -588,17 +691,26 @@ def main():
             try:
                 import tempfile
                 import numpy as np
-                with torch.no_grad():
-                    mc = model(samples, tok, encode_and_save=True)
-                    out = model(samples, tok, encode_and_save=False, memory_cache=mc)
-                    criterion(mc, out, targets, pmap, None)
-                m = criterion.last_match
-                m.check()
-                st = out["_stacked"]
+                # every resident batch (4 x 8 images x 6 layers = 192 (layer, image) pairs with the default settings), one forward + criterion each
+                batches = [(p_[0], p_[1], p_[3], p_[4]) for p_ in pool] if dynamic else [(samples.tensors, tok["input_ids"], targets, pmap)]
+                arrays = {"nb": np.array(len(batches))}
+                for bi, (img, ids, t_i, pm_i) in enumerate(batches):
+                    samples.tensors.copy_(img)
+                    tok["input_ids"].copy_(ids)
+                    t_dev = [{k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in t.items()} for t in t_i]
+                    with torch.no_grad():
+                        mc = model(samples, tok, encode_and_save=True)
+                        out = model(samples, tok, encode_and_save=False, memory_cache=mc)
+                        criterion(mc, out, t_dev, pm_i.to(dev), None)
+                    m = criterion.last_match
+                    m.check()
+                    st = out["_stacked"]
+                    arrays.update({f"logits{bi}": st["pred_logits"].float().cpu().numpy(), f"boxes{bi}": st["pred_boxes"].float().cpu().numpy(),
+                                   f"pm{bi}": pm_i.float().cpu().numpy(), f"sizes{bi}": np.array(m.sizes),
+                                   f"tgt_boxes{bi}": (m.tgt_boxes.cpu().numpy() if m.tgt_boxes is not None else np.zeros((0, 4), np.float32)),
+                                   f"src{bi}": m.src.cpu().numpy(), f"tgt{bi}": m.tgt.cpu().numpy()})
                 check_path = os.path.join(tempfile.mkdtemp(prefix="toist_bench_"), "match.npz")
-                np.savez(check_path, logits=st["pred_logits"].float().cpu().numpy(), boxes=st["pred_boxes"].float().cpu().numpy(), pm=pmap.float().cpu().numpy(),
-                         sizes=np.array(m.sizes), tgt_boxes=(m.tgt_boxes.cpu().numpy() if m.tgt_boxes is not None else np.zeros((0, 4), np.float32)),
-                         src=m.src.cpu().numpy(), tgt=m.tgt.cpu().numpy())
+                np.savez(check_path, **arrays)
             except Exception as e:  # the throughput line must survive a failing check; the field then says why
                 res["matcher_mismatch_images"] = f"not checked: {type(e).__name__}: {e}"
             cb = cpu_baseline(a.size, check_path)
@@ -606,6 +718,12 @@ def main():
                 res["matcher_mismatch_images"] = cb.pop("matcher_mismatch_images")
                 res["matcher_checked_layer_image_pairs"] = cb.pop("matcher_checked")
             res["cpu_baseline"] = cb
+        if world == 1 and not a.no_secondary and not a.masks and not a.no_cpu_baseline and use_graph:
+            # the other single-GPU configurations of BASELINE.json, short runs in child processes (time-boxed like cpu_baseline): the driver
+            # runs `bench.py --gpus 1` once, so this is where configs[2] / configs[4] get a driver-witnessed number
+            del model, criterion, opt
+            torch.cuda.empty_cache()
+            res["secondary"] = secondary_legs()
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

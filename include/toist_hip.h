@@ -32,9 +32,16 @@ extern "C" {
 
 #define TOIST_ABI_VERSION 1
 
-int toist_version(void);
+/* the library is built with -fvisibility=hidden: these entry points are its whole export table */
+#if defined(__GNUC__)
+#define TOIST_API __attribute__((visibility("default")))
+#else
+#define TOIST_API
+#endif
+
+TOIST_API int toist_version(void);
 /* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
-int toist_last_error(char* buf, size_t cap);
+TOIST_API int toist_last_error(char* buf, size_t cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Hungarian matcher.  Replaces HungarianMatcher.forward, /root/reference/models/matcher.py:39-87
@@ -51,7 +58,7 @@ int toist_last_error(char* buf, size_t cap);
  *            entries"), 2 = infeasible.
  *   cost_out optional [L, B*Q, Ttot] f32 (only the per-image diagonal blocks are written).
  */
-int toist_matcher(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
+TOIST_API int toist_matcher(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
                   const int32_t* tgt_off, const int32_t* match_off, int L, int B, int Q, int K, int max_T,
                   float w_class, float w_bbox, float w_giou, int64_t* src_idx, int64_t* tgt_idx,
                   int32_t* status, float* cost_out, void* stream);
@@ -166,9 +173,9 @@ typedef struct toist_gemm {
     int32_t a2_from;
 } toist_gemm;
 
-int toist_gemm_bf16(const toist_gemm* desc, void* stream);
+TOIST_API int toist_gemm_bf16(const toist_gemm* desc, void* stream);
 /* writes n <= 64 host-side entries into a device table (they travel as kernel arguments: graph-capturable, no staging buffer) */
-int toist_group_fill(const toist_group* rows, int n, toist_group* table, void* stream);
+TOIST_API int toist_group_fill(const toist_group* rows, int n, toist_group* table, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row kernels (bf16 data, f32 statistics).
@@ -179,28 +186,28 @@ int toist_group_fill(const toist_group* rows, int n, toist_group* table, void* s
  *    scores/probs are [nbatch*H, Sq, ld] with ld >= roundup8(Sk); key_pad [nbatch,Sk] u8 (1 = pad).
  *    p_drop (optional) receives dropout(p) for the PV product.
  */
-int toist_layernorm_fwd(const void* x, const float* gamma, const float* beta, float eps, int rows, int D,
+TOIST_API int toist_layernorm_fwd(const void* x, const float* gamma, const float* beta, float eps, int rows, int D,
                         void* y, float* mean, float* rstd, const void* add, void* y2, void* stream);
 /*  optional second output y2 = y + add (both bf16 [rows, D]): the `src + pos` / `tgt + query_pos` that the next attention
  *  feeds to its q / k projections (transformer.py:293, 366, 386) without a separate elementwise launch */
-int toist_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+TOIST_API int toist_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         int rows, int D, void* dx, float* dgamma, float* dbeta, void* dx_drop, float drop_p,
                         uint64_t seed, const uint64_t* seed_dev, float* partials, int partial_blocks, void* stream);
 /* `partials` (optional, instead of dgamma / dbeta): f32 [2][partial_blocks][D] per-block sums of dy*xhat and dy, written with plain
  * stores (no contended atomics) for the caller to fold -- toist_splitk_reduce_batch with splits = partial_blocks, M = 1, N = D.
  * partial_blocks = toist_layernorm_bwd_blocks(rows). */
-int toist_layernorm_bwd_blocks(int rows);
-int toist_softmax_fwd(const void* scores, const uint8_t* key_pad, int nbatch, int H, int Sq, int Sk, int ld,
+TOIST_API int toist_layernorm_bwd_blocks(int rows);
+TOIST_API int toist_softmax_fwd(const void* scores, const uint8_t* key_pad, int nbatch, int H, int Sq, int Sk, int ld,
                       void* p, void* p_drop, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
-int toist_softmax_bwd(const void* p, const void* dp, int rows, int Sk, int ld, void* ds, float drop_p,
+TOIST_API int toist_softmax_bwd(const void* p, const void* dp, int rows, int Sk, int ld, void* ds, float drop_p,
                       uint64_t seed, const uint64_t* seed_dev, void* stream);
 /* every dropout seed is `seed + (seed_dev ? *seed_dev : 0)`: seed_dev is an optional device word */
 /* out[n] += sum_m g[m][n]  (bias gradient; out is f32, caller zeroes it) */
-int toist_colsum(const void* g, int M, int N, int ld, float* out, void* stream);
+TOIST_API int toist_colsum(const void* g, int M, int N, int ld, float* out, void* stream);
 /* out = a + b, b broadcast with period b_period elements (with_pos_embed, transformer.py:287-288) */
-int toist_add_bf16(const void* a, const void* b, int64_t n, int64_t b_period, void* out, void* stream);
+TOIST_API int toist_add_bf16(const void* a, const void* b, int64_t n, int64_t b_period, void* out, void* stream);
 /* out = dropout(x): keep iff hash(seed, flat index) >= p*2^32, kept values scaled by 1/(1-p) */
-int toist_dropout_bf16(const void* x, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, void* out, void* stream);
+TOIST_API int toist_dropout_bf16(const void* x, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backbone-side layout / pooling kernels (NHWC bf16).
@@ -208,22 +215,22 @@ int toist_dropout_bf16(const void* x, int64_t n, float p, uint64_t seed, const u
  *  maxpool    : 3x3 / stride 2 / pad 1 (ResNet stem, reached through backbone.py:87-89)
  *  unpack     : bf16 NHWC [N,HW,C] -> f32 NCHW [N,C,HW] for API-edge feature maps
  */
-int toist_pack_image(const float* nchw, int N, int C, int H, int W, void* nhwc8, void* stream);
-int toist_maxpool3x3s2(const void* in, int N, int H, int W, int C, void* out, void* stream);
-int toist_unpack_nhwc(const void* nhwc, int N, int HW, int C, float* nchw, void* stream);
+TOIST_API int toist_pack_image(const float* nchw, int N, int C, int H, int W, void* nhwc8, void* stream);
+TOIST_API int toist_maxpool3x3s2(const void* in, int N, int H, int W, int C, void* out, void* stream);
+TOIST_API int toist_unpack_nhwc(const void* nhwc, int N, int HW, int C, float* nchw, void* stream);
 
 /* PositionEmbeddingSine.forward (position_encoding.py:30-49; normalize=True, scale=2*pi):
  * mask [B,H,W] u8 (1 = padded pixel) -> bf16 [B, H*W, 2*num_pos_feats] tokens and/or f32
  * [B, 2*num_pos_feats, H, W] (either output may be NULL). */
-int toist_sine_position(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, void* out_tok,
+TOIST_API int toist_sine_position(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, void* out_tok,
                         float* out_nchw, void* stream);
 
 /* RoBERTa input embeddings (HF RobertaEmbeddings, called at transformer.py:130):
  * out[t] = word[ids[t]] + type0 + pos[pos_ids[t]] (f32 tables -> bf16 [n,D]); bwd scatter-adds the
  * bf16 gradient rows into the dense f32 table gradients with atomics (any of them may be NULL). */
-int toist_embed_fwd(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
+TOIST_API int toist_embed_fwd(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
                     int n, int D, void* out, void* stream);
-int toist_embed_bwd(const void* g, const int64_t* ids, const int64_t* pos_ids, int n, int D, int64_t pad_id, float* dword,
+TOIST_API int toist_embed_bwd(const void* g, const int64_t* ids, const int64_t* pos_ids, int n, int D, int64_t pad_id, float* dword,
                     float* dpos, float* dtype0, void* stream); /* rows whose id == pad_id get no gradient (padding_idx) */
 
 /* ------------------------------------------------------------------------------------------------
@@ -237,11 +244,11 @@ int toist_embed_bwd(const void* g, const int64_t* ids, const int64_t* pos_ids, i
  *                 caller's finite-loss guard (/root/reference/engine.py:82-85) trips without a host sync per call
  *   bwd: upstream [L,4] = d(total)/d(loss); dlogits [L,B,Q,K], dboxes [L,B,Q,4] are fully written
  */
-int toist_criterion_fwd(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
+TOIST_API int toist_criterion_fwd(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
                         const int32_t* tgt_off, const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx,
                         const float* num_boxes, int L, int B, int Q, int K, float eos_coef, float* losses,
                         const int32_t* match_status, void* stream);
-int toist_criterion_bwd(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
+TOIST_API int toist_criterion_bwd(const float* logits, const float* boxes, const float* tgt_boxes, const float* pos_map,
                         const int32_t* tgt_off, const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx,
                         const float* num_boxes, int L, int B, int Q, int K, float eos_coef, const float* upstream,
                         float* dlogits, float* dboxes, void* stream);
@@ -256,15 +263,15 @@ int toist_criterion_bwd(const float* logits, const float* boxes, const float* tg
  *   bwd: upstream [L]; dproj_queries [L,B,Q,D] fully written; dproj_tokens [B,T,D] += (caller zeroes)
  * toist_l2norm_fwd/bwd: F.normalize(x, p=2, dim=-1) on fp32 rows and its backward (dx from x, dy).
  */
-int toist_contrastive_fwd(const float* proj_queries, const float* proj_tokens, const uint64_t* tok_mask, const int32_t* tgt_off,
+TOIST_API int toist_contrastive_fwd(const float* proj_queries, const float* proj_tokens, const uint64_t* tok_mask, const int32_t* tgt_off,
                           const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx, const float* num_boxes, int L,
                           int B, int Q, int T, int D, float temperature, float* losses, void* stream);
-int toist_contrastive_bwd(const float* proj_queries, const float* proj_tokens, const uint64_t* tok_mask, const int32_t* tgt_off,
+TOIST_API int toist_contrastive_bwd(const float* proj_queries, const float* proj_tokens, const uint64_t* tok_mask, const int32_t* tgt_off,
                           const int32_t* match_off, const int64_t* src_idx, const int64_t* tgt_idx, const float* num_boxes, int L,
                           int B, int Q, int T, int D, float temperature, const float* upstream, float* dproj_queries,
                           float* dproj_tokens, void* stream);
-int toist_l2norm_fwd(const float* x, int rows, int D, float* y, void* stream);
-int toist_l2norm_bwd(const float* x, const float* dy, int rows, int D, float* dx, void* stream);
+TOIST_API int toist_l2norm_fwd(const float* x, int rows, int D, float* y, void* stream);
+TOIST_API int toist_l2norm_bwd(const float* x, const float* dy, int rows, int D, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Segmentation branch (config 3), /root/reference/models/segmentation.py.
@@ -278,18 +285,18 @@ int toist_l2norm_bwd(const float* x, const float* dy, int rows, int D, float* dx
  *      (alpha, gamma=2) + dice sums against gt[gt_row[t]] u8 [TH,TW] (mdetr.py:827-853, segmentation.py:276-319):
  *      sums[t] += {focal, p*t, p, t}; bwd scatters coef[0]*dfocal + coef[1]*ddice into dpred (f32 atomics).
  */
-int toist_attnmap_softmax_fwd(const void* scores, const uint8_t* key_pad, int B, int Q, int H, int HW, int ld, void* out, void* stream);
-int toist_attnmap_softmax_bwd(const void* prob, const void* dprob, int BQ, int H, int HW, int ld, void* dscores, void* stream);
-int toist_groupnorm_fwd(const void* x, const float* gamma, const float* beta, int N, int HW, int C, int G, float eps, int relu,
+TOIST_API int toist_attnmap_softmax_fwd(const void* scores, const uint8_t* key_pad, int B, int Q, int H, int HW, int ld, void* out, void* stream);
+TOIST_API int toist_attnmap_softmax_bwd(const void* prob, const void* dprob, int BQ, int H, int HW, int ld, void* dscores, void* stream);
+TOIST_API int toist_groupnorm_fwd(const void* x, const float* gamma, const float* beta, int N, int HW, int C, int G, float eps, int relu,
                         void* y, float* stats, void* stream);
-int toist_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, int N, int HW, int C, int G,
+TOIST_API int toist_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, int N, int HW, int C, int G,
                         float eps, int relu, void* dx, float* dgamma, float* dbeta, float* bstats, void* stream);
-int toist_upsample_add(const void* in, const void* fpn, int BQ, int Q, int H, int W, int C, void* out, void* stream);
-int toist_upsample_add_bwd(const void* dout, int BQ, int H, int W, int C, void* din, void* stream);
-int toist_sum_queries(const void* in, int B, int Q, int64_t per, void* out, void* stream);
-int toist_mask_loss_fwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
+TOIST_API int toist_upsample_add(const void* in, const void* fpn, int BQ, int Q, int H, int W, int C, void* out, void* stream);
+TOIST_API int toist_upsample_add_bwd(const void* dout, int BQ, int H, int W, int C, void* din, void* stream);
+TOIST_API int toist_sum_queries(const void* in, int B, int Q, int64_t per, void* out, void* stream);
+TOIST_API int toist_mask_loss_fwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
                         int TH, int TW, float alpha, float* sums, void* stream);
-int toist_mask_loss_bwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
+TOIST_API int toist_mask_loss_bwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
                         int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred, void* stream);
 
 /* ---- optimizer tail: clip_grad_norm_ + AdamW + EMA + bf16 compute-copy refresh in one multi-tensor pass ------------
@@ -334,7 +341,7 @@ typedef struct toist_opt_state {
  * log-sum-exp, exact for scores of any magnitude) given, prob and prob_drop may both be NULL --
  * nothing score-shaped reaches HBM and toist_attn_bwd re-forms the probabilities (and the dropout mask, from the same
  * (seed, element index) hash) itself. */
-int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int Sq, int Sk,
+TOIST_API int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int Sq, int Sk,
                    int dh, int ld, float scale, void* prob, void* prob_drop, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* ctx,
                    int ldo, float* lse, void* stream);
 
@@ -346,7 +353,7 @@ int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk, const void
  * head, each a run of query tiles; their dk / dv sums meet in `workspace` (q_splits * 2 * B*Sk * H*32 floats) and a fold
  * kernel writes dk / dv.  prob == NULL selects the recomputing mode (query-major kernel): P = exp(scale q k^T - max) * rsum from the
  * forward's `lse`, key padding from `key_pad`, the keep mask from (seed + *seed_dev, row * ld + key) as in toist_attn_fwd. */
-int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const void* prob, const void* prob_drop,
+TOIST_API int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const void* prob, const void* prob_drop,
                    const void* ctx, int ldo, const void* dctx, int lddo, int B, int H, int Sq, int Sk, int dh, int ld, float scale,
                    float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int variant, float* workspace, int q_splits,
                    const float* lse, const uint8_t* key_pad, uint64_t seed, const uint64_t* seed_dev, void* stream);
@@ -357,7 +364,7 @@ int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, const void
  * centers[task] ([K, D] f32, stride centers_stride, updated IN PLACE) until (sum_k |shift_k|)^2 < tol (or max_iter), then
  * pick[sample] = index of the centre nearest to features[sample] ([*, D] f32) and chosen_center[sample] = that centre.
  * No host synchronisation; iters (optional) receives the iteration count per sample. */
-int toist_kmeans(const float* banks, int64_t bank_stride, float* centers, int64_t centers_stride, const int32_t* group_task,
+TOIST_API int toist_kmeans(const float* banks, int64_t bank_stride, float* centers, int64_t centers_stride, const int32_t* group_task,
                  const int32_t* group_off, const int32_t* members, int n_groups, const float* features, int N, int D, int K, float tol,
                  int max_iter, int32_t* pick, float* chosen_center, int32_t* iters, void* stream);
 
@@ -367,10 +374,10 @@ int toist_kmeans(const float* banks, int64_t bank_stride, float* centers, int64_
  * (row b*S + s, feature h*dh + e); bq / bk / bv (optional, f32 [H*dh]) are the projection biases, added on load so the packed
  * q | k | v projection needs no epilogue vector; key_pad [B, S] u8 (1 = padding) or NULL; stats f32 [B*H, S, 2] = (row maximum,
  * 1 / row sum) written by fwd, read by bwd, which re-forms the probabilities and the dropout mask ((seed + *seed_dev, element)). */
-int toist_attn_small_fwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int S,
+TOIST_API int toist_attn_small_fwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int S,
                          int dh, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* ctx, int ldo, float* stats,
                          const float* bq, const float* bk, const float* bv, void* stream);
-int toist_attn_small_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int S,
+TOIST_API int toist_attn_small_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int S,
                          int dh, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, const float* stats, const void* dctx,
                          int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, const float* bq, const float* bk,
                          const float* bv, void* stream);
@@ -379,20 +386,20 @@ int toist_attn_small_bwd(const void* q, int ldq, const void* kmat, int ldk, cons
  * segmentation.py:176-241 lay5 / out_lay; HBM-bound): NHWC bf16 in / out, weights [w_co][3][3][w_ci] bf16.
  * dgrad = 0: out[p, co] = shift[co] + sum x[p + tap, ci] w[co, tap, ci] (+ res);  c_src = w_ci, c_out = w_co.
  * dgrad = 1: out[p, ci] = sum dy[p - tap, co] w[co, tap, ci] (+ res);             c_src = w_co, c_out = w_ci. */
-int toist_conv3x3_small(int dgrad, const void* src, const void* w, const float* shift, const void* res, void* out, int n_img, int H, int W,
+TOIST_API int toist_conv3x3_small(int dgrad, const void* src, const void* w, const float* shift, const void* res, void* out, int n_img, int H, int W,
                         int c_src, int c_out, int w_co, int w_ci, void* stream);
 
 /* weight gradient of the same convolutions: every one of toist_wgrad3x3_small_blocks() workgroups writes an fp32 partial
  * [c_out][9 * c_in] to ws; fold them with toist_splitk_reduce_batch (splits = blocks, M = c_out, N = 9 * c_in). */
-int toist_wgrad3x3_small_blocks(void);
-int toist_wgrad3x3_small(const void* dy, const void* x, float* ws, int n_img, int H, int W, int c_in, int c_out, void* stream);
+TOIST_API int toist_wgrad3x3_small_blocks(void);
+TOIST_API int toist_wgrad3x3_small(const void* dy, const void* x, float* ws, int n_img, int H, int W, int c_in, int c_out, void* stream);
 
 /* ---- batched linear sum assignment on caller-supplied cost matrices ---------------------------------------------
  * scipy.optimize.linear_sum_assignment for the reference's other call sites (mdetr.py:100 memory-bank replacement on
  * an L1 cdist, mdetr.py:539 softkd matcher): problem p is the row-major fp32 matrix [rows[p], cols[p]] at
  * cost + offset[p]; min(rows, cols) pairs are written at row_idx / col_idx + out_off[p], rows ascending (SciPy's
  * order).  status[p]: 0 ok, 1 NaN or -inf in the matrix (SciPy: ValueError), 2 infeasible. */
-int toist_lsap(const float* cost, const int64_t* offset, const int32_t* rows, const int32_t* cols, int ld /* row stride, 0 = cols[p] */,
+TOIST_API int toist_lsap(const float* cost, const int64_t* offset, const int32_t* rows, const int32_t* cols, int ld /* row stride, 0 = cols[p] */,
                int n, int max_rows, int max_cols,
                int64_t max_cells /* max over problems of rows*cols: sizes the LDS */, const int64_t* out_off, int64_t* row_idx, int64_t* col_idx, int32_t* status, void* stream);
 
@@ -409,7 +416,7 @@ int toist_lsap(const float* cost, const int64_t* offset, const int32_t* rows, co
  * K = 3072: 24 tiles on 256 CUs).  batch = 1, no group, no row map; N %% 4 == 0. */
 #define TOIST_GEMM_SPLIT_EPILOGUE 4
 /* tile code the dispatcher would pick for this descriptor (`tile` = 0) */
-int toist_gemm_pick_tile(const toist_gemm* desc);
+TOIST_API int toist_gemm_pick_tile(const toist_gemm* desc);
 typedef struct toist_reduce_desc {
     const float* ws;          /* [splits][M][N] fp32 partials                */
     float* out;               /* [M][ldc] fp32                               */
@@ -418,13 +425,13 @@ typedef struct toist_reduce_desc {
     float alpha;
     int32_t accumulate;       /* 1: out += ..., 0: out = ...                 */
 } toist_reduce_desc;          /* 48 bytes */
-int toist_gemm_effective_split(const toist_gemm* desc);
-int toist_splitk_reduce_batch(const toist_reduce_desc* descs, int n, void* stream);
+TOIST_API int toist_gemm_effective_split(const toist_gemm* desc);
+TOIST_API int toist_splitk_reduce_batch(const toist_reduce_desc* descs, int n, void* stream);
 
-int toist_opt_chunk_elems(void);
-int toist_opt_sqnorm(const toist_opt_tensor* table, const int64_t* grads, const int32_t* chunks, int n_chunks, float* partial, void* stream);
-int toist_opt_finish_norm(const float* partial, int n_chunks, float max_norm, float beta1, float beta2, toist_opt_state* state, void* stream);
-int toist_opt_adamw_ema(const toist_opt_tensor* table, const int64_t* grads, const int32_t* chunks, int n_chunks,
+TOIST_API int toist_opt_chunk_elems(void);
+TOIST_API int toist_opt_sqnorm(const toist_opt_tensor* table, const int64_t* grads, const int32_t* chunks, int n_chunks, float* partial, void* stream);
+TOIST_API int toist_opt_finish_norm(const float* partial, int n_chunks, float max_norm, float beta1, float beta2, toist_opt_state* state, void* stream);
+TOIST_API int toist_opt_adamw_ema(const toist_opt_tensor* table, const int64_t* grads, const int32_t* chunks, int n_chunks,
                         const toist_opt_group* groups, const toist_opt_state* state, float beta1, float beta2, float eps,
                         float ema_decay, void* stream);
 
@@ -443,16 +450,16 @@ int toist_opt_adamw_ema(const toist_opt_tensor* table, const int64_t* grads, con
  *                 exclusive prefix sum of column_transitions over the flattened [n, w] array)
  *   rle_counts  : mask m owns positions[first_position[m] .. first_position[m+1]) and writes its
  *                 (transitions + 1) run lengths, zeros first, to counts[first_run[m] ...]  (= rleEncode's cnts) */
-int toist_mask_resize_pack(const float* src, int n, int h0, int w0, int max_h, int max_w, int crop_h, int crop_w, int h, int w,
+TOIST_API int toist_mask_resize_pack(const float* src, int n, int h0, int w0, int max_h, int max_w, int crop_h, int crop_w, int h, int w,
                            float threshold, uint64_t* bits, void* stream);
-int toist_mask_pack(const uint8_t* dense, int n, int h, int w, uint64_t* bits, void* stream);
-int toist_mask_unpack(const uint64_t* bits, int n, int h, int w, uint8_t* dense, void* stream);
-int toist_mask_area(const uint64_t* bits, int n, int h, int w, uint32_t* area, void* stream);
-int toist_mask_iou(const uint64_t* dt, int n_dt, const uint64_t* gt, int n_gt, const uint8_t* iscrowd, const uint32_t* area_dt,
+TOIST_API int toist_mask_pack(const uint8_t* dense, int n, int h, int w, uint64_t* bits, void* stream);
+TOIST_API int toist_mask_unpack(const uint64_t* bits, int n, int h, int w, uint8_t* dense, void* stream);
+TOIST_API int toist_mask_area(const uint64_t* bits, int n, int h, int w, uint32_t* area, void* stream);
+TOIST_API int toist_mask_iou(const uint64_t* dt, int n_dt, const uint64_t* gt, int n_gt, const uint8_t* iscrowd, const uint32_t* area_dt,
                    const uint32_t* area_gt, int h, int w, double* iou, void* stream);
-int toist_mask_rle_count(const uint64_t* bits, int n, int h, int w, int32_t* column_transitions, void* stream);
-int toist_mask_rle_emit(const uint64_t* bits, int n, int h, int w, const int64_t* column_offset, uint32_t* positions, void* stream);
-int toist_mask_rle_counts(const uint32_t* positions, const int64_t* first_position, const int64_t* first_run, int n, int h, int w,
+TOIST_API int toist_mask_rle_count(const uint64_t* bits, int n, int h, int w, int32_t* column_transitions, void* stream);
+TOIST_API int toist_mask_rle_emit(const uint64_t* bits, int n, int h, int w, const int64_t* column_offset, uint32_t* positions, void* stream);
+TOIST_API int toist_mask_rle_counts(const uint32_t* positions, const int64_t* first_position, const int64_t* first_run, int n, int h, int w,
                           uint32_t* counts, void* stream);
 
 /* COCOeval.evaluateImg over a batch of images (pycocotools cocoeval.py; reached from datasets/coco_eval.py:368-399).  Image i owns
@@ -462,7 +469,7 @@ int toist_mask_rle_counts(const uint32_t* positions, const int64_t* first_positi
  *   dt_ignore[same index]                          = matched an ignored ground truth, or unmatched with its area outside the range
  *   gt_range_ignore[A*gt_offset[i] + a*G_i + g]    = gt_ignore[g] or its area outside the range
  * gt_taken (A*T bytes per ground truth) is scratch.  Offsets tables have n_images + 1 entries. */
-int toist_coco_match(const double* iou, const int64_t* iou_offset, const double* dt_area, const int64_t* dt_offset, const double* gt_area,
+TOIST_API int toist_coco_match(const double* iou, const int64_t* iou_offset, const double* dt_area, const int64_t* dt_offset, const double* gt_area,
                      const uint8_t* gt_ignore, const uint8_t* gt_crowd, const int64_t* gt_offset, int n_images, const double* area_ranges,
                      int n_ranges, const double* iou_thresholds, int n_thresholds, int32_t* dt_match, uint8_t* dt_ignore,
                      uint8_t* gt_range_ignore, uint8_t* gt_taken, void* stream);

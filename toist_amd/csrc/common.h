@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <cstdlib>
+
 #include "../../include/toist_hip.h"
 
 typedef unsigned short bf16_t;  // raw bfloat16 bits
@@ -23,6 +26,37 @@ int check_launch(const char* what);  // hipGetLastError -> TOIST_EHIP / TOIST_OK
             return TOIST_EINVAL;                  \
         }                                         \
     } while (0)
+
+// ---- tuning switches --------------------------------------------------------------------
+// The dispatcher's thresholds were found with environment switches (tools/dbg/ab_*.sh).  A product build compiles them to their
+// defaults; `make KNOBS=1` (-DTOIST_TUNING_KNOBS) reads the environment once per process for A/B runs.
+#ifdef TOIST_TUNING_KNOBS
+inline long long tuning_knob(const char* name, long long dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoll(e) : dflt;
+}
+#else
+inline long long tuning_knob(const char*, long long dflt) { return dflt; }
+#endif
+
+// ---- per-device one-time kernel attributes (> 64 KiB of dynamic LDS) ----------------------
+// hipFuncSetAttribute is per device; a process that drives several devices must set it on each.  Lock-free and idempotent: two
+// threads racing on the first launch both set the same value.  `done` = one bit per device ordinal.
+template <typename F>
+inline bool lds_attr_once_flag(std::atomic<unsigned long long>& done, F&& set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (!set()) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
+template <typename F>
+inline bool lds_attr_once(int slot, F&& set) {
+    static std::atomic<unsigned long long> done[8];
+    return lds_attr_once_flag(done[slot & 7], static_cast<F&&>(set));
+}
 
 // ---- bf16 <-> f32 ------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }

@@ -186,13 +186,14 @@ static int contrastive_launch_ok(int L, int B, int Q, int T, int D, size_t* lds)
     *lds = contrastive_lds(Q, T, D);
     TOIST_REQUIRE(*lds <= 160 * 1024, "toist_contrastive: Q=%d T=%d D=%d needs %zu B of LDS (> 160 KiB)", Q, T, D, *lds);
     if (*lds > 64 * 1024) {
-        static std::once_flag once;
-        static hipError_t rc = hipSuccess;
-        std::call_once(once, [] {
-            rc = hipFuncSetAttribute((const void*)contrastive_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (rc == hipSuccess) rc = hipFuncSetAttribute((const void*)contrastive_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        });
-        if (rc != hipSuccess) { set_last_error("toist_contrastive: cannot enable large LDS: %s", hipGetErrorString(rc)); return TOIST_EHIP; }
+        static std::atomic<unsigned long long> done{0};     // one bit per device
+        if (!lds_attr_once_flag(done, [] {
+                return hipFuncSetAttribute((const void*)contrastive_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                       hipFuncSetAttribute((const void*)contrastive_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            })) {
+            set_last_error("toist_contrastive: cannot enable 160 KiB of LDS");
+            return TOIST_EHIP;
+        }
     }
     return TOIST_OK;
 }

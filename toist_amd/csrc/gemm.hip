@@ -253,6 +253,16 @@ __device__ __forceinline__ void dma16(unsigned lds_dst, const i32x4_t& r, int el
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// shader clock (experiments: per-phase cycle counters behind flags bit 11)
+__device__ __forceinline__ unsigned long long cyc_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+
 // ---- LDS tile layouts ------------------------------------------------------------------------------
 // k-contiguous tile: [ROWS][BK], 16-byte chunk (row, kc) lives in slot kc ^ ((row / RPL) % CPR) of its row
 // (CPR = BK/8 chunks per row, RPL = 16/CPR rows per 256-byte LDS line): the 16 lanes of a ds_read_b128
@@ -498,9 +508,10 @@ __device__ __forceinline__ void epilogue_tile(const toist_gemm& p, f32x4_t (&acc
 // lean_epilogue_ok() admits exactly that; everything else keeps the general path.
 template <int BN, int WM, int WN, int FM, int FN>
 __device__ __forceinline__ void epilogue_lean(const toist_gemm& p, f32x4_t (&acc)[FM][FN], float* band, const int m0, const int n0, const int bz,
-                                              const long long coff) {
+                                              const long long coff, const int tid_ = -1) {
     constexpr int CPR = BN / 8, CH = (32 * CPR + 255) / 256, LDT = BN + 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // tid_ >= 0: the calling workgroup is several 256-thread quads, each finishing its own 2x2-wave tile through its own band buffer
+    const int tid = tid_ >= 0 ? tid_ : (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c16 = lane & 15;
     const int M = p.M, N = p.N;
     const toist_epilogue& e = p.epi;
@@ -1126,7 +1137,7 @@ static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
 // what epilogue_lean (and the panel kernel's epilogue) covers
 static bool lean_epilogue_ok(const toist_gemm& d) {
     // TOIST_LEAN_EPILOGUE: 0 = never, 1 = only scale / shift / residual / ReLU / mask, 2 (default) = also dropout, GELU, aux-based gradients, row map
-    static const int level = [] { const char* v = getenv("TOIST_LEAN_EPILOGUE"); return v ? atoi(v) : 2; }();
+    static const int level = (int)tuning_knob("TOIST_LEAN_EPILOGUE", 2);
     const toist_epilogue& e = d.epi;
     if (level == 1 && (e.drop_where || e.cmap || (e.act != TOIST_ACT_NONE && e.act != TOIST_ACT_RELU && e.act != TOIST_ACT_MASK_POS))) return false;
     if (level <= 0 || d.split_k > 1 || d.group != nullptr || d.a_colsum != nullptr) return false;
@@ -1382,15 +1393,12 @@ __device__ __forceinline__ void store16_asm(const i32x4_t& r, const int byte_off
     asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(byte_off), "s"(r) : "memory");
 }
 
-constexpr int P2_BAND = 32 * (64 + 4) * 4;            // bytes of the f32 epilogue band (32 rows x 64 columns, pitch 68)
-constexpr int P2_HEAD = (P2_BAND + 1023) & ~1023;     // ring stages start here
+constexpr int P2_HEAD = 0;     // ring stages start here (the epilogue needs no LDS band: fragments are finished where the MFMA left them)
 
-__device__ __forceinline__ unsigned long long cyc_now() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
+// 8 bytes of every lane (see store16_asm)
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+__device__ __forceinline__ void store8_asm(const i32x4_t& r, const int byte_off, const u32x2_t& v) {
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(byte_off), "s"(r) : "memory");
 }
 
 // PROF (experiments, flags bit 11 + a workspace): wave 0 of every workgroup adds up the shader cycles of its four tile phases
@@ -1399,7 +1407,6 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
     constexpr int BN = 64, BK = 64, WM = BM / 2, WN = 32, FM = WM / 16, FN = 2, KS = 8;
     constexpr int SUB = BM * BK;                  // one k-tile of an A block (elements)
     constexpr int PW = BM / 32;                   // 1 KiB pieces per wave: per A k-tile, per residual tile, per mask tile
-    constexpr int LDT = BN + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* const smem = reinterpret_cast<bf16_t*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1473,13 +1480,13 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
         a_col[it] = swz_k<BK>(a_row[it], pch % (BK / 8)) * 8;
         a_off[it] = a_row[it] * lda + a_col[it];
         r_row[it] = pch >> 3;
-        const int cc = n0 + (pch & 7) * 8;
+        const int cc = n0 + ((pch & 7) ^ ((r_row[it] >> 1) & 7)) * 8;       // 16-byte chunk c of row r sits in slot c ^ ((r >> 1) & 7): conflict-free 8-byte fragment reads
         r_colok[it] = cc < N;
         r_off[it] = r_row[it] * p.epi.ldr + cc;
         x_off[it] = r_row[it] * p.epi.ldaux + cc;
     }
     const int P = PW * (kt + (has_res ? 1 : 0) + (has_aux ? 1 : 0));    // DMA instructions per wave per tile
-    constexpr int S = FM;                                               // store instructions per wave per tile
+    constexpr int S = FM * FN;                                          // store instructions per wave per tile
     auto issue = [&](const int slot, const int tile_m) {
         const int m0 = tile_m * BM;
         const unsigned sb = ring0 + (unsigned)(slot * stage) * 2u;
@@ -1501,27 +1508,43 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
         }
     };
 
-    // ---- epilogue invariants (the arithmetic of panel_kernel / epilogue_lean, bit for bit) ----
-    const int c8 = tid & 7, brow = tid >> 3;
-    const int ncol = n0 + c8 * 8;
-    const bool col_ok = ncol < N;
-    const int rloc = (brow >> 4) * WM + (brow & 15);
+    // ---- epilogue invariants: a lane finishes, for each of its FM x FN fragments, the 4 consecutive columns of ONE row the MFMA left it
+    // (the arithmetic of panel_kernel / epilogue_lean, element for element): no LDS band, no barrier, 8-byte accesses ----
     const int ldc = p.ldc;
     const float alpha = p.epi.alpha;
     const int drop = p.epi.drop_where;
     const unsigned long long dseed = drop ? p.epi.drop_seed + (p.epi.drop_seed_dev ? *p.epi.drop_seed_dev : 0ull) : 0ull;
     const unsigned dth = (unsigned)(p.epi.drop_p * 4294967296.0);
     const float dsc = 1.f / (1.f - p.epi.drop_p);
-    float csc[8], csh[8];
+    int ncol[FN];                                       // first of this lane's 4 columns in fragment column j
+    bool col_ok[FN];                                    // N % 8 == 0: the 4 columns are valid or absent together
+    float csc[FN][4], csh[FN][4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { csc[j] = 1.f; csh[j] = 0.f; }
-    if (col_ok) {
-        if (p.epi.scale != nullptr) load_cols8(p.epi.scale + ncol, 8, csc, 1.f);
-        if (p.epi.shift != nullptr) load_cols8(p.epi.shift + ncol, 8, csh, 0.f);
+    for (int jj = 0; jj < FN; ++jj) {
+        ncol[jj] = n0 + wn * WN + jj * 16 + g * 4;
+        col_ok[jj] = ncol[jj] < N;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { csc[jj][e] = alpha; csh[jj][e] = 0.f; }
+        if (col_ok[jj]) {
+            if (p.epi.scale != nullptr) {
+                const float4 t4 = *reinterpret_cast<const float4*>(p.epi.scale + ncol[jj]);
+                csc[jj][0] = alpha * t4.x; csc[jj][1] = alpha * t4.y; csc[jj][2] = alpha * t4.z; csc[jj][3] = alpha * t4.w;
+            }
+            if (p.epi.shift != nullptr) {
+                const float4 t4 = *reinterpret_cast<const float4*>(p.epi.shift + ncol[jj]);
+                csh[jj][0] = t4.x; csh[jj][1] = t4.y; csh[jj][2] = t4.z; csh[jj][3] = t4.w;
+            }
+        }
     }
+    // residual / mask fragment (i, j) of this lane inside a stage's [BM][64] tile: row wm*WM + 16 i + c16, 8 bytes at column wn*32 + 16 j + 4 g
+    int rx_off[FM][FN];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) csc[j] *= alpha;
-    float* const band = reinterpret_cast<float*>(smem);
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < FN; ++jj) {
+            const int r = wm * WM + i * 16 + c16, c = wn * 4 + jj * 2 + (g >> 1);
+            rx_off[i][jj] = r * BN + ((c ^ ((r >> 1) & 7)) * 8) + (g & 1) * 4;
+        }
     // The prologue's own (compiler-visible) loads end here: naming their registers as asm operands makes hipcc place ITS wait for them in
     // front of this statement instead of at their first use inside the tile loop, where it would be a vmcnt(0) per tile.  From here on
     // the wave's counter holds only what `issue` and the stores put there.
@@ -1530,7 +1553,9 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
 #pragma unroll
         for (int jj = 0; jj < FN; ++jj) asm volatile("" : "+v"(bq[ks][jj]));
 #pragma unroll
-    for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(csc[q]), "+v"(csh[q]));
+    for (int jj = 0; jj < FN; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(csc[jj][e]), "+v"(csh[jj][e]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     const int D = ns - 1;
@@ -1583,43 +1608,38 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
         }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            if (i > 0) lds_barrier();         // the previous band has been read (band 0: the tile-top barrier did that)
+            const int m = tm * BM + wm * WM + i * 16 + c16;
 #pragma unroll
-            for (int jj = 0; jj < FN; ++jj) *reinterpret_cast<f32x4_t*>(band + (wm * 16 + c16) * LDT + wn * WN + jj * 16 + g * 4) = acc[i][jj];
-            lds_barrier();
-            const int rt = rloc + 16 * i, m = tm * BM + rt;
-            const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(band + brow * LDT + c8 * 8);
-            const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(band + brow * LDT + c8 * 8 + 4);
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            for (int jj = 0; jj < FN; ++jj) {
+                float v[4] = {acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = v[q] * csc[q] + csh[q];
-            const unsigned long long didx = (unsigned long long)m * N + ncol;
-            if (drop == 1) {
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * csc[jj][e] + csh[jj][e];
+                const unsigned long long didx = (unsigned long long)m * N + ncol[jj];
+                if (drop == 1) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = dropout_keep(dseed, didx + q, dth) ? v[q] * dsc : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = dropout_keep(dseed, didx + e, dth) ? v[e] * dsc : 0.f;
+                }
+                if (has_res) {
+                    const uint2 r2 = *reinterpret_cast<const uint2*>(sR + rx_off[i][jj]);
+                    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+                    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+                }
+                if (ACT == TOIST_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (has_aux) {
+                    const uint2 x2 = *reinterpret_cast<const uint2*>(sX + rx_off[i][jj]);
+                    v[0] = __uint_as_float(x2.x << 16) > 0.f ? v[0] : 0.f; v[1] = __uint_as_float(x2.x & 0xffff0000u) > 0.f ? v[1] : 0.f;
+                    v[2] = __uint_as_float(x2.y << 16) > 0.f ? v[2] : 0.f; v[3] = __uint_as_float(x2.y & 0xffff0000u) > 0.f ? v[3] : 0.f;
+                }
+                if (drop == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = dropout_keep(dseed, didx + e, dth) ? v[e] * dsc : 0.f;
+                }
+                const u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                store8_asm(rsC, (col_ok[jj] && m < M) ? (m * ldc + ncol[jj]) * 2 : OOB, o);
             }
-            if (has_res) {
-                float x[8];
-                unpack8(*reinterpret_cast<const uint4*>(sR + rt * BN + c8 * 8), x);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += x[q];
-            }
-            if (ACT == TOIST_ACT_RELU) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-            }
-            if (has_aux) {
-                float x[8];
-                unpack8(*reinterpret_cast<const uint4*>(sX + rt * BN + c8 * 8), x);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = x[q] > 0.f ? v[q] : 0.f;
-            }
-            if (drop == 2) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = dropout_keep(dseed, didx + q, dth) ? v[q] * dsc : 0.f;
-            }
-            const u32x4_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-            store16_asm(rsC, (col_ok && m < M) ? (m * ldc + ncol) * 2 : OOB, o);
         }
         if (PROF) { t1 = cyc_now(); pc[3] += t1 - t0; t0 = t1; }
         if (++slot == ns) slot = 0;
@@ -1651,7 +1671,7 @@ static bool panel_applies(const toist_gemm& d) {
 }
 
 static long long panel_min_tiles() {   // (32 -- the 800-query decoder linears, 52 tiles -- measured 559.8 -> 563.8 images/s over two noisy rounds: not taken)
-    static const long long v = [] { const char* e = getenv("TOIST_PANEL_MIN_TILES"); return e ? atoll(e) : 128LL; }();
+    static const long long v = tuning_knob("TOIST_PANEL_MIN_TILES", 128);
     return v;
 }
 
@@ -1693,7 +1713,13 @@ static int launch_panel2(const toist_gemm& d, int variant, hipStream_t st) {
     int bm = (variant & 16) ? 32 : 64;
     const int kt = (d.K + 63) / 64;
     const bool has_res = d.epi.res != nullptr, has_aux = d.epi.act == TOIST_ACT_MASK_POS;
-    if (ns == 0) { ns = 3; bm = 64; }
+    if (ns == 0) {
+        // measured (tools/r3/panel2.py, MI355X): two ring stages everywhere (a deeper ring never paid: the tile loop is bound by its own
+        // instruction stream, not by load latency); 64-row blocks while two workgroups of them fit a CU's LDS (80 KB each: no mask tile at
+        // K = 256), 32-row blocks otherwise (three workgroups per CU)
+        ns = 2;
+        bm = (2 * 64 * 64 * 2 * (kt + (has_res ? 1 : 0) + (has_aux ? 1 : 0)) <= 80 * 1024) ? 64 : 32;
+    }
     if (ns < 2 || ns > 4) { set_last_error("toist_gemm_bf16: panel ring of %d stages (2..4)", ns); return TOIST_EINVAL; }
     const int stage = bm * 64 * 2 * (kt + (has_res ? 1 : 0) + (has_aux ? 1 : 0));
     int lds = P2_HEAD + ns * stage;
@@ -1702,25 +1728,19 @@ static int launch_panel2(const toist_gemm& d, int variant, hipStream_t st) {
     const int nt_m = (d.M + bm - 1) / bm, nt_n = (d.N + 63) / 64;
     const int m_per = (nt_m + 7) / 8;
     int per_cu = (160 * 1024) / lds;              // workgroups a CU holds (LDS); registers allow 2 waves per SIMD
-    static const int max_per_cu = [] { const char* e = getenv("TOIST_PANEL_PER_CU"); return e ? atoi(e) : 2; }();
+    const int max_per_cu = bm == 64 ? 2 : 3;      // registers: 2 (164 VGPRs) / 3 (136) waves per SIMD
     if (per_cu > max_per_cu) per_cu = max_per_cu;
     int groups = (32 * per_cu) / nt_n;
     if (groups > m_per) groups = m_per;
     if (groups < 1) groups = 1;
     dim3 grid(8u * (unsigned)(groups * nt_n), 1, 1);
     const bool rowk = d.b_kind == TOIST_B_ROWK;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
 #define TOIST_PANEL2_ONE(BKD, ACT, BM_)                                                                                                   \
     do {                                                                                                                                  \
-        static bool attr[64] = {};                                                                                                        \
-        const int di = dev & 63;                                                                                                          \
-        if (!attr[di]) {   /* idempotent; a race sets the same value twice */                                                             \
-            if (hipFuncSetAttribute((const void*)panel2_kernel<BKD, ACT, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { \
-                set_last_error("toist_gemm_bf16: cannot enable 160 KB of LDS for the panel kernel");                                      \
-                return TOIST_EHIP;                                                                                                        \
-            }                                                                                                                             \
-            attr[di] = true;                                                                                                              \
+        static std::atomic<unsigned long long> done{0};                                                                                   \
+        if (!lds_attr_once_flag(done, [] { return hipFuncSetAttribute((const void*)panel2_kernel<BKD, ACT, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; })) { \
+            set_last_error("toist_gemm_bf16: cannot enable 160 KB of LDS for the panel kernel");                                          \
+            return TOIST_EHIP;                                                                                                            \
         }                                                                                                                                 \
         hipLaunchKernelGGL((panel2_kernel<BKD, ACT, BM_>), grid, dim3(256), lds, st, d, ns);                                              \
     } while (0)
@@ -1764,16 +1784,15 @@ static bool conv3_applies(const toist_gemm& d) {
 }
 
 static int launch_conv3(const toist_gemm& d, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {   // > 64 KiB of dynamic LDS has to be enabled per kernel (idempotent, not a mutable result)
-        if (hipFuncSetAttribute((const void*)conv3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) != hipSuccess) {
-            set_last_error("toist_gemm_bf16: cannot enable %d bytes of LDS for the 3x3 kernel", C3_LDS);
-            return TOIST_EHIP;
-        }
-        attr_set = true;
+    // > 64 KiB of dynamic LDS has to be enabled per kernel and per device (idempotent)
+    if (!lds_attr_once(0, [] {
+            return hipFuncSetAttribute((const void*)conv3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)conv3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)conv3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)conv3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS) == hipSuccess;
+        })) {
+        set_last_error("toist_gemm_bf16: cannot enable %d bytes of LDS for the 3x3 kernel", C3_LDS);
+        return TOIST_EHIP;
     }
     const int tiles = ((d.M + C3_BM - 1) / C3_BM) * ((d.N + C3_BN - 1) / C3_BN);
     dim3 grid((tiles + 7) & ~7, 1, 1);
@@ -1912,8 +1931,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_tall_kernel(const ReduceBat
 // box).  Applied to EVERY launch the same cap is neutral to negative (1024: -1.4 %).
 static long long persist_wgs() {
     static const long long v = [] {
-        const char* e = getenv("TOIST_PERSIST_WGS");
-        const long long n = e ? atoll(e) : 768;
+        const long long n = tuning_knob("TOIST_PERSIST_WGS", 768);
         return n <= 0 ? (1LL << 40) : n;
     }();
     return v;
@@ -1925,12 +1943,12 @@ static long long persist_wgs() {
 // third of the time: 445.6 vs 449.0 images/s on the same box.
 // 64x64x64 launches with at most this many workgroups take the 3-slot ring (TOIST_RING3_MAX_WGS)
 static long long ring3_max_wgs() {
-    static const long long v = [] { const char* e = getenv("TOIST_RING3_MAX_WGS"); return e ? atoll(e) : 512LL; }();
+    static const long long v = tuning_knob("TOIST_RING3_MAX_WGS", 512);
     return v;
 }
 
 static bool xcd_pinned_groups() {
-    static const bool v = [] { const char* e = getenv("TOIST_GROUP_XCD"); return e != nullptr && atoi(e) != 0; }();
+    static const bool v = tuning_knob("TOIST_GROUP_XCD", 0) != 0;
     return v;
 }
 
@@ -2038,7 +2056,7 @@ static int auto_tile(const toist_gemm& d) {
     const long long t128 = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.batch > 0 ? d.batch : 1) * (d.split_k > 0 ? d.split_k : 1);
     // (round 2: the 128x64 tile beats 128x128 on every large problem measured -- 4096^3: 675 vs 555 TFLOP/s, 8192 x 8192 x 2048: 708 vs 443;
     // 128x128 needs 231-247 VGPRs, two waves per SIMD)
-    static const int big_tile = [] { const char* e = getenv("TOIST_BIG_TILE"); return e ? atoi(e) : 130; }();
+    static const int big_tile = (int)tuning_knob("TOIST_BIG_TILE", 130);
     if (t128 >= 1024 && d.K >= 1024) return big_tile;
     if (d.K > 64 && d.N <= 32 && d.M >= 4096) return 132;   // a 64-wide tile would idle half (or more) of its MFMA columns
     if (d.K > 64 && d.M <= 32 && d.N >= 128) return 133;
@@ -2049,7 +2067,7 @@ static int auto_tile(const toist_gemm& d) {
     // 1.5-1.6 rounds (12800 x 512 x 1024) the 64x64 grid stays ahead (29.3 vs 31.0), as it does below one round (tools/dbg/gemm_tiles.py).
     const long long t64 = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) * (d.batch > 0 ? d.batch : 1) * (d.split_k > 0 ? d.split_k : 1);
     const long long rounds = t64 / 1024, last = t64 - rounds * 1024;
-    static const bool wide = [] { const char* e = std::getenv("TOIST_TILE_64x128"); return !(e && e[0] == '0'); }();
+    static const bool wide = tuning_knob("TOIST_TILE_64x128", 1) != 0;
     if (wide && d.K >= 512 && (d.N % 128) == 0 && rounds >= 1 && rounds <= 2 && last * 4 < 1024 &&
         (d.a_kind == TOIST_A_ROWK || d.a_kind == TOIST_A_CONV) && !d.group)
         return 134;
@@ -2210,9 +2228,9 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     if ((d.tile & 255) == 135 || (d.tile == 0 && (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) >= panel_min_tiles())) {
         if (panel_applies(d)) {
             // tile word 135 | variant << 8: variant 1 = the round-2 kernel, otherwise panel2_kernel (see launch_panel2)
-            static const int def_variant = [] { const char* e = getenv("TOIST_PANEL_VARIANT"); return e ? atoi(e) : 1; }();
+            static const int def_variant = (int)tuning_knob("TOIST_PANEL_VARIANT", 0);
             const int variant = (d.tile >> 8) ? (d.tile >> 8) : def_variant;
-            const int rcp = (variant == 1 || !panel2_applies(d)) ? launch_panel(d, st) : launch_panel2(d, variant, st);
+            const int rcp = (variant == 1 || !panel2_applies(d)) ? launch_panel(d, st) : launch_panel2(d, variant == 255 ? 0 : variant, st);
             return rcp != TOIST_OK ? rcp : check_launch("toist_gemm_bf16(panel)");
         }
         TOIST_REQUIRE((d.tile & 255) != 135, "toist_gemm_bf16: the short-K panel kernel does not cover this call");

@@ -386,10 +386,11 @@ extern "C" int toist_matcher(const float* logits, const float* boxes, const floa
         lds += stage;
     }
     if (lds > 64 * 1024) {   // one-time, thread-safe opt-in to the full 160 KiB LDS window (no other global state in this library)
-        static std::once_flag once;
-        static hipError_t once_rc = hipSuccess;
-        std::call_once(once, [] { once_rc = hipFuncSetAttribute((const void*)matcher_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        if (once_rc != hipSuccess) { set_last_error("toist_matcher: set LDS size: %s", hipGetErrorString(once_rc)); return TOIST_EHIP; }
+        static std::atomic<unsigned long long> done{0};     // one bit per device: the attribute is per device
+        if (!lds_attr_once_flag(done, [] { return hipFuncSetAttribute((const void*)matcher_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; })) {
+            set_last_error("toist_matcher: cannot enable 160 KiB of LDS");
+            return TOIST_EHIP;
+        }
     }
     hipLaunchKernelGGL(matcher_kernel, dim3(L * B), dim3(MATCH_THREADS), lds, (hipStream_t)stream, logits, boxes, tgt_boxes,
                        pos_map, tgt_off_dev, match_off_dev, L, B, Q, K, w_class, w_bbox, w_giou,
@@ -408,10 +409,11 @@ extern "C" int toist_lsap(const float* cost, const int64_t* offset, const int32_
     TOIST_REQUIRE(lds <= 160 * 1024, "toist_lsap: problems up to %d x %d (%lld cells) need %zu B of LDS (> 160 KiB)", max_rows, max_cols,
                   (long long)max_cells, lds);
     if (lds > 64 * 1024) {
-        static std::once_flag once;
-        static hipError_t once_rc = hipSuccess;
-        std::call_once(once, [] { once_rc = hipFuncSetAttribute((const void*)lsap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        if (once_rc != hipSuccess) { set_last_error("toist_lsap: cannot enable large LDS: %s", hipGetErrorString(once_rc)); return TOIST_EHIP; }
+        static std::atomic<unsigned long long> done{0};
+        if (!lds_attr_once_flag(done, [] { return hipFuncSetAttribute((const void*)lsap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; })) {
+            set_last_error("toist_lsap: cannot enable 160 KiB of LDS");
+            return TOIST_EHIP;
+        }
     }
     hipLaunchKernelGGL(lsap_kernel, dim3(n), dim3(64), lds, (hipStream_t)stream, cost, (const long long*)offset, rows, cols, ld,
                        (const long long*)out_off, (long long*)row_idx, (long long*)col_idx, status);

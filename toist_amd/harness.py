@@ -200,3 +200,139 @@ def evaluate(model, criterion, cluster_criterion, postprocessors, weight_dict, b
         if "segm" in evaluator.coco_eval:
             stats["coco_eval_masks"] = evaluator.coco_eval["segm"].stats.tolist()
     return stats
+
+
+# ---- the captured training step as a library feature -------------------------------------------------------------------------
+class CapturedTrainStep:
+    """The reference's training step (engine.py:54-101: encode -> decode -> SetCriterion -> weighted sum -> backward -> clip + AdamW + EMA)
+    replayed from hipGraphs, one per input-shape BUCKET, with real variable-size batches.
+
+    The reference resizes images to 480..800 x <= 1333 (datasets/tdod.py:305-319) and pads a batch to its largest image
+    (util/misc.py:185-209); captions are padded to the longest of the batch.  A captured graph has static shapes, so a batch is padded a
+    little further -- height / width up to multiples of `pad_hw`, tokens up to a multiple of `pad_tokens` -- with the padding masked out
+    exactly as the reference masks its own padding (NestedTensor.mask, attention_mask): the results are those of the eager step on the
+    same (more generously padded) batch.  One graph is captured per bucket (Hp, Wp, Lp) on first use and kept in an LRU of `max_graphs`;
+    targets travel through matcher.StaticTargets (fixed-address device image, any number of targets per image up to
+    `max_targets_per_image`), dropout masks change per replay through the device seed word, learning rates are re-read from the
+    optimizer's device table (`optimizer.sync_hyperparams()` after changing them).
+
+    step(samples, tokenized, targets, positive_map) -> total loss (device scalar, valid until the next step of the same bucket).
+    The FIRST step of a new bucket runs eagerly (it is a real training step) and the graph is captured right after it, without
+    executing anything; later steps of that bucket are one host-to-device copy of the inputs + one graph launch.
+    Single process per GPU; with torch.distributed active the step falls back to the eager path (collectives are not captured)."""
+
+    def __init__(self, model, criterion, optimizer, weight_dict, *, batch, max_targets_per_image=16, pad_hw=64, pad_tokens=8, max_graphs=4,
+                 contrastive=None, device=None):
+        from collections import OrderedDict
+        from . import kernels
+        self.model, self.criterion, self.optimizer, self.weight_dict = model, criterion, optimizer, weight_dict
+        self.batch, self.max_t = int(batch), int(max_targets_per_image)
+        self.pad_hw, self.pad_tokens, self.max_graphs = int(pad_hw), int(pad_tokens), int(max_graphs)
+        self.device = torch.device(device) if device is not None else next(model.parameters()).device
+        det = getattr(model, "detr", model)
+        self.num_queries = det.query_embed.weight.shape[0]
+        self.contrastive = bool(getattr(det, "contrastive_align_loss", False)) if contrastive is None else bool(contrastive)
+        self._buckets = OrderedDict()          # (Hp, Wp, Lp) -> dict(graph, images, mask, ids, att, targets, loss)
+        self._side = torch.cuda.Stream(device=self.device)
+        if kernels.SEED_DEV is None:
+            kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=self.device)
+        from . import engine
+        engine.REUSE_GRAD_BUFFERS = True       # the loop owns the gradients: one flat buffer per program, shared by every bucket's graph and the eager steps
+        self.captures = 0
+        self.replays = 0
+
+    # -- helpers ------------------------------------------------------------------------------------------------------------------
+    def bucket_of(self, samples, tokenized):
+        H, W = samples.tensors.shape[-2:]
+        L = tokenized["input_ids"].shape[1]
+        up = lambda v, m: (int(v) + m - 1) // m * m
+        return up(H, self.pad_hw), up(W, self.pad_hw), up(L, self.pad_tokens)
+
+    def _static_inputs(self, key):
+        from .matcher import StaticTargets
+        from .misc import NestedTensor
+        from .transformer import TokenizedText
+        Hp, Wp, Lp = key
+        dev = self.device
+        pad_id = getattr(getattr(self.model, "detr", self.model).transformer.text_encoder.config, "pad_token_id", 1)
+        ent = {"samples": NestedTensor(torch.zeros(self.batch, 3, Hp, Wp, device=dev), torch.ones(self.batch, Hp, Wp, dtype=torch.bool, device=dev)),
+               "tok": TokenizedText({"input_ids": torch.full((self.batch, Lp), pad_id, dtype=torch.int64, device=dev),
+                                     "attention_mask": torch.zeros(self.batch, Lp, dtype=torch.int64, device=dev)}),
+               "targets": StaticTargets(self.batch, self.max_t, self.num_queries, 256, dev), "graph": None, "loss": None, "pad_id": pad_id}
+        return ent
+
+    def _fill(self, ent, samples, tokenized, targets, positive_map, packed):
+        img, msk = ent["samples"].tensors, ent["samples"].mask
+        B, _, H, W = samples.tensors.shape
+        if B != self.batch:
+            raise ValueError(f"CapturedTrainStep was built for batches of {self.batch} images (got {B})")
+        if (H, W) != tuple(img.shape[-2:]):
+            img.zero_()
+            msk.fill_(True)
+        img[:, :, :H, :W].copy_(samples.tensors, non_blocking=True)
+        msk[:, :H, :W].copy_(samples.mask, non_blocking=True)
+        ids, att = ent["tok"]["input_ids"], ent["tok"]["attention_mask"]
+        L = tokenized["input_ids"].shape[1]
+        if L != ids.shape[1]:
+            ids.fill_(ent["pad_id"])
+            att.zero_()
+        ids[:, :L].copy_(tokenized["input_ids"], non_blocking=True)
+        att[:, :L].copy_(tokenized["attention_mask"], non_blocking=True)
+        st = ent["targets"]
+        if packed is None:
+            host_t = [{k_: (v.cpu() if torch.is_tensor(v) else v) for k_, v in t.items()} for t in targets]
+            masks = self.criterion.token_masks_host(host_t, tokenized) if self.contrastive else None
+            st.load(host_t, positive_map.cpu() if torch.is_tensor(positive_map) else positive_map, masks)
+        else:
+            st.load_packed(packed)
+
+    def _fwd_bwd_opt(self, ent):
+        from . import kernels
+        from .mdetr import weighted_total
+        kernels.SEED_DEV.add_(1000003)
+        mc = self.model(ent["samples"], ent["tok"], encode_and_save=True)
+        out = self.model(ent["samples"], ent["tok"], encode_and_save=False, memory_cache=mc)
+        losses = self.criterion(mc, out, ent["targets"], None, None)
+        total = weighted_total(losses, self.weight_dict)
+        total.backward()
+        self.optimizer.step()
+        return total
+
+    # -- the step -------------------------------------------------------------------------------------------------------------------
+    def step(self, samples, tokenized, targets=None, positive_map=None, packed=None):
+        from . import engine
+        distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        key = self.bucket_of(samples, tokenized)
+        ent = self._buckets.get(key)
+        fresh = ent is None
+        if fresh:
+            ent = self._static_inputs(key)
+            self._buckets[key] = ent
+            while len(self._buckets) > self.max_graphs:
+                self._buckets.popitem(last=False)          # least recently used bucket: its graph and activation pool are released
+        self._buckets.move_to_end(key)
+        self._fill(ent, samples, tokenized, targets, positive_map, packed)
+        if ent["graph"] is not None:
+            ent["graph"].replay()
+            self.replays += 1
+            return ent["loss"]
+        # first batch of this bucket: a real, eager training step, launched on the object's own stream -- the stream the graph is captured
+        # on right afterwards, so that every per-stream cache of the launchers (split-K scratch, reduction arena) exists before the
+        # capture begins instead of being allocated inside it ...
+        side = self._side
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.optimizer.zero_grad(set_to_none=True)
+            total = self._fwd_bwd_opt(ent)
+            if not distributed:
+                # ... then the capture of the same call sequence on the static inputs (nothing executes during capture)
+                self.optimizer.zero_grad(set_to_none=True)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    ent["loss"] = self._fwd_bwd_opt(ent)
+                ent["graph"] = graph
+                self.captures += 1
+        torch.cuda.current_stream().wait_stream(side)
+        return total
+
+    __call__ = step

@@ -31,6 +31,7 @@ PROFILE = None
 SEED_DEV = None
 FORCE_TILE = 0    # experiments: overrides tile == 0 (auto) in every gemm() call
 FORCE_SPLIT = 0   # experiments: overrides split_k when > 0 and the call accumulates
+DEBUG_FLAGS = 0   # experiments: extra flag bits (ablation switches of the PROF kernels) when DEBUG_WS is set
 DEBUG_WS = None   # experiments: f32 device buffer handed to un-split gemm() calls as `workspace` with flags bit 11 (per-phase cycle counters of panel2_kernel)
 
 
@@ -218,7 +219,7 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
         _PENDING.setdefault(deferred[0], []).append(deferred[1])
     if DEBUG_WS is not None and split_k <= 1:
         d.workspace = _p(DEBUG_WS, torch.float32)
-        d.flags |= 2048
+        d.flags |= 2048 | DEBUG_FLAGS
     prof = PROFILE
     if prof is None:
         _lib.check(_lib.lib().toist_gemm_bf16(ctypes.byref(d), _stream()), "toist_gemm_bf16")
