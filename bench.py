@@ -456,8 +456,8 @@ def main():
             feed()
         with sync:
             total = fwd_bwd()
-            bwd_cut("text")
-            bwd_cut("backbone")
+            for name in parallel.BACKWARD_CUTS:      # text | layer4 | layer3 | stem .. layer2: each flat buffer is all-reduced when its segment is done
+                bwd_cut(name)
             sync.finish()
         optimize()
         return total
@@ -498,10 +498,22 @@ def main():
                     with torch.cuda.graph(graph_text, stream=side):
                         bwd_cut("text")
                     n_text = len(flats)
-                    graph_bb = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph_bb, stream=side):
-                        bwd_cut("backbone")
+                    # the ResNet body backward as three graphs (layer4 | layer3 | stem .. layer2; --masks: one, the body is one program):
+                    # the all-reduce of a stage's gradients is issued between them
+                    bb_graphs, bb_ends = [], []
+                    for name in parallel.BACKWARD_CUTS[1:]:
+                        if name != "backbone" and name not in cut_state["mc"].get("_native", {}).get("cuts", {}):
+                            continue
+                        g_ = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g_, stream=side):
+                            bwd_cut(name)
+                        bb_graphs.append(g_)
+                        bb_ends.append(len(flats))
                     functions.GRAD_SYNC = None
+                    # gradients that no program's flat buffer carries (parameters fed to a program as an INPUT and differentiated by
+                    # autograd: query_embed.weight): static tensors of the captured head graph, reduced with the head segment
+                    spans = [(f.data_ptr(), f.data_ptr() + f.numel() * f.element_size()) for f in flats]
+                    rest_grads = [p.grad for _, p in named if p.grad is not None and not any(lo <= p.grad.data_ptr() < hi for lo, hi in spans)]
                     graph_b = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph_b, stream=side):
                         optimize()
@@ -528,28 +540,34 @@ def main():
             def run_step():
                 # main stream: [forward + criterion + backward of heads / decoder / encoder] -> [backbone backward] -> tail
                 # text stream:                                                  [RoBERTa backward] (beside the backbone)
-                # RCCL stream:               all-reduce(transformer) -> all-reduce(text) ............ all-reduce(backbone)
+                # RCCL stream:               all-reduce(transformer) -> all-reduce(text) -> all-reduce(layer4) -> all-reduce(layer3) -> all-reduce(layer2)
                 main = torch.cuda.current_stream()
                 if feed is not None:
                     feed()
                 graph_a.replay()
                 if world > 1:
-                    h_head = parallel.all_reduce_mean_async(flats[:n_head], bf16=a.bf16_grads)
+                    h_head = parallel.all_reduce_mean_async(flats[:n_head] + rest_grads, bf16=a.bf16_grads)
                 text_stream.wait_stream(main)
                 with torch.cuda.stream(text_stream):
                     graph_text.replay()
                     if world > 1:
                         h_text = parallel.all_reduce_mean_async(flats[n_head:n_text], bf16=a.bf16_grads)
-                graph_bb.replay()
+                h_bb, beg = [], n_text
+                for g_, end in zip(bb_graphs, bb_ends):      # layer4 -> all-reduce under layer3 -> all-reduce under layer2 -> ...
+                    g_.replay()
+                    if world > 1 and end > beg:
+                        h_bb.append(parallel.all_reduce_mean_async(flats[beg:end], bf16=a.bf16_grads))
+                    beg = end
                 if world > 1:
-                    h_bb = parallel.all_reduce_mean_async(flats[n_text:], bf16=a.bf16_grads)
                     h_head.wait()
                     h_text.wait()
-                    h_bb.wait()
+                    for h_ in h_bb:
+                        h_.wait()
                 main.wait_stream(text_stream)
                 graph_b.replay()
                 return static_loss
-        run_step()
+        for _ in range(max(a.warmup, 1)):      # W untimed steps on the path that is timed (the eager steps above only prepared the capture)
+            run_step()
     else:
         for _ in range(a.warmup):
             step()
@@ -592,11 +610,22 @@ def main():
         t = torch.tensor([dt], device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
+    params_identical, params_differing = None, []
+    if world > 1:
+        # after the timed steps every rank must hold the same parameters (same broadcast start, averaged gradients, same optimizer tail)
+        with torch.no_grad():
+            digest = torch.stack([p.detach().double().sum() for _, p in named]).to(dev)
+            lo, hi = digest.clone(), digest.clone()
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+            params_identical = bool(torch.equal(lo, hi))
+            params_differing = [named[i][0] for i in (lo != hi).nonzero().flatten().tolist()]
     collectives = None
     if world > 1 and use_graph and split_graph and flats:
         # the three gradient collectives of the step, each alone on the machine: what the RCCL ring achieves per xGMI link
         collectives = {name: parallel.measure_all_reduce(fl, bf16=a.bf16_grads) for name, fl in
-                       (("transformer+heads", flats[:n_head]), ("text_encoder", flats[n_head:n_text]), ("backbone", flats[n_text:])) if fl}
+                       [("transformer+heads", flats[:n_head]), ("text_encoder", flats[n_head:n_text])] +
+                       [("backbone stage %d of %d (layer4 first)" % (i + 1, len(bb_ends)), flats[b_:e_]) for i, (b_, e_) in enumerate(zip([n_text] + bb_ends[:-1], bb_ends))] if fl}
 
     if rank == 0:
         ips = a.batch * world * a.steps / dt
@@ -609,7 +638,7 @@ def main():
                                    "16-token captions, detection loss (labels+boxes+cardinality" + ("+contrastive_align" if contrastive else "") + (", no aux layers" if a.frozen else ", 5 aux layers") + "), dropout 0.1, "
                                    "clip 0.1 + AdamW + EMA" + (" (torch)" if a.torch_optimizer else " (fused HIP tail)") + "; random-init weights; " +
                                    ("every step a different batch (4 resident batches, 0..10 targets per image) through fixed-address inputs" if dynamic else "one fixed batch"),
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4), "launch": ("4 hipGraphs (head | text || backbone | tail), gradient all-reduces under the backbone backward" if split_graph else "hipGraph replay") if use_graph else "eager",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4), "launch": ("%d hipGraphs (head | text || backbone layer4 | layer3 | layer2 | tail), gradient all-reduces under the backbone backward" % (3 + len(bb_graphs)) if split_graph else "hipGraph replay") if use_graph else "eager",
                        "gflop_per_image": gflop_img,
                        "mfma_frac_whole_step": round(ips / world * gflop_img / 1000.0 / PEAK_BF16_TFLOPS, 5)},
         }
@@ -618,8 +647,12 @@ def main():
             res["repeats"] = {"ms_per_step": [round(v, 3) for v in region_ms], "min": round(srt[0], 3), "median": round(srt[len(srt) // 2], 3),
                               "images_per_s_median": round(a.batch * world / (srt[len(srt) // 2] * 1e-3), 1),
                               "note": "the K-step timed region run %d times back to back; `value` / `ms_per_step` are the first" % len(region_ms)}
+        if world > 1:
+            res["config"]["parameters_identical_across_ranks"] = params_identical
         if collectives is not None:
             res["collectives"] = collectives
+            if not params_identical:
+                res["config"]["parameters_differing"] = {"count": len(params_differing), "first": params_differing[:12]}
             res["config"]["gradient_wire_dtype"] = "bf16" if a.bf16_grads else "f32"
         if prof is not None and prof["records"]:
             tot_ms, tot_fl, per_key = 0.0, 0.0, {}

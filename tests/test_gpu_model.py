@@ -310,8 +310,8 @@ def test_reused_gradient_buffers_match_fresh_ones(dev, setup):
 
 
 def test_backward_cuts_reproduce_the_uncut_gradients(dev, setup):
-    """toist_amd.parallel.enable_backward_cuts splits loss.backward() into three segments (head | text | backbone) for
-    the data-parallel step; the segmented pass must produce the same gradients as the plain one."""
+    """toist_amd.parallel.enable_backward_cuts splits loss.backward() into segments (head | text | backbone layer4 | layer3 | stem ..
+    layer2) for the data-parallel step; the segmented pass must produce the same gradients as the plain one."""
     from toist_amd import harness, parallel
     model, criterion, weight_dict, sd, args = setup
     model.eval()
@@ -332,7 +332,17 @@ def test_backward_cuts_reproduce_the_uncut_gradients(dev, setup):
             assert text_w.grad is None and bb_w.grad is None          # the first backward stopped at the cuts
             parallel.backward_cut(mc, "text")
             assert text_w.grad is not None and bb_w.grad is None
+            # the ResNet body runs as three stage programs: layer4, then layer3, then stem .. layer2, each with its own flat gradient buffer
+            l3_w, l2_w = model.backbone[0].body.layer3[10].conv2.weight, model.backbone[0].body.layer2[0].conv1.weight
+            assert set(mc["_native"]["cuts"]) == {"text", "backbone", "backbone.layer3", "backbone.layer2"}
             parallel.backward_cut(mc, "backbone")
+            assert bb_w.grad is not None and l3_w.grad is None and l2_w.grad is None
+            parallel.backward_cut(mc, "backbone.layer3")
+            assert l3_w.grad is not None and l2_w.grad is None
+            parallel.backward_cut(mc, "backbone.layer2")
+            assert l2_w.grad is not None
+            flats = {p_.grad.untyped_storage().data_ptr() for p_ in (bb_w, l3_w, l2_w)}
+            assert len(flats) == 3, "the three stages must own separate flat gradient buffers"
         return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
 
     try:

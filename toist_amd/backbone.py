@@ -163,7 +163,9 @@ class BackboneBase(nn.Module):
             parts[-1] = "1"
         return self.body.get_submodule(".".join(parts))
 
-    def _program(self, levels):
+    def _program(self, levels, first=1, last=4, stem=True):
+        """Forward program of residual stages first .. last (with the stem in front when `stem`): prog(tape, ps, x) with x = the image
+        batch (stem) or the previous stage's NHWC bf16 output; ps holds the parameters under their names inside `body`."""
         body = self.body
         bn_cache = {}
 
@@ -174,18 +176,21 @@ class BackboneBase(nn.Module):
 
         def prog(tape, ps, images):
             x = images.data
-            N, C, H, W = x.shape
-            xin = torch.empty(N, H, W, 8, dtype=BF16, device=x.device)
-            k.pack_image(x.contiguous(), xin)
-            s0, t0 = bn("bn1")
-            y = ops.conv2d(xin, engine.krsc(ps["conv1.weight"].w), stride=2, pad=3, shift=t0, act=k.ACT_RELU, cin_real=C)
-            OH, OW = (y.shape[1] + 2 - 3) // 2 + 1, (y.shape[2] + 2 - 3) // 2 + 1
-            pooled = torch.empty(N, OH, OW, 64, dtype=BF16, device=x.device)
-            k.maxpool3x3s2(y, pooled)
-            del y
-            cur = engine.Var(pooled, needs_grad=False)
+            if stem:
+                N, C, H, W = x.shape
+                xin = torch.empty(N, H, W, 8, dtype=BF16, device=x.device)
+                k.pack_image(x.contiguous(), xin)
+                s0, t0 = bn("bn1")
+                y = ops.conv2d(xin, engine.krsc(ps["conv1.weight"].w), stride=2, pad=3, shift=t0, act=k.ACT_RELU, cin_real=C)
+                OH, OW = (y.shape[1] + 2 - 3) // 2 + 1, (y.shape[2] + 2 - 3) // 2 + 1
+                pooled = torch.empty(N, OH, OW, 64, dtype=BF16, device=x.device)
+                k.maxpool3x3s2(y, pooled)
+                del y
+                cur = engine.Var(pooled, needs_grad=False)
+            else:
+                cur = images          # the previous stage's output: its gradient (w.r.t. the pre-ReLU sum, masked by the first block here) flows back
             outs = []
-            for li in range(1, 5):
+            for li in range(first, last + 1):
                 layer = getattr(body, f"layer{li}")
                 for bi, blk in enumerate(layer):
                     pre = f"layer{li}.{bi}."
@@ -207,14 +212,10 @@ class BackboneBase(nn.Module):
 
         return prog
 
-    def forward_native(self, images, levels=(4,), premasked=()):
-        """images: fp32 NCHW on the device -> tuple of NHWC bf16 feature maps (post-ReLU) for `levels`.
-        A gradient fed back into an output is taken w.r.t. the post-ReLU values and masked by (out > 0)
-        here, unless its index is listed in `premasked` (the consumer's dgrad epilogue already did it:
-        input_proj, toist_amd/mdetr.py)."""
-        named = engine.named_cache(self, "body", lambda: OrderedDict(self.body.named_parameters()))
-        prog = self._program(levels)
-
+    @staticmethod
+    def _with_output_masks(prog, premasked):
+        """Wrap a stage program: a gradient fed back into output i is taken w.r.t. the post-ReLU values and masked by (out > 0) here,
+        unless i is listed in `premasked` (the consumer's data-gradient epilogue already did it)."""
         def wrapped(tape, ps, img):
             outs, extra = prog(tape, ps, img)
             finals = []
@@ -232,9 +233,49 @@ class BackboneBase(nn.Module):
                 tape.record(bwd)
                 finals.append(f)
             return finals, extra
+        return wrapped
 
+    STAGES = ((1, 2, True), (3, 3, False), (4, 4, False))     # stem + layer1 + layer2 | layer3 | layer4: one backward program (and one flat gradient buffer) each
+
+    def forward_native(self, images, levels=(4,), premasked=(), stage_cuts=None):
+        """images: fp32 NCHW on the device -> tuple of NHWC bf16 feature maps (post-ReLU) for `levels`.
+        A gradient fed back into an output is taken w.r.t. the post-ReLU values and masked by (out > 0)
+        here, unless its index is listed in `premasked` (the consumer's dgrad epilogue already did it:
+        input_proj, toist_amd/mdetr.py).
+
+        stage_cuts (a list, data-parallel jobs): the body runs as THREE programs (STAGES) instead of one and the autograd graph is
+        cut between them -- (stage output, detached leaf fed to the next stage) pairs are appended to the list -- so that the gradient
+        all-reduce of layer4 / layer3 can travel underneath the backward pass of the stages below (toist_amd.parallel.backward_cut);
+        only for levels == (4,) (the detection model)."""
+        if stage_cuts is not None and tuple(levels) == (4,):
+            return self._forward_staged(images, premasked, stage_cuts)
+        named = engine.named_cache(self, "body", lambda: OrderedDict(self.body.named_parameters()))
+        wrapped = self._with_output_masks(self._program(levels), premasked)
         return functions.run_program(wrapped, named, [images], cache=self._cache, training=self.training, transforms=self._transforms(),
                                      group_wgrads=True, store_once=lambda n, t: t.dim() == 4)     # every conv weight: one weight-gradient GEMM each
+
+    def _forward_staged(self, images, premasked, stage_cuts):
+        tr_all = self._transforms()
+        caches = self.__dict__.setdefault("_stage_caches", [{} for _ in self.STAGES])
+        x = images
+        for si, (first, last, stem) in enumerate(self.STAGES):
+            def build(first=first, last=last, stem=stem):
+                keep = tuple(f"layer{li}." for li in range(first, last + 1)) + (("conv1.",) if stem else ())
+                return OrderedDict((n, p) for n, p in self.body.named_parameters() if n.startswith(keep))
+            named = engine.named_cache(self, f"body.stage{si}", build)
+            tr = {n: f for n, f in tr_all.items() if n in named}
+            is_last = si == len(self.STAGES) - 1
+            # an inner stage hands its last block's output on as it is: the next stage's first block returns the gradient already masked
+            prog = self._program((last,), first, last, stem)
+            wrapped = self._with_output_masks(prog, premasked if is_last else (0,))
+            (y,) = functions.run_program(wrapped, named, [x], cache=caches[si], training=self.training, transforms=tr, group_wgrads=True,
+                                         store_once=lambda n, t: t.dim() == 4)
+            if not is_last and y.requires_grad:
+                leaf = y.detach().requires_grad_(True)
+                stage_cuts.append((y, leaf))
+                y = leaf
+            x = y
+        return (x,)
 
     # ---- reference-compatible API ------------------------------------------------------------------
     def forward(self, tensor_list: NestedTensor):

@@ -565,10 +565,13 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
             for (int eb = 0; eb < 2; ++eb) {
                 if (part != nullptr) {
                     const size_t plane = (size_t)(gridDim.x / H) * Sk * H * DH;            // B*Sk x H*32
-                    float* pk = part + ((size_t)blockIdx.y * 2 + 0) * plane + ((size_t)b * Sk + key) * (H * DH) + h * DH + eb * 16 + g * 4;
-                    float* pv = part + ((size_t)blockIdx.y * 2 + 1) * plane + ((size_t)b * Sk + key) * (H * DH) + h * DH + eb * 16 + g * 4;
-                    *reinterpret_cast<float4*>(pk) = make_float4(accK[i][eb][0], accK[i][eb][1], accK[i][eb][2], accK[i][eb][3]);
-                    *reinterpret_cast<float4*>(pv) = make_float4(accV[i][eb][0], accV[i][eb][1], accV[i][eb][2], accV[i][eb][3]);
+                    // partial sums travel as bf16 (round 3): the four query-split partials of an encoder layer were 27.9 MB of fp32 written and
+                    // read back per launch against 5 MB of dQ / dK / dV (profiles/r02_pmc_traffic.json); the fold adds them in fp32
+                    bf16_t* const pb = reinterpret_cast<bf16_t*>(part);
+                    bf16_t* pk = pb + ((size_t)blockIdx.y * 2 + 0) * plane + ((size_t)b * Sk + key) * (H * DH) + h * DH + eb * 16 + g * 4;
+                    bf16_t* pv = pb + ((size_t)blockIdx.y * 2 + 1) * plane + ((size_t)b * Sk + key) * (H * DH) + h * DH + eb * 16 + g * 4;
+                    *reinterpret_cast<uint2*>(pk) = make_uint2(pack2bf(accK[i][eb][0], accK[i][eb][1]), pack2bf(accK[i][eb][2], accK[i][eb][3]));
+                    *reinterpret_cast<uint2*>(pv) = make_uint2(pack2bf(accV[i][eb][0], accV[i][eb][1]), pack2bf(accV[i][eb][2], accV[i][eb][3]));
                 } else {
                     *reinterpret_cast<uint2*>(dk + ((size_t)b * Sk + key) * lddk + h * DH + eb * 16 + g * 4) =
                         make_uint2(pack2bf(accK[i][eb][0] * scale, accK[i][eb][1] * scale), pack2bf(accK[i][eb][2] * scale, accK[i][eb][3] * scale));
@@ -581,23 +584,29 @@ __global__ __launch_bounds__(512) void attn_bwd_rows_kernel(const bf16_t* __rest
 }
 
 // dk = scale * sum_s part[s][0], dv = sum_s part[s][1]: rows = B*Sk, d = H*32 columns, 4 columns per thread
-__global__ __launch_bounds__(256) void attn_bwd_fold_kernel(const float* __restrict__ part, int splits, long long rows, int d, float scale,
+__global__ __launch_bounds__(256) void attn_bwd_fold_kernel(const float* __restrict__ part_, int splits, long long rows, int d, float scale,
                                                             bf16_t* __restrict__ dk, int lddk, bf16_t* __restrict__ dv, int lddv) {
+    const bf16_t* const part = reinterpret_cast<const bf16_t*>(part_);     // bf16 partials, 8 columns (16 bytes) per thread
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int c4 = d >> 2;
-    if (idx >= rows * c4) return;
-    const long long r = idx / c4;
-    const int c = (int)(idx - r * c4) * 4;
+    const int c8 = d >> 3;
+    if (idx >= rows * c8) return;
+    const long long r = idx / c8;
+    const int c = (int)(idx - r * c8) * 8;
     const size_t plane = (size_t)rows * d;
-    float4 ak = make_float4(0.f, 0.f, 0.f, 0.f), av = ak;
+    float ak[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int sp = 0; sp < splits; ++sp) {
-        const float4 a = *reinterpret_cast<const float4*>(part + ((size_t)sp * 2 + 0) * plane + (size_t)r * d + c);
-        const float4 bq = *reinterpret_cast<const float4*>(part + ((size_t)sp * 2 + 1) * plane + (size_t)r * d + c);
-        ak.x += a.x; ak.y += a.y; ak.z += a.z; ak.w += a.w;
-        av.x += bq.x; av.y += bq.y; av.z += bq.z; av.w += bq.w;
+        const uint4 a = *reinterpret_cast<const uint4*>(part + ((size_t)sp * 2 + 0) * plane + (size_t)r * d + c);
+        const uint4 b = *reinterpret_cast<const uint4*>(part + ((size_t)sp * 2 + 1) * plane + (size_t)r * d + c);
+        const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ak[2 * q] += __uint_as_float(aw[q] << 16); ak[2 * q + 1] += __uint_as_float(aw[q] & 0xffff0000u);
+            av[2 * q] += __uint_as_float(bw[q] << 16); av[2 * q + 1] += __uint_as_float(bw[q] & 0xffff0000u);
+        }
     }
-    *reinterpret_cast<uint2*>(dk + (size_t)r * lddk + c) = make_uint2(pack2bf(ak.x * scale, ak.y * scale), pack2bf(ak.z * scale, ak.w * scale));
-    *reinterpret_cast<uint2*>(dv + (size_t)r * lddv + c) = make_uint2(pack2bf(av.x, av.y), pack2bf(av.z, av.w));
+    *reinterpret_cast<uint4*>(dk + (size_t)r * lddk + c) = make_uint4(pack2bf(ak[0] * scale, ak[1] * scale), pack2bf(ak[2] * scale, ak[3] * scale),
+                                                                    pack2bf(ak[4] * scale, ak[5] * scale), pack2bf(ak[6] * scale, ak[7] * scale));
+    *reinterpret_cast<uint4*>(dv + (size_t)r * lddv + c) = make_uint4(pack2bf(av[0], av[1]), pack2bf(av[2], av[3]), pack2bf(av[4], av[5]), pack2bf(av[6], av[7]));
 }
 
 }  // namespace toist
@@ -673,10 +682,12 @@ extern "C" int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk,
         else if (Sk <= 256) TOIST_ATTN_BWD_ROWS(16);
         else TOIST_ATTN_BWD_ROWS(32);
         if (q_splits > 1) {
+            TOIST_REQUIRE((lddk % 8) == 0 && (lddv % 8) == 0 && ((((size_t)dk) | ((size_t)dv)) & 15) == 0,
+                          "toist_attn_bwd: query splits fold into 16-byte chunks of dk / dv (row strides %% 8, 16-byte aligned bases)");
             const int rc2 = check_launch("toist_attn_bwd");
             if (rc2 != TOIST_OK) return rc2;
-            const long long rows = (long long)B * Sk, n4 = rows * (H * 32 / 4);
-            hipLaunchKernelGGL(attn_bwd_fold_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, workspace, q_splits, rows, H * 32, scale,
+            const long long rows = (long long)B * Sk, n8 = rows * (H * 32 / 8);
+            hipLaunchKernelGGL(attn_bwd_fold_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, workspace, q_splits, rows, H * 32, scale,
                                (bf16_t*)dk, lddk, (bf16_t*)dv, lddv);
         }
     } else {

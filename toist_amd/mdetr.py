@@ -218,7 +218,8 @@ class MDETR(nn.Module):
                 cuts["text"] = ([flat], [leaf])
                 flat = leaf
             captions = EncodedText(tokenized, flat)
-        feats = body.forward_native(samples.tensors, levels, premasked=(len(levels) - 1,))
+        stage_cuts = [] if cut_on else None          # data-parallel: the ResNet body runs as three programs with cuts between them
+        feats = body.forward_native(samples.tensors, levels, premasked=(len(levels) - 1,), stage_cuts=stage_cuts)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         # Data-parallel jobs may cut the autograd graph at the outputs of the backbone and of the text encoder
@@ -229,6 +230,9 @@ class MDETR(nn.Module):
             leaves = [f.detach().requires_grad_(f.requires_grad) for f in feats]
             cuts["backbone"] = (list(feats), leaves)
             feats = leaves
+            # backward order: "backbone" (layer4, or the whole body when it ran as one program), then layer3, then stem .. layer2
+            for name, (y, leaf) in zip(("backbone.layer2", "backbone.layer3"), stage_cuts or ()):
+                cuts[name] = ([y], [leaf])
         c5 = feats[-1]
         B, h, w, _ = c5.shape
         mask = nearest_mask(samples.mask, (h, w))

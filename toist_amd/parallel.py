@@ -123,14 +123,21 @@ def all_reduce_mean(flats, group=None):
 
 
 def enable_backward_cuts(model, on=True):
-    """Make `model` (MDETR or DETRsegm) cut the autograd graph at the outputs of the backbone and of the text encoder:
-    loss.backward() then leaves those two programs to backward_cut(memory_cache, "text" / "backbone"), so the gradients
-    of every finished segment can be all-reduced underneath the segments still running."""
+    """Make `model` (MDETR or DETRsegm) cut the autograd graph at the outputs of the backbone and of the text encoder -- and, for the
+    detection model, between the three stage programs of the ResNet body (layer4 | layer3 | stem .. layer2): loss.backward() then
+    leaves those programs to backward_cut(memory_cache, name) for name in BACKWARD_CUTS, so the gradients of every finished segment
+    can be all-reduced underneath the segments still running (only layer2's 5 MB are left without cover)."""
     getattr(model, "detr", model).split_backward = bool(on)
 
 
+BACKWARD_CUTS = ("text", "backbone", "backbone.layer3", "backbone.layer2")     # the order a step runs them in after loss.backward()
+
+
 def backward_cut(memory_cache, name):
-    """Run the backward pass of the segment cut off under `name` ("text" or "backbone") from the gradients left at the cut."""
+    """Run the backward pass of the segment cut off under `name` from the gradients left at the cut: "text" (RoBERTa + resizer),
+    "backbone" (ResNet layer4 -- or the whole body when it ran as one program), then "backbone.layer3" and "backbone.layer2"
+    (stem .. layer2; frozen below layer2) when the body ran as three stage programs (detection model with cuts enabled).  Each
+    segment's flat gradient buffer is complete when its call returns: all-reduce it while the next segment runs."""
     cut = memory_cache.get("_native", {}).get("cuts", {}).get(name)
     if not cut:
         return
