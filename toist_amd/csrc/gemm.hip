@@ -250,6 +250,20 @@ __device__ __forceinline__ void dma16(unsigned lds_dst, const i32x4_t& r, int el
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(r) : "memory");
 }
+// the same with the tile-dependent part of the source offset in the instruction's SGPR offset: the lane offset (bytes, or OOB) is a
+// loop invariant, no vector arithmetic per piece
+__device__ __forceinline__ void dma16s(unsigned lds_dst, const i32x4_t& r, int voff_bytes, int soff_bytes) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff_bytes), "s"(r), "s"(soff_bytes) : "memory");
+}
+// two pieces (LDS destinations 4 KiB apart: pieces it = 0, 1 of a wave) with one M0 save / restore
+__device__ __forceinline__ void dma16s2(unsigned lds_dst, const i32x4_t& r, int voff0, int voff1, int soff_bytes) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %5 offen lds\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %5 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff0), "v"(voff1), "s"(r), "s"(soff_bytes), "s"(lds_dst + 4096u) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -1487,24 +1501,56 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
     }
     const int P = PW * (kt + (has_res ? 1 : 0) + (has_aux ? 1 : 0));    // DMA instructions per wave per tile
     constexpr int S = FM * FN;                                          // store instructions per wave per tile
+    // Lane offsets of a FULL tile (every row < M): loop invariants in bytes, out-of-range where the K tail / the column tail says so; the
+    // tile's row offset m0 * ld travels in the buffer instruction's scalar offset -- no vector instruction per piece.  (The DMA issue
+    // of a tile used to be ~90 instructions: address adds, predicates and an M0 save / restore per piece.)
+    int va[4][PW], vr[PW], vx[PW];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int it = 0; it < PW; ++it) va[t][it] = (t < kt && t * BK + a_col[it] < K) ? (a_off[it] + t * BK) * 2 : OOB;
+#pragma unroll
+    for (int it = 0; it < PW; ++it) {
+        vr[it] = r_colok[it] ? r_off[it] * 2 : OOB;
+        vx[it] = r_colok[it] ? x_off[it] * 2 : OOB;
+    }
     auto issue = [&](const int slot, const int tile_m) {
         const int m0 = tile_m * BM;
-        const unsigned sb = ring0 + (unsigned)(slot * stage) * 2u;
+        const unsigned sb = ring0 + (unsigned)(slot * stage) * 2u + (unsigned)wave * 1024u;
+        if (m0 + BM <= M) {
+            const int so = m0 * lda * 2;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < kt) {
+                    if constexpr (PW == 2) dma16s2(sb + (unsigned)(t * SUB * 2), rsA, va[t][0], va[t][1], so);
+                    else dma16s(sb + (unsigned)(t * SUB * 2), rsA, va[t][0], so);
+                }
+            if (has_res) {
+                if constexpr (PW == 2) dma16s2(sb + (unsigned)(res_off * 2), rsR, vr[0], vr[1], m0 * p.epi.ldr * 2);
+                else dma16s(sb + (unsigned)(res_off * 2), rsR, vr[0], m0 * p.epi.ldr * 2);
+            }
+            if (has_aux) {
+                if constexpr (PW == 2) dma16s2(sb + (unsigned)(aux_off * 2), rsX, vx[0], vx[1], m0 * p.epi.ldaux * 2);
+                else dma16s(sb + (unsigned)(aux_off * 2), rsX, vx[0], m0 * p.epi.ldaux * 2);
+            }
+            return;
+        }
+        // the last, partial tile of the matrix: per-lane row predicates (same number of instructions per wave)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int it = 0; it < PW; ++it)
-                if (t < kt) dma16(sb + (unsigned)(t * SUB * 2) + (unsigned)(it * 4 + wave) * 1024u, rsA, m0 * lda + a_off[it] + t * BK,
+                if (t < kt) dma16(sb + (unsigned)(t * SUB * 2) + (unsigned)(it * 4) * 1024u, rsA, m0 * lda + a_off[it] + t * BK,
                                   m0 + a_row[it] < M && t * BK + a_col[it] < K);
         if (has_res) {
 #pragma unroll
             for (int it = 0; it < PW; ++it)
-                dma16(sb + (unsigned)(res_off * 2) + (unsigned)(it * 4 + wave) * 1024u, rsR, m0 * p.epi.ldr + r_off[it], m0 + r_row[it] < M && r_colok[it]);
+                dma16(sb + (unsigned)(res_off * 2) + (unsigned)(it * 4) * 1024u, rsR, m0 * p.epi.ldr + r_off[it], m0 + r_row[it] < M && r_colok[it]);
         }
         if (has_aux) {
 #pragma unroll
             for (int it = 0; it < PW; ++it)
-                dma16(sb + (unsigned)(aux_off * 2) + (unsigned)(it * 4 + wave) * 1024u, rsX, m0 * p.epi.ldaux + x_off[it], m0 + r_row[it] < M && r_colok[it]);
+                dma16(sb + (unsigned)(aux_off * 2) + (unsigned)(it * 4) * 1024u, rsX, m0 * p.epi.ldaux + x_off[it], m0 + r_row[it] < M && r_colok[it]);
         }
     };
 
@@ -1614,8 +1660,8 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
                 float v[4] = {acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] * csc[jj][e] + csh[jj][e];
-                const unsigned long long didx = (unsigned long long)m * N + ncol[jj];
                 if (drop == 1) {
+                    const unsigned long long didx = (unsigned long long)m * N + ncol[jj];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = dropout_keep(dseed, didx + e, dth) ? v[e] * dsc : 0.f;
                 }
@@ -1624,20 +1670,31 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
                     v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
                     v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
                 }
-                if (ACT == TOIST_ACT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
                 if (has_aux) {
                     const uint2 x2 = *reinterpret_cast<const uint2*>(sX + rx_off[i][jj]);
                     v[0] = __uint_as_float(x2.x << 16) > 0.f ? v[0] : 0.f; v[1] = __uint_as_float(x2.x & 0xffff0000u) > 0.f ? v[1] : 0.f;
                     v[2] = __uint_as_float(x2.y << 16) > 0.f ? v[2] : 0.f; v[3] = __uint_as_float(x2.y & 0xffff0000u) > 0.f ? v[3] : 0.f;
                 }
                 if (drop == 2) {
+                    if (ACT == TOIST_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    const unsigned long long didx = (unsigned long long)m * N + ncol[jj];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = dropout_keep(dseed, didx + e, dth) ? v[e] * dsc : 0.f;
                 }
-                const u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                if (ACT == TOIST_ACT_RELU && drop != 2) {
+                    // ReLU on the packed bf16 pairs (one v_pk_max_i16 per pair instead of a v_max_f32 per value): rounding is monotone and
+                    // keeps the sign, so max(round(v), 0) = round(max(v, 0)); a negative (or -0) half has its int16 sign bit set
+                    // (written as asm: hipcc's SLP pass merged two __builtin_elementwise_max calls on <2 x i16> into one and fed its result
+                    // to BOTH words -- seen in the ISA, wrong values in tools/r3/panel2.py)
+                    unsigned r0, r1;
+                    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r0) : "v"(o[0]));
+                    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r1) : "v"(o[1]));
+                    o[0] = r0; o[1] = r1;
+                }
                 store8_asm(rsC, (col_ok[jj] && m < M) ? (m * ldc + ncol[jj]) * 2 : OOB, o);
             }
         }

@@ -90,13 +90,26 @@ def flush_reductions():
 GROUP_MAX = 64
 
 
+_GROUP_TABLES = {}      # (device, rows) -> filled device table
+
+
 def group_table(rows, device):
     """Device toist_group table from host rows [a_ptr, b_ptr, c_off, rscale_off, colsum_off] (csrc/gemm.hip: the rows travel as kernel
-    arguments)."""
+    arguments).  Tables are kept: a training loop presents the same pointers step after step (always under hipGraph replay, nearly
+    always with the caching allocator), so the 25 fill launches of a step run once -- a table filled before a capture is simply read
+    by the captured launches.  A table filled DURING a capture is not kept (its fill is part of that graph only)."""
+    key = (str(device), tuple(int(v) for r in rows for v in (list(r) + [0] * (6 - len(r)))))
+    hit = _GROUP_TABLES.get(key)
+    if hit is not None:
+        return hit
     n = len(rows)
-    flat = (ctypes.c_int64 * (6 * n))(*[int(v) for r in rows for v in (list(r) + [0] * (6 - len(r)))])
+    flat = (ctypes.c_int64 * (6 * n))(*key[1])
     dev = torch.empty(n, 6, dtype=torch.int64, device=device)
     _lib.check(_lib.lib().toist_group_fill(ctypes.cast(flat, ctypes.c_void_p), n, _p(dev), _stream()), "toist_group_fill")
+    if not torch.cuda.is_current_stream_capturing():
+        if len(_GROUP_TABLES) >= 1024:
+            _GROUP_TABLES.clear()
+        _GROUP_TABLES[key] = dev
     return dev
 
 
