@@ -152,6 +152,22 @@ def _ddp_worker(rank, world, port, out):
         m3(xs[rank]).backward()
         sync.finish()
     res["accumulate"] = close(grads(m3), {k: 2 * v for k, v in want.items()})
+    # 5. a parameter with a gradient on rank 0 only (conditionally used branch): the ranks agree on the set to reduce (the
+    # collective sequences used to differ and hang); the rank without a gradient contributes zeros, like DDP(find_unused_parameters=True)
+    torch.manual_seed(0)
+    m4 = _Toy()
+    extra = torch.nn.Parameter(torch.ones(3))
+    m4.register_parameter("extra", extra)
+    sync4 = parallel.GradSync(m4)
+    with sync4:
+        loss = m4(xs[rank])
+        if rank == 0:
+            loss = loss + (extra * torch.tensor([1.0, 2.0, 3.0])).sum()
+        loss.backward()
+        sync4.finish()
+    g4 = grads(m4)
+    res["unused_on_one_rank"] = "extra" in g4 and torch.allclose(g4["extra"], torch.tensor([0.5, 1.0, 1.5])) and \
+        close({k: v for k, v in g4.items() if k != "extra"}, want)
     out[rank] = res
     dist.barrier()
     dist.destroy_process_group()
@@ -163,4 +179,4 @@ def test_ddp_wrapping_delivers_averaged_gradients():
     out = mgr.dict()
     mp.spawn(_ddp_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     for r in range(world):
-        assert out[r] == {"torch_ddp": True, "toist_ddp": True, "no_sync_local": True, "gradsync": True, "accumulate": True}, out[r]
+        assert out[r] == {"torch_ddp": True, "toist_ddp": True, "no_sync_local": True, "gradsync": True, "accumulate": True, "unused_on_one_rank": True}, out[r]

@@ -177,3 +177,29 @@ def test_compute_copy_registry_is_keyed_by_tensor_identity():
     gc.collect()
     engine.prune_copies()
     assert ptr not in engine.COPIES
+
+
+def test_store_once_row_ranges_are_tracked_on_the_root_view():
+    """ADVICE r2 (engine.py ParamView): the store-once state of a packed parameter is a set of row ranges on the ROOT view -- a second slice
+    of the same rows sees the first launch (it must accumulate, not store), marking one slice does not mark its siblings, and the rows
+    nothing wrote are reported for zeroing."""
+    import torch
+    from toist_amd.engine import ParamView
+    g = torch.zeros(12, 4)
+    root = ParamView(None, g, fresh=True)
+    q1, v1 = root.rows(0, 8), root.rows(8, 12)
+    assert not root.written and not q1.written and not v1.written
+    q1.mark_written()
+    assert q1.written and not v1.written and not root.written           # a sibling slice and the whole slot stay unwritten
+    assert root.rows(0, 8).written and root.rows(2, 6).written          # a NEW view of the stored rows accumulates
+    assert not root.rows(4, 10).written
+    assert root.unwritten_rows() == [(8, 12)]
+    v1.mark_written()
+    assert root.written and root.unwritten_rows() == []
+    root.written = False
+    assert not q1.written and root.unwritten_rows() == [(0, 12)]
+    root.mark_written()
+    assert q1.written and root.rows(3, 4).rows(0, 1).written and root.unwritten_rows() == []
+    nested = ParamView(None, torch.zeros(12, 4), fresh=True)
+    nested.rows(4, 12).rows(2, 4).mark_written()                         # rows 6..8 of the root
+    assert nested.unwritten_rows() == [(0, 6), (8, 12)]

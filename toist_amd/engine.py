@@ -131,9 +131,12 @@ class Tape:
                     ops.conv2d_wgrad_group(items, key[2], stride=key[3], pad=key[4], accumulate=not key[5])
             self.groups = {}
         k.flush_reductions()   # deferred split-K partials of this program -> parameter gradients
-        for v in self.fresh_views:      # a store-once slot no weight-gradient launch reached (its branch received no gradient): zero, as before
-            if not v.written:
-                v.g.zero_()
+        for v in self.fresh_views:      # store-once rows no weight-gradient launch reached (their branch received no gradient): zero, as an accumulating slot would read
+            for a, b in v.unwritten_rows():
+                if v.g.dim() == 0:
+                    v.g.zero_()
+                else:
+                    v.g[a:b].zero_()
 
 
 # ---- bf16 compute copies of the fp32 master weights ------------------------------------------------------------
@@ -225,28 +228,88 @@ def named_cache(owner, key, build):
 
 
 class ParamView:
-    """bf16 compute copy + fp32 gradient slot of one nn.Parameter (or a row slice of one)."""
+    """bf16 compute copy + fp32 gradient slot of one nn.Parameter (or a row slice of one).
 
-    __slots__ = ("w", "g", "f32", "fresh", "written", "parent")
+    Store-once bookkeeping lives on the ROOT view as a list of written row ranges: a slice made by rows() reads and writes the same
+    record, so a second weight-gradient launch on an already stored range accumulates (whatever view object it came through), and
+    rows no launch reached are zeroed at the end of the backward pass (unwritten_rows)."""
 
-    def __init__(self, w_bf16, grad_f32, f32=None, fresh=False, parent=None):
+    __slots__ = ("w", "g", "f32", "fresh", "parent", "_lo", "_hi", "_ranges")
+
+    def __init__(self, w_bf16, grad_f32, f32=None, fresh=False, parent=None, lo=None, hi=None):
         self.w = w_bf16    # bf16 tensor used by the kernels (None for fp32-only params)
         self.g = grad_f32  # fp32 gradient slot: zero-initialised accumulator, or (fresh) uninitialised memory a weight-gradient GEMM overwrites
         self.f32 = f32     # fp32 master values for params consumed in fp32 (biases, LN affine)
-        self.fresh = fresh         # store-once gradient (see ParamSet): the first weight-gradient launch stores instead of accumulating
-        self.written = False       # a weight-gradient launch has covered (a row range of) this slot during the current backward
+        self.fresh = fresh         # store-once gradient (see ParamSet): the first weight-gradient launch on a row range stores instead of accumulating
         self.parent = parent
+        self._lo, self._hi = lo, hi   # row range inside the root (None: all of it)
+        self._ranges = []          # root only: row ranges [a, b) covered by weight-gradient launches of the current backward; (None, None) = everything
+
+    def _root(self):
+        v = self
+        while v.parent is not None:
+            v = v.parent
+        return v
+
+    def _span(self):
+        """this view's row range in root coordinates"""
+        lo, hi, v = 0, None, self
+        chain = []
+        while v is not None:
+            chain.append(v)
+            v = v.parent
+        for v in reversed(chain):              # root first: nested rows() offsets add up
+            if v._lo is not None:
+                lo, hi = lo + v._lo, lo + v._hi
+        return lo, hi
+
+    @property
+    def written(self):
+        """True when every row of this view has been stored by a weight-gradient launch of the current backward."""
+        root = self._root()
+        if any(a is None for a, _ in root._ranges):
+            return True
+        lo, hi = self._span()
+        if hi is None:
+            n = root.g.shape[0] if root.g is not None and root.g.dim() > 0 else 1
+            lo, hi = 0, n
+        pos = lo
+        for a, b in sorted(root._ranges):
+            if a > pos:
+                break
+            pos = max(pos, b)
+        return pos >= hi
+
+    @written.setter
+    def written(self, value):
+        if value:
+            self.mark_written()
+        else:
+            self._root()._ranges = []
 
     def rows(self, a, b):
         """Row slice [a:b) of a packed parameter (e.g. the q / k / v blocks of in_proj_weight)."""
         return ParamView(None if self.w is None else self.w[a:b], None if self.g is None else self.g[a:b],
-                         None if self.f32 is None else self.f32[a:b], fresh=self.fresh, parent=self)
+                         None if self.f32 is None else self.f32[a:b], fresh=self.fresh, parent=self, lo=a, hi=b)
 
     def mark_written(self):
-        v = self
-        while v is not None:
-            v.written = True
-            v = v.parent
+        root = self._root()
+        lo, hi = self._span()
+        root._ranges.append((None, None) if hi is None else (lo, hi))
+
+    def unwritten_rows(self):
+        """root view: list of row ranges no launch has stored (the whole slot when nothing was written)."""
+        if any(a is None for a, _ in self._ranges):
+            return []
+        n = self.g.shape[0] if self.g.dim() > 0 else 1
+        gaps, pos = [], 0
+        for a, b in sorted(self._ranges):
+            if a > pos:
+                gaps.append((pos, a))
+            pos = max(pos, b)
+        if pos < n:
+            gaps.append((pos, n))
+        return gaps
 
 
 # Opt-in for training loops that never keep a parameter gradient beyond optimizer.zero_grad(): the flat gradient buffer of

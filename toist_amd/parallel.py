@@ -54,14 +54,30 @@ class GradSync:
             if op == dist.ReduceOp.SUM:
                 flat.div_(self.world)
         rest = []
-        if self.world > 1:
-            for p in (q for m in self.models for q in m.parameters()):
+        if self.world > 1 and self.models:
+            # Every rank must issue the SAME sequence of collectives.  A parameter differentiated by plain autograd may have a gradient on
+            # one rank and none on another (a conditionally used module, an empty micro-batch): the ranks first agree on the set with one
+            # small MAX all-reduce of a per-parameter state (0 no gradient, 1 travelled in a flat buffer, 2 needs its own reduction),
+            # a rank without a gradient contributes zeros -- what torch DDP does under find_unused_parameters=True.
+            params = [q for m in self.models for q in m.parameters() if q.requires_grad]
+            state = []
+            for p in params:
                 g = p.grad
-                if g is None or not p.requires_grad:
-                    continue
-                a = g.data_ptr()
-                if not any(lo <= a < hi for lo, hi in self.ranges):
-                    rest.append(g)
+                if g is None:
+                    state.append(0)
+                else:
+                    a = g.data_ptr()
+                    state.append(1 if any(lo <= a < hi for lo, hi in self.ranges) else 2)
+            if params:
+                dev = next((p.grad.device for p in params if p.grad is not None), params[0].device)
+                st = torch.tensor(state, dtype=torch.int32, device=dev)
+                dist.all_reduce(st, op=dist.ReduceOp.MAX, group=self.group)
+                agreed = st.tolist()
+                for p, mine, glob in zip(params, state, agreed):
+                    if glob == 2 and mine != 1:
+                        if p.grad is None:
+                            p.grad = torch.zeros_like(p)
+                        rest.append(p.grad)
         if rest:
             all_reduce_mean(rest, self.group)
         self.pending, self.ranges = [], []
@@ -176,6 +192,7 @@ class DistributedDataParallel(torch.nn.Module):
         broadcast_parameters(module, 0, process_group)
 
     def forward(self, *args, **kwargs):
+        functions.GRAD_SYNC = None          # a forward whose backward never ran (NaN skip, exception, no_sync) must not leave its hook behind
         if self.require_backward_grad_sync and self._sync.world > 1 and torch.is_grad_enabled():
             functions.GRAD_SYNC = self._on_flat
         return self.module(*args, **kwargs)
