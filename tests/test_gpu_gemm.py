@@ -602,3 +602,65 @@ def test_lean_epilogue_equals_the_general_one(dev, tile, M, N, K):
     for out in (out_b, out_f):
         k.gemm(M, N, K, k.A_ROWK, k.operand(x, K), k.B_KROW, k.operand(wt, ldn), out, N, res=res, ldr=N, act=k.ACT_MASK_POS, aux=aux, ldaux=N, tile=tile)
     assert torch.equal(out_b, out_f.to(BF))
+
+
+def _ulp_close(got, ref32, what):
+    """bf16 result of an f32 accumulation in a different order: half a bf16 ulp of the f32 reference (2^-8 relative at the bottom of
+    a binade) plus the order noise."""
+    err = (got.float() - ref32).abs()
+    bound = 4.0e-3 * ref32.abs() + 2e-4
+    assert bool((err <= bound).all()), f"{what}: max excess {float((err - bound).max()):.3e}"
+
+
+@pytest.mark.parametrize("M,N,K", [(12800, 256, 1024), (1000, 264, 320), (4096, 1024, 1088)])
+def test_gemm128_kernel_plain(dev, M, N, K):
+    """csrc/gemm.hip gemm128_kernel (tile code 136: 128 x 128 tiles, 64 x 64 wave tiles, the k-tile's halves on wave pairs, folded in
+    the epilogue) against the generic tiles' f32 output: forward (row-major B, scale/shift/residual/ReLU) and data gradient (k-major
+    B, residual, aux mask), ragged M/N tiles and k-tile counts that are not multiples of the 4-slot ring."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(dev)
+    bias, res = torch.randn(N, generator=g).to(dev), torch.randn(M, N, generator=g).to(BF).to(dev)
+    aux = torch.randn(M, N, generator=g).to(BF).to(dev)
+    for kw in (dict(res=res, act=k.ACT_RELU), dict(act=k.ACT_NONE)):
+        got = ops.linear(x, w, bias, tile=136, split_k=1, **kw)
+        ref = ops.linear(x, w, bias, tile=65, split_k=1, out_dtype=torch.float32, **kw)
+        _ulp_close(got, ref, f"forward {kw['act']}")
+    wt = w.t().contiguous()
+    out_b = torch.empty(M, N, dtype=BF, device=dev)
+    out_f = torch.empty(M, N, dtype=torch.float32, device=dev)
+    for out, tile in ((out_b, 136), (out_f, 65)):
+        k.gemm(M, N, K, k.A_ROWK, k.operand(x, K), k.B_KROW, k.operand(wt, N), out, N, res=res, ldr=N, act=k.ACT_MASK_POS, aux=aux, ldaux=N, tile=tile)
+    _ulp_close(out_b, out_f, "dgrad")
+
+
+@pytest.mark.parametrize("Nb,H,W,C,Co,R,pad,dil", [(8, 40, 40, 256, 256, 3, 1, 1), (2, 37, 43, 128, 256, 3, 2, 2), (3, 19, 23, 64, 192, 3, 1, 1), (2, 30, 30, 64, 128, 1, 0, 1)])
+def test_gemm128_kernel_convolution_gathers(dev, Nb, H, W, C, Co, R, pad, dil):
+    """gemm128_kernel as the stride-1 convolution gather (forward, FrozenBN scale/shift + ReLU) and as the transposed gather of the
+    data gradient (reversed tap walk against the two-level k-major weights, aux mask): border taps, dilation, a ragged last row tile,
+    18 / 9 k-tiles (not multiples of the ring), against the 64 x 64 tiles storing f32.  The first shape is layer 3 of the bench batch,
+    where the dispatcher picks this kernel by itself: the tile-0 call must equal the explicit tile-136 call bit for bit."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(Nb * H + C)
+    x = torch.randn(Nb, H, W, C, generator=g).to(BF).to(dev)
+    w = (torch.randn(Co, R, R, C, generator=g) / math.sqrt(R * R * C)).to(BF).to(dev)
+    dy = torch.randn(Nb, H, W, Co, generator=g).to(BF).to(dev)
+    aux = torch.randn(Nb, H, W, C, generator=g).to(BF).to(dev)
+    res = torch.randn(Nb, H, W, Co, generator=g).to(BF).to(dev)
+    scale, shift = (torch.rand(Co, generator=g) + 0.5).to(dev), torch.randn(Co, generator=g).to(dev)
+    if R > 1:
+        got = ops.conv2d(x, w, pad=pad, dil=dil, scale=scale, shift=shift, res=res, act=k.ACT_RELU, tile=136)
+        ref = ops.conv2d(x, w, pad=pad, dil=dil, scale=scale, shift=shift, res=res, act=k.ACT_RELU, tile=65, out_dtype=torch.float32)
+        _ulp_close(got, ref, "forward gather")
+        dx = torch.empty(Nb, H, W, C, dtype=BF, device=dev)
+        dx32 = torch.empty(Nb, H, W, C, dtype=torch.float32, device=dev)
+        ops.conv2d_dgrad(dy, w, (H, W), pad=pad, dil=dil, act=k.ACT_MASK_POS, aux=aux, out=dx, tile=136)
+        ops.conv2d_dgrad(dy, w, (H, W), pad=pad, dil=dil, act=k.ACT_MASK_POS, aux=aux, out=dx32, tile=65)
+        _ulp_close(dx, dx32, "transposed gather")
+        if Nb * H * W >= 12800:
+            assert torch.equal(ops.conv2d(x, w, pad=pad, dil=dil, scale=scale, shift=shift, res=res, act=k.ACT_RELU), got)
+            assert torch.equal(ops.conv2d_dgrad(dy, w, (H, W), pad=pad, dil=dil, act=k.ACT_MASK_POS, aux=aux), dx)
+    else:   # a 1x1 is a plain GEMM to ops.conv2d: K = 64 is below the kernel's minimum, the explicit tile must be refused loudly
+        with pytest.raises(RuntimeError, match="128x128"):
+            ops.conv2d(x, w, scale=scale, shift=shift, tile=136)

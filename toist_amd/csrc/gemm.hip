@@ -1146,6 +1146,285 @@ __global__ __launch_bounds__(256) void conv3_kernel(const toist_gemm p) {
 }
 
 
+// ---- 128 x 128 tiles with 64 x 64 wave tiles for deep row-major GEMMs (round 3) ---------------------------------------------------------
+// The 1x1 convolutions with K >= 512 (ResNet conv1 of every bottleneck and the data gradient of conv3: 12800 x 256 x 1024 in layer 3,
+// 45 launches per step at 20 - 24 us) run on 64 x 64 tiles, which are bound by the texture path: every k-tile of a workgroup stages
+// 16 KB for 8 MFMAs per wave (800 tiles x 16 k-tiles x 16 KB = 205 MB through 256 CUs at <= 64 B/clk each), and a 32 x 32 wave tile
+// reads 1 KiB of LDS operands per MFMA.  What the experiments of this round say a kernel needs (profiles/r03_conv3_variants.txt,
+// r03_panel2_phase_cycles.txt): (1) 64 x 64 outputs per wave (0.5 KiB of LDS reads per MFMA); (2) two waves per SIMD from ONE barrier
+// domain -- here the two k-halves of every 64-deep k-tile go to two waves of a SIMD pair, their partial sums are exchanged once at the
+// end; (3) few instructions per MFMA: the lane offsets of the DMA pieces are loop invariants, the k offset travels in the buffer
+// instruction's scalar offset, ring slots are compile-time (4-step unrolled loop), fragments are read one k-tile ahead; (4) no register
+// spills (128 accumulator + fragment registers, ~40 for everything else) and no LDS band in the epilogue (fragments are finished where
+// the MFMA left them, 8-byte accesses).  Staged bytes per MFMA: half of the 64 x 64 tiling.
+constexpr int G8_BM = 128, G8_BN = 128, G8_BK = 64, G8_NS = 4;
+constexpr int G8_TILE = G8_BM * G8_BK;                 // elements of one operand tile (16 KiB)
+constexpr int G8_STAGE_BYTES = 2 * G8_TILE * 2;        // A + B
+constexpr int G8_LDS = G8_NS * G8_STAGE_BYTES;         // 128 KiB
+
+struct G8Frags { bf16x8_t a[4]; bf16x8_t b[4]; };
+
+template <int AK, int BKD>
+__global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
+    constexpr int BM = G8_BM, BN = G8_BN, BK = G8_BK, WM = 64, WN = 64, FM = 4, FN = 4;
+    constexpr bool B_KM = BKD == TOIST_B_KROW;
+    constexpr bool GATHER = AK != TOIST_A_ROWK;          // stride-1 convolution gather (A_CONV) / its transposed gather (A_CONVT, same plane size)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1, g = lane >> 4, c16 = lane & 15;
+    const int M = p.M, N = p.N, K = p.K;
+    const int nt_n = (N + BN - 1) / BN, nt_m = (M + BM - 1) / BM;
+    const int tiles = nt_m * nt_n;
+    const int tile_id = (int)(blockIdx.x & 7) * ((tiles + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (tile_id >= tiles) return;
+    int tile_m, tile_n;
+    tile_order(tile_id, nt_m, nt_n, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const toist_operand oa = p.a;
+    const int lda = oa.ld, ldb = p.b.ld;
+    const int T = K / BK;                               // k-tiles (K % 64 == 0)
+    const int ntaps = GATHER ? oa.R * oa.S : 1, nch = T / ntaps;        // k = tap * (nch * 64) + channel
+    // gathers: the descriptor base is moved to the source pixel of tap (0, 0) of output pixel (0, 0, 0), so that lane offsets (pixel)
+    // and tap offsets (scalar) are both non-negative.  A_CONVT walks the taps in reverse: source = p + pad - (R-1) dil + r' dil.
+    const int sh_y = GATHER ? (AK == TOIST_A_CONV ? -oa.pad : oa.pad - (oa.R - 1) * oa.dil) : 0;
+    const int sh_x = GATHER ? (AK == TOIST_A_CONV ? -oa.pad : oa.pad - (oa.S - 1) * oa.dil) : 0;
+    const i32x4_t rsA = make_rsrc(GATHER ? (const void*)((const bf16_t*)oa.ptr + ((long long)sh_y * oa.SW + sh_x) * oa.SC) : oa.ptr);
+    const i32x4_t rsB = make_rsrc(p.b.ptr);
+    const unsigned lds0 = (unsigned)(size_t)lds_raw;
+    const bool timing = (p.flags & 2048) && p.workspace != nullptr;     // experiments: shader-clock stamps of prologue / loop / epilogue
+    unsigned long long T0 = 0, T1 = 0, T2 = 0;
+    if (timing) T0 = cyc_now();
+
+    // ---- DMA pieces: two of A and two of B per wave and k-tile; lane offsets in bytes (or out of range), k in the scalar offset ----
+    int va[2], vb[2];
+    unsigned tapok[2] = {0xffffu, 0xffffu};             // gathers: bit t = this lane's source pixel of tap t lies inside the plane
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int pch = (it * 8 + wave) * 64 + lane;
+        const int row = pch >> 3, kc = swz_k<BK>(row, pch & 7);
+        const int m = m0 + row;
+        if (GATHER) {
+            const int plane = oa.PH * oa.PW;
+            const int mm = m < M ? m : 0;
+            const int n = mm / plane, rem = mm - n * plane;
+            const int py = rem / oa.PW, px = rem - py * oa.PW;
+            va[it] = m < M ? (((n * oa.SH + py) * oa.SW + px) * oa.SC + kc * 8) * 2 : OOB;
+            unsigned ok = 0;
+            for (int t = 0; t < ntaps; ++t) {
+                const int r = t / oa.S, s_ = t - r * oa.S;
+                const int iy = py + sh_y + r * oa.dil, ix = px + sh_x + s_ * oa.dil;
+                if (iy >= 0 && iy < oa.SH && ix >= 0 && ix < oa.SW) ok |= 1u << t;
+            }
+            tapok[it] = ok;
+        } else {
+            va[it] = (m < M) ? (m * lda + kc * 8) * 2 : OOB;
+        }
+        if (B_KM) {    // k-major tile [BK k][BN n]
+            const int krow = pch / (BN / 8), rc = swz_m<BN>(krow, pch % (BN / 8));
+            const int nn = n0 + rc * 8;
+            vb[it] = nn < N ? (nn + krow * ldb) * 2 : OOB;
+        } else {
+            vb[it] = (n0 + row < N) ? ((n0 + row) * ldb + kc * 8) * 2 : OOB;
+        }
+    }
+    // issue-side walker over the k-tiles: (tap, 64-channel chunk)
+    int i_tap = 0, i_chunk = 0;
+    int va_eff[2] = {(tapok[0] & 1u) ? va[0] : OOB, (tapok[1] & 1u) ? va[1] : OOB};
+    int so_tap = 0;                                     // bytes: source offset of the current tap (gathers)
+    const long long b_tap = p.b.tap_stride;
+    auto issue = [&](const int slot) {                  // all four pieces of the next k-tile in one statement (M0 saved once)
+        const unsigned da = lds0 + (unsigned)(slot * G8_STAGE_BYTES) + (unsigned)wave * 1024u, db = da + (unsigned)(G8_TILE * 2);
+        const int soa = so_tap + i_chunk * (BK * 2);
+        int sob;
+        if (B_KM) sob = (i_chunk * BK * ldb + (GATHER ? (ntaps - 1 - i_tap) * (int)b_tap : 0)) * 2;   // A_CONVT walks the taps in reverse: weight tap = last - t'
+        else sob = (i_tap * nch + i_chunk) * (BK * 2);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, %9 offen lds\n\t"
+                     "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, %9 offen lds\n\t"
+                     "s_mov_b32 m0, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, %10 offen lds\n\t"
+                     "s_mov_b32 m0, %12\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %10 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(da), "s"(da + 8192u), "v"(va_eff[0]), "v"(va_eff[1]), "v"(vb[0]), "v"(vb[1]), "s"(rsA), "s"(rsB), "s"(soa), "s"(sob), "s"(db), "s"(db + 8192u)
+                     : "memory");
+        if (++i_chunk == nch) {                         // next tap: its scalar offset and this lane's validity
+            i_chunk = 0;
+            ++i_tap;
+            if (GATHER && i_tap < ntaps) {
+                const int r = i_tap / oa.S, s_ = i_tap - r * oa.S;
+                so_tap = ((r * oa.dil) * oa.SW + s_ * oa.dil) * oa.SC * 2;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) va_eff[it] = ((tapok[it] >> i_tap) & 1u) ? va[it] : OOB;
+            }
+        }
+    };
+    issue(0);
+    issue(1);
+    issue(2);
+
+    // ---- fragment addresses (bytes inside a stage): rows 16 apart share their swizzle -> one base + immediates ----
+    const int a_row = wm * WM + c16;
+    const int a_base = (a_row * BK + swz_k<BK>(a_row, kh * 4 + g) * 8) * 2;
+    int b_base[FN][2];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        if (B_KM) {
+            const int k = kh * 32 + 8 * g + (c16 >> 2);
+            const int rc = ((wn * WN + j * 16) >> 3) + ((c16 & 3) >> 1), sub = (c16 & 1) * 4;
+            b_base[j][0] = G8_TILE * 2 + (k * BN + swz_m<BN>(k, rc) * 8 + sub) * 2;
+            b_base[j][1] = G8_TILE * 2 + ((k + 4) * BN + swz_m<BN>(k + 4, rc) * 8 + sub) * 2;
+        } else {
+            const int row = wn * WN + j * 16 + c16;
+            b_base[j][0] = G8_TILE * 2 + (row * BK + swz_k<BK>(row, kh * 4 + g) * 8) * 2;
+            b_base[j][1] = 0;
+        }
+    }
+    auto load_frags = [&](G8Frags& f, auto slotc) {
+        constexpr int SLOT = decltype(slotc)::value;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) f.a[i] = *reinterpret_cast<const bf16x8_t*>(lds_raw + a_base + SLOT * G8_STAGE_BYTES + i * 16 * BK * 2);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            if (B_KM) {
+                typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+                union { struct { s16x4_t a, b; } h; bf16x8_t v; } u;
+                u.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_raw + b_base[j][0] + SLOT * G8_STAGE_BYTES));
+                u.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_raw + b_base[j][1] + SLOT * G8_STAGE_BYTES));
+                f.b[j] = u.v;
+            } else {
+                f.b[j] = *reinterpret_cast<const bf16x8_t*>(lds_raw + b_base[j][0] + SLOT * G8_STAGE_BYTES);
+            }
+        }
+    };
+
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    wait_vm<8>();                                       // k-tile 0 landed (tiles 1 and 2 may fly)
+    __builtin_amdgcn_s_barrier();
+    G8Frags fa, fb;
+    load_frags(fa, std::integral_constant<int, 0>{});
+
+    if (timing) T1 = cyc_now();
+    int t = 0;
+    // one k-tile: `cur` = its fragments (read during the previous step), `nxt` receives those of k-tile t + 1 from ring slot SLOT + 1
+    auto step = [&](auto slotc, G8Frags& cur, G8Frags& nxt) {
+        constexpr int SLOT = decltype(slotc)::value;
+        // this wave's loads younger than k-tile t + 1: the four pieces of k-tile t + 2
+        if (t + 2 < T) wait_vm<4>();
+        else wait_vm<0>();
+        lds_barrier();          // k-tile t + 1 landed for every wave; every fragment read issued so far has returned
+        if (t + 3 < T) issue((SLOT + 3) & 3);           // the slot of k-tile t - 1: its fragments were consumed by the previous step's MFMAs
+        // hipcc's own LDS wait for `cur` lands here, in front of the reads issued below
+#pragma unroll
+        for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(cur.a[i]));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(cur.b[j]));
+        if (t + 1 < T) load_frags(nxt, std::integral_constant<int, (SLOT + 1) & 3>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
+        ++t;
+    };
+#pragma unroll 1
+    while (t + 4 <= T) {
+        step(std::integral_constant<int, 0>{}, fa, fb);
+        step(std::integral_constant<int, 1>{}, fb, fa);
+        step(std::integral_constant<int, 2>{}, fa, fb);
+        step(std::integral_constant<int, 3>{}, fb, fa);
+    }
+    if (t < T) step(std::integral_constant<int, 0>{}, fa, fb);      // T % 4 leftover k-tiles: the ring position continues at 0
+    if (t < T) step(std::integral_constant<int, 1>{}, fb, fa);
+    if (t < T) step(std::integral_constant<int, 2>{}, fa, fb);
+    if (timing) T2 = cyc_now();
+    wait_vm<0>();
+    lds_barrier();                                       // every wave is done with the ring
+
+    // ---- epilogue operands first: per-column vectors, residual and mask rows of this lane's 2 x 4 fragments are all REQUESTED before
+    // anything waits for one of them (fetched fragment by fragment they cost a dependent L2 / HBM round trip each: 7.2k cycles of
+    // epilogue for 15k of k-loop on 12800 x 256 x 1024, 16k with residual + mask -- tools/r3/gemm128_phases.py) ----
+    const toist_epilogue& e = p.epi;
+    const bf16_t* const resp = (const bf16_t*)e.res;
+    const bf16_t* const auxp = (const bf16_t*)e.aux;
+    bf16_t* const outp = (bf16_t*)p.c;
+    const int act = e.act;
+    const float alpha = e.alpha;
+    const bool masked = act == TOIST_ACT_MASK_POS;
+    float4 sc[FN], sh[FN];
+    uint2 rr[2][FN], xx[2][FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * WN + j * 16 + g * 4;
+        const bool nok = n < N;                          // N % 8 == 0: the 4 columns are valid or absent together
+        sc[j] = (e.scale && nok) ? *reinterpret_cast<const float4*>(e.scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+        sh[j] = (e.shift && nok) ? *reinterpret_cast<const float4*>(e.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int m = m0 + wm * WM + (kh * 2 + ii) * 16 + c16;
+            const bool ok = nok && m < M;
+            rr[ii][j] = (resp && ok) ? *reinterpret_cast<const uint2*>(resp + (size_t)m * e.ldr + n) : make_uint2(0u, 0u);
+            xx[ii][j] = (masked && ok) ? *reinterpret_cast<const uint2*>(auxp + (size_t)m * e.ldaux + n) : make_uint2(0u, 0u);
+        }
+    }
+    // ---- fold the k-halves half and half: wave kh keeps fragment rows {2 kh, 2 kh + 1}, hands the other two to its partner (same wm, wn) ----
+    float* const xch = reinterpret_cast<float*>(lds_raw);
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+            *reinterpret_cast<f32x4_t*>(xch + ((wave * 8 + ii * 4 + j) * 64 + lane) * 4) = kh == 0 ? acc[2 + ii][j] : acc[ii][j];
+    lds_barrier();
+    const int partner = wave ^ 4;
+    f32x4_t fin[2][FN];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const f32x4_t o = *reinterpret_cast<const f32x4_t*>(xch + ((partner * 8 + ii * 4 + j) * 64 + lane) * 4);
+            fin[ii][j] = (kh == 0 ? acc[ii][j] : acc[2 + ii][j]) + o;
+        }
+    // ---- every wave finishes its 2 x 4 fragments where the MFMA left them: lane = row c16, 4 consecutive columns (8-byte accesses);
+    // the arithmetic of epilogue_lean, element for element ----
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * WN + j * 16 + g * 4;
+        if (n >= N) continue;
+        const float mul[4] = {alpha * sc[j].x, alpha * sc[j].y, alpha * sc[j].z, alpha * sc[j].w};
+        const float add[4] = {sh[j].x, sh[j].y, sh[j].z, sh[j].w};
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int m = m0 + wm * WM + (kh * 2 + ii) * 16 + c16;
+            if (m >= M) continue;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fin[ii][j][q] * mul[q] + add[q];
+            if (resp) {
+                const uint2 r2 = rr[ii][j];
+                v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+                v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+            }
+            if (act == TOIST_ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            } else if (masked) {
+                const uint2 x2 = xx[ii][j];
+                v[0] = __uint_as_float(x2.x << 16) > 0.f ? v[0] : 0.f; v[1] = __uint_as_float(x2.x & 0xffff0000u) > 0.f ? v[1] : 0.f;
+                v[2] = __uint_as_float(x2.y << 16) > 0.f ? v[2] : 0.f; v[3] = __uint_as_float(x2.y & 0xffff0000u) > 0.f ? v[3] : 0.f;
+            }
+            *reinterpret_cast<uint2*>(outp + (size_t)m * p.ldc + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        }
+    }
+    if (timing && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* o = p.workspace + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[4] = (float)T; o[5] = (float)(T1 - T0); o[6] = (float)(T2 - T1); o[7] = (float)(cyc_now() - T2);
+    }
+}
+
 static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
 
 // what epilogue_lean (and the panel kernel's epilogue) covers
@@ -1840,6 +2119,69 @@ static bool conv3_applies(const toist_gemm& d) {
     return d.M >= 2048;                                                // tiny grids: the generic 64x64 tiles fill more CUs
 }
 
+// gemm128_kernel (tile code 136): one problem, K a multiple of 64 with at least 4 k-tiles, bf16 rows finished by {alpha, scale, shift,
+// residual, ReLU | aux > 0 mask}.  Operands: row-major A with row-major or plain k-major B (1x1 convolutions, nn.Linear and their data
+// gradients); stride-1 convolution gather with row-major weights (forward); its transposed gather on a same-size plane with the
+// two-level k-major weights (data gradient) -- up to 16 taps, source channels a multiple of 64.
+static bool gemm128_applies(const toist_gemm& d) {
+    const bool plain = d.a_kind == TOIST_A_ROWK && (d.b_kind == TOIST_B_ROWK || (d.b_kind == TOIST_B_KROW && d.b.kin == 0));
+    const bool fwd = d.a_kind == TOIST_A_CONV && d.b_kind == TOIST_B_ROWK;
+    const bool dgr = d.a_kind == TOIST_A_CONVT && d.b_kind == TOIST_B_KROW;
+    if (!plain && !fwd && !dgr) return false;
+    if (d.K < 256 || (d.K % 64) != 0 || (d.b.ld % 8) != 0) return false;
+    if (d.batch != 1 || d.split_k != 1 || d.group != nullptr || d.a2 != nullptr || d.a_colsum != nullptr || (d.flags & 1)) return false;
+    const long long lim = 1ll << 30;
+    if ((long long)d.K * d.b.ld >= lim || (long long)d.N * d.b.ld >= lim) return false;       // 32-bit byte offsets
+    if (plain) {
+        if ((d.a.ld % 8) != 0 || (long long)d.M * d.a.ld >= lim) return false;
+    } else {
+        const toist_operand& a = d.a;
+        if (a.stride != 1 || a.R * a.S > 16 || (a.SC % 64) != 0 || d.K != a.R * a.S * a.SC) return false;
+        if ((long long)(d.M / (a.PH * a.PW) + 1) * a.SH * a.SW * a.SC >= lim) return false;
+        if (fwd && d.b.ld != d.K) return false;
+        if (dgr && (a.PH != a.SH || a.PW != a.SW || d.b.kin != a.SC)) return false;
+        if (dgr && (a.pad - (a.R - 1) * a.dil > 0 || a.pad - (a.S - 1) * a.dil > 0)) return false;   // the shifted base must not lie beyond tap (0, 0)
+    }
+    const toist_epilogue& e = d.epi;
+    if (!lean_epilogue_ok(d) || e.drop_where || e.cmap) return false;
+    if (e.act != TOIST_ACT_NONE && e.act != TOIST_ACT_RELU && e.act != TOIST_ACT_MASK_POS) return false;
+    if ((d.N % 8) != 0 || (d.ldc % 4) != 0 || (e.res && (e.ldr % 4) != 0) || (e.act == TOIST_ACT_MASK_POS && (e.ldaux % 4) != 0)) return false;
+    return true;
+}
+
+// Where the dispatcher picks it (profiles/r03_gemm128_us.txt): one block per CU, so it needs about a chip of 128 x 128 tiles and a deep
+// reduction to amortise its prologue / k-fold epilogue.  Gathers: every stride-1 3x3 of layers 2-4 at the bench batch (-1 .. -9 us per
+// launch against the 64 x 64 tiles and the halo kernel).  Plain GEMMs: K >= 768 with 150..256 tiles (12800 x 256 x 1024: 15.2 vs 18.4 us)
+// or >= 1024 tiles (4096^3: 144 vs 170 us); 300..500 tiles lose to the 64 x 64 tiles' finer tail.
+static bool gemm128_pays(const toist_gemm& d) {
+    static const int on = (int)tuning_knob("TOIST_GEMM128", 1);
+    if (!on || !gemm128_applies(d)) return false;
+    const long long tiles = (long long)((d.M + G8_BM - 1) / G8_BM) * ((d.N + G8_BN - 1) / G8_BN);
+    if (d.a_kind != TOIST_A_ROWK) return tiles >= 96 && (d.N % G8_BN) == 0;
+    if (d.K < 768) return false;
+    return (tiles >= 150 && tiles <= 256 && d.N <= 256) || (tiles >= 1024 && d.K >= 1024);
+}
+
+static int launch_gemm128(const toist_gemm& d, hipStream_t st) {
+    static std::atomic<unsigned long long> done{0};
+    if (!lds_attr_once_flag(done, [] {
+            return hipFuncSetAttribute((const void*)gemm128_kernel<TOIST_A_ROWK, TOIST_B_ROWK>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)gemm128_kernel<TOIST_A_ROWK, TOIST_B_KROW>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)gemm128_kernel<TOIST_A_CONV, TOIST_B_ROWK>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)gemm128_kernel<TOIST_A_CONVT, TOIST_B_KROW>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess;
+        })) {
+        set_last_error("toist_gemm_bf16: cannot enable %d bytes of LDS for the 128x128 kernel", G8_LDS);
+        return TOIST_EHIP;
+    }
+    const int tiles = ((d.M + G8_BM - 1) / G8_BM) * ((d.N + G8_BN - 1) / G8_BN);
+    dim3 grid((tiles + 7) & ~7, 1, 1);
+    if (d.a_kind == TOIST_A_CONV) hipLaunchKernelGGL((gemm128_kernel<TOIST_A_CONV, TOIST_B_ROWK>), grid, dim3(512), G8_LDS, st, d);
+    else if (d.a_kind == TOIST_A_CONVT) hipLaunchKernelGGL((gemm128_kernel<TOIST_A_CONVT, TOIST_B_KROW>), grid, dim3(512), G8_LDS, st, d);
+    else if (d.b_kind == TOIST_B_KROW) hipLaunchKernelGGL((gemm128_kernel<TOIST_A_ROWK, TOIST_B_KROW>), grid, dim3(512), G8_LDS, st, d);
+    else hipLaunchKernelGGL((gemm128_kernel<TOIST_A_ROWK, TOIST_B_ROWK>), grid, dim3(512), G8_LDS, st, d);
+    return TOIST_OK;
+}
+
 static int launch_conv3(const toist_gemm& d, hipStream_t st) {
     // > 64 KiB of dynamic LDS has to be enabled per kernel and per device (idempotent)
     if (!lds_attr_once(0, [] {
@@ -2277,6 +2619,11 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // the 3x3 shared-halo kernel: picked for dgrad (measured 395 vs 351 TFLOP/s on layer 3), explicit tile code 131 otherwise
     // (forward: 384 vs 451 for the generic tiles)
+    if (d.tile == 136 || (d.tile == 0 && gemm128_pays(d))) {
+        TOIST_REQUIRE(gemm128_applies(d), "toist_gemm_bf16: the 128x128 kernel does not cover this call");
+        const int rc8 = launch_gemm128(d, st);
+        return rc8 != TOIST_OK ? rc8 : check_launch("toist_gemm_bf16(gemm128)");
+    }
     if ((d.tile == 131 || (d.tile == 0 && d.a_kind == TOIST_A_CONVT)) && conv3_applies(d)) {
         const int rc3 = launch_conv3(d, st);
         return rc3 != TOIST_OK ? rc3 : check_launch("toist_gemm_bf16(conv3)");

@@ -169,7 +169,7 @@ def conv2d(x, w, *, stride=1, pad=0, dil=1, scale=None, shift=None, res=None, ac
     return out
 
 
-def conv2d_dgrad(dy, w, in_hw, *, stride=1, pad=0, dil=1, scale=None, res=None, act=k.ACT_NONE, aux=None, out=None, flags=0):
+def conv2d_dgrad(dy, w, in_hw, *, stride=1, pad=0, dil=1, scale=None, res=None, act=k.ACT_NONE, aux=None, out=None, flags=0, tile=0):
     """dx [N,H,W,C] = transposed-gather of dy [N,OH,OW,Co] with w [Co,R,S,C] read in place (k-major)."""
     Nb, OH, OW, Co = dy.shape
     Cw, R, S, C = w.shape
@@ -198,7 +198,7 @@ def conv2d_dgrad(dy, w, in_hw, *, stride=1, pad=0, dil=1, scale=None, res=None, 
         a = k.operand(dy, 0, geom=k.ConvGeom(OH, OW, Co, H, W, R, S, stride, pad, dil))
         b = k.operand(w, R * S * C, kin=Co, tap_stride=C)
         k.gemm(M, C, R * S * Co, k.A_CONVT, a, k.B_KROW, b, out, C, scale=scale, res=res, ldr=ldr, act=act, aux=aux,
-               ldaux=ldaux, flags=flags, flops=fl)
+               ldaux=ldaux, flags=flags, flops=fl, tile=tile)
     return out
 
 
