@@ -336,7 +336,8 @@ def main():
     # short-K panel kernel (csrc/gemm.hip panel_kernel, dispatcher tile code 135) -- the 1x1 convolutions of the backbone with K <= 256 and
     # their data gradients, 81 launches per step.  ~100 flop per algorithmic byte, below the ridge (2500 TFLOP/s / 8 TB/s = 312): HBM-bound.
     global ROOFLINE_KEYS
-    ROOFLINE_KEYS = frozenset({(135, kernels.A_ROWK, kernels.B_ROWK), (135, kernels.A_ROWK, kernels.B_KROW)})
+    ROOFLINE_KEYS = frozenset({(135, kernels.A_ROWK, kernels.B_ROWK), (135, kernels.A_ROWK, kernels.B_KROW),       # hbm: the short-K panel kernel
+                               (136, kernels.A_CONV, kernels.B_ROWK), (136, kernels.A_CONVT, kernels.B_KROW)})     # mfma: the 3x3 family on gemm128_kernel
     if a.distill:
         return bench_distillation(a, dev, rank, world)
     if a.mixed_sizes:
@@ -654,6 +655,18 @@ def main():
             if not params_identical:
                 res["config"]["parameters_differing"] = {"count": len(params_differing), "first": params_differing[:12]}
             res["config"]["gradient_wire_dtype"] = "bf16" if a.bf16_grads else "f32"
+        if prof is not None and prof["key"] is not None:
+            # second roofline entry: the 3x3 convolutions (stride-1 gathers, forward + data gradient) are the largest MFMA-bound family
+            conv = [r for r in prof["records"] if r[3][0] == 136]
+            prof["records"] = [r for r in prof["records"] if r[3][0] != 136]
+            if conv:
+                c_ms = sum(r[0].elapsed_time(r[1]) for r in conv)
+                c_fl = sum(r[2] for r in conv)
+                c_ach = c_fl / (c_ms * 1e-3) / 1e12
+                res["roofline_mfma"] = {"bound": "mfma", "achieved": round(c_ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(c_ach / PEAK_BF16_TFLOPS, 5),
+                                        "kernel": "gemm128_kernel<A_CONV | A_CONVT> (3x3 stride-1 convolutions of ResNet layers 2-4 and their data gradients: 128x128 tiles, 64x64 wave tiles)",
+                                        "launches": len(conv), "avg_launch_us": round(1000 * c_ms / len(conv), 2), "avg_gflop_per_launch": round(c_fl / len(conv) / 1e9, 3),
+                                        "timed": "HIP events around each launch, the same eager steps as `roofline`"}
         if prof is not None and prof["records"]:
             tot_ms, tot_fl, per_key = 0.0, 0.0, {}
             for e0, e1, fl, key, shape, nbytes in prof["records"]:
@@ -677,21 +690,22 @@ def main():
             if prof["key"] is not None and traffic is None:
                 # fallback: HBM bytes per launch of this kernel from the committed PMC passes (tools/run_gpu_round.sh + tools/pmc_traffic.py)
                 why_live = traffic_src
-                pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
-                if os.path.exists(pj):
-                    meta = json.load(open(pj))
-                    ks = {k_: v for k_, v in meta["kernels"].items() if "panel_kernel" in k_}
+                pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+                pname = next((n_ for n_ in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(pdir, n_))), None)
+                if pname is not None:
+                    meta = json.load(open(os.path.join(pdir, pname)))
+                    ks = {k_: v for k_, v in meta["kernels"].items() if "panel_kernel" in k_ or "panel2_kernel" in k_}
                     disp = sum(v["dispatches"] for v in ks.values())
                     if disp:
                         traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in ks.values()) / disp)
-                        traffic_src = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --no-graph` at commit "
+                        traffic_src = ("profiles/" + pname + ": rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --no-graph` at commit "
                                        + str(meta.get("commit", "?")) + " (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction applied); not re-measured in this run"
                                        + ("" if not why_live else " -- " + why_live))
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             gbs = sum(r[5] for r in prof["records"]) / (tot_ms * 1e-3) / 1e9
             if prof["key"] is not None:
                 res["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 5),
-                                   "kernel": "panel_kernel<{B_ROWK,B_KROW},act> (1x1 convolutions with K <= 256 and their data gradients: the largest single share of the step's kernel time)",
+                                   "kernel": "panel2_kernel<{B_ROWK,B_KROW},act,BM> (1x1 convolutions with K <= 256 and their data gradients: the largest single share of the step's kernel time)",
                                    "tflops": round(ach, 2), "mfma_frac": round(ach / PEAK_BF16_TFLOPS, 5)}
             else:
                 res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5),

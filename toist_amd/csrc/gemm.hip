@@ -1157,6 +1157,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(const toist_gemm p) {
 // instruction's scalar offset, ring slots are compile-time (4-step unrolled loop), fragments are read one k-tile ahead; (4) no register
 // spills (128 accumulator + fragment registers, ~40 for everything else) and no LDS band in the epilogue (fragments are finished where
 // the MFMA left them, 8-byte accesses).  Staged bytes per MFMA: half of the 64 x 64 tiling.
+#ifndef GEMM_UNIT   // main translation unit only
 constexpr int G8_BM = 128, G8_BN = 128, G8_BK = 64, G8_NS = 4;
 constexpr int G8_TILE = G8_BM * G8_BK;                 // elements of one operand tile (16 KiB)
 constexpr int G8_STAGE_BYTES = 2 * G8_TILE * 2;        // A + B
@@ -1424,6 +1425,224 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
         o[4] = (float)T; o[5] = (float)(T1 - T0); o[6] = (float)(T2 - T1); o[7] = (float)(cyc_now() - T2);
     }
 }
+
+// gemm128w_kernel (tile code 137): the weight-gradient form of gemm128_kernel.  dW[co][(r, s, c)] = sum over pixels of dy[pixel][co] *
+// x[pixel shifted by the tap][c]: BOTH operands are k-major (k = pixel), the reduction is 3 200 .. 51 200 deep and the output is a few
+// dozen 128 x 128 tiles per convolution -- the identical residual blocks of a stage run as one grouped launch (blockIdx.y = problem x
+// k-slice).  Same skeleton as above (4-slot DMA ring, k-halves on wave pairs, fragments one k-tile ahead); both fragment sets come
+// out of LDS through ds_read_b64_tr_b16.  The 3 x 3 gather needs no table: a 128-column tile lies inside ONE tap (C % 128 == 0), so a
+// lane's source address is its pixel's address plus a per-tile constant, and the only per-k-tile bookkeeping is the lane's running
+// (y, x) -- advanced by 64 pixels per k-tile with two conditional subtractions -- against the tap's valid window (~20 VALU per k-tile
+// against 16 MFMAs; the generic tile spends ~130 VALU + 60 SALU per 32 MFMAs on it).  Output: f32, alpha * rscale[m] (the folded
+// FrozenBN scale), += into the gradient buffer, or raw k-slice partials into the caller's arena.
+template <int BKD>
+__global__ __launch_bounds__(512, 2) void gemm128w_kernel(const toist_gemm p) {
+    constexpr int BM = G8_BM, BN = G8_BN, BK = G8_BK, WM = 64, WN = 64, FM = 4, FN = 4;
+    constexpr bool GATHER = BKD == TOIST_B_CONVX;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1, g = lane >> 4, c16 = lane & 15;
+    const int M = p.M, N = p.N, K = p.K;
+    const int nt_n = (N + BN - 1) / BN, nt_m = (M + BM - 1) / BM;
+    const int tiles = nt_m * nt_n;
+    const int tile_id = (int)(blockIdx.x & 7) * ((tiles + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (tile_id >= tiles) return;
+    int tile_m, tile_n;
+    tile_order(tile_id, nt_m, nt_n, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int z = blockIdx.y, bz = z / p.split_k, ksl = z - bz * p.split_k;
+    const toist_operand ob = p.b;
+    const bf16_t* a_ptr = (const bf16_t*)p.a.ptr;
+    const bf16_t* b_ptr = (const bf16_t*)ob.ptr;
+    long long coff = 0, rs_off = 0;
+    if (p.group) {
+        const toist_group gq = p.group[bz];
+        a_ptr = (const bf16_t*)gq.a;
+        b_ptr = (const bf16_t*)gq.b;
+        coff = gq.c_off;
+        rs_off = gq.rscale_off;
+    }
+    const int lda = p.a.ld, ldb = GATHER ? ob.SC : ob.ld;
+    const int ktiles = K / BK;                          // K % 64 == 0
+    const int kper = (ktiles + p.split_k - 1) / p.split_k;
+    const int kt_beg = ksl * kper;
+    const int T = ((kt_beg + kper < ktiles) ? kt_beg + kper : ktiles) - kt_beg;     // k-tiles of this slice
+    if (T <= 0) return;
+    // gather: this tile's tap and the window of pixel coordinates whose shifted source lies inside the plane
+    int tap_dy = 0, tap_dx = 0, c0 = n0;
+    if (GATHER) {
+        const int tap = n0 / ob.SC;
+        const int r = tap / ob.S, s_ = tap - r * ob.S;
+        c0 = n0 - tap * ob.SC;
+        tap_dy = r * ob.dil - ob.pad;
+        tap_dx = s_ * ob.dil - ob.pad;
+    }
+    const i32x4_t rsA = make_rsrc(a_ptr);
+    const i32x4_t rsB = make_rsrc(GATHER ? (const void*)(b_ptr + ((long long)tap_dy * ob.SW + tap_dx) * ob.SC) : (const void*)b_ptr);
+    const unsigned lds0 = (unsigned)(size_t)lds_raw;
+
+    // ---- DMA pieces: k-major tiles [64 k][128 m | n]; lane offsets in bytes, the k-tile in the scalar offset ----
+    int va[2], vb[2], py[2], px[2];
+    const int W = ob.PW, H = ob.PH;
+    const int q64 = GATHER ? BK / W : 0, r64 = GATHER ? BK - q64 * W : 0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int pch = (it * 8 + wave) * 64 + lane;
+        const int krow = pch / (BM / 8), rc = swz_m<BM>(krow, pch % (BM / 8));
+        const int mm = m0 + rc * 8, nn = n0 + rc * 8;
+        va[it] = mm < M ? (mm + krow * lda) * 2 : OOB;
+        vb[it] = nn < N ? ((GATHER ? c0 + rc * 8 : nn) + krow * ldb) * 2 : OOB;
+        py[it] = px[it] = 0;
+        if (GATHER) {
+            const int pix = (kt_beg * BK + krow) % (H * W);
+            py[it] = pix / W;
+            px[it] = pix - py[it] * W;
+        }
+    }
+    int i_t = 0;                                        // k-tiles issued so far
+    auto issue = [&](const int slot) {
+        const unsigned da = lds0 + (unsigned)(slot * G8_STAGE_BYTES) + (unsigned)wave * 1024u, db = da + (unsigned)(G8_TILE * 2);
+        const int kt = kt_beg + i_t;
+        const int soa = kt * BK * lda * 2, sob = kt * BK * ldb * 2;
+        int vbe[2] = {vb[0], vb[1]};
+        if (GATHER) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int sy = py[it] + tap_dy, sx = px[it] + tap_dx;
+                if (sy < 0 || sy >= H || sx < 0 || sx >= W) vbe[it] = OOB;
+                px[it] += r64;                          // the same k-row of the next k-tile: 64 pixels on
+                py[it] += q64;
+                if (px[it] >= W) { px[it] -= W; ++py[it]; }
+                while (py[it] >= H) py[it] -= H;
+            }
+        }
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %7, %9 offen lds\n\t"
+                     "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %7, %9 offen lds\n\t"
+                     "s_mov_b32 m0, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, %10 offen lds\n\t"
+                     "s_mov_b32 m0, %12\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %10 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(da), "s"(da + 8192u), "v"(va[0]), "v"(va[1]), "v"(vbe[0]), "v"(vbe[1]), "s"(rsA), "s"(rsB), "s"(soa), "s"(sob), "s"(db), "s"(db + 8192u)
+                     : "memory");
+        ++i_t;
+    };
+    issue(0);
+    issue(1);
+    issue(2);
+
+    // ---- fragment addresses: [4 k][16 rows] blocks of the k-major tiles, transposed on the way out of LDS ----
+    int a_base[FM][2], b_base[FN][2];
+    {
+        const int k = kh * 32 + 8 * g + (c16 >> 2), sub = (c16 & 1) * 4;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int rc = ((wm * WM + i * 16) >> 3) + ((c16 & 3) >> 1);
+            a_base[i][0] = (k * BM + swz_m<BM>(k, rc) * 8 + sub) * 2;
+            a_base[i][1] = ((k + 4) * BM + swz_m<BM>(k + 4, rc) * 8 + sub) * 2;
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int rc = ((wn * WN + j * 16) >> 3) + ((c16 & 3) >> 1);
+            b_base[j][0] = G8_TILE * 2 + (k * BN + swz_m<BN>(k, rc) * 8 + sub) * 2;
+            b_base[j][1] = G8_TILE * 2 + ((k + 4) * BN + swz_m<BN>(k + 4, rc) * 8 + sub) * 2;
+        }
+    }
+    auto load_frags = [&](G8Frags& f, auto slotc) {
+        constexpr int SLOT = decltype(slotc)::value;
+        typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            union { struct { s16x4_t a, b; } h; bf16x8_t v; } u;
+            u.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_raw + a_base[i][0] + SLOT * G8_STAGE_BYTES));
+            u.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_raw + a_base[i][1] + SLOT * G8_STAGE_BYTES));
+            f.a[i] = u.v;
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            union { struct { s16x4_t a, b; } h; bf16x8_t v; } u;
+            u.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_raw + b_base[j][0] + SLOT * G8_STAGE_BYTES));
+            u.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_raw + b_base[j][1] + SLOT * G8_STAGE_BYTES));
+            f.b[j] = u.v;
+        }
+    };
+
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    wait_vm<8>();                                       // k-tile 0 landed (tiles 1 and 2 may fly; a slice has at least 4 k-tiles)
+    __builtin_amdgcn_s_barrier();
+    G8Frags fa, fb;
+    load_frags(fa, std::integral_constant<int, 0>{});
+    int t = 0;
+    auto step = [&](auto slotc, G8Frags& cur, G8Frags& nxt) {
+        constexpr int SLOT = decltype(slotc)::value;
+        if (t + 2 < T) wait_vm<4>();
+        else wait_vm<0>();
+        lds_barrier();
+        if (t + 3 < T) issue((SLOT + 3) & 3);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(cur.a[i]));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(cur.b[j]));
+        if (t + 1 < T) load_frags(nxt, std::integral_constant<int, (SLOT + 1) & 3>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
+        ++t;
+    };
+#pragma unroll 1
+    while (t + 4 <= T) {
+        step(std::integral_constant<int, 0>{}, fa, fb);
+        step(std::integral_constant<int, 1>{}, fb, fa);
+        step(std::integral_constant<int, 2>{}, fa, fb);
+        step(std::integral_constant<int, 3>{}, fb, fa);
+    }
+    if (t < T) step(std::integral_constant<int, 0>{}, fa, fb);
+    if (t < T) step(std::integral_constant<int, 1>{}, fb, fa);
+    if (t < T) step(std::integral_constant<int, 2>{}, fa, fb);
+    wait_vm<0>();
+    lds_barrier();
+
+    // ---- fold the k-halves half and half (as above), then f32 rows: lane = row c16 of a fragment, 4 consecutive columns (16 bytes) ----
+    float* const xch = reinterpret_cast<float*>(lds_raw);
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+            *reinterpret_cast<f32x4_t*>(xch + ((wave * 8 + ii * 4 + j) * 64 + lane) * 4) = kh == 0 ? acc[2 + ii][j] : acc[ii][j];
+    lds_barrier();
+    const int partner = wave ^ 4;
+    const toist_epilogue& e = p.epi;
+    const bool partial = p.split_k > 1;
+    float* const outp = partial ? p.workspace + ((size_t)bz * p.split_k + ksl) * M * N : (float*)p.c + coff;
+    const int ldo = partial ? N : p.ldc;
+    const float* const rsc = (!partial && e.rscale) ? e.rscale + rs_off : nullptr;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+        const int m = m0 + wm * WM + (kh * 2 + ii) * 16 + c16;
+        const float rs = partial ? 1.f : (rsc && m < M ? e.alpha * rsc[m] : e.alpha);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * WN + j * 16 + g * 4;
+            const f32x4_t o = *reinterpret_cast<const f32x4_t*>(xch + ((partner * 8 + ii * 4 + j) * 64 + lane) * 4);
+            f32x4_t v = (kh == 0 ? acc[ii][j] : acc[2 + ii][j]) + o;
+            if (m >= M || n >= N) continue;             // M, N % 8 == 0: the 4 columns are valid or absent together
+            float* cp = outp + (size_t)m * ldo + n;
+            if (!partial) {
+                v *= rs;
+                if (e.accumulate) v += *reinterpret_cast<const f32x4_t*>(cp);
+            }
+            *reinterpret_cast<f32x4_t*>(cp) = v;
+        }
+    }
+}
+
+#endif  // GEMM_UNIT (128x128 kernels)
 
 static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
 
@@ -2119,6 +2338,8 @@ static bool conv3_applies(const toist_gemm& d) {
     return d.M >= 2048;                                                // tiny grids: the generic 64x64 tiles fill more CUs
 }
 
+#ifndef GEMM_UNIT
+static int clamp_split(int split_k, int K, int tile);
 // gemm128_kernel (tile code 136): one problem, K a multiple of 64 with at least 4 k-tiles, bf16 rows finished by {alpha, scale, shift,
 // residual, ReLU | aux > 0 mask}.  Operands: row-major A with row-major or plain k-major B (1x1 convolutions, nn.Linear and their data
 // gradients); stride-1 convolution gather with row-major weights (forward); its transposed gather on a same-size plane with the
@@ -2181,6 +2402,67 @@ static int launch_gemm128(const toist_gemm& d, hipStream_t st) {
     else hipLaunchKernelGGL((gemm128_kernel<TOIST_A_ROWK, TOIST_B_ROWK>), grid, dim3(512), G8_LDS, st, d);
     return TOIST_OK;
 }
+
+// gemm128w_kernel (tile code 137): weight gradients -- k-major A (dy [pixels][Co]), B = k-major rows (1x1) or the stride-1 same-size
+// gather with whole 128-column tiles inside a tap; f32 output with alpha / rscale / accumulate, or k-slice partials; grouped or single.
+static bool gemm128w_applies(const toist_gemm& d) {
+    if (d.a_kind != TOIST_A_KROW) return false;
+    const bool plain = d.b_kind == TOIST_B_KROW && d.b.kin == 0, gather = d.b_kind == TOIST_B_CONVX;
+    if (!plain && !gather) return false;
+    if ((d.K % 64) != 0 || (d.M % 8) != 0 || (d.N % 8) != 0 || (d.a.ld % 8) != 0) return false;
+    if (d.batch_inner != 1 || (d.batch != 1 && d.group == nullptr) || d.a2 != nullptr || d.a_colsum != nullptr || (d.flags & (1 | TOIST_GEMM_SPLIT_EPILOGUE))) return false;
+    const int split = clamp_split(d.split_k, d.K, 65);                                  // the slices the launch will really make
+    const int ktiles = d.K / 64, kper = (ktiles + split - 1) / split;
+    if (kper < 4 || (long long)(split - 1) * kper + 4 > ktiles) return false;          // every k-slice holds at least 4 k-tiles
+    if (split > 1 && d.workspace == nullptr) return false;
+    const long long lim = 1ll << 30;
+    if ((long long)d.K * d.a.ld >= lim) return false;                                   // 32-bit byte offsets
+    if (plain) {
+        if ((d.b.ld % 8) != 0 || (long long)d.K * d.b.ld >= lim) return false;
+    } else {
+        const toist_operand& b = d.b;
+        if (b.stride != 1 || b.PH != b.SH || b.PW != b.SW || (b.SC % 128) != 0 || d.N != b.R * b.S * b.SC) return false;
+        if ((d.K % (b.PH * b.PW)) != 0 || (long long)(d.K + b.SW * (b.pad + 1)) * b.SC >= lim) return false;
+    }
+    const toist_epilogue& e = d.epi;
+    if (!e.out_f32 || e.scale || e.shift || e.res || e.pre_out || e.act != TOIST_ACT_NONE || e.drop_where || e.cmap || e.res_div > 0) return false;
+    if ((d.ldc % 4) != 0 || (((size_t)d.c) & 15) != 0) return false;
+    return true;
+}
+
+// where it replaces the grouped / split tiles the host asked for (profiles/r03_gemm128w_us.txt)
+static bool gemm128w_pays(const toist_gemm& d) {
+    static const int on = (int)tuning_knob("TOIST_GEMM128W", 1);
+    if (!on || !gemm128w_applies(d)) return false;
+    const long long wgs = (long long)((d.M + G8_BM - 1) / G8_BM) * ((d.N + G8_BN - 1) / G8_BN) * d.batch * clamp_split(d.split_k, d.K, 65);
+    return wgs >= 128 && (d.M % 64) == 0 && (d.N % 128) == 0;
+}
+
+// the big generic tiles the host asks for on (grouped) weight gradients -- and the automatic choice -- give way to the 128x128 kernel
+static bool wgrad_tile_replaced(const toist_gemm& d) {
+    const int t = d.tile & 255;
+    return (t == 0 || t == 129 || t == 130 || t == 134) && d.a_kind == TOIST_A_KROW && gemm128w_pays(d);
+}
+
+static int launch_gemm128w(const toist_gemm& d, hipStream_t st) {
+    static std::atomic<unsigned long long> done{0};
+    if (!lds_attr_once_flag(done, [] {
+            return hipFuncSetAttribute((const void*)gemm128w_kernel<TOIST_B_KROW>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)gemm128w_kernel<TOIST_B_CONVX>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess;
+        })) {
+        set_last_error("toist_gemm_bf16: cannot enable %d bytes of LDS for the 128x128 weight-gradient kernel", G8_LDS);
+        return TOIST_EHIP;
+    }
+    const int tiles = ((d.M + G8_BM - 1) / G8_BM) * ((d.N + G8_BN - 1) / G8_BN);
+    toist_gemm dd = d;
+    dd.split_k = clamp_split(d.split_k, d.K, 65);
+    dim3 grid((tiles + 7) & ~7, dd.batch * dd.split_k, 1);
+    if (d.b_kind == TOIST_B_CONVX) hipLaunchKernelGGL((gemm128w_kernel<TOIST_B_CONVX>), grid, dim3(512), G8_LDS, st, dd);
+    else hipLaunchKernelGGL((gemm128w_kernel<TOIST_B_KROW>), grid, dim3(512), G8_LDS, st, dd);
+    return TOIST_OK;
+}
+
+#endif  // GEMM_UNIT (128x128 kernels, host side)
 
 static int launch_conv3(const toist_gemm& d, hipStream_t st) {
     // > 64 KiB of dynamic LDS has to be enabled per kernel and per device (idempotent)
@@ -2512,10 +2794,13 @@ extern "C" int toist_group_fill(const toist_group* rows, int n, toist_group* tab
 extern "C" int toist_gemm_pick_tile(const toist_gemm* desc) {
     using namespace toist;
     if (desc == nullptr) return 0;
-    if (desc->tile & 255) return desc->tile & 255;
     toist_gemm d = *desc;
     if (d.batch <= 0) d.batch = 1;
     if (d.split_k <= 0) d.split_k = 1;
+    if (wgrad_tile_replaced(d)) return 137;
+    if (desc->tile & 255) return desc->tile & 255;
+    if (gemm128_pays(d)) return 136;                    // the order of toist_gemm_bf16's dispatch
+    if (d.a_kind == TOIST_A_CONVT && conv3_applies(d)) return 131;
     if ((long long)((d.M + 63) / 64) * ((d.N + 63) / 64) >= panel_min_tiles() && panel_applies(d)) return 135;
     return auto_tile(d);
 }
@@ -2523,7 +2808,10 @@ extern "C" int toist_gemm_pick_tile(const toist_gemm* desc) {
 extern "C" int toist_gemm_effective_split(const toist_gemm* desc) {
     using namespace toist;
     if (desc == nullptr) return 0;
-    const int tile = (desc->tile & 255) ? (desc->tile & 255) : auto_tile(*desc);
+    toist_gemm d = *desc;
+    if (d.batch <= 0) d.batch = 1;
+    if (d.workspace == nullptr) d.workspace = (float*)16;      // asked BEFORE the caller sizes the scratch: "a workspace will be there"
+    const int tile = wgrad_tile_replaced(d) ? 137 : (desc->tile & 255) ? (desc->tile & 255) : auto_tile(*desc);
     return clamp_split(desc->split_k, desc->K, tile);
 }
 
@@ -2641,6 +2929,8 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     }
     int tile = d.tile & 255;
     const int ring = d.tile >> 8;   // 0 = pick; else slots of the DMA ring (2..4)
+    if (tile == 137) TOIST_REQUIRE(gemm128w_applies(d), "toist_gemm_bf16: the 128x128 weight-gradient kernel does not cover this call");
+    if (wgrad_tile_replaced(d)) tile = 137;
     if (tile == 0) tile = auto_tile(d);
     d.split_k = clamp_split(d.split_k, d.K, tile);
     // tile codes: 64 = 64x64x32, 65 = 64x64x64, 128 = 128x128x32, 129 = 128x128x64, 130 = 128x64x64, 132 = 128x32x64, 133 = 32x128x64
@@ -2651,6 +2941,7 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     switch (tile) {       // tile families by translation unit
         case 65: rc = launch_tiles_b(tile, d, ring, st); break;
         case 130: case 134: rc = launch_tiles_c(tile, d, ring, st); break;
+        case 137: rc = launch_gemm128w(d, st); break;
         default: rc = launch_tiles_a(tile, d, ring, st); break;
     }
     if (rc != TOIST_OK) return rc;
