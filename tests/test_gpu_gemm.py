@@ -664,3 +664,58 @@ def test_gemm128_kernel_convolution_gathers(dev, Nb, H, W, C, Co, R, pad, dil):
     else:   # a 1x1 is a plain GEMM to ops.conv2d: K = 64 is below the kernel's minimum, the explicit tile must be refused loudly
         with pytest.raises(RuntimeError, match="128x128"):
             ops.conv2d(x, w, scale=scale, shift=shift, tile=136)
+
+
+@pytest.mark.parametrize("Nb,H,W,C,Co,R,dil,n,min_tiles", [
+    (8, 16, 16, 1024, 256, 1, 1, 9, 1),         # grouped 1x1, pairs pinned to XCDs (9 problems, the last XCD slots empty)
+    (8, 16, 16, 128, 256, 3, 1, 9, 1),          # grouped 3x3 gather: border taps, image boundaries inside k-tiles (256 pixels per image)
+    (4, 24, 16, 128, 128, 3, 2, 3, 1 << 20),    # grouped AND split along K (arena partials + batched fold), dilation 2, fewer than 8 pairs... times the slices
+    (8, 40, 40, 256, 256, 1, 1, 1, 1),          # one problem split along K by the host's heuristic (deferred fold)
+    (2, 20, 12, 128, 128, 3, 1, 2, 1),          # 480 pixels: K % 64 != 0 -> the generic tiles must take it (same call, same answer)
+])
+def test_gemm128w_weight_gradient_kernel(dev, Nb, H, W, C, Co, R, dil, n, min_tiles):
+    """csrc/gemm.hip gemm128w_kernel (tile code 137: both operands k-major through ds_read_b64_tr_b16, table-free 3x3 gather, f32
+    alpha * rscale * acc += into the gradient slice or k-slice partials, (problem, slice) pairs pinned to XCDs) as the dispatcher picks
+    it for single and grouped weight gradients, against the 64 x 64 tiles on the same calls: same products in f32, another summation
+    order.  The first four cases must really run the new kernel (toist_gemm_pick_tile says so)."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(Nb * H + C + R)
+    pad = dil * (R // 2)
+    flat = torch.zeros(n * Co * R * R * C + 64, dtype=torch.float32, device=dev)
+    items = []
+    for i in range(n):
+        dy = torch.randn(Nb, H, W, Co, generator=g).to(BF).to(dev)
+        x = torch.randn(Nb, H, W, C, generator=g).to(BF).to(dev)
+        out = flat[16 + i * Co * R * R * C: 16 + (i + 1) * Co * R * R * C].view(Co, R, R, C)
+        items.append((dy, x, out, (torch.rand(Co, generator=g) + 0.5).to(dev)))
+
+    def run(tile):
+        flat.copy_(base)
+        old = (ops.GROUP_TILE, ops.GROUP_MIN_TILES, k.FORCE_TILE)
+        ops.GROUP_TILE, ops.GROUP_MIN_TILES, k.FORCE_TILE = tile, min_tiles, tile
+        try:
+            if n == 1:
+                dy, x, out, rs = items[0]
+                ops.conv2d_wgrad(dy, x, out.shape, pad=pad, dil=dil, out=out, rscale=rs, defer=True)
+            else:
+                ops.conv2d_wgrad_group(items, items[0][2].shape, pad=pad, dil=dil)
+            k.flush_reductions()
+        finally:
+            ops.GROUP_TILE, ops.GROUP_MIN_TILES, k.FORCE_TILE = old
+        return flat.clone()
+
+    base = torch.randn(flat.shape, generator=g).to(dev) * 0.1          # accumulate = True: the kernel adds to what is there
+    ref = run(65)
+    picked = []
+    k.PROFILE = {"key": (137, k.A_KROW, k.B_CONVX if R == 3 else k.B_KROW), "records": [], "other": {}}
+    try:
+        got = run(0)
+        picked = list(k.PROFILE["records"])
+    finally:
+        k.PROFILE = None
+    assert torch.equal(got[:16], base[:16]) and torch.equal(got[-48:], base[-48:])               # nothing written outside the slices
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    if (Nb * H * W) % 64 == 0:
+        assert len(picked) == 1, "the dispatcher did not pick gemm128w_kernel"
+    else:
+        assert len(picked) == 0 and torch.equal(got, ref)

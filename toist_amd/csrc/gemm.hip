@@ -1445,12 +1445,28 @@ __global__ __launch_bounds__(512, 2) void gemm128w_kernel(const toist_gemm p) {
     const int M = p.M, N = p.N, K = p.K;
     const int nt_n = (N + BN - 1) / BN, nt_m = (M + BM - 1) / BM;
     const int tiles = nt_m * nt_n;
-    const int tile_id = (int)(blockIdx.x & 7) * ((tiles + 7) >> 3) + (int)(blockIdx.x >> 3);
-    if (tile_id >= tiles) return;
+    const int nz = p.batch * p.split_k;                 // (problem, k-slice) pairs
+    // Workgroup -> (pair, tile).  With 128 x 128 tiles every operand k-tile is wanted by nt_n (A) or nt_m (B) workgroups: spread over
+    // the XCDs, each of the 8 L2s pulls its own copy through the fabric (22 grouped layer-3 1x1 problems: 2.3 GB of operand tiles for
+    // 0.7 GB of operands, 5-7 TB/s at the measured 320 us -- the launch was bound by that).  From 8 pairs on, a pair therefore lives on
+    // ONE XCD: the dispatcher deals workgroups round-robin (id % 8 = XCD), so XCD x works through pairs x, x + 8, ... , all tiles of
+    // a pair on consecutive ids of that XCD, walking K in step -- the pair's operands cross the fabric once.
+    int z, tile_id;
+    if (nz >= 8) {
+        const int xcd = (int)(blockIdx.x & 7), sq = (int)(blockIdx.x >> 3);
+        const int zi = sq / tiles;
+        z = xcd + 8 * zi;
+        tile_id = sq - zi * tiles;
+        if (z >= nz) return;
+    } else {
+        z = blockIdx.y;
+        tile_id = (int)(blockIdx.x & 7) * ((tiles + 7) >> 3) + (int)(blockIdx.x >> 3);
+        if (tile_id >= tiles) return;
+    }
     int tile_m, tile_n;
     tile_order(tile_id, nt_m, nt_n, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int z = blockIdx.y, bz = z / p.split_k, ksl = z - bz * p.split_k;
+    const int bz = z / p.split_k, ksl = z - bz * p.split_k;
     const toist_operand ob = p.b;
     const bf16_t* a_ptr = (const bf16_t*)p.a.ptr;
     const bf16_t* b_ptr = (const bf16_t*)ob.ptr;
@@ -2456,7 +2472,9 @@ static int launch_gemm128w(const toist_gemm& d, hipStream_t st) {
     const int tiles = ((d.M + G8_BM - 1) / G8_BM) * ((d.N + G8_BN - 1) / G8_BN);
     toist_gemm dd = d;
     dd.split_k = clamp_split(d.split_k, d.K, 65);
-    dim3 grid((tiles + 7) & ~7, dd.batch * dd.split_k, 1);
+    const int nz = dd.batch * dd.split_k;
+    dim3 grid((tiles + 7) & ~7, nz, 1);
+    if (nz >= 8) grid = dim3(8 * ((nz + 7) / 8) * tiles, 1, 1);     // pairs pinned to XCDs (see the kernel)
     if (d.b_kind == TOIST_B_CONVX) hipLaunchKernelGGL((gemm128w_kernel<TOIST_B_CONVX>), grid, dim3(512), G8_LDS, st, dd);
     else hipLaunchKernelGGL((gemm128w_kernel<TOIST_B_KROW>), grid, dim3(512), G8_LDS, st, dd);
     return TOIST_OK;
