@@ -1158,14 +1158,13 @@ __global__ __launch_bounds__(256) void conv3_kernel(const toist_gemm p) {
 // spills (128 accumulator + fragment registers, ~40 for everything else) and no LDS band in the epilogue (fragments are finished where
 // the MFMA left them, 8-byte accesses).  Staged bytes per MFMA: half of the 64 x 64 tiling.
 #ifndef GEMM_UNIT   // main translation unit only
-constexpr int G8_BM = 128, G8_BN = 128, G8_BK = 64, G8_NS = 4;
+constexpr int G8_BM = 128, G8_BN = 128, G8_BK = 64;
 constexpr int G8_TILE = G8_BM * G8_BK;                 // elements of one operand tile (16 KiB)
 constexpr int G8_STAGE_BYTES = 2 * G8_TILE * 2;        // A + B
-constexpr int G8_LDS = G8_NS * G8_STAGE_BYTES;         // 128 KiB
 
 struct G8Frags { bf16x8_t a[4]; bf16x8_t b[4]; };
 
-template <int AK, int BKD>
+template <int AK, int BKD, int NS>   // NS = slots of the DMA ring (4 or 5: 128 / 160 KiB of LDS, one workgroup per CU either way)
 __global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
     constexpr int BM = G8_BM, BN = G8_BN, BK = G8_BK, WM = 64, WN = 64, FM = 4, FN = 4;
     constexpr bool B_KM = BKD == TOIST_B_KROW;
@@ -1245,7 +1244,8 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
                      "s_mov_b32 m0, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, %10 offen lds\n\t"
                      "s_mov_b32 m0, %12\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %10 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "s"(da), "s"(da + 8192u), "v"(va_eff[0]), "v"(va_eff[1]), "v"(vb[0]), "v"(vb[1]), "s"(rsA), "s"(rsB), "s"(soa), "s"(sob), "s"(db), "s"(db + 8192u)
+                     : "s"(da), "s"(da + 8192u), "v"(va_eff[0]), "v"(va_eff[1]), "v"(vb[0]), "v"(vb[1]), "s"(rsA), "s"(rsB), "s"(__builtin_amdgcn_readfirstlane(soa)),
+                       "s"(__builtin_amdgcn_readfirstlane(sob)), "s"(db), "s"(db + 8192u)
                      : "memory");
         if (++i_chunk == nch) {                         // next tap: its scalar offset and this lane's validity
             i_chunk = 0;
@@ -1258,9 +1258,8 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
             }
         }
     };
-    issue(0);
-    issue(1);
-    issue(2);
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) issue(i);
 
     // ---- fragment addresses (bytes inside a stage): rows 16 apart share their swizzle -> one base + immediates ----
     const int a_row = wm * WM + c16;
@@ -1303,7 +1302,7 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    wait_vm<8>();                                       // k-tile 0 landed (tiles 1 and 2 may fly)
+    wait_vm<4 * (NS - 2)>();                            // k-tile 0 landed (the younger ones may fly; K holds at least NS k-tiles)
     __builtin_amdgcn_s_barrier();
     G8Frags fa, fb;
     load_frags(fa, std::integral_constant<int, 0>{});
@@ -1313,17 +1312,18 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
     // one k-tile: `cur` = its fragments (read during the previous step), `nxt` receives those of k-tile t + 1 from ring slot SLOT + 1
     auto step = [&](auto slotc, G8Frags& cur, G8Frags& nxt) {
         constexpr int SLOT = decltype(slotc)::value;
-        // this wave's loads younger than k-tile t + 1: the four pieces of k-tile t + 2
-        if (t + 2 < T) wait_vm<4>();
+        // this wave's loads younger than k-tile t + 1: k-tiles t + 2 .. t + NS - 2, four pieces each
+        if (NS == 5 && t + 3 < T) wait_vm<8>();
+        else if (t + 2 < T) wait_vm<4>();
         else wait_vm<0>();
         lds_barrier();          // k-tile t + 1 landed for every wave; every fragment read issued so far has returned
-        if (t + 3 < T) issue((SLOT + 3) & 3);           // the slot of k-tile t - 1: its fragments were consumed by the previous step's MFMAs
+        if (t + NS - 1 < T) issue((SLOT + NS - 1) % NS);   // the slot of k-tile t - 1: its fragments were consumed by the previous step's MFMAs
         // hipcc's own LDS wait for `cur` lands here, in front of the reads issued below
 #pragma unroll
         for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(cur.a[i]));
 #pragma unroll
         for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(cur.b[j]));
-        if (t + 1 < T) load_frags(nxt, std::integral_constant<int, (SLOT + 1) & 3>{});
+        if (t + 1 < T) load_frags(nxt, std::integral_constant<int, (SLOT + 1) % NS>{});
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -1331,16 +1331,17 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
         ++t;
     };
+    // ring slot and fragment buffer are compile-time: the loop body is one trip round the ring (two for the odd ring: the fragment
+    // buffers alternate); the leftover k-tiles continue at ring position 0
+    constexpr int U = (NS % 2) ? 2 * NS : NS;
+    auto run = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        if constexpr (S % 2 == 0) step(std::integral_constant<int, S % NS>{}, fa, fb);
+        else step(std::integral_constant<int, S % NS>{}, fb, fa);
+    };
 #pragma unroll 1
-    while (t + 4 <= T) {
-        step(std::integral_constant<int, 0>{}, fa, fb);
-        step(std::integral_constant<int, 1>{}, fb, fa);
-        step(std::integral_constant<int, 2>{}, fa, fb);
-        step(std::integral_constant<int, 3>{}, fb, fa);
-    }
-    if (t < T) step(std::integral_constant<int, 0>{}, fa, fb);      // T % 4 leftover k-tiles: the ring position continues at 0
-    if (t < T) step(std::integral_constant<int, 1>{}, fb, fa);
-    if (t < T) step(std::integral_constant<int, 2>{}, fa, fb);
+    while (t + U <= T) static_for<U>(run);
+    static_for<U - 1>([&](auto sc) { if (t < T) run(sc); });
     if (timing) T2 = cyc_now();
     wait_vm<0>();
     lds_barrier();                                       // every wave is done with the ring
@@ -1435,7 +1436,7 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
 // (y, x) -- advanced by 64 pixels per k-tile with two conditional subtractions -- against the tap's valid window (~20 VALU per k-tile
 // against 16 MFMAs; the generic tile spends ~130 VALU + 60 SALU per 32 MFMAs on it).  Output: f32, alpha * rscale[m] (the folded
 // FrozenBN scale), += into the gradient buffer, or raw k-slice partials into the caller's arena.
-template <int BKD>
+template <int BKD, int NS>   // NS = slots of the DMA ring: NS - 2 k-tiles (32 KiB each) in flight per CU behind the one being read
 __global__ __launch_bounds__(512, 2) void gemm128w_kernel(const toist_gemm p) {
     constexpr int BM = G8_BM, BN = G8_BN, BK = G8_BK, WM = 64, WN = 64, FM = 4, FN = 4;
     constexpr bool GATHER = BKD == TOIST_B_CONVX;
@@ -1538,13 +1539,13 @@ __global__ __launch_bounds__(512, 2) void gemm128w_kernel(const toist_gemm p) {
                      "s_mov_b32 m0, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %8, %10 offen lds\n\t"
                      "s_mov_b32 m0, %12\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %8, %10 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "s"(da), "s"(da + 8192u), "v"(va[0]), "v"(va[1]), "v"(vbe[0]), "v"(vbe[1]), "s"(rsA), "s"(rsB), "s"(soa), "s"(sob), "s"(db), "s"(db + 8192u)
+                     : "s"(da), "s"(da + 8192u), "v"(va[0]), "v"(va[1]), "v"(vbe[0]), "v"(vbe[1]), "s"(rsA), "s"(rsB), "s"(__builtin_amdgcn_readfirstlane(soa)),
+                       "s"(__builtin_amdgcn_readfirstlane(sob)), "s"(db), "s"(db + 8192u)
                      : "memory");
         ++i_t;
     };
-    issue(0);
-    issue(1);
-    issue(2);
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) issue(i);
 
     // ---- fragment addresses: [4 k][16 rows] blocks of the k-major tiles, transposed on the way out of LDS ----
     int a_base[FM][2], b_base[FN][2];
@@ -1588,39 +1589,49 @@ __global__ __launch_bounds__(512, 2) void gemm128w_kernel(const toist_gemm p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    wait_vm<8>();                                       // k-tile 0 landed (tiles 1 and 2 may fly; a slice has at least 4 k-tiles)
+    wait_vm<4 * (NS - 2)>();                            // k-tile 0 landed (the younger ones may fly; a slice has at least NS k-tiles)
     __builtin_amdgcn_s_barrier();
     G8Frags fa, fb;
     load_frags(fa, std::integral_constant<int, 0>{});
     int t = 0;
+#ifdef TOIST_TUNING_KNOBS
+    const int ABL = (p.flags >> 12) & 7;                // experiments: 1 = no MFMAs, 2 = no fragment reads, 4 = no DMA in the loop
+#else
+    constexpr int ABL = 0;
+#endif
     auto step = [&](auto slotc, G8Frags& cur, G8Frags& nxt) {
         constexpr int SLOT = decltype(slotc)::value;
-        if (t + 2 < T) wait_vm<4>();
+        // this wave's loads younger than k-tile t + 1: k-tiles t + 2 .. t + NS - 2, four pieces each
+        if (NS == 5 && t + 3 < T) wait_vm<8>();
+        else if (t + 2 < T) wait_vm<4>();
         else wait_vm<0>();
         lds_barrier();
-        if (t + 3 < T) issue((SLOT + 3) & 3);
+        if (t + NS - 1 < T && !(ABL & 4)) issue((SLOT + NS - 1) % NS);
 #pragma unroll
         for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(cur.a[i]));
 #pragma unroll
         for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(cur.b[j]));
-        if (t + 1 < T) load_frags(nxt, std::integral_constant<int, (SLOT + 1) & 3>{});
+        if (t + 1 < T && !(ABL & 2)) load_frags(nxt, std::integral_constant<int, (SLOT + 1) % NS>{});
         __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 1)) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
+        }
         ++t;
     };
+    // ring slot and fragment buffer are compile-time: the loop body is one trip round the ring (two for an odd ring: the fragment
+    // buffers alternate)
+    constexpr int U = (NS % 2) ? 2 * NS : NS;
+    auto run = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        if constexpr (S % 2 == 0) step(std::integral_constant<int, S % NS>{}, fa, fb);
+        else step(std::integral_constant<int, S % NS>{}, fb, fa);
+    };
 #pragma unroll 1
-    while (t + 4 <= T) {
-        step(std::integral_constant<int, 0>{}, fa, fb);
-        step(std::integral_constant<int, 1>{}, fb, fa);
-        step(std::integral_constant<int, 2>{}, fa, fb);
-        step(std::integral_constant<int, 3>{}, fb, fa);
-    }
-    if (t < T) step(std::integral_constant<int, 0>{}, fa, fb);
-    if (t < T) step(std::integral_constant<int, 1>{}, fb, fa);
-    if (t < T) step(std::integral_constant<int, 2>{}, fa, fb);
+    while (t + U <= T) static_for<U>(run);
+    static_for<U - 1>([&](auto sc) { if (t < T) run(sc); });
     wait_vm<0>();
     lds_barrier();
 
@@ -2399,24 +2410,31 @@ static bool gemm128_pays(const toist_gemm& d) {
     return (tiles >= 150 && tiles <= 256 && d.N <= 256) || (tiles >= 1024 && d.K >= 1024);
 }
 
-static int launch_gemm128(const toist_gemm& d, hipStream_t st) {
+template <int NS>
+static int launch_gemm128_ring(const toist_gemm& d, hipStream_t st) {
     static std::atomic<unsigned long long> done{0};
+    constexpr int LDS = NS * G8_STAGE_BYTES;
     if (!lds_attr_once_flag(done, [] {
-            return hipFuncSetAttribute((const void*)gemm128_kernel<TOIST_A_ROWK, TOIST_B_ROWK>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess &&
-                   hipFuncSetAttribute((const void*)gemm128_kernel<TOIST_A_ROWK, TOIST_B_KROW>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess &&
-                   hipFuncSetAttribute((const void*)gemm128_kernel<TOIST_A_CONV, TOIST_B_ROWK>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess &&
-                   hipFuncSetAttribute((const void*)gemm128_kernel<TOIST_A_CONVT, TOIST_B_KROW>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess;
+            return hipFuncSetAttribute((const void*)gemm128_kernel<TOIST_A_ROWK, TOIST_B_ROWK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)gemm128_kernel<TOIST_A_ROWK, TOIST_B_KROW, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)gemm128_kernel<TOIST_A_CONV, TOIST_B_ROWK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)gemm128_kernel<TOIST_A_CONVT, TOIST_B_KROW, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
         })) {
-        set_last_error("toist_gemm_bf16: cannot enable %d bytes of LDS for the 128x128 kernel", G8_LDS);
+        set_last_error("toist_gemm_bf16: cannot enable %d bytes of LDS for the 128x128 kernel", LDS);
         return TOIST_EHIP;
     }
     const int tiles = ((d.M + G8_BM - 1) / G8_BM) * ((d.N + G8_BN - 1) / G8_BN);
     dim3 grid((tiles + 7) & ~7, 1, 1);
-    if (d.a_kind == TOIST_A_CONV) hipLaunchKernelGGL((gemm128_kernel<TOIST_A_CONV, TOIST_B_ROWK>), grid, dim3(512), G8_LDS, st, d);
-    else if (d.a_kind == TOIST_A_CONVT) hipLaunchKernelGGL((gemm128_kernel<TOIST_A_CONVT, TOIST_B_KROW>), grid, dim3(512), G8_LDS, st, d);
-    else if (d.b_kind == TOIST_B_KROW) hipLaunchKernelGGL((gemm128_kernel<TOIST_A_ROWK, TOIST_B_KROW>), grid, dim3(512), G8_LDS, st, d);
-    else hipLaunchKernelGGL((gemm128_kernel<TOIST_A_ROWK, TOIST_B_ROWK>), grid, dim3(512), G8_LDS, st, d);
+    if (d.a_kind == TOIST_A_CONV) hipLaunchKernelGGL((gemm128_kernel<TOIST_A_CONV, TOIST_B_ROWK, NS>), grid, dim3(512), LDS, st, d);
+    else if (d.a_kind == TOIST_A_CONVT) hipLaunchKernelGGL((gemm128_kernel<TOIST_A_CONVT, TOIST_B_KROW, NS>), grid, dim3(512), LDS, st, d);
+    else if (d.b_kind == TOIST_B_KROW) hipLaunchKernelGGL((gemm128_kernel<TOIST_A_ROWK, TOIST_B_KROW, NS>), grid, dim3(512), LDS, st, d);
+    else hipLaunchKernelGGL((gemm128_kernel<TOIST_A_ROWK, TOIST_B_ROWK, NS>), grid, dim3(512), LDS, st, d);
     return TOIST_OK;
+}
+
+static int launch_gemm128(const toist_gemm& d, hipStream_t st) {
+    static const int ring = (int)tuning_knob("TOIST_G8_RING", 5);
+    return (ring == 5 && d.K >= 5 * G8_BK) ? launch_gemm128_ring<5>(d, st) : launch_gemm128_ring<4>(d, st);
 }
 
 // gemm128w_kernel (tile code 137): weight gradients -- k-major A (dy [pixels][Co]), B = k-major rows (1x1) or the stride-1 same-size
@@ -2463,10 +2481,12 @@ static bool wgrad_tile_replaced(const toist_gemm& d) {
 static int launch_gemm128w(const toist_gemm& d, hipStream_t st) {
     static std::atomic<unsigned long long> done{0};
     if (!lds_attr_once_flag(done, [] {
-            return hipFuncSetAttribute((const void*)gemm128w_kernel<TOIST_B_KROW>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess &&
-                   hipFuncSetAttribute((const void*)gemm128w_kernel<TOIST_B_CONVX>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS) == hipSuccess;
+            return hipFuncSetAttribute((const void*)gemm128w_kernel<TOIST_B_KROW, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G8_STAGE_BYTES) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)gemm128w_kernel<TOIST_B_CONVX, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G8_STAGE_BYTES) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)gemm128w_kernel<TOIST_B_KROW, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * G8_STAGE_BYTES) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)gemm128w_kernel<TOIST_B_CONVX, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * G8_STAGE_BYTES) == hipSuccess;
         })) {
-        set_last_error("toist_gemm_bf16: cannot enable %d bytes of LDS for the 128x128 weight-gradient kernel", G8_LDS);
+        set_last_error("toist_gemm_bf16: cannot enable %d bytes of LDS for the 128x128 weight-gradient kernel", 5 * G8_STAGE_BYTES);
         return TOIST_EHIP;
     }
     const int tiles = ((d.M + G8_BM - 1) / G8_BM) * ((d.N + G8_BN - 1) / G8_BN);
@@ -2475,8 +2495,16 @@ static int launch_gemm128w(const toist_gemm& d, hipStream_t st) {
     const int nz = dd.batch * dd.split_k;
     dim3 grid((tiles + 7) & ~7, nz, 1);
     if (nz >= 8) grid = dim3(8 * ((nz + 7) / 8) * tiles, 1, 1);     // pairs pinned to XCDs (see the kernel)
-    if (d.b_kind == TOIST_B_CONVX) hipLaunchKernelGGL((gemm128w_kernel<TOIST_B_CONVX>), grid, dim3(512), G8_LDS, st, dd);
-    else hipLaunchKernelGGL((gemm128w_kernel<TOIST_B_KROW>), grid, dim3(512), G8_LDS, st, dd);
+    static const int ring = (int)tuning_knob("TOIST_G8W_RING", 5);
+    const int kper = (d.K / 64 + dd.split_k - 1) / dd.split_k;
+    const bool five = ring == 5 && (long long)(dd.split_k - 1) * kper + 5 <= d.K / 64;      // every slice holds a ring's worth of k-tiles
+    if (d.b_kind == TOIST_B_CONVX) {
+        if (five) hipLaunchKernelGGL((gemm128w_kernel<TOIST_B_CONVX, 5>), grid, dim3(512), 5 * G8_STAGE_BYTES, st, dd);
+        else hipLaunchKernelGGL((gemm128w_kernel<TOIST_B_CONVX, 4>), grid, dim3(512), 4 * G8_STAGE_BYTES, st, dd);
+    } else {
+        if (five) hipLaunchKernelGGL((gemm128w_kernel<TOIST_B_KROW, 5>), grid, dim3(512), 5 * G8_STAGE_BYTES, st, dd);
+        else hipLaunchKernelGGL((gemm128w_kernel<TOIST_B_KROW, 4>), grid, dim3(512), 4 * G8_STAGE_BYTES, st, dd);
+    }
     return TOIST_OK;
 }
 
