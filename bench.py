@@ -479,7 +479,7 @@ def main():
             from toist_amd import functions
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), kernels.tables_beside_graph():     # pointer tables of grouped launches: filled once, beside the captures
                 for _ in range(max(a.warmup, 2)):
                     step()
                 opt.zero_grad(set_to_none=True)

@@ -327,9 +327,11 @@ class CapturedTrainStep:
             if not distributed:
                 # ... then the capture of the same call sequence on the static inputs (nothing executes during capture)
                 self.optimizer.zero_grad(set_to_none=True)
+                from . import kernels
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
-                    ent["loss"] = self._fwd_bwd_opt(ent)
+                with kernels.tables_beside_graph():     # pointer tables of grouped launches: filled once, not on every replay
+                    with torch.cuda.graph(graph, stream=side):
+                        ent["loss"] = self._fwd_bwd_opt(ent)
                 ent["graph"] = graph
                 self.captures += 1
         torch.cuda.current_stream().wait_stream(side)

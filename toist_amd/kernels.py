@@ -97,13 +97,25 @@ def group_table(rows, device):
     """Device toist_group table from host rows [a_ptr, b_ptr, c_off, rscale_off, colsum_off] (csrc/gemm.hip: the rows travel as kernel
     arguments).  Tables are kept: a training loop presents the same pointers step after step (always under hipGraph replay, nearly
     always with the caching allocator), so the 25 fill launches of a step run once -- a table filled before a capture is simply read
-    by the captured launches.  A table filled DURING a capture is not kept (its fill is part of that graph only)."""
+    by the captured launches.  A table needed DURING a capture is filled beside the graph (see below)."""
     key = (str(device), tuple(int(v) for r in rows for v in (list(r) + [0] * (6 - len(r)))))
     hit = _GROUP_TABLES.get(key)
     if hit is not None:
         return hit
     n = len(rows)
     flat = (ctypes.c_int64 * (6 * n))(*key[1])
+    if torch.cuda.is_current_stream_capturing() and FILL_TABLES_OUTSIDE_GRAPH:
+        # The pointers in `rows` are fixed for the life of the graph being captured, so the table is filled NOW, by a launch on a
+        # stream that is not capturing, instead of by a kernel node that would re-write the same 48 bytes per row on every replay
+        # (25 launches per training step).  The table must NOT come from the graph's memory pool: a block handed out during a capture
+        # may have held an earlier temporary of the same capture, whose producer kernels run again at every replay and would overwrite
+        # a table that is no longer re-filled behind them (seen as a memory fault in the first replayed step).  It is carved from an
+        # arena allocated before the capture; when the arena is exhausted the fill stays a graph node.
+        dev = _arena_table(str(device), n)
+        if dev is not None:
+            side = _fill_stream(device)
+            _lib.check(_lib.lib().toist_group_fill(ctypes.cast(flat, ctypes.c_void_p), n, _p(dev), ctypes.c_void_p(side.cuda_stream)), "toist_group_fill")
+            return dev
     dev = torch.empty(n, 6, dtype=torch.int64, device=device)
     _lib.check(_lib.lib().toist_group_fill(ctypes.cast(flat, ctypes.c_void_p), n, _p(dev), _stream()), "toist_group_fill")
     if not torch.cuda.is_current_stream_capturing():
@@ -111,6 +123,68 @@ def group_table(rows, device):
             _GROUP_TABLES.clear()
         _GROUP_TABLES[key] = dev
     return dev
+
+
+# Opt-in (harness.CapturedTrainStep, bench.py): whoever captures sets this around the capture and calls sync_table_fills() before the first
+# replay -- the fill is not ordered against the graph by any stream dependency (a wait on it cannot be recorded into the capture, and
+# synchronising the fill stream during a capture invalidates the capture on ROCm 7.2).  Other captures keep the fill as a graph node.
+FILL_TABLES_OUTSIDE_GRAPH = False
+_TABLE_ARENAS = {}      # device -> [int64 tensor [rows, 6] allocated outside any capture, rows used]
+_TABLE_ARENA_ROWS = 1 << 16     # 3 MB: ~2000 tables of 32 problems
+_FILL_STREAMS = {}
+_RETIRED_ARENAS = []
+
+
+def _arena_table(dev_key, n):
+    ar = _TABLE_ARENAS.get(dev_key)
+    if ar is None or ar[1] + n > ar[0].shape[0]:
+        return None
+    t = ar[0][ar[1]:ar[1] + n]
+    ar[1] += n
+    return t
+
+
+def _arena_prepare(device):
+    """(outside captures) make sure the table arena of `device` has room for a capture's worth of tables"""
+    key = str(device)
+    ar = _TABLE_ARENAS.get(key)
+    if ar is None or ar[1] + 4096 > ar[0].shape[0]:
+        if ar is not None:
+            _RETIRED_ARENAS.append(ar[0])       # captured graphs read their tables from it for as long as they live
+        _TABLE_ARENAS[key] = [torch.empty(_TABLE_ARENA_ROWS, 6, dtype=torch.int64, device=device), 0]
+
+
+def _fill_stream(device):
+    s = _FILL_STREAMS.get(str(device))
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _FILL_STREAMS[str(device)] = s
+    return s
+
+
+def sync_table_fills():
+    """Wait for table fills launched beside a capture (call once after capture_end, before the first replay)."""
+    for s in _FILL_STREAMS.values():
+        s.synchronize()
+
+
+class tables_beside_graph:
+    """with kernels.tables_beside_graph(): <capture(s)> -- pointer tables of grouped launches are filled once, beside the capture, and
+    the fills are joined on exit (TOIST_FILL_OUTSIDE_GRAPH=0 keeps them inside the graph)."""
+
+    def __enter__(self):
+        global FILL_TABLES_OUTSIDE_GRAPH
+        self.old = FILL_TABLES_OUTSIDE_GRAPH
+        FILL_TABLES_OUTSIDE_GRAPH = _os.environ.get("TOIST_FILL_OUTSIDE_GRAPH", "1") != "0"
+        if FILL_TABLES_OUTSIDE_GRAPH and not torch.cuda.is_current_stream_capturing():
+            _arena_prepare(torch.device("cuda", torch.cuda.current_device()))
+        return self
+
+    def __exit__(self, *exc):
+        global FILL_TABLES_OUTSIDE_GRAPH
+        FILL_TABLES_OUTSIDE_GRAPH = self.old
+        sync_table_fills()
+        return False
 
 
 def _raw_stream():
