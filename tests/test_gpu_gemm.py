@@ -666,18 +666,22 @@ def test_gemm128_kernel_convolution_gathers(dev, Nb, H, W, C, Co, R, pad, dil):
             ops.conv2d(x, w, scale=scale, shift=shift, tile=136)
 
 
-@pytest.mark.parametrize("Nb,H,W,C,Co,R,dil,n,min_tiles", [
-    (8, 16, 16, 1024, 256, 1, 1, 9, 1),         # grouped 1x1, pairs pinned to XCDs (9 problems, the last XCD slots empty)
-    (8, 16, 16, 128, 256, 3, 1, 9, 1),          # grouped 3x3 gather: border taps, image boundaries inside k-tiles (256 pixels per image)
-    (4, 24, 16, 128, 128, 3, 2, 3, 1 << 20),    # grouped AND split along K (arena partials + batched fold), dilation 2, fewer than 8 pairs... times the slices
-    (8, 40, 40, 256, 256, 1, 1, 1, 1),          # one problem split along K by the host's heuristic (deferred fold)
-    (2, 20, 12, 128, 128, 3, 1, 2, 1),          # 480 pixels: K % 64 != 0 -> the generic tiles must take it (same call, same answer)
+@pytest.mark.parametrize("Nb,H,W,C,Co,R,dil,n,min_tiles,expect", [
+    (8, 16, 16, 1024, 256, 1, 1, 9, 1, 137),         # grouped 1x1, pairs pinned to XCDs (9 problems, the last XCD slots empty)
+    (8, 16, 16, 128, 256, 3, 1, 9, 1, 137),          # grouped 3x3 gather: border taps, image boundaries inside k-tiles (256 pixels per image)
+    (4, 24, 16, 128, 128, 3, 2, 3, 1 << 20, 137),    # grouped AND split along K (arena partials + batched fold), dilation 2
+    (8, 40, 40, 256, 256, 1, 1, 1, 1, 0),            # one problem split along K by the host's heuristic (deferred fold): 137 or 138, whichever pays
+    (2, 20, 12, 128, 128, 3, 1, 2, 1, -1),           # 480 pixels: K % 64 != 0 -> the generic tiles must take it (same call, same answer)
+    (8, 16, 16, 1024, 256, 1, 1, 16, 1, 138),        # 256 x 128 block tiles: 16 grouped 1x1 problems of 1 x 8 tiles
+    (4, 20, 16, 128, 512, 3, 1, 8, 1, 138),          # ... and the 3x3 gather with 32-pixel k-tiles (rows of 16 pixels, images of 320)
+    (8, 24, 24, 256, 256, 3, 2, 2, 1 << 20, 138),    # ... grouped and split, dilation 2
 ])
-def test_gemm128w_weight_gradient_kernel(dev, Nb, H, W, C, Co, R, dil, n, min_tiles):
+def test_gemm128w_weight_gradient_kernel(dev, Nb, H, W, C, Co, R, dil, n, min_tiles, expect):
     """csrc/gemm.hip gemm128w_kernel (tile code 137: both operands k-major through ds_read_b64_tr_b16, table-free 3x3 gather, f32
     alpha * rscale * acc += into the gradient slice or k-slice partials, (problem, slice) pairs pinned to XCDs) as the dispatcher picks
-    it for single and grouped weight gradients, against the 64 x 64 tiles on the same calls: same products in f32, another summation
-    order.  The first four cases must really run the new kernel (toist_gemm_pick_tile says so)."""
+    it for single and grouped weight gradients, and gemm256w_kernel (tile 138: the same with 256 x 128 block tiles, 32-pixel k-tiles, no
+    k-fold), against the 64 x 64 tiles on the same calls: same products in f32, another summation order.  `expect` = the tile
+    toist_gemm_pick_tile must report for the call (0: either of the two, -1: neither)."""
     from toist_amd import kernels as k, ops
     g = torch.Generator().manual_seed(Nb * H + C + R)
     pad = dil * (R // 2)
@@ -706,16 +710,18 @@ def test_gemm128w_weight_gradient_kernel(dev, Nb, H, W, C, Co, R, dil, n, min_ti
 
     base = torch.randn(flat.shape, generator=g).to(dev) * 0.1          # accumulate = True: the kernel adds to what is there
     ref = run(65)
-    picked = []
-    k.PROFILE = {"key": (137, k.A_KROW, k.B_CONVX if R == 3 else k.B_KROW), "records": [], "other": {}}
+    bk = k.B_CONVX if R == 3 else k.B_KROW
+    k.PROFILE = {"key": frozenset({(137, k.A_KROW, bk), (138, k.A_KROW, bk)}), "records": [], "other": {}}
     try:
         got = run(0)
-        picked = list(k.PROFILE["records"])
+        picked = [r[3][0] for r in k.PROFILE["records"]]
     finally:
         k.PROFILE = None
     assert torch.equal(got[:16], base[:16]) and torch.equal(got[-48:], base[-48:])               # nothing written outside the slices
     assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
-    if (Nb * H * W) % 64 == 0:
-        assert len(picked) == 1, "the dispatcher did not pick gemm128w_kernel"
+    if expect == -1:
+        assert picked == [] and torch.equal(got, ref)
+    elif expect == 0:
+        assert len(picked) == 1
     else:
-        assert len(picked) == 0 and torch.equal(got, ref)
+        assert picked == [expect], f"the dispatcher picked {picked}"

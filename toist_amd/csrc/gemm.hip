@@ -1669,6 +1669,221 @@ __global__ __launch_bounds__(512, 2) void gemm128w_kernel(const toist_gemm p) {
     }
 }
 
+// gemm256w_kernel (tile code 138): gemm128w_kernel with a 256 x 128 block tile.  The 128 x 128 weight-gradient kernel is bound by the
+// L2 -> LDS stream (26 B/clk/CU with MFMAs and fragment reads switched off, profiles/r03_gemm128w_ablation.txt), so the next factor is flop
+// per staged byte: 256 x 128 needs (256 + 128) / (256 * 128) = 3/4 of the bytes per flop, and layer 3's 256 output channels become ONE row of
+// tiles (the grouped 3x3 launch: 18 instead of 36 workgroups per problem, 2 rounds per XCD instead of 4).  8 waves = 4 x 2 of 64 x 64, no k-split
+// (so no fold in the epilogue); k-tiles of 32 pixels -- [32][256] + [32][128] bf16 = 24 KiB per ring slot, 6 slots, five k-tiles in flight --
+// keep the 16 MFMAs per wave and barrier of the 128 x 128 kernel.
+constexpr int G9_BM = 256, G9_BN = 128, G9_BK = 32, G9_NS = 6;
+constexpr int G9_A_BYTES = G9_BM * G9_BK * 2, G9_STAGE_BYTES = (G9_BM + G9_BN) * G9_BK * 2;     // 16 KiB, 24 KiB
+constexpr int G9_LDS = G9_NS * G9_STAGE_BYTES;                                                 // 144 KiB
+
+template <int BKD>
+__global__ __launch_bounds__(512, 2) void gemm256w_kernel(const toist_gemm p) {
+    constexpr int BM = G9_BM, BN = G9_BN, BK = G9_BK, NS = G9_NS, WM = 64, WN = 64, FM = 4, FN = 4;
+    constexpr bool GATHER = BKD == TOIST_B_CONVX;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c16 = lane & 15;
+    const int M = p.M, N = p.N, K = p.K;
+    const int nt_n = (N + BN - 1) / BN, nt_m = (M + BM - 1) / BM;
+    const int tiles = nt_m * nt_n;
+    const int nz = p.batch * p.split_k;
+    int z, tile_id;                                     // (problem, k-slice) pairs pinned to XCDs from 8 pairs on (see gemm128w_kernel)
+    if (nz >= 8) {
+        const int xcd = (int)(blockIdx.x & 7), sq = (int)(blockIdx.x >> 3);
+        const int zi = sq / tiles;
+        z = xcd + 8 * zi;
+        tile_id = sq - zi * tiles;
+        if (z >= nz) return;
+    } else {
+        z = blockIdx.y;
+        tile_id = (int)(blockIdx.x & 7) * ((tiles + 7) >> 3) + (int)(blockIdx.x >> 3);
+        if (tile_id >= tiles) return;
+    }
+    const int tile_m = tile_id / nt_n, tile_n = tile_id - tile_m * nt_n;     // the N tiles of an M row run together: they share the A k-tiles
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int bz = z / p.split_k, ksl = z - bz * p.split_k;
+    const toist_operand ob = p.b;
+    const bf16_t* a_ptr = (const bf16_t*)p.a.ptr;
+    const bf16_t* b_ptr = (const bf16_t*)ob.ptr;
+    long long coff = 0, rs_off = 0;
+    if (p.group) {
+        const toist_group gq = p.group[bz];
+        a_ptr = (const bf16_t*)gq.a;
+        b_ptr = (const bf16_t*)gq.b;
+        coff = gq.c_off;
+        rs_off = gq.rscale_off;
+    }
+    const int lda = p.a.ld, ldb = GATHER ? ob.SC : ob.ld;
+    const int k64 = K / 64;                             // the k-slices are cut in 64-row units (the host sizes its partials with that rule)
+    const int kper = (k64 + p.split_k - 1) / p.split_k;
+    const int kt_beg = 2 * ksl * kper;
+    const int T = 2 * (((ksl + 1) * kper < k64 ? (ksl + 1) * kper : k64) - ksl * kper);     // 32-row k-tiles of this slice
+    if (T <= 0) return;
+    int tap_dy = 0, tap_dx = 0, c0 = n0;
+    if (GATHER) {
+        const int tap = n0 / ob.SC;
+        const int r = tap / ob.S, s_ = tap - r * ob.S;
+        c0 = n0 - tap * ob.SC;
+        tap_dy = r * ob.dil - ob.pad;
+        tap_dx = s_ * ob.dil - ob.pad;
+    }
+    const i32x4_t rsA = make_rsrc(a_ptr);
+    const i32x4_t rsB = make_rsrc(GATHER ? (const void*)(b_ptr + ((long long)tap_dy * ob.SW + tap_dx) * ob.SC) : (const void*)b_ptr);
+    const unsigned lds0 = (unsigned)(size_t)lds_raw;
+
+    // ---- DMA pieces per wave and k-tile: two of A ([32 k][256 m]), one of B ([32 k][128 n]) ----
+    int va[2], vb, py = 0, px = 0;
+    const int W = ob.PW, H = ob.PH;
+    const int q32 = GATHER ? BK / W : 0, r32 = GATHER ? BK - q32 * W : 0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int pch = (it * 8 + wave) * 64 + lane;
+        const int krow = pch / (BM / 8), rc = swz_m<BM>(krow, pch % (BM / 8));
+        const int mm = m0 + rc * 8;
+        va[it] = mm < M ? (mm + krow * lda) * 2 : OOB;
+    }
+    {
+        const int pch = wave * 64 + lane;
+        const int krow = pch / (BN / 8), rc = swz_m<BN>(krow, pch % (BN / 8));
+        const int nn = n0 + rc * 8;
+        vb = nn < N ? ((GATHER ? c0 + rc * 8 : nn) + krow * ldb) * 2 : OOB;
+        if (GATHER) {
+            const int pix = (kt_beg * BK + krow) % (H * W);
+            py = pix / W;
+            px = pix - py * W;
+        }
+    }
+    int i_t = 0;
+    auto issue = [&](const int slot) {
+        const unsigned da = lds0 + (unsigned)(slot * G9_STAGE_BYTES) + (unsigned)wave * 1024u, db = lds0 + (unsigned)(slot * G9_STAGE_BYTES + G9_A_BYTES) + (unsigned)wave * 1024u;
+        const int kt = kt_beg + i_t;
+        const int soa = kt * BK * lda * 2, sob = kt * BK * ldb * 2;
+        int vbe = vb;
+        if (GATHER) {
+            const int sy = py + tap_dy, sx = px + tap_dx;
+            if (sy < 0 || sy >= H || sx < 0 || sx >= W) vbe = OOB;
+            px += r32;
+            py += q32;
+            if (px >= W) { px -= W; ++py; }
+            while (py >= H) py -= H;
+        }
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, %8 offen lds\n\t"
+                     "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %6, %8 offen lds\n\t"
+                     "s_mov_b32 m0, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %7, %9 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(da), "s"(da + 8192u), "v"(va[0]), "v"(va[1]), "v"(vbe), "s"(rsA), "s"(rsB), "s"(__builtin_amdgcn_readfirstlane(soa)),
+                       "s"(__builtin_amdgcn_readfirstlane(sob)), "s"(db)
+                     : "memory");
+        ++i_t;
+    };
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) issue(i);         // a slice holds at least NS k-tiles (gemm256w_applies)
+
+    int a_base[FM][2], b_base[FN][2];
+    {
+        const int k = 8 * g + (c16 >> 2), sub = (c16 & 1) * 4;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int rc = ((wm * WM + i * 16) >> 3) + ((c16 & 3) >> 1);
+            a_base[i][0] = (k * BM + swz_m<BM>(k, rc) * 8 + sub) * 2;
+            a_base[i][1] = ((k + 4) * BM + swz_m<BM>(k + 4, rc) * 8 + sub) * 2;
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int rc = ((wn * WN + j * 16) >> 3) + ((c16 & 3) >> 1);
+            b_base[j][0] = G9_A_BYTES + (k * BN + swz_m<BN>(k, rc) * 8 + sub) * 2;
+            b_base[j][1] = G9_A_BYTES + ((k + 4) * BN + swz_m<BN>(k + 4, rc) * 8 + sub) * 2;
+        }
+    }
+    auto load_frags = [&](G8Frags& f, auto slotc) {
+        constexpr int SLOT = decltype(slotc)::value;
+        typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            union { struct { s16x4_t a, b; } h; bf16x8_t v; } u;
+            u.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_raw + a_base[i][0] + SLOT * G9_STAGE_BYTES));
+            u.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_raw + a_base[i][1] + SLOT * G9_STAGE_BYTES));
+            f.a[i] = u.v;
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            union { struct { s16x4_t a, b; } h; bf16x8_t v; } u;
+            u.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_raw + b_base[j][0] + SLOT * G9_STAGE_BYTES));
+            u.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds_raw + b_base[j][1] + SLOT * G9_STAGE_BYTES));
+            f.b[j] = u.v;
+        }
+    };
+
+    f32x4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    wait_vm<3 * (NS - 2)>();                            // k-tile 0 landed (three pieces per k-tile and wave)
+    __builtin_amdgcn_s_barrier();
+    G8Frags fa, fb;
+    load_frags(fa, std::integral_constant<int, 0>{});
+    int t = 0;
+    auto step = [&](auto slotc, G8Frags& cur, G8Frags& nxt) {
+        constexpr int SLOT = decltype(slotc)::value;
+        // this wave's loads younger than k-tile t + 1: k-tiles t + 2 .. t + NS - 2
+        if (t + 4 < T) wait_vm<9>();
+        else if (t + 3 < T) wait_vm<6>();
+        else if (t + 2 < T) wait_vm<3>();
+        else wait_vm<0>();
+        lds_barrier();
+        if (t + NS - 1 < T) issue((SLOT + NS - 1) % NS);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(cur.a[i]));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(cur.b[j]));
+        if (t + 1 < T) load_frags(nxt, std::integral_constant<int, (SLOT + 1) % NS>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.b[j], cur.a[i], acc[i][j], 0, 0, 0);
+        ++t;
+    };
+    auto run = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        if constexpr (S % 2 == 0) step(std::integral_constant<int, S % NS>{}, fa, fb);
+        else step(std::integral_constant<int, S % NS>{}, fb, fa);
+    };
+#pragma unroll 1
+    while (t + NS <= T) static_for<NS>(run);
+    static_for<NS - 1>([&](auto sc) { if (t < T) run(sc); });
+
+    // ---- f32 rows straight from the fragments: lane = row c16, 4 consecutive columns (16 bytes) ----
+    const toist_epilogue& e = p.epi;
+    const bool partial = p.split_k > 1;
+    float* const outp = partial ? p.workspace + ((size_t)bz * p.split_k + ksl) * M * N : (float*)p.c + coff;
+    const int ldo = partial ? N : p.ldc;
+    const float* const rsc = (!partial && e.rscale) ? e.rscale + rs_off : nullptr;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * WM + i * 16 + c16;
+        const float rs = partial ? 1.f : (rsc && m < M ? e.alpha * rsc[m] : e.alpha);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * WN + j * 16 + g * 4;
+            if (m >= M || n >= N) continue;
+            f32x4_t v = acc[i][j];
+            float* cp = outp + (size_t)m * ldo + n;
+            if (!partial) {
+                v *= rs;
+                if (e.accumulate) v += *reinterpret_cast<const f32x4_t*>(cp);
+            }
+            *reinterpret_cast<f32x4_t*>(cp) = v;
+        }
+    }
+}
+
 #endif  // GEMM_UNIT (128x128 kernels)
 
 static bool aligned16(const void* p) { return (((size_t)p) & 15) == 0; }
@@ -2472,10 +2687,47 @@ static bool gemm128w_pays(const toist_gemm& d) {
     return wgs >= 128 && (d.M % 64) == 0 && (d.N % 128) == 0;
 }
 
+// gemm256w_kernel (tile code 138): what gemm128w_kernel takes, with M a multiple of 256 and k-slices of at least 6 x 32 rows
+static bool gemm256w_applies(const toist_gemm& d) {
+    if (!gemm128w_applies(d) || (d.M % G9_BM) != 0 || (d.N % G9_BN) != 0) return false;
+    const int split = clamp_split(d.split_k, d.K, 65);
+    const int k64 = d.K / 64, kper = (k64 + split - 1) / split;
+    return 2 * (k64 - (split - 1) * kper) >= G9_NS;      // the last (shortest) slice fills the ring
+}
+
+static bool gemm256w_pays(const toist_gemm& d) {
+    static const int on = (int)tuning_knob("TOIST_GEMM256W", 1);
+    if (!on || !gemm256w_applies(d)) return false;
+    const long long wgs = (long long)(d.M / G9_BM) * (d.N / G9_BN) * d.batch * clamp_split(d.split_k, d.K, 65);
+    return wgs >= 128;
+}
+
+static int launch_gemm256w(const toist_gemm& d, hipStream_t st) {
+    static std::atomic<unsigned long long> done{0};
+    if (!lds_attr_once_flag(done, [] {
+            return hipFuncSetAttribute((const void*)gemm256w_kernel<TOIST_B_KROW>, hipFuncAttributeMaxDynamicSharedMemorySize, G9_LDS) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)gemm256w_kernel<TOIST_B_CONVX>, hipFuncAttributeMaxDynamicSharedMemorySize, G9_LDS) == hipSuccess;
+        })) {
+        set_last_error("toist_gemm_bf16: cannot enable %d bytes of LDS for the 256x128 weight-gradient kernel", G9_LDS);
+        return TOIST_EHIP;
+    }
+    toist_gemm dd = d;
+    dd.split_k = clamp_split(d.split_k, d.K, 65);
+    const int tiles = (d.M / G9_BM) * (d.N / G9_BN);
+    const int nz = dd.batch * dd.split_k;
+    dim3 grid((tiles + 7) & ~7, nz, 1);
+    if (nz >= 8) grid = dim3(8 * ((nz + 7) / 8) * tiles, 1, 1);
+    if (d.b_kind == TOIST_B_CONVX) hipLaunchKernelGGL((gemm256w_kernel<TOIST_B_CONVX>), grid, dim3(512), G9_LDS, st, dd);
+    else hipLaunchKernelGGL((gemm256w_kernel<TOIST_B_KROW>), grid, dim3(512), G9_LDS, st, dd);
+    return TOIST_OK;
+}
+
 // the big generic tiles the host asks for on (grouped) weight gradients -- and the automatic choice -- give way to the 128x128 kernel
-static bool wgrad_tile_replaced(const toist_gemm& d) {
+static int wgrad_tile_replaced(const toist_gemm& d) {       // 0 = no, else 137 / 138
     const int t = d.tile & 255;
-    return (t == 0 || t == 129 || t == 130 || t == 134) && d.a_kind == TOIST_A_KROW && gemm128w_pays(d);
+    if (!((t == 0 || t == 129 || t == 130 || t == 134) && d.a_kind == TOIST_A_KROW)) return 0;
+    if (gemm256w_pays(d)) return 138;
+    return gemm128w_pays(d) ? 137 : 0;
 }
 
 static int launch_gemm128w(const toist_gemm& d, hipStream_t st) {
@@ -2843,7 +3095,7 @@ extern "C" int toist_gemm_pick_tile(const toist_gemm* desc) {
     toist_gemm d = *desc;
     if (d.batch <= 0) d.batch = 1;
     if (d.split_k <= 0) d.split_k = 1;
-    if (wgrad_tile_replaced(d)) return 137;
+    if (const int wt = wgrad_tile_replaced(d)) return wt;
     if (desc->tile & 255) return desc->tile & 255;
     if (gemm128_pays(d)) return 136;                    // the order of toist_gemm_bf16's dispatch
     if (d.a_kind == TOIST_A_CONVT && conv3_applies(d)) return 131;
@@ -2857,7 +3109,7 @@ extern "C" int toist_gemm_effective_split(const toist_gemm* desc) {
     toist_gemm d = *desc;
     if (d.batch <= 0) d.batch = 1;
     if (d.workspace == nullptr) d.workspace = (float*)16;      // asked BEFORE the caller sizes the scratch: "a workspace will be there"
-    const int tile = wgrad_tile_replaced(d) ? 137 : (desc->tile & 255) ? (desc->tile & 255) : auto_tile(*desc);
+    const int tile = wgrad_tile_replaced(d) ? 137 : (desc->tile & 255) ? (desc->tile & 255) : auto_tile(*desc);     // 137 and 138 slice alike
     return clamp_split(desc->split_k, desc->K, tile);
 }
 
@@ -2976,7 +3228,8 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
     int tile = d.tile & 255;
     const int ring = d.tile >> 8;   // 0 = pick; else slots of the DMA ring (2..4)
     if (tile == 137) TOIST_REQUIRE(gemm128w_applies(d), "toist_gemm_bf16: the 128x128 weight-gradient kernel does not cover this call");
-    if (wgrad_tile_replaced(d)) tile = 137;
+    if (tile == 138) TOIST_REQUIRE(gemm256w_applies(d), "toist_gemm_bf16: the 256x128 weight-gradient kernel does not cover this call");
+    if (const int wt = wgrad_tile_replaced(d)) tile = wt;
     if (tile == 0) tile = auto_tile(d);
     d.split_k = clamp_split(d.split_k, d.K, tile);
     // tile codes: 64 = 64x64x32, 65 = 64x64x64, 128 = 128x128x32, 129 = 128x128x64, 130 = 128x64x64, 132 = 128x32x64, 133 = 32x128x64
@@ -2988,6 +3241,7 @@ extern "C" int toist_gemm_bf16(const toist_gemm* desc, void* stream) {
         case 65: rc = launch_tiles_b(tile, d, ring, st); break;
         case 130: case 134: rc = launch_tiles_c(tile, d, ring, st); break;
         case 137: rc = launch_gemm128w(d, st); break;
+        case 138: rc = launch_gemm256w(d, st); break;
         default: rc = launch_tiles_a(tile, d, ring, st); break;
     }
     if (rc != TOIST_OK) return rc;
