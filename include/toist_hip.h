@@ -257,8 +257,8 @@ TOIST_API int toist_criterion_bwd(const float* logits, const float* boxes, const
  * Contrastive-alignment loss for all decoder layers at once.  Replaces SetCriterion.loss_contrastive_align
  * (/root/reference/models/mdetr.py:601-666) given the device-resident assignment of toist_matcher.
  *   proj_queries [L,B,Q,D] f32, proj_tokens [B,T,D] f32: the L2-normalised projections (mdetr.py:429-433)
- *   tok_mask     uint64 [sum_i T_i, 2]: bit t of row r = token t belongs to a positive span of target r
- *                (what the reference derives on the host from tokens_positive + char_to_token, :614-643; T <= 128)
+ *   tok_mask     uint64 [sum_i T_i, 4]: bit t of row r = token t belongs to a positive span of target r
+ *                (what the reference derives on the host from tokens_positive + char_to_token, :614-643; T <= 256 = max_text_len)
  *   fwd: losses [L] f32 += loss_contrastive_align of layer l (caller zeroes);  temperature = --temperature_NCE
  *   bwd: upstream [L]; dproj_queries [L,B,Q,D] fully written; dproj_tokens [B,T,D] += (caller zeroes)
  * toist_l2norm_fwd/bwd: F.normalize(x, p=2, dim=-1) on fp32 rows and its backward (dx from x, dy).

@@ -65,17 +65,20 @@ def test_reference_golden_losses_with_contrastive_align(dev):
         assert abs(float(v) - ref[k_]) <= 1e-4 * abs(ref[k_]) + 1e-5, f"no-aux {k_}: {float(v)} vs reference {ref[k_]}"
 
 
-def test_contrastive_align_gradients_vs_oracle(dev):
+@pytest.mark.parametrize("T", [7, 200])
+def test_contrastive_align_gradients_vs_oracle(dev, T):
     """d loss / d proj_queries, d proj_tokens of the device kernel against fp32 autograd through the oracle's restatement
-    (oracle/model_ref.loss_contrastive_align, pinned to the reference by criterion.npz); l2 normalisation forward / backward too."""
+    (oracle/model_ref.loss_contrastive_align, pinned to the reference by criterion.npz); l2 normalisation forward / backward too.
+    T = 200: captions beyond 128 tokens (the reference pads to max_text_len = 256 at most, mdetr.py:601-666) -- four mask words per
+    target, token projections read from L2 instead of LDS, spans in the upper words."""
     from oracle import model_ref
     from toist_amd.mdetr import l2_normalize
     d, sizes, targets = _golden_contrastive_inputs(dev)
     logits, boxes = torch.from_numpy(d["pred_logits"]), torch.from_numpy(d["pred_boxes"])
     g = torch.Generator().manual_seed(5)
     raw_q = torch.randn(6, 2, 100, 64, generator=g).requires_grad_(True)
-    raw_t = torch.randn(2, 7, 64, generator=g).requires_grad_(True)
-    spans = [[[(1, 2)], [(2, 3)], [(1, 1), (4, 4)]][:s] for s in sizes]
+    raw_t = torch.randn(2, T, 64, generator=g).requires_grad_(True)
+    spans = [([[(1, 2)], [(2, 3)], [(1, 1), (4, 4)]] if T == 7 else [[(1, 2), (127, 129)], [(150, 152)], [(1, 1), (190, 199)]])[:s] for s in sizes]
     pm = torch.from_numpy(d["pm"])
     w = torch.tensor([0.3, 1.0, 0.7, 1.3, 0.9, 1.1])
     # oracle

@@ -18,7 +18,10 @@
 namespace toist {
 
 static constexpr int CA_THREADS = 256;
-static constexpr int CA_MAX_TOK = 128;   // 2 x 64-bit mask words per target
+static constexpr int CA_MW = 4;          // 64-bit mask words per target row
+static constexpr int CA_MAX_TOK = 64 * CA_MW;   // 256 = the reference's max_text_len (models/mdetr.py:601-666 pads captions to it at most)
+static constexpr int CA_LDS_MAX = 160 * 1024 - 256;   // dynamic LDS the kernels may ask for (they also hold a few static words)
+static constexpr int CA_STAGE_TOK = 128; // token projections are staged in LDS up to this many tokens, read from L2 beyond (LDS: Q x T f32 logits)
 
 __device__ __forceinline__ float ca_block_sum(float v, float* red) {
     v = wave_sum(v);
@@ -36,7 +39,7 @@ template <int MODE>
 __global__ __launch_bounds__(CA_THREADS) void contrastive_kernel(
     const float* __restrict__ pq,            // [L,B,Q,D] normalised query projections
     const float* __restrict__ pt,            // [B,T,D]   normalised token projections
-    const unsigned long long* __restrict__ tok_mask,   // [sum targets, 2] token bits of every target row
+    const unsigned long long* __restrict__ tok_mask,   // [sum targets, CA_MW] token bits of every target row
     const int* __restrict__ tgt_off, const int* __restrict__ match_off, const long long* __restrict__ src_idx,
     const long long* __restrict__ tgt_idx, const float* __restrict__ num_boxes, int L, int B, int Q, int T, int D,
     float inv_temp,
@@ -46,10 +49,12 @@ __global__ __launch_bounds__(CA_THREADS) void contrastive_kernel(
     float* __restrict__ dpt) {               // MODE 1: [B,T,D] (+=, caller zeroes)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int DP = D + 1;
-    unsigned long long* qm = reinterpret_cast<unsigned long long*>(sm);   // [Q][2] token bits of the target matched to query q (0 = unmatched)
-    float* sq = sm + 4 * Q;                  // [Q][DP]
-    float* st = sq + Q * DP;                 // [T][DP]
-    float* lg = st + T * DP;                 // [Q][T]  logits, then d(logits)
+    const bool staged = T <= CA_STAGE_TOK;
+    const int TP = staged ? DP : D;          // row pitch of the token projections as read below
+    unsigned long long* qm = reinterpret_cast<unsigned long long*>(sm);   // [Q][CA_MW] token bits of the target matched to query q (0 = unmatched)
+    float* sq = sm + 2 * CA_MW * Q;          // [Q][DP]
+    float* st_lds = sq + Q * DP;             // [T][DP] when staged
+    float* lg = st_lds + (staged ? T * DP : 0);   // [Q][T]  logits, then d(logits)
     float* row_lse = lg + Q * T;             // [Q]
     float* col_lse = row_lse + Q;            // [T]
     float* col_np = col_lse + T;             // [T] positives per token
@@ -57,29 +62,31 @@ __global__ __launch_bounds__(CA_THREADS) void contrastive_kernel(
     const int lb = blockIdx.x, l = lb / B, b = lb - l * B, tid = threadIdx.x;
     const int Mtot = match_off[B];
 
-    for (int i = tid; i < 2 * Q; i += CA_THREADS) qm[i] = 0ull;
+    for (int i = tid; i < CA_MW * Q; i += CA_THREADS) qm[i] = 0ull;
     const float* gq = pq + (size_t)(l * B + b) * Q * D;
     const float* gt = pt + (size_t)b * T * D;
     for (int i = tid; i < Q * D; i += CA_THREADS) sq[(i / D) * DP + (i % D)] = gq[i];
-    for (int i = tid; i < T * D; i += CA_THREADS) st[(i / D) * DP + (i % D)] = gt[i];
+    if (staged)
+        for (int i = tid; i < T * D; i += CA_THREADS) st_lds[(i / D) * DP + (i % D)] = gt[i];
+    const float* const st = staged ? st_lds : gt;
     __syncthreads();
     for (int m = match_off[b] + tid; m < match_off[b + 1]; m += CA_THREADS) {
         const int q = (int)src_idx[(size_t)l * Mtot + m];
         const size_t t = (size_t)tgt_off[b] + (size_t)tgt_idx[(size_t)l * Mtot + m];
-        qm[2 * q] = tok_mask[2 * t];          // a query is matched to at most one target
-        qm[2 * q + 1] = tok_mask[2 * t + 1];
+#pragma unroll
+        for (int w = 0; w < CA_MW; ++w) qm[CA_MW * q + w] = tok_mask[CA_MW * t + w];          // a query is matched to at most one target
     }
     for (int i = tid; i < Q * T; i += CA_THREADS) {
         const int q = i / T, t = i - q * T;
         const float* a = sq + q * DP;
-        const float* c = st + t * DP;
+        const float* c = st + t * TP;
         float acc = 0.f;
         for (int d = 0; d < D; ++d) acc += a[d] * c[d];
         lg[i] = acc * inv_temp;
     }
     __syncthreads();
 
-    auto bit = [&](int q, int t) -> bool { return (qm[2 * q + (t >> 6)] >> (t & 63)) & 1ull; };
+    auto bit = [&](int q, int t) -> bool { return (qm[CA_MW * q + (t >> 6)] >> (t & 63)) & 1ull; };
     float part = 0.f;
     // box -> token (rows)
     for (int q = tid; q < Q; q += CA_THREADS) {
@@ -124,7 +131,9 @@ __global__ __launch_bounds__(CA_THREADS) void contrastive_kernel(
     for (int i = tid; i < Q * T; i += CA_THREADS) {
         const int q = i / T, t = i - q * T;
         const float v = lg[i];
-        const int npr = __popcll(qm[2 * q]) + __popcll(qm[2 * q + 1]);
+        int npr = 0;
+#pragma unroll
+        for (int w = 0; w < CA_MW; ++w) npr += __popcll(qm[CA_MW * q + w]);
         const float pm = bit(q, t) ? 1.f : 0.f;
         float g = 0.f;
         if (npr > 0) g += __expf(v - row_lse[q]) - pm / ((float)npr + 1e-6f);
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(CA_THREADS) void contrastive_kernel(
     for (int i = tid; i < Q * D; i += CA_THREADS) {
         const int q = i / D, d = i - q * D;
         float acc = 0.f;
-        for (int t = 0; t < T; ++t) acc += lg[q * T + t] * st[t * DP + d];
+        for (int t = 0; t < T; ++t) acc += lg[q * T + t] * st[t * TP + d];
         oq[i] = acc;
     }
     float* ot = dpt + (size_t)b * T * D;
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(CA_THREADS) void contrastive_kernel(
 }
 
 static size_t contrastive_lds(int Q, int T, int D) {
-    const size_t f = (size_t)4 * Q + (size_t)Q * (D + 1) + (size_t)T * (D + 1) + (size_t)Q * T + Q + 2 * (size_t)T;
+    const size_t f = (size_t)2 * CA_MW * Q + (size_t)Q * (D + 1) + (T <= CA_STAGE_TOK ? (size_t)T * (D + 1) : 0) + (size_t)Q * T + Q + 2 * (size_t)T;
     return f * sizeof(float);
 }
 
@@ -184,14 +193,14 @@ static int contrastive_launch_ok(int L, int B, int Q, int T, int D, size_t* lds)
     TOIST_REQUIRE(L > 0 && B > 0 && Q > 0 && T > 0 && D > 0, "toist_contrastive: bad shape L=%d B=%d Q=%d T=%d D=%d", L, B, Q, T, D);
     TOIST_REQUIRE(T <= CA_MAX_TOK, "toist_contrastive: %d tokens (the token masks hold %d)", T, CA_MAX_TOK);
     *lds = contrastive_lds(Q, T, D);
-    TOIST_REQUIRE(*lds <= 160 * 1024, "toist_contrastive: Q=%d T=%d D=%d needs %zu B of LDS (> 160 KiB)", Q, T, D, *lds);
+    TOIST_REQUIRE(*lds <= CA_LDS_MAX, "toist_contrastive: Q=%d T=%d D=%d needs %zu B of LDS (> %d)", Q, T, D, *lds, CA_LDS_MAX);
     if (*lds > 64 * 1024) {
         static std::atomic<unsigned long long> done{0};     // one bit per device
         if (!lds_attr_once_flag(done, [] {
-                return hipFuncSetAttribute((const void*)contrastive_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-                       hipFuncSetAttribute((const void*)contrastive_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                return hipFuncSetAttribute((const void*)contrastive_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, CA_LDS_MAX) == hipSuccess &&
+                       hipFuncSetAttribute((const void*)contrastive_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CA_LDS_MAX) == hipSuccess;
             })) {
-            set_last_error("toist_contrastive: cannot enable 160 KiB of LDS");
+            set_last_error("toist_contrastive: cannot enable %d bytes of LDS", CA_LDS_MAX);
             return TOIST_EHIP;
         }
     }

@@ -1346,9 +1346,12 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
     wait_vm<0>();
     lds_barrier();                                       // every wave is done with the ring
 
-    // ---- epilogue operands first: per-column vectors, residual and mask rows of this lane's 2 x 4 fragments are all REQUESTED before
-    // anything waits for one of them (fetched fragment by fragment they cost a dependent L2 / HBM round trip each: 7.2k cycles of
-    // epilogue for 15k of k-loop on 12800 x 256 x 1024, 16k with residual + mask -- tools/r3/gemm128_phases.py) ----
+    // ---- epilogue: rows through LDS, 16-byte accesses.  Finished where the MFMA leaves them (lane = row c16, 4 columns), output, residual
+    // and mask move as 8-byte pieces 32 bytes apart -- 24 vector-memory instructions per lane, each touching a quarter of 16 cache lines:
+    // 7.2k cycles of epilogue for 15k of k-loop on 12800 x 256 x 1024, 15k with residual + mask (tools/r3/gemm128_phases.py).  Instead
+    // the two fragment rows a wave owns after the k-fold are laid out as [64 rows][128 columns] f32 in the idle ring (both k-half groups
+    // at once), and every thread finishes 8 consecutive columns of a row: 16 lanes = one 256-byte row segment.  Residual / mask chunks
+    // of all four passes are requested before the fold.
     const toist_epilogue& e = p.epi;
     const bf16_t* const resp = (const bf16_t*)e.res;
     const bf16_t* const auxp = (const bf16_t*)e.aux;
@@ -1356,22 +1359,37 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
     const int act = e.act;
     const float alpha = e.alpha;
     const bool masked = act == TOIST_ACT_MASK_POS;
-    float4 sc[FN], sh[FN];
-    uint2 rr[2][FN], xx[2][FN];
+    constexpr int LDT = BN + 4;                          // f32 pitch of a band row (+4: conflict-free f32x4 writes)
+    const int c8 = tid & 15, r_lo = tid >> 4;            // this thread's column chunk and its row inside a 32-row half band
+    const int ncol = n0 + c8 * 8;
+    const bool col_ok = ncol < N;                        // N % 8 == 0: a chunk is whole or absent
+    float mul[8], add[8];
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * WN + j * 16 + g * 4;
-        const bool nok = n < N;                          // N % 8 == 0: the 4 columns are valid or absent together
-        sc[j] = (e.scale && nok) ? *reinterpret_cast<const float4*>(e.scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-        sh[j] = (e.shift && nok) ? *reinterpret_cast<const float4*>(e.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < 8; ++j) { mul[j] = alpha; add[j] = 0.f; }
+    if (col_ok) {
+        if (e.scale) {
+            float t8[8];
+            load_cols8(e.scale + ncol, 8, t8, 1.f);
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int m = m0 + wm * WM + (kh * 2 + ii) * 16 + c16;
-            const bool ok = nok && m < M;
-            rr[ii][j] = (resp && ok) ? *reinterpret_cast<const uint2*>(resp + (size_t)m * e.ldr + n) : make_uint2(0u, 0u);
-            xx[ii][j] = (masked && ok) ? *reinterpret_cast<const uint2*>(auxp + (size_t)m * e.ldaux + n) : make_uint2(0u, 0u);
+            for (int j = 0; j < 8; ++j) mul[j] = alpha * t8[j];
         }
+        if (e.shift) load_cols8(e.shift + ncol, 8, add, 0.f);
     }
+    // pass (ii, q): band row 32 q + r_lo of the [64][128] layout = fragment row 2 q + ii of wave row (r_lo >> 4)
+    int mrow[2][2];
+    uint4 rres[2][2], raux[2][2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = m0 + (r_lo >> 4) * WM + (q * 2 + ii) * 16 + (r_lo & 15);
+            mrow[ii][q] = m;
+            rres[ii][q] = raux[ii][q] = make_uint4(0u, 0u, 0u, 0u);
+            if (col_ok && m < M) {
+                if (resp) rres[ii][q] = *reinterpret_cast<const uint4*>(resp + (size_t)m * e.ldr + ncol);
+                if (masked) raux[ii][q] = *reinterpret_cast<const uint4*>(auxp + (size_t)m * e.ldaux + ncol);
+            }
+        }
     // ---- fold the k-halves half and half: wave kh keeps fragment rows {2 kh, 2 kh + 1}, hands the other two to its partner (same wm, wn) ----
     float* const xch = reinterpret_cast<float*>(lds_raw);
 #pragma unroll
@@ -1389,35 +1407,38 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
             const f32x4_t o = *reinterpret_cast<const f32x4_t*>(xch + ((partner * 8 + ii * 4 + j) * 64 + lane) * 4);
             fin[ii][j] = (kh == 0 ? acc[ii][j] : acc[2 + ii][j]) + o;
         }
-    // ---- every wave finishes its 2 x 4 fragments where the MFMA left them: lane = row c16, 4 consecutive columns (8-byte accesses);
-    // the arithmetic of epilogue_lean, element for element ----
+    float* const band = xch + 8 * 8 * 64 * 4;            // behind the exchange area (64 KiB): [64][LDT] f32 = 33 KiB
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * WN + j * 16 + g * 4;
-        if (n >= N) continue;
-        const float mul[4] = {alpha * sc[j].x, alpha * sc[j].y, alpha * sc[j].z, alpha * sc[j].w};
-        const float add[4] = {sh[j].x, sh[j].y, sh[j].z, sh[j].w};
+    for (int ii = 0; ii < 2; ++ii) {
+        if (ii) lds_barrier();                           // the previous pass is read
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            const int m = m0 + wm * WM + (kh * 2 + ii) * 16 + c16;
-            if (m >= M) continue;
-            float v[4];
+        for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4_t*>(band + (kh * 32 + wm * 16 + c16) * LDT + wn * WN + j * 16 + g * 4) = fin[ii][j];
+        lds_barrier();
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = fin[ii][j][q] * mul[q] + add[q];
+        for (int q = 0; q < 2; ++q) {
+            const int m = mrow[ii][q];
+            if (!col_ok || m >= M) continue;
+            const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(band + (q * 32 + r_lo) * LDT + c8 * 8);
+            const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(band + (q * 32 + r_lo) * LDT + c8 * 8 + 4);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * mul[j] + add[j];
             if (resp) {
-                const uint2 r2 = rr[ii][j];
-                v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-                v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+                float x[8];
+                unpack8(rres[ii][q], x);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += x[j];
             }
             if (act == TOIST_ACT_RELU) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
             } else if (masked) {
-                const uint2 x2 = xx[ii][j];
-                v[0] = __uint_as_float(x2.x << 16) > 0.f ? v[0] : 0.f; v[1] = __uint_as_float(x2.x & 0xffff0000u) > 0.f ? v[1] : 0.f;
-                v[2] = __uint_as_float(x2.y << 16) > 0.f ? v[2] : 0.f; v[3] = __uint_as_float(x2.y & 0xffff0000u) > 0.f ? v[3] : 0.f;
+                float x[8];
+                unpack8(raux[ii][q], x);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = x[j] > 0.f ? v[j] : 0.f;
             }
-            *reinterpret_cast<uint2*>(outp + (size_t)m * p.ldc + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            *reinterpret_cast<uint4*>(outp + (size_t)m * p.ldc + ncol) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
         }
     }
     if (timing && lane == 0) {
@@ -2608,21 +2629,21 @@ static bool gemm128_applies(const toist_gemm& d) {
     const toist_epilogue& e = d.epi;
     if (!lean_epilogue_ok(d) || e.drop_where || e.cmap) return false;
     if (e.act != TOIST_ACT_NONE && e.act != TOIST_ACT_RELU && e.act != TOIST_ACT_MASK_POS) return false;
-    if ((d.N % 8) != 0 || (d.ldc % 4) != 0 || (e.res && (e.ldr % 4) != 0) || (e.act == TOIST_ACT_MASK_POS && (e.ldaux % 4) != 0)) return false;
+    if ((d.N % 8) != 0) return false;                     // ldc / ldr / ldaux % 8 and 16-byte bases: lean_epilogue_ok above
     return true;
 }
 
 // Where the dispatcher picks it (profiles/r03_gemm128_us.txt): one block per CU, so it needs about a chip of 128 x 128 tiles and a deep
-// reduction to amortise its prologue / k-fold epilogue.  Gathers: every stride-1 3x3 of layers 2-4 at the bench batch (-1 .. -9 us per
-// launch against the 64 x 64 tiles and the halo kernel).  Plain GEMMs: K >= 768 with 150..256 tiles (12800 x 256 x 1024: 15.2 vs 18.4 us)
-// or >= 1024 tiles (4096^3: 144 vs 170 us); 300..500 tiles lose to the 64 x 64 tiles' finer tail.
+// reduction to amortise its prologue / k-fold epilogue.  Gathers: every stride-1 3x3 of layers 2-4 at the bench batch (-1 .. -16 us per
+// launch against the 64 x 64 tiles and the halo kernel).  Plain GEMMs: K >= 768 from 150 tiles on (12800 x 256 x 1024: 14.7 / 15.5 vs
+// 18.2 / 20.3 us forward / data gradient, 12800 x 512 x 1024: 25.4 / 27.5 vs 29.2 / 31.8, 4096^3: 150 vs 169); K = 512 loses (two rounds of
+// 8 k-tiles do not amortise the fixed costs), 100 tiles are a draw.
 static bool gemm128_pays(const toist_gemm& d) {
     static const int on = (int)tuning_knob("TOIST_GEMM128", 1);
     if (!on || !gemm128_applies(d)) return false;
     const long long tiles = (long long)((d.M + G8_BM - 1) / G8_BM) * ((d.N + G8_BN - 1) / G8_BN);
     if (d.a_kind != TOIST_A_ROWK) return tiles >= 96 && (d.N % G8_BN) == 0;
-    if (d.K < 768) return false;
-    return (tiles >= 150 && tiles <= 256 && d.N <= 256) || (tiles >= 1024 && d.K >= 1024);
+    return d.K >= 768 && tiles >= 150;
 }
 
 template <int NS>

@@ -10,6 +10,8 @@ from torch import nn
 
 from . import kernels as k
 
+TOKEN_MASK_WORDS = 4      # 64-bit words of a target's token-span mask: 256 tokens = the reference's max_text_len (csrc/contrastive.hip: CA_MW)
+
 
 class MatchResult:
     """Device-resident assignment for L layers: src/tgt [L, Mtot] int64, per-image slices by `match_off`."""
@@ -50,7 +52,7 @@ class StaticTargets:
         self.B, self.max_per_image, self.Q, self.K = batch, max_per_image, num_queries, K
         self.cap = cap = batch * max_per_image
         self.device = torch.device(device)
-        sizes = [cap * 4 * 4, cap * K * 4, cap * 2 * 8, (batch + 1) * 4, (batch + 1) * 4, 4]
+        sizes = [cap * 4 * 4, cap * K * 4, cap * TOKEN_MASK_WORDS * 8, (batch + 1) * 4, (batch + 1) * 4, 4]
         offs, total = [], 0
         for n in sizes:
             offs.append(total)
@@ -60,7 +62,7 @@ class StaticTargets:
 
         def views(buf):
             cut = lambda i, dt, shape: buf[offs[i]:offs[i] + sizes[i]].view(dt).view(shape)
-            return (cut(0, torch.float32, (cap, 4)), cut(1, torch.float32, (cap, K)), cut(2, torch.int64, (cap, 2)), cut(3, torch.int32, (batch + 1,)),
+            return (cut(0, torch.float32, (cap, 4)), cut(1, torch.float32, (cap, K)), cut(2, torch.int64, (cap, TOKEN_MASK_WORDS)), cut(3, torch.int32, (batch + 1,)),
                     cut(4, torch.int32, (batch + 1,)), cut(5, torch.float32, (1,)))
 
         self._views = views
@@ -73,7 +75,7 @@ class StaticTargets:
     def pack(self, targets, positive_map, token_masks=None, out=None):
         """Host image of one batch (pinned uint8 tensor in the arena layout, + the per-image target counts): build it ahead of time -- in a
         loader worker -- and hand it to load_packed().  targets: list of dicts with HOST tensors `boxes` [T_i, 4]; positive_map: host
-        [sum T_i, K]; token_masks: host int64 [sum T_i, 2] (SetCriterion.token_masks_host) when the contrastive-alignment loss is on."""
+        [sum T_i, K]; token_masks: host int64 [sum T_i, TOKEN_MASK_WORDS] (SetCriterion.token_masks_host) when the contrastive-alignment loss is on."""
         sizes = [int(t["boxes"].shape[0]) for t in targets]
         if len(sizes) != self.B or max(sizes, default=0) > self.max_per_image:
             raise ValueError(f"StaticTargets holds {self.B} images x <= {self.max_per_image} targets; got sizes {sizes}")

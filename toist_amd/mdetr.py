@@ -18,6 +18,7 @@ from .matcher import StaticTargets, build_matcher
 from .misc import NestedTensor
 from .transformer import build_transformer
 from .distill import ClusterCriterion, char_span_to_tokens, noun_token_features
+from .matcher import TOKEN_MASK_WORDS
 
 BF16 = torch.bfloat16
 
@@ -290,7 +291,7 @@ class SetCriterion(nn.Module):
         self.temperature = temperature
         self.last_match = None
         self._maps, self._nb, self._nb_reduced = {}, {}, {}
-        self._tokmask = None       # (member mask tensors, concatenated [sum T, 2] int64): spans of the last batch, uploaded once
+        self._tokmask = None       # (member mask tensors, concatenated [sum T, 4] int64): spans of the last batch, uploaded once
         self._pending_status = []  # (pinned host copy, event) of matcher status words not yet looked at
 
     # -- helpers ------------------------------------------------------------------------------------------
@@ -383,11 +384,11 @@ class SetCriterion(nn.Module):
         self._pending_status = keep
 
     def token_masks_host(self, targets, tokenized):
-        """int64 [sum T, 2] host tensor of the targets' token-span bit masks (input of StaticTargets.load)."""
+        """int64 [sum T, TOKEN_MASK_WORDS] host tensor of the targets' token-span bit masks (input of StaticTargets.load)."""
         rows = []
         for i, tgt in enumerate(targets):
             rows += self._span_bits(tgt, i, tokenized)
-        return torch.tensor(rows, dtype=torch.int64).reshape(len(rows), 2)
+        return torch.tensor(rows, dtype=torch.int64).reshape(len(rows), TOKEN_MASK_WORDS)
 
     @staticmethod
     def _span_bits(tgt, i, tokenized):
@@ -403,16 +404,16 @@ class SetCriterion(nn.Module):
                         spans.append(ft)
             bits = 0
             for bp, ep in spans:
-                if ep >= 128:
-                    raise ValueError("contrastive_align: token spans beyond position 127 are not supported by the device kernel")
+                if ep >= 64 * TOKEN_MASK_WORDS:
+                    raise ValueError("contrastive_align: token position %d is beyond max_text_len = %d (mdetr.py:601-666)" % (ep, 64 * TOKEN_MASK_WORDS))
                 for tkn in range(bp, ep + 1):
                     bits |= 1 << tkn
-            lo, hi = bits & ((1 << 64) - 1), bits >> 64
-            rows.append([lo - (1 << 64) if lo >= (1 << 63) else lo, hi - (1 << 64) if hi >= (1 << 63) else hi])
+            words = [(bits >> (64 * w)) & ((1 << 64) - 1) for w in range(TOKEN_MASK_WORDS)]
+            rows.append([w - (1 << 64) if w >= (1 << 63) else w for w in words])         # two's complement: the tensor is int64
         return rows
 
     def _token_masks(self, targets, tokenized, device):
-        """int64 [sum T, 2] token bit masks of every target's positive spans (the host part of mdetr.py:614-643, done once per
+        """int64 [sum T, TOKEN_MASK_WORDS] token bit masks of every target's positive spans (the host part of mdetr.py:614-643, done once per
         batch instead of once per layer and call: the spans do not depend on the assignment)."""
         parts = []
         for i, tgt in enumerate(targets):
@@ -420,13 +421,13 @@ class SetCriterion(nn.Module):
             if m is None or m.device != device:
                 n = int(tgt["boxes"].shape[0])
                 rows = self._span_bits(tgt, i, tokenized)
-                m = torch.tensor(rows, dtype=torch.int64).reshape(n, 2).to(device)
+                m = torch.tensor(rows, dtype=torch.int64).reshape(n, TOKEN_MASK_WORDS).to(device)
                 tgt["_tok_mask"] = m
             parts.append(m)
         ent = self._tokmask
         if ent is not None and len(ent[0]) == len(parts) and all(a is b for a, b in zip(ent[0], parts)):
             return ent[1]
-        cat = torch.cat(parts) if parts else torch.zeros(0, 2, dtype=torch.int64, device=device)
+        cat = torch.cat(parts) if parts else torch.zeros(0, TOKEN_MASK_WORDS, dtype=torch.int64, device=device)
         self._tokmask = (parts, cat)
         return cat
 
