@@ -219,6 +219,12 @@ TOIST_API int toist_pack_image(const float* nchw, int N, int C, int H, int W, vo
 TOIST_API int toist_maxpool3x3s2(const void* in, int N, int H, int W, int C, void* out, void* stream);
 TOIST_API int toist_unpack_nhwc(const void* nhwc, int N, int HW, int C, float* nchw, void* stream);
 
+/* ResNet stem in one launch (torchvision ResNet.conv1 / bn1 / relu / maxpool as used by /root/reference/models/backbone.py:64-91; frozen there):
+ * image f32 NCHW [N, C <= 8, H, W] -> conv 7x7 / stride 2 / pad 3 with `weight` bf16 [64][7][7][8] (KRSC, channels padded to 8, FrozenBN scale
+ * folded in) + shift[64] (f32, may be NULL) + ReLU -> max-pool 3x3 / stride 2 / pad 1 -> out bf16 NHWC [N, PH, PW, 64],
+ * OH = (H - 1) / 2 + 1, PH = (OH - 1) / 2 + 1 (likewise for the width).  Replaces toist_pack_image + a toist_gemm_bf16 gather + toist_maxpool3x3s2. */
+TOIST_API int toist_stem_fwd(const float* image, const void* weight, const float* shift, int N, int C, int H, int W, void* out, void* stream);
+
 /* PositionEmbeddingSine.forward (position_encoding.py:30-49; normalize=True, scale=2*pi):
  * mask [B,H,W] u8 (1 = padded pixel) -> bf16 [B, H*W, 2*num_pos_feats] tokens and/or f32
  * [B, 2*num_pos_feats, H, W] (either output may be NULL). */

@@ -725,3 +725,31 @@ def test_gemm128w_weight_gradient_kernel(dev, Nb, H, W, C, Co, R, dil, n, min_ti
         assert len(picked) == 1
     else:
         assert picked == [expect], f"the dispatcher picked {picked}"
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 128, 160), (1, 71, 93), (3, 40, 24)])
+def test_fused_stem_matches_the_three_launch_path(dev, N, H, W):
+    """csrc/stem.hip (conv 7x7/2 + FrozenBN shift + ReLU + max-pool 3x3/2 from the fp32 NCHW image in one launch) against pack_image +
+    the implicit-GEMM convolution + maxpool3x3s2 on the same bf16 weights: same products, f32 sums in another order, so the pooled bf16
+    values agree to a bf16 ulp; and against fp32 torch on the bf16-rounded operands.  Odd sizes: ragged tiles, image borders inside tiles."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(H + W)
+    img = torch.randn(N, 3, H, W, generator=g).to(dev)
+    w = (torch.randn(64, 7, 7, 3, generator=g) / math.sqrt(147)).to(dev)
+    w8 = torch.nn.functional.pad(w, (0, 5)).to(BF).contiguous()
+    shift = torch.randn(64, generator=g).to(dev) * 0.3
+    CH, CW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    PH, PW = (CH - 1) // 2 + 1, (CW - 1) // 2 + 1
+    out = torch.empty(N, PH, PW, 64, dtype=BF, device=dev)
+    k.stem_fwd(img, w8, shift, out)
+    xin = torch.empty(N, H, W, 8, dtype=BF, device=dev)
+    k.pack_image(img, xin)
+    y = ops.conv2d(xin, w8, stride=2, pad=3, shift=shift, act=k.ACT_RELU, cin_real=3)
+    ref = torch.empty(N, PH, PW, 64, dtype=BF, device=dev)
+    k.maxpool3x3s2(y, ref)
+    err = (out.float() - ref.float()).abs()
+    assert bool((err <= 8e-3 * ref.float().abs() + 1e-3).all()), float(err.max())
+    t = torch.nn.functional.conv2d(img.to(BF).float(), w8[..., :3].float().permute(0, 3, 1, 2), stride=2, padding=3) + shift.view(1, -1, 1, 1)
+    t = torch.nn.functional.max_pool2d(torch.relu(t), 3, 2, 1).permute(0, 2, 3, 1)
+    err = (out.float() - t).abs()
+    assert bool((err <= 8e-3 * t.abs() + 2e-3).all()), float(err.max())

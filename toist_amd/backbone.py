@@ -8,6 +8,7 @@ instantiates through `torchvision.models.resnet101` (backbone.py:87-89); torchvi
 used.  FrozenBN is folded: the bf16 compute copy of each conv weight is pre-multiplied by the BN
 scale and the shift rides in the GEMM epilogue.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -20,6 +21,7 @@ from .misc import NestedTensor
 from .position_encoding import build_position_encoding
 
 BF16 = torch.bfloat16
+FUSED_STEM = os.environ.get("TOIST_FUSED_STEM", "1") != "0"     # conv1 + bn1 + relu + maxpool as one launch (csrc/stem.hip)
 
 
 _BN_EPOCH = [0]   # bumped whenever any FrozenBatchNorm2d invalidates its folded scale/shift
@@ -178,14 +180,22 @@ class BackboneBase(nn.Module):
             x = images.data
             if stem:
                 N, C, H, W = x.shape
-                xin = torch.empty(N, H, W, 8, dtype=BF16, device=x.device)
-                k.pack_image(x.contiguous(), xin)
                 s0, t0 = bn("bn1")
-                y = ops.conv2d(xin, engine.krsc(ps["conv1.weight"].w), stride=2, pad=3, shift=t0, act=k.ACT_RELU, cin_real=C)
-                OH, OW = (y.shape[1] + 2 - 3) // 2 + 1, (y.shape[2] + 2 - 3) // 2 + 1
-                pooled = torch.empty(N, OH, OW, 64, dtype=BF16, device=x.device)
-                k.maxpool3x3s2(y, pooled)
-                del y
+                w1 = engine.krsc(ps["conv1.weight"].w)
+                if FUSED_STEM and tuple(w1.shape) == (64, 7, 7, 8) and x.dtype == torch.float32:
+                    # conv1 + bn1 + relu + maxpool in one launch, straight from the fp32 NCHW batch (csrc/stem.hip): the stem is frozen
+                    # (backbone.py:64-66 of the reference), so its 105 MB convolution output is not needed by anything
+                    CH, CW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+                    pooled = torch.empty(N, (CH - 1) // 2 + 1, (CW - 1) // 2 + 1, 64, dtype=BF16, device=x.device)
+                    k.stem_fwd(x.contiguous(), w1, t0, pooled)
+                else:
+                    xin = torch.empty(N, H, W, 8, dtype=BF16, device=x.device)
+                    k.pack_image(x.contiguous(), xin)
+                    y = ops.conv2d(xin, w1, stride=2, pad=3, shift=t0, act=k.ACT_RELU, cin_real=C)
+                    OH, OW = (y.shape[1] + 2 - 3) // 2 + 1, (y.shape[2] + 2 - 3) // 2 + 1
+                    pooled = torch.empty(N, OH, OW, 64, dtype=BF16, device=x.device)
+                    k.maxpool3x3s2(y, pooled)
+                    del y
                 cur = engine.Var(pooled, needs_grad=False)
             else:
                 cur = images          # the previous stage's output: its gradient (w.r.t. the pre-ReLU sum, masked by the first block here) flows back

@@ -17,7 +17,7 @@ from ._lib import (A_CONV, A_CONVT, A_KROW, A_ROWK, ACT_GELU, ACT_GELU_BWD, ACT_
 __all__ = [
     "A_ROWK", "A_KROW", "A_CONV", "A_CONVT", "B_ROWK", "B_KROW", "B_CONVX", "ACT_NONE", "ACT_RELU", "ACT_GELU",
     "ACT_SIGMOID", "ACT_MASK_POS", "ACT_GELU_BWD", "ACT_SIGMOID_BWD", "ConvGeom", "operand", "gemm", "matcher",
-    "layernorm_fwd", "layernorm_bwd", "softmax_fwd", "softmax_bwd", "colsum", "add", "dropout", "pack_image", "maxpool3x3s2",
+    "layernorm_fwd", "layernorm_bwd", "softmax_fwd", "softmax_bwd", "colsum", "add", "dropout", "pack_image", "maxpool3x3s2", "stem_fwd",
     "unpack_nhwc", "sine_position", "embed_fwd", "embed_bwd", "criterion_fwd", "criterion_bwd", "attnmap_softmax_fwd", "attnmap_softmax_bwd",
     "groupnorm_fwd", "groupnorm_bwd", "upsample_add", "upsample_add_bwd", "sum_queries", "mask_loss_fwd", "mask_loss_bwd",
 ]
@@ -408,6 +408,14 @@ def dropout(x, p, seed, out):
 def pack_image(nchw, out):
     N, C, H, W = nchw.shape
     _lib.check(_lib.lib().toist_pack_image(_p(nchw, torch.float32), N, C, H, W, _p(out, torch.bfloat16), _stream()), "toist_pack_image")
+
+
+def stem_fwd(images, w, shift, out):
+    """csrc/stem.hip: f32 NCHW images -> conv 7x7/2 (w bf16 [64,7,7,8], BN scale folded) + shift + ReLU + max-pool 3x3/2 -> bf16 NHWC `out`."""
+    N, C, H, W = images.shape
+    assert tuple(w.shape) == (64, 7, 7, 8) and w.is_contiguous() and images.is_contiguous() and out.is_contiguous()
+    _lib.check(_lib.lib().toist_stem_fwd(_p(images, torch.float32), _p(w, torch.bfloat16), _p(shift, torch.float32), N, C, H, W,
+                                         _p(out, torch.bfloat16), _stream()), "toist_stem_fwd")
 
 
 def maxpool3x3s2(x, out):
