@@ -9,6 +9,7 @@ mkdir -p $O
 ( time timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=10 ) > $O/pytest.log 2>&1
 tail -25 $O/pytest.log | cut -c1-250
 cp gpurun_out/fullsize_parity.json $O/ 2>/dev/null
+( time timeout 600 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1; tail -4 $O/smoke.log | cut -c1-200
 ( time timeout 1500 python bench.py ) > $O/bench_default.log 2>&1
 grep '^{"metric"' $O/bench_default.log | tail -1 > $O/bench_default.json
 python - <<PY
