@@ -658,6 +658,11 @@ def test_gemm128_kernel_convolution_gathers(dev, Nb, H, W, C, Co, R, pad, dil):
         ops.conv2d_dgrad(dy, w, (H, W), pad=pad, dil=dil, act=k.ACT_MASK_POS, aux=aux, out=dx, tile=136)
         ops.conv2d_dgrad(dy, w, (H, W), pad=pad, dil=dil, act=k.ACT_MASK_POS, aux=aux, out=dx32, tile=65)
         _ulp_close(dx, dx32, "transposed gather")
+        # stride 2 (conv2 of the first bottleneck of layers 2-4): forward gather only
+        res2 = res[:, ::2, ::2].contiguous()
+        got2 = ops.conv2d(x, w, stride=2, pad=pad, dil=dil, scale=scale, shift=shift, res=res2, act=k.ACT_RELU, tile=136)
+        ref2 = ops.conv2d(x, w, stride=2, pad=pad, dil=dil, scale=scale, shift=shift, res=res2, act=k.ACT_RELU, tile=65, out_dtype=torch.float32)
+        _ulp_close(got2, ref2, "strided forward gather")
         if Nb * H * W >= 12800:
             assert torch.equal(ops.conv2d(x, w, pad=pad, dil=dil, scale=scale, shift=shift, res=res, act=k.ACT_RELU), got)
             assert torch.equal(ops.conv2d_dgrad(dy, w, (H, W), pad=pad, dil=dil, act=k.ACT_MASK_POS, aux=aux), dx)

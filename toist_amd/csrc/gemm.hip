@@ -1208,11 +1208,12 @@ __global__ __launch_bounds__(512, 2) void gemm128_kernel(const toist_gemm p) {
             const int mm = m < M ? m : 0;
             const int n = mm / plane, rem = mm - n * plane;
             const int py = rem / oa.PW, px = rem - py * oa.PW;
-            va[it] = m < M ? (((n * oa.SH + py) * oa.SW + px) * oa.SC + kc * 8) * 2 : OOB;
+            const int st = AK == TOIST_A_CONV ? oa.stride : 1;         // strided forward gathers; the transposed gather is stride 1 only
+            va[it] = m < M ? (((n * oa.SH + py * st) * oa.SW + px * st) * oa.SC + kc * 8) * 2 : OOB;
             unsigned ok = 0;
             for (int t = 0; t < ntaps; ++t) {
                 const int r = t / oa.S, s_ = t - r * oa.S;
-                const int iy = py + sh_y + r * oa.dil, ix = px + sh_x + s_ * oa.dil;
+                const int iy = py * st + sh_y + r * oa.dil, ix = px * st + sh_x + s_ * oa.dil;
                 if (iy >= 0 && iy < oa.SH && ix >= 0 && ix < oa.SW) ok |= 1u << t;
             }
             tapok[it] = ok;
@@ -2605,7 +2606,7 @@ static bool conv3_applies(const toist_gemm& d) {
 static int clamp_split(int split_k, int K, int tile);
 // gemm128_kernel (tile code 136): one problem, K a multiple of 64 with at least 4 k-tiles, bf16 rows finished by {alpha, scale, shift,
 // residual, ReLU | aux > 0 mask}.  Operands: row-major A with row-major or plain k-major B (1x1 convolutions, nn.Linear and their data
-// gradients); stride-1 convolution gather with row-major weights (forward); its transposed gather on a same-size plane with the
+// gradients); convolution gather of stride 1 or 2 with row-major weights (forward); its stride-1 transposed gather on a same-size plane with the
 // two-level k-major weights (data gradient) -- up to 16 taps, source channels a multiple of 64.
 static bool gemm128_applies(const toist_gemm& d) {
     const bool plain = d.a_kind == TOIST_A_ROWK && (d.b_kind == TOIST_B_ROWK || (d.b_kind == TOIST_B_KROW && d.b.kin == 0));
@@ -2620,7 +2621,7 @@ static bool gemm128_applies(const toist_gemm& d) {
         if ((d.a.ld % 8) != 0 || (long long)d.M * d.a.ld >= lim) return false;
     } else {
         const toist_operand& a = d.a;
-        if (a.stride != 1 || a.R * a.S > 16 || (a.SC % 64) != 0 || d.K != a.R * a.S * a.SC) return false;
+        if ((a.stride != 1 && !fwd) || a.stride < 1 || a.stride > 2 || a.R * a.S > 16 || (a.SC % 64) != 0 || d.K != a.R * a.S * a.SC) return false;
         if ((long long)(d.M / (a.PH * a.PW) + 1) * a.SH * a.SW * a.SC >= lim) return false;
         if (fwd && d.b.ld != d.K) return false;
         if (dgr && (a.PH != a.SH || a.PW != a.SW || d.b.kin != a.SC)) return false;
