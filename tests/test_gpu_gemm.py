@@ -758,3 +758,42 @@ def test_fused_stem_matches_the_three_launch_path(dev, N, H, W):
     t = torch.nn.functional.max_pool2d(torch.relu(t), 3, 2, 1).permute(0, 2, 3, 1)
     err = (out.float() - t).abs()
     assert bool((err <= 8e-3 * t.abs() + 2e-3).all()), float(err.max())
+
+
+@pytest.mark.parametrize("Nb,H,W,C,Co,R,split", [(8, 32, 32, 128, 256, 3, 8), (8, 64, 64, 256, 512, 1, 16), (4, 48, 80, 128, 128, 3, 15)])
+def test_gemm128w_strided_weight_gradients(dev, Nb, H, W, C, Co, R, split):
+    """Stride-2 weight gradients (conv2 and the downsample convolution of the first bottleneck of a ResNet stage) on gemm128w_kernel /
+    gemm256w_kernel: the source pixel of an output pixel is rebuilt per k-tile from the lane's running (image, y, x); against the 64 x 64
+    tiles on the same call (split along K by the host's rule, deferred fold) and against fp32 autograd."""
+    from toist_amd import kernels as k, ops
+    g = torch.Generator().manual_seed(H + C + R)
+    pad = R // 2
+    OH, OW = (H + 2 * pad - R) // 2 + 1, (W + 2 * pad - R) // 2 + 1
+    x = torch.randn(Nb, H, W, C, generator=g).to(BF).to(dev)
+    dy = torch.randn(Nb, OH, OW, Co, generator=g).to(BF).to(dev)
+    rs = (torch.rand(Co, generator=g) + 0.5).to(dev)
+
+    def run(tile):
+        out = torch.zeros(Co, R, R, C, dtype=torch.float32, device=dev)
+        old = k.FORCE_TILE
+        k.FORCE_TILE = tile
+        try:
+            ops.conv2d_wgrad(dy, x, (Co, R, R, C), stride=2, pad=pad, out=out, rscale=rs, defer=True, split_k=split)   # slices as the step's tape picks them
+            k.flush_reductions()
+        finally:
+            k.FORCE_TILE = old
+        return out
+
+    ref = run(65)
+    k.PROFILE = {"key": frozenset({(137, k.A_KROW, k.B_CONVX), (138, k.A_KROW, k.B_CONVX)}), "records": [], "other": {}}
+    try:
+        got = run(0)
+        picked = [r[3][0] for r in k.PROFILE["records"]]
+    finally:
+        k.PROFILE = None
+    assert len(picked) == 1, "the dispatcher did not pick the 128-wide weight-gradient kernels"
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    w = torch.zeros(Co, C, R, R, requires_grad=True)
+    torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2).cpu(), w, stride=2, padding=pad).backward(dy.float().permute(0, 3, 1, 2).cpu())
+    want = w.grad.permute(0, 2, 3, 1) * rs.cpu()[:, None, None, None]
+    assert float((got.cpu() - want).abs().max()) <= 2e-3 * float(want.abs().max())

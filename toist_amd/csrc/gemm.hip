@@ -1517,11 +1517,14 @@ __global__ __launch_bounds__(512, 2) void gemm128w_kernel(const toist_gemm p) {
         tap_dx = s_ * ob.dil - ob.pad;
     }
     const i32x4_t rsA = make_rsrc(a_ptr);
-    const i32x4_t rsB = make_rsrc(GATHER ? (const void*)(b_ptr + ((long long)tap_dy * ob.SW + tap_dx) * ob.SC) : (const void*)b_ptr);
+    // strided gathers (conv2 / downsample of the first bottleneck of a stage): the source pixel of output pixel (img, y, x) is
+    // (img, y * stride + dy, x * stride + dx) -- no longer the pixel's own address plus a constant, so the lane offset is rebuilt per k-tile
+    const bool strided = GATHER && ob.stride != 1;
+    const i32x4_t rsB = make_rsrc((GATHER && !strided) ? (const void*)(b_ptr + ((long long)tap_dy * ob.SW + tap_dx) * ob.SC) : (const void*)b_ptr);
     const unsigned lds0 = (unsigned)(size_t)lds_raw;
 
     // ---- DMA pieces: k-major tiles [64 k][128 m | n]; lane offsets in bytes, the k-tile in the scalar offset ----
-    int va[2], vb[2], py[2], px[2];
+    int va[2], vb[2], py[2], px[2], pimg[2];
     const int W = ob.PW, H = ob.PH;
     const int q64 = GATHER ? BK / W : 0, r64 = GATHER ? BK - q64 * W : 0;
 #pragma unroll
@@ -1531,28 +1534,44 @@ __global__ __launch_bounds__(512, 2) void gemm128w_kernel(const toist_gemm p) {
         const int mm = m0 + rc * 8, nn = n0 + rc * 8;
         va[it] = mm < M ? (mm + krow * lda) * 2 : OOB;
         vb[it] = nn < N ? ((GATHER ? c0 + rc * 8 : nn) + krow * ldb) * 2 : OOB;
-        py[it] = px[it] = 0;
+        py[it] = px[it] = pimg[it] = 0;
         if (GATHER) {
-            const int pix = (kt_beg * BK + krow) % (H * W);
+            const int p0 = kt_beg * BK + krow;
+            pimg[it] = p0 / (H * W);
+            const int pix = p0 - pimg[it] * (H * W);
             py[it] = pix / W;
             px[it] = pix - py[it] * W;
+            if (strided) vb[it] = nn < N ? (c0 + rc * 8) * 2 : OOB;        // the channel part only; the pixel part is rebuilt per k-tile
         }
     }
     int i_t = 0;                                        // k-tiles issued so far
     auto issue = [&](const int slot) {
         const unsigned da = lds0 + (unsigned)(slot * G8_STAGE_BYTES) + (unsigned)wave * 1024u, db = da + (unsigned)(G8_TILE * 2);
         const int kt = kt_beg + i_t;
-        const int soa = kt * BK * lda * 2, sob = kt * BK * ldb * 2;
+        const int soa = kt * BK * lda * 2, sob = strided ? 0 : kt * BK * ldb * 2;
         int vbe[2] = {vb[0], vb[1]};
         if (GATHER) {
+            if (strided) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {        // selects, no nested branches (a branchy form of this was miscompiled for piece 0)
+                    const int sy = py[it] * ob.stride + tap_dy, sx = px[it] * ob.stride + tap_dx;
+                    const bool ok = (unsigned)sy < (unsigned)ob.SH && (unsigned)sx < (unsigned)ob.SW && vb[it] != OOB;
+                    const int off = vb[it] + ((pimg[it] * ob.SH + sy) * ob.SW + sx) * ob.SC * 2;
+                    vbe[it] = ok ? off : OOB;
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int sy = py[it] + tap_dy, sx = px[it] + tap_dx;
+                    if (sy < 0 || sy >= H || sx < 0 || sx >= W) vbe[it] = OOB;
+                }
+            }
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
-                const int sy = py[it] + tap_dy, sx = px[it] + tap_dx;
-                if (sy < 0 || sy >= H || sx < 0 || sx >= W) vbe[it] = OOB;
                 px[it] += r64;                          // the same k-row of the next k-tile: 64 pixels on
                 py[it] += q64;
                 if (px[it] >= W) { px[it] -= W; ++py[it]; }
-                while (py[it] >= H) py[it] -= H;
+                while (py[it] >= H) { py[it] -= H; ++pimg[it]; }
             }
         }
         unsigned keep;
@@ -1753,11 +1772,12 @@ __global__ __launch_bounds__(512, 2) void gemm256w_kernel(const toist_gemm p) {
         tap_dx = s_ * ob.dil - ob.pad;
     }
     const i32x4_t rsA = make_rsrc(a_ptr);
-    const i32x4_t rsB = make_rsrc(GATHER ? (const void*)(b_ptr + ((long long)tap_dy * ob.SW + tap_dx) * ob.SC) : (const void*)b_ptr);
+    const bool strided = GATHER && ob.stride != 1;       // see gemm128w_kernel
+    const i32x4_t rsB = make_rsrc((GATHER && !strided) ? (const void*)(b_ptr + ((long long)tap_dy * ob.SW + tap_dx) * ob.SC) : (const void*)b_ptr);
     const unsigned lds0 = (unsigned)(size_t)lds_raw;
 
     // ---- DMA pieces per wave and k-tile: two of A ([32 k][256 m]), one of B ([32 k][128 n]) ----
-    int va[2], vb, py = 0, px = 0;
+    int va[2], vb, py = 0, px = 0, pimg = 0;
     const int W = ob.PW, H = ob.PH;
     const int q32 = GATHER ? BK / W : 0, r32 = GATHER ? BK - q32 * W : 0;
 #pragma unroll
@@ -1773,24 +1793,34 @@ __global__ __launch_bounds__(512, 2) void gemm256w_kernel(const toist_gemm p) {
         const int nn = n0 + rc * 8;
         vb = nn < N ? ((GATHER ? c0 + rc * 8 : nn) + krow * ldb) * 2 : OOB;
         if (GATHER) {
-            const int pix = (kt_beg * BK + krow) % (H * W);
+            const int p0 = kt_beg * BK + krow;
+            pimg = p0 / (H * W);
+            const int pix = p0 - pimg * (H * W);
             py = pix / W;
             px = pix - py * W;
+            if (strided) vb = nn < N ? (c0 + rc * 8) * 2 : OOB;
         }
     }
     int i_t = 0;
     auto issue = [&](const int slot) {
         const unsigned da = lds0 + (unsigned)(slot * G9_STAGE_BYTES) + (unsigned)wave * 1024u, db = lds0 + (unsigned)(slot * G9_STAGE_BYTES + G9_A_BYTES) + (unsigned)wave * 1024u;
         const int kt = kt_beg + i_t;
-        const int soa = kt * BK * lda * 2, sob = kt * BK * ldb * 2;
+        const int soa = kt * BK * lda * 2, sob = strided ? 0 : kt * BK * ldb * 2;
         int vbe = vb;
         if (GATHER) {
-            const int sy = py + tap_dy, sx = px + tap_dx;
-            if (sy < 0 || sy >= H || sx < 0 || sx >= W) vbe = OOB;
+            if (strided) {
+                const int sy = py * ob.stride + tap_dy, sx = px * ob.stride + tap_dx;
+                const bool ok = (unsigned)sy < (unsigned)ob.SH && (unsigned)sx < (unsigned)ob.SW && vb != OOB;
+                const int off = vb + ((pimg * ob.SH + sy) * ob.SW + sx) * ob.SC * 2;
+                vbe = ok ? off : OOB;
+            } else {
+                const int sy = py + tap_dy, sx = px + tap_dx;
+                if (sy < 0 || sy >= H || sx < 0 || sx >= W) vbe = OOB;
+            }
             px += r32;
             py += q32;
             if (px >= W) { px -= W; ++py; }
-            while (py >= H) py -= H;
+            while (py >= H) { py -= H; ++pimg; }
         }
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %6, %8 offen lds\n\t"
@@ -2692,8 +2722,10 @@ static bool gemm128w_applies(const toist_gemm& d) {
         if ((d.b.ld % 8) != 0 || (long long)d.K * d.b.ld >= lim) return false;
     } else {
         const toist_operand& b = d.b;
-        if (b.stride != 1 || b.PH != b.SH || b.PW != b.SW || (b.SC % 128) != 0 || d.N != b.R * b.S * b.SC) return false;
-        if ((d.K % (b.PH * b.PW)) != 0 || (long long)(d.K + b.SW * (b.pad + 1)) * b.SC >= lim) return false;
+        if (b.stride < 1 || b.stride > 2 || (b.SC % 128) != 0 || d.N != b.R * b.S * b.SC) return false;
+        if (b.stride == 1 && (b.PH != b.SH || b.PW != b.SW)) return false;                 // stride 1: the same-size plane trick (address = pixel + constant)
+        if ((d.K % (b.PH * b.PW)) != 0) return false;
+        if ((long long)(d.K / (b.PH * b.PW) + 1) * b.SH * b.SW * b.SC + (long long)b.SW * (b.pad + 1) * b.SC >= lim) return false;
     }
     const toist_epilogue& e = d.epi;
     if (!e.out_f32 || e.scale || e.shift || e.res || e.pre_out || e.act != TOIST_ACT_NONE || e.drop_where || e.cmap || e.res_div > 0) return false;
