@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--mixed-sizes", action="store_true", help="configs[1] on a stream of batches of three padded image sizes (640x640, 576x704, 512x768) through "
                     "toist_amd.harness.CapturedTrainStep: one cached hipGraph per shape bucket, the library's replayed step with variable-size inputs")
     ap.add_argument("--no-secondary", action="store_true", help="do not run the short configs[2] / configs[2]-frozen / configs[4] legs (child processes) that the default N = 1 run appends as `secondary`")
-    ap.add_argument("--repeats", type=int, default=3, help="hipGraph replay: the K-step timed region is run this many times (value = the FIRST region; min / median reported beside it)")
+    ap.add_argument("--repeats", type=int, default=3, help="hipGraph replay: the K-step timed region is run this many times (value = the MEDIAN region; first / min reported beside it)")
     ap.add_argument("--allow-eager-fallback", action="store_true", help="N > 1: if hipGraph capture fails, run eager instead of aborting (a different launch protocol: labelled in config.launch)")
     ap.add_argument("--no-overlap", action="store_true", help="keep the text branch on the main stream (no parallel graph branch)")
     ap.add_argument("--torch-optimizer", action="store_true", help="diagnostic: torch clip_grad_norm_ + fused AdamW + foreach EMA instead of the HIP tail")
@@ -153,20 +153,21 @@ def secondary_legs():
     return out
 
 
-def pmc_traffic_live(kernel_substr, timeout=300):
+def pmc_traffic_live(families, timeout=300):
     """HBM bytes per launch of the roofline kernel, measured now: two rocprofv3 PMC passes over a short eager run of this script
     (FETCH_SIZE and WRITE_SIZE in SEPARATE runs, counters only with --kernel-trace, from /tmp), units and corrections as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes (both counters in KiB; FETCH_SIZE doubled on gfx950 for 16-byte-per-lane loads).
-    Returns (bytes_per_launch, dispatches, note) or (None, 0, reason)."""
+    `families` = {name: (kernel-name substrings)}.  Returns ({name: (bytes_per_launch, dispatches)}, note); a family that was not
+    seen is missing from the dict, a failed pass gives ({}, reason)."""
     import csv
     import shutil
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, 0, "rocprofv3 not found"
+        return {}, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="toist_pmc_", dir="/tmp")
-    kib, disp = {}, 0
+    kib = {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
@@ -174,18 +175,24 @@ def pmc_traffic_live(kernel_substr, timeout=300):
                    "--no-cpu-baseline", "--no-graph", "--no-roofline", "--steps", "2", "--warmup", "1"]
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=timeout)
             path = os.path.join(out, "p_counter_collection.csv")
-            tot, n = 0.0, 0
+            acc = {fam: [0.0, 0] for fam in families}
             with open(path) as f:
                 for row in csv.DictReader(f):
-                    if row.get("Counter_Name") == ctr and any(k_ in row.get("Kernel_Name", "") for k_ in kernel_substr):
-                        tot += float(row["Counter_Value"])
-                        n += 1
-            if n == 0:
-                return None, 0, f"no {kernel_substr} dispatch in the {ctr} pass"
-            kib[ctr], disp = tot / n, n
-        return int(2 * kib["FETCH_SIZE"] * 1024 + kib["WRITE_SIZE"] * 1024), disp, None
+                    if row.get("Counter_Name") != ctr:
+                        continue
+                    kn = row.get("Kernel_Name", "")
+                    for fam, subs in families.items():
+                        if any(k_ in kn for k_ in subs):
+                            acc[fam][0] += float(row["Counter_Value"])
+                            acc[fam][1] += 1
+            kib[ctr] = {fam: (t / n, n) for fam, (t, n) in acc.items() if n}
+        out = {}
+        for fam in families:
+            if fam in kib["FETCH_SIZE"] and fam in kib["WRITE_SIZE"]:
+                out[fam] = (int(2 * kib["FETCH_SIZE"][fam][0] * 1024 + kib["WRITE_SIZE"][fam][0] * 1024), kib["FETCH_SIZE"][fam][1])
+        return out, (None if out else "no dispatch of %s in the PMC passes" % (sorted(families),))
     except Exception as e:  # profiler missing / timed out / unreadable output: the committed passes are quoted instead
-        return None, 0, f"{type(e).__name__}: {e}"
+        return {}, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -337,7 +344,8 @@ def main():
     # their data gradients, 81 launches per step.  ~100 flop per algorithmic byte, below the ridge (2500 TFLOP/s / 8 TB/s = 312): HBM-bound.
     global ROOFLINE_KEYS
     ROOFLINE_KEYS = frozenset({(135, kernels.A_ROWK, kernels.B_ROWK), (135, kernels.A_ROWK, kernels.B_KROW),       # hbm: the short-K panel kernel
-                               (136, kernels.A_CONV, kernels.B_ROWK), (136, kernels.A_CONVT, kernels.B_KROW)})     # mfma: the 3x3 family on gemm128_kernel
+                               (136, kernels.A_CONV, kernels.B_ROWK), (136, kernels.A_CONVT, kernels.B_KROW),      # mfma: gemm128_kernel, 3x3 gathers ...
+                               (136, kernels.A_ROWK, kernels.B_ROWK), (136, kernels.A_ROWK, kernels.B_KROW)})      # ... and its deep-K 1x1 / linear launches
     if a.distill:
         return bench_distillation(a, dev, rank, world)
     if a.mixed_sizes:
@@ -596,6 +604,8 @@ def main():
                 run_step()
             barrier()
             region_ms.append(1000 * (time.perf_counter() - t1) / a.steps)
+        if len(region_ms) > 1:      # `value` = the MEDIAN region (every region is K steps between barrier + synchronize); the first one is kept in `repeats`
+            dt = sorted(region_ms)[len(region_ms) // 2] * a.steps / 1000.0
     if not a.no_roofline and use_graph:
         # kernel-level timing needs per-launch HIP events, which a replayed graph cannot carry: time the
         # same K steps once more, eagerly, on the same stream right after the timed region (every rank runs
@@ -647,7 +657,8 @@ def main():
             srt = sorted(region_ms)
             res["repeats"] = {"ms_per_step": [round(v, 3) for v in region_ms], "min": round(srt[0], 3), "median": round(srt[len(srt) // 2], 3),
                               "images_per_s_median": round(a.batch * world / (srt[len(srt) // 2] * 1e-3), 1),
-                              "note": "the K-step timed region run %d times back to back; `value` / `ms_per_step` are the first" % len(region_ms)}
+                              "first": round(region_ms[0], 3),
+                              "note": "the K-step timed region (barrier + synchronize on both sides) run %d times back to back; `value` / `ms_per_step` are the MEDIAN region, `first` is the first" % len(region_ms)}
         if world > 1:
             res["config"]["parameters_identical_across_ranks"] = params_identical
         if collectives is not None:
@@ -655,65 +666,72 @@ def main():
             if not params_identical:
                 res["config"]["parameters_differing"] = {"count": len(params_differing), "first": params_differing[:12]}
             res["config"]["gradient_wire_dtype"] = "bf16" if a.bf16_grads else "f32"
-        if prof is not None and prof["key"] is not None:
-            # second roofline entry: the 3x3 convolutions (stride-1 gathers, forward + data gradient) are the largest MFMA-bound family
-            conv = [r for r in prof["records"] if r[3][0] == 136]
-            prof["records"] = [r for r in prof["records"] if r[3][0] != 136]
-            if conv:
-                c_ms = sum(r[0].elapsed_time(r[1]) for r in conv)
-                c_fl = sum(r[2] for r in conv)
-                c_ach = c_fl / (c_ms * 1e-3) / 1e12
-                res["roofline_mfma"] = {"bound": "mfma", "achieved": round(c_ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(c_ach / PEAK_BF16_TFLOPS, 5),
-                                        "kernel": "gemm128_kernel<A_CONV | A_CONVT> (3x3 stride-1 convolutions of ResNet layers 2-4 and their data gradients: 128x128 tiles, 64x64 wave tiles)",
-                                        "launches": len(conv), "avg_launch_us": round(1000 * c_ms / len(conv), 2), "avg_gflop_per_launch": round(c_fl / len(conv) / 1e9, 3),
-                                        "timed": "HIP events around each launch, the same eager steps as `roofline`"}
-        if prof is not None and prof["records"]:
-            tot_ms, tot_fl, per_key = 0.0, 0.0, {}
-            for e0, e1, fl, key, shape, nbytes in prof["records"]:
-                ms = e0.elapsed_time(e1)
-                tot_ms += ms
-                tot_fl += fl
-                k_ = per_key.setdefault(str(key), [0.0, 0.0, 0])
-                k_[0] += ms
-                k_[1] += fl
-                k_[2] += 1
-            n = len(prof["records"])
-            alg_bytes = sum(r[5] for r in prof["records"]) / n
-            traffic, traffic_src = None, None
-            if prof["key"] is not None and world == 1 and not a.no_pmc:
-                traffic, n_disp, why = pmc_traffic_live(("panel_kernel", "panel2_kernel"))
-                if traffic is not None:
+        if prof is not None and prof["records"] and prof["key"] is not None:
+            # Two kernel families are timed launch by launch (HIP events on the launch stream, the eager steps): the short-K panel kernel
+            # (tile code 135, HBM-bound) and gemm128_kernel (tile code 136: the 3x3 convolutions of layers 2-4, their data gradients and the
+            # deep 1x1 launches, MFMA-bound).  `roofline` is the family with the LARGER share of the step's kernel time in THIS run; the
+            # other one is reported under its own name.  Both carry `traffic` from one pair of rocprofv3 PMC passes.
+            fams = {"hbm": [r for r in prof["records"] if r[3][0] == 135], "mfma": [r for r in prof["records"] if r[3][0] == 136]}
+            pmc, why = {}, "PMC passes skipped (--no-pmc / N > 1)"
+            if world == 1 and not a.no_pmc:
+                pmc, why = pmc_traffic_live({"hbm": ("panel_kernel", "panel2_kernel"), "mfma": ("gemm128_kernel",)})
+            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            pname = next((n_ for n_ in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(pdir, n_))), None)
+            entries, fam_ms = {}, {}
+            for fam, recs in fams.items():
+                if not recs:
+                    continue
+                ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+                fl, nb, n = sum(r[2] for r in recs), sum(r[5] for r in recs), len(recs)
+                fam_ms[fam] = ms / a.steps
+                tfl, gbs = fl / (ms * 1e-3) / 1e12, nb / (ms * 1e-3) / 1e9
+                subs = ("panel_kernel", "panel2_kernel") if fam == "hbm" else ("gemm128_kernel",)
+                traffic, traffic_src = None, None
+                if fam in pmc:
+                    traffic = pmc[fam][0]
                     traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over `bench.py --no-graph --steps 2`, "
-                                   "%d panel kernel dispatches per pass, 2*FETCH_SIZE + WRITE_SIZE per launch (KiB units, gfx950 FETCH correction)" % n_disp)
-                else:
-                    traffic_src = "live PMC passes failed (" + str(why) + ")"
-            if prof["key"] is not None and traffic is None:
-                # fallback: HBM bytes per launch of this kernel from the committed PMC passes (tools/run_gpu_round.sh + tools/pmc_traffic.py)
-                why_live = traffic_src
-                pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-                pname = next((n_ for n_ in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(pdir, n_))), None)
-                if pname is not None:
+                                   "%d dispatches per pass, 2*FETCH_SIZE + WRITE_SIZE per launch (KiB units, gfx950 FETCH correction)" % pmc[fam][1])
+                elif pname is not None:
                     meta = json.load(open(os.path.join(pdir, pname)))
-                    ks = {k_: v for k_, v in meta["kernels"].items() if "panel_kernel" in k_ or "panel2_kernel" in k_}
+                    ks = {k_: v for k_, v in meta["kernels"].items() if any(s_ in k_ for s_ in subs)}
                     disp = sum(v["dispatches"] for v in ks.values())
                     if disp:
                         traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in ks.values()) / disp)
-                        traffic_src = ("profiles/" + pname + ": rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --no-graph` at commit "
-                                       + str(meta.get("commit", "?")) + " (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction applied); not re-measured in this run"
-                                       + ("" if not why_live else " -- " + why_live))
+                        traffic_src = ("profiles/" + pname + ": rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --no-graph` at commit " + str(meta.get("commit", "?"))
+                                       + " (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction applied); not re-measured in this run -- " + str(why))
+                common = {"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src if traffic is not None else str(why),
+                          "algorithmic_bytes_per_launch": round(nb / n), "launches": n, "launches_per_step": n // a.steps, "ms_per_step": round(ms / a.steps, 3),
+                          "avg_launch_us": round(1000 * ms / n, 2), "avg_gflop_per_launch": round(fl / n / 1e9, 3),
+                          "timed": "HIP events around each launch, %d eager steps %s" % (a.steps, "after the graph-replayed timed region" if use_graph else "inside the timed region")}
+                if fam == "hbm":
+                    entries[fam] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 5),
+                                    "kernel": "panel2_kernel<{B_ROWK,B_KROW},act,BM> (tile code 135: 1x1 convolutions / linears with K <= 256 and their data gradients)",
+                                    "tflops": round(tfl, 2), "mfma_frac": round(tfl / PEAK_BF16_TFLOPS, 5)}
+                else:
+                    entries[fam] = {"bound": "mfma", "achieved": round(tfl, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / PEAK_BF16_TFLOPS, 5),
+                                    "kernel": "gemm128_kernel<A kind, B kind, NS> (tile code 136: 3x3 convolutions of ResNet layers 2-4, their data gradients, 1x1 / linear launches with K >= 768; 128x128 tiles, 64x64 wave tiles)",
+                                    "algorithmic_gbs": round(gbs, 1)}
+                entries[fam].update(common)
+            if entries:
+                top = max(fam_ms, key=fam_ms.get)
+                res["roofline"] = dict(entries[top], why_this_kernel="largest share of the step's kernel time among the timed families in this run: " +
+                                       ", ".join("%s %.2f ms/step" % (("panel2_kernel" if f_ == "hbm" else "gemm128_kernel"), v) for f_, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])))
+                for fam, ent in entries.items():
+                    res["roofline_" + fam] = ent
+        elif prof is not None and prof["records"]:
+            tot_ms = sum(r[0].elapsed_time(r[1]) for r in prof["records"])
+            tot_fl = sum(r[2] for r in prof["records"])
+            n = len(prof["records"])
+            per_key = {}
+            for e0, e1, fl, key, shape, nbytes in prof["records"]:
+                k_ = per_key.setdefault(str(key), [0.0, 0.0, 0])
+                k_[0] += e0.elapsed_time(e1)
+                k_[1] += fl
+                k_[2] += 1
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            gbs = sum(r[5] for r in prof["records"]) / (tot_ms * 1e-3) / 1e9
-            if prof["key"] is not None:
-                res["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 5),
-                                   "kernel": "panel2_kernel<{B_ROWK,B_KROW},act,BM> (1x1 convolutions with K <= 256 and their data gradients: the largest single share of the step's kernel time)",
-                                   "tflops": round(ach, 2), "mfma_frac": round(ach / PEAK_BF16_TFLOPS, 5)}
-            else:
-                res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5),
-                                   "kernel": "all gemm launches"}
-            res["roofline"].update({"traffic": traffic, "traffic_unit": "bytes/launch",
-                               "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes),
-                               "timed": "HIP events around each launch, %d eager steps %s" % (a.steps, "after the graph-replayed timed region" if use_graph else "inside the timed region"),
-                               "launches": n, "avg_launch_us": round(1000 * tot_ms / n, 2), "avg_gflop_per_launch": round(tot_fl / n / 1e9, 3)})
+            res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 5),
+                               "kernel": "all gemm launches", "traffic": None, "launches": n, "avg_launch_us": round(1000 * tot_ms / n, 2),
+                               "avg_gflop_per_launch": round(tot_fl / n / 1e9, 3)}
             if a.profile_all:
                 shapes = {}
                 for e0, e1, fl, key, shape, nbytes in prof["records"]:

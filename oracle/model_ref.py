@@ -303,10 +303,16 @@ def loss_contrastive_align(out, token_spans, indices, num_boxes, temperature=0.0
 
 
 def set_criterion(out, targets, positive_map, *, eos_coef=0.1, weights=(1.0, 5.0, 2.0), world_size=1, token_spans=None,
-                  temperature=0.07, return_indices=False):
+                  temperature=0.07, return_indices=False, indices=None):
     """SetCriterion.forward, non-list branch, mdetr.py:990-1021 (labels, boxes, cardinality
-    [, contrastive_align]; aux layers re-matched)."""
+    [, contrastive_align]; aux layers re-matched).  `indices` (tests only): assignments to use instead of matching, one list of
+    (src, tgt) pairs per layer in the order main, aux 0, aux 1, ... -- a gradient comparison between two implementations
+    whose outputs differ in the last bits must not be dominated by a near-tied assignment that flipped."""
+    given = list(indices) if indices is not None else None
+
     def match(o):
+        if given is not None:
+            return given.pop(0)
         return matcher_ref.hungarian_match(o["pred_logits"], o["pred_boxes"], [t["boxes"] for t in targets], positive_map, *weights)
 
     num_boxes = max(float(sum(len(t["boxes"]) for t in targets)) / world_size, 1.0)

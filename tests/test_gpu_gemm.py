@@ -633,6 +633,12 @@ def test_gemm128_kernel_plain(dev, M, N, K):
     for out, tile in ((out_b, 136), (out_f, 65)):
         k.gemm(M, N, K, k.A_ROWK, k.operand(x, K), k.B_KROW, k.operand(wt, N), out, N, res=res, ldr=N, act=k.ACT_MASK_POS, aux=aux, ldaux=N, tile=tile)
     _ulp_close(out_b, out_f, "dgrad")
+    # directly against fp32 torch math on the same bf16-rounded operands (not through another HIP kernel)
+    y32 = x.float().cpu() @ w.float().cpu().t() + bias.cpu()
+    _ulp_close(ops.linear(x, w, bias, tile=136, split_k=1, res=res, act=k.ACT_RELU).cpu(), torch.relu(y32 + res.float().cpu()), "forward vs fp32 torch")
+    _ulp_close(ops.linear(x, w, bias, tile=136, split_k=1).cpu(), y32, "plain forward vs fp32 torch")
+    d32 = (x.float().cpu() @ wt.float().cpu() + res.float().cpu()) * (aux.float().cpu() > 0)
+    _ulp_close(out_b.cpu(), d32, "dgrad vs fp32 torch")
 
 
 @pytest.mark.parametrize("Nb,H,W,C,Co,R,pad,dil", [(8, 40, 40, 256, 256, 3, 1, 1), (2, 37, 43, 128, 256, 3, 2, 2), (3, 19, 23, 64, 192, 3, 1, 1), (2, 30, 30, 64, 128, 1, 0, 1)])
@@ -663,6 +669,13 @@ def test_gemm128_kernel_convolution_gathers(dev, Nb, H, W, C, Co, R, pad, dil):
         got2 = ops.conv2d(x, w, stride=2, pad=pad, dil=dil, scale=scale, shift=shift, res=res2, act=k.ACT_RELU, tile=136)
         ref2 = ops.conv2d(x, w, stride=2, pad=pad, dil=dil, scale=scale, shift=shift, res=res2, act=k.ACT_RELU, tile=65, out_dtype=torch.float32)
         _ulp_close(got2, ref2, "strided forward gather")
+        # directly against fp32 F.conv2d / autograd on the same bf16-rounded operands
+        xc, wc = x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2)      # CPU fp32: no library convolution on the device
+        aff = lambda t: t.permute(0, 2, 3, 1) * scale.cpu() + shift.cpu()
+        _ulp_close(got.cpu(), torch.relu(aff(F.conv2d(xc, wc, padding=pad, dilation=dil)) + res.float().cpu()), "forward gather vs F.conv2d")
+        _ulp_close(got2.cpu(), torch.relu(aff(F.conv2d(xc, wc, stride=2, padding=pad, dilation=dil)) + res2.float().cpu()), "strided forward gather vs F.conv2d")
+        d32 = torch.nn.grad.conv2d_input(xc.shape, wc, dy.float().cpu().permute(0, 3, 1, 2), padding=pad, dilation=dil).permute(0, 2, 3, 1)
+        _ulp_close(dx.cpu(), d32 * (aux.float().cpu() > 0), "transposed gather vs conv2d_input")
         if Nb * H * W >= 12800:
             assert torch.equal(ops.conv2d(x, w, pad=pad, dil=dil, scale=scale, shift=shift, res=res, act=k.ACT_RELU), got)
             assert torch.equal(ops.conv2d_dgrad(dy, w, (H, W), pad=pad, dil=dil, act=k.ACT_MASK_POS, aux=aux), dx)
@@ -724,6 +737,12 @@ def test_gemm128w_weight_gradient_kernel(dev, Nb, H, W, C, Co, R, dil, n, min_ti
         k.PROFILE = None
     assert torch.equal(got[:16], base[:16]) and torch.equal(got[-48:], base[-48:])               # nothing written outside the slices
     assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # directly against fp32 torch (conv2d_weight on the same bf16-rounded operands), problem by problem
+    for i, (dy, x, out, rs) in enumerate(items[:3]):
+        w32 = torch.nn.grad.conv2d_weight(x.float().cpu().permute(0, 3, 1, 2), (Co, C, R, R), dy.float().cpu().permute(0, 3, 1, 2), padding=pad, dilation=dil)
+        want = w32.permute(0, 2, 3, 1) * rs.cpu()[:, None, None, None] + base[16 + i * Co * R * R * C: 16 + (i + 1) * Co * R * R * C].view(Co, R, R, C).cpu()
+        mine = got[16 + i * Co * R * R * C: 16 + (i + 1) * Co * R * R * C].view(Co, R, R, C).cpu()
+        assert float((mine - want).abs().max()) <= 2e-3 * float(want.abs().max()), f"problem {i} vs fp32 conv2d_weight"
     if expect == -1:
         assert picked == [] and torch.equal(got, ref)
     elif expect == 0:
