@@ -364,6 +364,77 @@ TOIST_API int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, 
                    float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int variant, float* workspace, int q_splits,
                    const float* lse, const uint8_t* key_pad, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
+/* ---- attention cores, second generation (head dim 32; csrc/attn2.hip).  Same operands as toist_attn_fwd / toist_attn_bwd (per-head column
+ * slices of [B*S, ld*] bf16 buffers), flash-style only: nothing score-shaped is stored, the key count is unbounded.
+ *   toist_attn2_fwd   ctx = dropout(softmax(scale q k^T + key padding)) v; lse (f32 [B*H, Sq, 2]) receives (maximum of the RAW dot
+ *                     products of the row, 1 / sum of exp(scale (s - max))).  The keep mask of element (row = bh * Sq + q, key) is the
+ *                     16-bit field key & 1 of pair_hash((row * round8(Sk) + key) >> 1) compared with round(drop_p * 65536).
+ *   toist_attn2_bwd   key-owning backward: dk / dv are written once; workgroup x of a head owns keys [128 x, 128 x + 128).  With
+ *                     toist_attn2_splits(Sk) == 1 dq is written directly; otherwise every split leaves ITS share of dq in
+ *                     dq_part (bf16 [splits][B*Sq][H*32], already multiplied by scale) and the consumer adds the shares
+ *                     (toist_rowgemm's fold prologue); dq may then be NULL. */
+TOIST_API int toist_attn2_splits(int Sk);
+TOIST_API int toist_attn2_fwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int Sq,
+                    int Sk, int dh, float scale, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* ctx, int ldo, float* lse,
+                    void* stream);
+TOIST_API int toist_attn2_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const void* ctx, int ldo, const void* dctx, int lddo,
+                    const float* lse, const uint8_t* key_pad, int B, int H, int Sq, int Sk, int dh, float scale, float drop_p, uint64_t seed,
+                    const uint64_t* seed_dev, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, void* dq_part, void* stream);
+
+/* ---- row-complete transformer sub-layers (d_model = 256; csrc/tlayer.hip).  One launch computes out[m][0..255] for blocks of 16
+ * rows over the whole reduction length K and finishes the rows on chip:
+ *   TOIST_ROW_LN_FWD  x + dropout(sublayer(x)) followed by LayerNorm -- `norm1(src + dropout1(src2))`, `norm2(src + dropout2(src2))` of
+ *                     /root/reference/models/transformer.py:297-303 and norm1 / norm3 / norm4 of :376-407:
+ *                       z = bf16(res + dropout(a w^T + bias));  out = LayerNorm(z) gamma + beta;  out2 = bf16(out + add) (optional);
+ *                       z, mean, rstd are kept for the backward pass;
+ *   TOIST_ROW_LN_BWD  the data gradient a w (+ res + res2: gradients arriving over residual connections) is the gradient w.r.t. a
+ *                     LayerNorm OUTPUT; the launch applies the LayerNorm backward (saved z / mean / rstd, gamma) and writes
+ *                       out = dz (gradient of the LayerNorm input = of the residual stream), out2 = dropout-masked dz (the gradient
+ *                       of the dropout(sublayer) term, same (seed, m * 256 + n) hash as the forward pass; optional),
+ *                       partials[2][blocks][256] f32 = per-block sums of g * xhat and g over the block's rows (d gamma / d beta, folded
+ *                       by toist_splitk_reduce_batch; blocks = toist_rowgemm_blocks(M)); NULL when gamma is frozen;
+ *   TOIST_ROW_PLAIN   out = bf16(a w (+ bias) + res + res2).
+ * w is the nn.Linear parameter's bf16 copy read in place: TOIST_B_ROWK = [256][K] rows (forward: y = a w^T), TOIST_B_KROW = [K][256]
+ * rows (data gradient: da = dy w).  Fold prologue (fold_parts > 1): columns [0, fold_cols) of every A row are the f32 sum of fold_parts
+ * bf16 slabs (slab s, row m, column c at fold + s * fold_stride + m * fold_cols + c) -- the key-split partial dQ of toist_attn2_bwd --
+ * rounded once and WRITTEN BACK to a (the weight-gradient GEMM reads the folded rows later).
+ * All pointers 16-byte aligned, leading dimensions multiples of 8 elements, K a multiple of 128 (<= 4096).  The caller owns every
+ * buffer; nothing is allocated, nothing synchronises. */
+enum { TOIST_ROW_PLAIN = 0, TOIST_ROW_LN_FWD = 1, TOIST_ROW_LN_BWD = 2 };
+
+typedef struct toist_rowgemm_desc {
+    int32_t M, K;             /* rows, reduction length; the output is [M, 256] */
+    int32_t b_kind;           /* TOIST_B_ROWK or TOIST_B_KROW */
+    int32_t epi;              /* TOIST_ROW_* */
+    const void* a;            /* bf16 [M, K], row stride lda (written when folding) */
+    const void* w;            /* bf16 weights, row stride ldw */
+    int32_t lda, ldw;
+    const void* fold;         /* bf16 slabs of the fold prologue, or NULL */
+    int64_t fold_stride;      /* elements between slabs */
+    int32_t fold_parts, fold_cols;
+    const float* bias;        /* f32 [256] or NULL */
+    const void* res;          /* bf16 [M, 256], row stride ldr, or NULL */
+    const void* res2;         /* bf16 [M, 256], row stride ldr2, or NULL */
+    int32_t ldr, ldr2;
+    float drop_p;             /* LN_FWD: dropout of (a w^T + bias);  LN_BWD: the mask of out2 */
+    float eps;                /* LN_FWD */
+    uint64_t drop_seed;
+    const uint64_t* drop_seed_dev;   /* optional device word added to drop_seed (graph replay) */
+    const float* gamma;       /* f32 [256] */
+    const float* beta;        /* f32 [256] (LN_FWD) */
+    void* z;                  /* bf16 [M, 256] contiguous: LN_FWD output (optional), LN_BWD input */
+    float* mean;              /* f32 [M]: LN_FWD output (optional), LN_BWD input */
+    float* rstd;
+    void* out;                /* bf16 [M, 256], row stride ldo */
+    int32_t ldo, reserved;
+    const void* add;          /* LN_FWD: bf16 [M, 256] contiguous constant added into out2 */
+    void* out2;               /* bf16 [M, 256] contiguous (see above), or NULL */
+    float* partials;          /* LN_BWD: f32 [2][blocks][256], or NULL */
+} toist_rowgemm_desc;
+
+TOIST_API int toist_rowgemm_blocks(int M);
+TOIST_API int toist_rowgemm(const toist_rowgemm_desc* d, void* stream);
+
 /* ---- k-means of the distillation step on the device (models/kmeans.py:21-96 as mdetr.py:213-234 calls it).  One workgroup per
  * distinct task of the batch: group g covers samples members[group_off[g] .. group_off[g+1]) (batch order), all of task
  * group_task[g]; for each sample: Lloyd iterations over banks[task] ([N, D] f32, stride bank_stride elements) from
@@ -440,6 +511,11 @@ TOIST_API int toist_opt_finish_norm(const float* partial, int n_chunks, float ma
 TOIST_API int toist_opt_adamw_ema(const toist_opt_tensor* table, const int64_t* grads, const int32_t* chunks, int n_chunks,
                         const toist_opt_group* groups, const toist_opt_state* state, float beta1, float beta2, float eps,
                         float ema_decay, void* stream);
+/* the same update issued by at most max_blocks workgroups (0 = one per chunk): a slim launch that shares the chip with other work -- the
+ * late parameter groups of toist_amd.optim, updated beside the next forward pass */
+TOIST_API int toist_opt_adamw_ema_blocks(const toist_opt_tensor* table, const int64_t* grads, const int32_t* chunks, int n_chunks,
+                               const toist_opt_group* groups, const toist_opt_state* state, float beta1, float beta2, float eps,
+                               float ema_decay, int max_blocks, void* stream);
 
 /* ---- evaluation masks (replaces PostProcessSegm's dense resizes, models/postprocessors.py:73-109, and what
  * datasets/coco_eval.py:307-332 asks of pycocotools: mask_util.encode, and maskUtils.iou / area inside COCOeval).

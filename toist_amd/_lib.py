@@ -45,6 +45,20 @@ class Gemm(Structure):
     ]
 
 
+ROW_PLAIN, ROW_LN_FWD, ROW_LN_BWD = 0, 1, 2
+
+
+class RowGemm(Structure):
+    """toist_rowgemm_desc (include/toist_hip.h): row-complete sub-layer launch of csrc/tlayer.hip"""
+    _fields_ = [
+        ("M", c_int32), ("K", c_int32), ("b_kind", c_int32), ("epi", c_int32), ("a", c_void_p), ("w", c_void_p), ("lda", c_int32), ("ldw", c_int32),
+        ("fold", c_void_p), ("fold_stride", c_int64), ("fold_parts", c_int32), ("fold_cols", c_int32), ("bias", c_void_p), ("res", c_void_p),
+        ("res2", c_void_p), ("ldr", c_int32), ("ldr2", c_int32), ("drop_p", c_float), ("eps", c_float), ("drop_seed", c_uint64),
+        ("drop_seed_dev", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("z", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
+        ("out", c_void_p), ("ldo", c_int32), ("reserved", c_int32), ("add", c_void_p), ("out2", c_void_p), ("partials", c_void_p),
+    ]
+
+
 class ReduceDesc(Structure):
     _fields_ = [("ws", c_void_p), ("out", c_void_p), ("rscale", c_void_p), ("splits", c_int32), ("M", c_int32), ("N", c_int32),
                 ("ldc", c_int32), ("alpha", c_float), ("accumulate", c_int32)]
@@ -91,6 +105,13 @@ _SIGNATURES = {
     "toist_attn_bwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32] + [c_int32] * 6 +
                        [c_float, c_float, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_uint64,
                         c_void_p, c_void_p], ctypes.c_int),
+    "toist_attn2_splits": ([c_int32], ctypes.c_int),
+    "toist_attn2_fwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 5 + [c_float, c_float, c_uint64, c_void_p, c_void_p,
+                        c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "toist_attn2_bwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p] + [c_int32] * 5 +
+                        [c_float, c_float, c_uint64, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "toist_rowgemm_blocks": ([c_int32], ctypes.c_int),
+    "toist_rowgemm": ([POINTER(RowGemm), c_void_p], ctypes.c_int),
     "toist_kmeans": ([c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_float, c_int32,
                      c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_attn_small_fwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 4 + [c_float, c_float, c_uint64, c_void_p, c_void_p,
@@ -108,6 +129,7 @@ _SIGNATURES = {
     "toist_opt_sqnorm": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_opt_finish_norm": ([c_void_p, c_int32, c_float, c_float, c_float, c_void_p, c_void_p], ctypes.c_int),
     "toist_opt_adamw_ema": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p], ctypes.c_int),
+    "toist_opt_adamw_ema_blocks": ([c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_int32, c_void_p], ctypes.c_int),
     "toist_mask_resize_pack": ([c_void_p] + [c_int32] * 9 + [c_float, c_void_p, c_void_p], ctypes.c_int),
     "toist_mask_pack": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_mask_unpack": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),

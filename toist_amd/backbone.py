@@ -14,6 +14,7 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
+from .knobs import knob
 from . import engine, functions
 from . import kernels as k
 from . import ops
@@ -21,7 +22,7 @@ from .misc import NestedTensor
 from .position_encoding import build_position_encoding
 
 BF16 = torch.bfloat16
-FUSED_STEM = os.environ.get("TOIST_FUSED_STEM", "1") != "0"     # conv1 + bn1 + relu + maxpool as one launch (csrc/stem.hip)
+FUSED_STEM = knob("TOIST_FUSED_STEM", True)     # conv1 + bn1 + relu + maxpool as one launch (csrc/stem.hip)
 
 
 _BN_EPOCH = [0]   # bumped whenever any FrozenBatchNorm2d invalidates its folded scale/shift

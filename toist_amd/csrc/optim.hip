@@ -87,8 +87,10 @@ __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v,
 __global__ __launch_bounds__(256) void adamw_ema_kernel(const toist_opt_tensor* __restrict__ T, const int64_t* __restrict__ G,
                                                         const int2* __restrict__ chunks, const toist_opt_group* __restrict__ groups,
                                                         const toist_opt_state* __restrict__ st, float b1, float b2, float eps,
-                                                        float decay) {
-    const int2 ch = chunks[blockIdx.x];
+                                                        float decay, int n_chunks) {
+  // gridDim.x < n_chunks: a slim launch (the late groups' update beside the next forward pass) walks the chunks with few workgroups
+  for (int cb = blockIdx.x; cb < n_chunks; cb += gridDim.x) {
+    const int2 ch = chunks[cb];
     const toist_opt_tensor t = T[ch.x];
     const float* g = reinterpret_cast<const float*>(G[ch.x]);
     const long long beg = (long long)ch.y * OPT_CHUNK;
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(const toist_opt_tensor* 
             t.w[beg + i] = f2bf(pv * s);
         }
     }
+  }
 }
 
 }  // namespace toist
@@ -180,12 +183,19 @@ extern "C" int toist_opt_finish_norm(const float* partial, int n_chunks, float m
     return check_launch("toist_opt_finish_norm");
 }
 
+extern "C" int toist_opt_adamw_ema_blocks(const toist_opt_tensor* table, const int64_t* grads, const int32_t* chunks, int n_chunks,
+                                          const toist_opt_group* groups, const toist_opt_state* state, float beta1, float beta2, float eps,
+                                          float ema_decay, int max_blocks, void* stream) {
+    TOIST_REQUIRE(table && grads && chunks && groups && state && n_chunks > 0, "toist_opt_adamw_ema: bad args");
+    TOIST_REQUIRE(eps > 0.f && ema_decay >= 0.f && ema_decay <= 1.f, "toist_opt_adamw_ema: bad eps / ema_decay");
+    const int blocks = (max_blocks > 0 && max_blocks < n_chunks) ? max_blocks : n_chunks;
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, grads, (const int2*)chunks, groups, state,
+                       beta1, beta2, eps, ema_decay, n_chunks);
+    return check_launch("toist_opt_adamw_ema");
+}
+
 extern "C" int toist_opt_adamw_ema(const toist_opt_tensor* table, const int64_t* grads, const int32_t* chunks, int n_chunks,
                                    const toist_opt_group* groups, const toist_opt_state* state, float beta1, float beta2, float eps,
                                    float ema_decay, void* stream) {
-    TOIST_REQUIRE(table && grads && chunks && groups && state && n_chunks > 0, "toist_opt_adamw_ema: bad args");
-    TOIST_REQUIRE(eps > 0.f && ema_decay >= 0.f && ema_decay <= 1.f, "toist_opt_adamw_ema: bad eps / ema_decay");
-    hipLaunchKernelGGL(adamw_ema_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, grads, (const int2*)chunks, groups, state,
-                       beta1, beta2, eps, ema_decay);
-    return check_launch("toist_opt_adamw_ema");
+    return toist_opt_adamw_ema_blocks(table, grads, chunks, n_chunks, groups, state, beta1, beta2, eps, ema_decay, 0, stream);
 }

@@ -7,7 +7,6 @@ them in reverse.  Activations are bf16, statistics / parameter gradients fp32.  
 and FrozenBN backward steps are folded into the epilogue of the GEMM that produces the gradient.
 """
 import math
-import os as _os_early
 
 import weakref
 
@@ -15,6 +14,7 @@ import torch
 
 from . import kernels as k
 from . import ops
+from .knobs import knob
 
 BF16 = torch.bfloat16
 
@@ -51,12 +51,29 @@ class Var:
 # Measured on MI355X (B=8, 640x640): text branch || image branch +8.7 % images/s (+14 % once the rest of the step had shrunk).  Forking the weight-gradient
 # GEMMs from the data-gradient chain was measured too (0 % to -6 %: those kernels already fill the chip and
 # every fork is a cross-stream edge of the graph) and is deliberately not done.
-OVERLAP = _os_early.environ.get("TOIST_OVERLAP", "capture")   # "capture": fork the text branch inside captured graphs only; "on" / "off"
+OVERLAP = knob("TOIST_OVERLAP", "capture")   # "capture": fork the text branch inside captured graphs only; "on" / "off"
 FUSED_ATTENTION = True   # head-dim-32 attention cores run as one fused forward launch (csrc/attn.hip); False = 3 launches
 LSE_ONLY = True          # the fused cores keep only the log-sum-exp of every score row; backward re-forms P and the dropout mask
 FUSED_BLOCKS = True      # encoder / decoder layers: packed in_proj in one launch, decoder K/V of all layers grouped, LayerNorm emits y + pos
 _SIDE = {}
-SIDE_PRIORITY = int(_os_early.environ.get("TOIST_SIDE_PRIORITY", "0"))   # -1 = high: the small kernels of a side branch get free CU slots first
+SIDE_PRIORITY = knob("TOIST_SIDE_PRIORITY", 0)   # -1 = high: the small kernels of a side branch get free CU slots first
+
+
+# Work that must run at the head of the text branch, on its stream, before RoBERTa reads its weights: the late parameter groups of
+# toist_amd.optim.FusedClipAdamWEMA (the text encoder's AdamW + EMA launch of the PREVIOUS step runs beside the ResNet forward).
+_TEXT_PRELUDE = []
+
+
+def register_text_prelude(opt):
+    _TEXT_PRELUDE[:] = [r for r in _TEXT_PRELUDE if r() is not None]
+    _TEXT_PRELUDE.append(weakref.ref(opt))
+
+
+def run_text_prelude():
+    for r in _TEXT_PRELUDE:
+        opt = r()
+        if opt is not None:
+            opt.flush_late()
 
 
 def side_stream(device, name):
@@ -73,8 +90,7 @@ def overlap_enabled():
     return OVERLAP == "capture" and torch.cuda.is_current_stream_capturing()
 
 
-import os as _os
-GROUP_WGRADS = _os.environ.get("TOIST_GROUP_WGRADS", "1") != "0"   # same-shape weight gradients of a program run as grouped launches at its end
+GROUP_WGRADS = knob("TOIST_GROUP_WGRADS", True)   # same-shape weight gradients of a program run as grouped launches at its end
 
 
 class Tape:
@@ -316,7 +332,7 @@ class ParamView:
 # a program (and its ~600 per-parameter views) is then reused from step to step instead of being re-sliced every forward.
 # Off by default: with it, a gradient tensor stashed by the caller would be overwritten by the next forward pass.
 REUSE_GRAD_BUFFERS = False
-STORE_ONCE = __import__('os').environ.get('TOIST_STORE_ONCE', '1') != '0'      # weight gradients of nn.Linear / nn.Conv2d overwrite their (un-zeroed) slots instead of accumulating into zeroed ones
+STORE_ONCE = knob("TOIST_STORE_ONCE", True)      # weight gradients of nn.Linear / nn.Conv2d overwrite their (un-zeroed) slots instead of accumulating into zeroed ones
 POISON_FRESH = False   # tests: fill the store-once slots with NaN before every backward
 
 

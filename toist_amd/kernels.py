@@ -6,11 +6,10 @@ memory and streams only.  There is no fallback: a CPU tensor or a missing librar
 """
 import ctypes
 
-import os as _os
-
 import torch
 
 from . import _lib
+from .knobs import knob
 from ._lib import (A_CONV, A_CONVT, A_KROW, A_ROWK, ACT_GELU, ACT_GELU_BWD, ACT_MASK_POS, ACT_NONE, ACT_RELU,
                    ACT_SIGMOID, ACT_SIGMOID_BWD, B_CONVX, B_KROW, B_ROWK, Epilogue, Gemm, Operand)
 
@@ -175,7 +174,7 @@ class tables_beside_graph:
     def __enter__(self):
         global FILL_TABLES_OUTSIDE_GRAPH
         self.old = FILL_TABLES_OUTSIDE_GRAPH
-        FILL_TABLES_OUTSIDE_GRAPH = _os.environ.get("TOIST_FILL_OUTSIDE_GRAPH", "1") != "0"
+        FILL_TABLES_OUTSIDE_GRAPH = knob("TOIST_FILL_OUTSIDE_GRAPH", True)
         if FILL_TABLES_OUTSIDE_GRAPH and not torch.cuda.is_current_stream_capturing():
             _arena_prepare(torch.device("cuda", torch.cuda.current_device()))
         return self
@@ -351,7 +350,7 @@ def layernorm_fwd(x, gamma, beta, eps, y, mean=None, rstd=None, add=None, y2=Non
         "toist_layernorm_fwd")
 
 
-LN_DEFER = _os.environ.get("TOIST_LN_DEFER", "1") != "0"
+LN_DEFER = knob("TOIST_LN_DEFER", True)
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma=None, dbeta=None, dx_drop=None, drop_p=0.0, seed=0, defer=False):
@@ -553,9 +552,9 @@ def opt_finish_norm(partial, n_chunks, max_norm, beta1, beta2, state):
                                                 _stream()), "toist_opt_finish_norm")
 
 
-def opt_adamw_ema(table, grads, chunks, n_chunks, groups, state, beta1, beta2, eps, ema_decay):
-    _lib.check(_lib.lib().toist_opt_adamw_ema(_p(table, torch.uint8), _p(grads, torch.int64), _p(chunks, torch.int32), n_chunks,
-                                              _p(groups, torch.float32), _p(state, torch.uint8), beta1, beta2, eps, ema_decay, _stream()),
+def opt_adamw_ema(table, grads, chunks, n_chunks, groups, state, beta1, beta2, eps, ema_decay, max_blocks=0):
+    _lib.check(_lib.lib().toist_opt_adamw_ema_blocks(_p(table, torch.uint8), _p(grads, torch.int64), _p(chunks, torch.int32), n_chunks,
+                                                     _p(groups, torch.float32), _p(state, torch.uint8), beta1, beta2, eps, ema_decay, max_blocks, _stream()),
                "toist_opt_adamw_ema")
 
 
@@ -612,6 +611,74 @@ def attn_bwd(q, kmat, v, prob, prob_drop, ctx, dctx, B, H, Sq, Sk, dh, scale, dr
                                          _p(dq, torch.bfloat16), dq.stride(0), _p(dk, torch.bfloat16), dk.stride(0), _p(dv, torch.bfloat16), dv.stride(0),
                                          variant, _p(ws, torch.float32), q_splits, _p(lse, torch.float32), _p(key_pad, torch.uint8), seed,
                                          _p(SEED_DEV) if (prob is None and drop_p > 0) else None, _stream()), "toist_attn_bwd")
+
+
+def attn2_splits(Sk):
+    return int(_lib.lib().toist_attn2_splits(Sk))
+
+
+def attn2_fwd(q, kmat, v, key_pad, B, H, Sq, Sk, dh, scale, drop_p, seed, ctx, lse):
+    """Flash-style attention core (csrc/attn2.hip): q / k / v / ctx are column slices of packed [B*S, ld] bf16 buffers; lse f32 [B*H, Sq, 2]."""
+    _lib.check(_lib.lib().toist_attn2_fwd(_p(q, torch.bfloat16), q.stride(0), _p(kmat, torch.bfloat16), kmat.stride(0), _p(v, torch.bfloat16), v.stride(0),
+                                          _p(key_pad, torch.uint8), B, H, Sq, Sk, dh, scale, drop_p, seed, _p(SEED_DEV) if drop_p > 0 else None,
+                                          _p(ctx, torch.bfloat16), ctx.stride(0), _p(lse, torch.float32), _stream()), "toist_attn2_fwd")
+
+
+def attn2_bwd(q, kmat, v, ctx, dctx, lse, key_pad, B, H, Sq, Sk, dh, scale, drop_p, seed, dq, dk, dv, dq_part=None):
+    """Key-owning backward of attn2_fwd: dk / dv written once; dq directly when attn2_splits(Sk) == 1, else its per-split shares go to
+    dq_part (bf16 [splits, B*Sq, H*dh]) for the consumer's fold (kernels.rowgemm(fold=...))."""
+    _lib.check(_lib.lib().toist_attn2_bwd(_p(q, torch.bfloat16), q.stride(0), _p(kmat, torch.bfloat16), kmat.stride(0), _p(v, torch.bfloat16), v.stride(0),
+                                          _p(ctx, torch.bfloat16), ctx.stride(0), _p(dctx, torch.bfloat16), dctx.stride(0), _p(lse, torch.float32),
+                                          _p(key_pad, torch.uint8), B, H, Sq, Sk, dh, scale, drop_p, seed, _p(SEED_DEV) if drop_p > 0 else None,
+                                          _p(dq, torch.bfloat16), dq.stride(0) if dq is not None else 0, _p(dk, torch.bfloat16), dk.stride(0),
+                                          _p(dv, torch.bfloat16), dv.stride(0), _p(dq_part, torch.bfloat16), _stream()), "toist_attn2_bwd")
+
+
+def rowgemm(a, w, out, *, b_kind, epi, K=None, bias=None, res=None, res2=None, drop_p=0.0, drop_seed=0, gamma=None, beta=None, eps=1e-5,
+            z=None, mean=None, rstd=None, add=None, out2=None, fold=None, fold_cols=0, dgamma=None, dbeta=None):
+    """Row-complete sub-layer launch (csrc/tlayer.hip, include/toist_hip.h: toist_rowgemm): out[M, 256] from a[M, K] and the nn.Linear
+    weight copy `w` read in place (b_kind B_ROWK = forward, B_KROW = data gradient), finished on chip by epi = ROW_PLAIN / ROW_LN_FWD /
+    ROW_LN_BWD.  fold = bf16 [parts, M, fold_cols] partial sums that replace (and are written back into) a[:, :fold_cols].
+    ROW_LN_BWD: dgamma / dbeta (f32 [256], accumulated) receive the parameter gradients through per-block partials queued for
+    flush_reductions(), exactly like layernorm_bwd(defer=True)."""
+    M = a.shape[0]
+    d = _lib.RowGemm()
+    d.M, d.K, d.b_kind, d.epi = M, (a.shape[1] if K is None else K), b_kind, epi
+    d.a, d.lda, d.w, d.ldw = _p(a, torch.bfloat16), a.stride(0), _p(w, torch.bfloat16), w.stride(0)
+    if fold is not None:
+        d.fold, d.fold_parts, d.fold_cols, d.fold_stride = _p(fold, torch.bfloat16), fold.shape[0], fold_cols, fold.stride(0)
+        assert fold.shape[1] == M and fold.shape[2] == fold_cols and fold.stride(1) == fold_cols
+    d.bias = _p(bias, torch.float32)
+    if res is not None:
+        d.res, d.ldr = _p(res, torch.bfloat16), res.stride(0)
+    if res2 is not None:
+        d.res2, d.ldr2 = _p(res2, torch.bfloat16), res2.stride(0)
+    d.drop_p, d.eps, d.drop_seed = drop_p, eps, drop_seed
+    d.drop_seed_dev = _p(SEED_DEV) if drop_p > 0 else None
+    d.gamma, d.beta = _p(gamma, torch.float32), _p(beta, torch.float32)
+    for name, t in (("z", z), ("add", add), ("out2", out2)):
+        if t is not None:
+            assert t.is_contiguous() and t.shape[-1] == 256
+            setattr(d, name, _p(t, torch.bfloat16))
+    d.mean, d.rstd = _p(mean, torch.float32), _p(rstd, torch.float32)
+    d.out, d.ldo = _p(out, torch.bfloat16), out.stride(0)
+    keep = None
+    if epi == _lib.ROW_LN_BWD and dgamma is not None:
+        key = (a.device, _raw_stream())
+        if any(it[0].out in (dgamma.data_ptr(), dbeta.data_ptr()) for it in _PENDING.get(key, ())):
+            flush_reductions()          # two queued folds into one output would race
+        blocks = int(_lib.lib().toist_rowgemm_blocks(M))
+        partials = _arena_take(2 * blocks * 256, a.device)
+        for i, o in enumerate((dgamma, dbeta)):
+            rd = _lib.ReduceDesc(partials.data_ptr() + 4 * i * blocks * 256, o.data_ptr(), None, blocks, 1, 256, 256, 1.0, 1)
+            _PENDING.setdefault(key, []).append((rd, (o, partials)))
+        d.partials = _p(partials, torch.float32)
+        keep = partials
+    _lib.check(_lib.lib().toist_rowgemm(ctypes.byref(d), _stream()), "toist_rowgemm")
+    return keep
+
+
+ROW_PLAIN, ROW_LN_FWD, ROW_LN_BWD = _lib.ROW_PLAIN, _lib.ROW_LN_FWD, _lib.ROW_LN_BWD
 
 
 def kmeans(banks, centers, group_task, group_off, members, features, tol, max_iter, pick, chosen_center, iters=None):

@@ -5,11 +5,10 @@ Shapes follow the kernels' native layouts (bf16, feature axis innermost): token 
 physical layout of a channels_last OIHW parameter).  Nothing here touches autograd; the modules in
 toist_amd build their forward/backward passes out of these calls.
 """
-import os as _os
-
 import torch
 
 from . import kernels as k
+from .knobs import knob
 
 BF16 = torch.bfloat16
 
@@ -20,7 +19,7 @@ def _ld(t):
     return t.stride(0)
 
 
-SPLIT_TARGET = int(_os.environ.get("TOIST_SPLIT_TARGET", "768"))
+SPLIT_TARGET = knob("TOIST_SPLIT_TARGET", 768)
 
 
 def _split_k_for(tiles, ktiles, target=None, max_split=256):
@@ -34,7 +33,7 @@ def _split_k_for(tiles, ktiles, target=None, max_split=256):
 
 
 # ------------------------------------------------------------------------------------------ linear
-SPLIT_LINEAR = _os.environ.get("TOIST_SPLIT_LINEAR", "1") != "0"
+SPLIT_LINEAR = knob("TOIST_SPLIT_LINEAR", True)
 SPLIT_MAX_TILES, SPLIT_MIN_KTILES, SPLIT_KTILES_PER_SLICE, SPLIT_TARGET_WGS = 64, 32, 8, 384
 
 
@@ -202,7 +201,7 @@ def conv2d_dgrad(dy, w, in_hw, *, stride=1, pad=0, dil=1, scale=None, res=None, 
     return out
 
 
-PARITY_DGRAD = _os.environ.get("TOIST_PARITY_DGRAD", "1") != "0"
+PARITY_DGRAD = knob("TOIST_PARITY_DGRAD", True)
 # taps (r*3 + s) of a 3x3 / stride 2 / pad 1 kernel grouped by the parity (y & 1, x & 1) of the dx pixel they reach, each group in
 # the order a plain stride-1 gather dy[yy + r', xx + s'] visits them:  (0,0): 1 tap | (0,1): 2 | (1,0): 2 | (1,1): 4
 _S2_TAPS = (4, 5, 3, 7, 1, 8, 6, 2, 0)
@@ -264,10 +263,10 @@ def conv2d_wgrad(dy, x, w_shape, *, stride=1, pad=0, dil=1, out=None, flags=0, s
     return out
 
 
-GROUP_TILE = int(_os.environ.get("TOIST_GROUP_TILE", "0"))   # tile code of grouped weight-gradient launches (0 = the dispatcher's choice)
-GROUP_TILE_3X3 = int(_os.environ.get("TOIST_GROUP_TILE_3X3", "130"))
-GROUP_TILE_1X1 = int(_os.environ.get("TOIST_GROUP_TILE_1X1", "134"))
-GROUP_SPLIT_TILE = int(_os.environ.get("TOIST_GROUP_SPLIT_TILE", "130"))   # grouped AND split along K: 128x64 tiles with twice the slices (+0.7% step over 64x64)
+GROUP_TILE = knob("TOIST_GROUP_TILE", 0)   # tile code of grouped weight-gradient launches (0 = the dispatcher's choice)
+GROUP_TILE_3X3 = knob("TOIST_GROUP_TILE_3X3", 130)
+GROUP_TILE_1X1 = knob("TOIST_GROUP_TILE_1X1", 134)
+GROUP_SPLIT_TILE = knob("TOIST_GROUP_SPLIT_TILE", 130)   # grouped AND split along K: 128x64 tiles with twice the slices (+0.7% step over 64x64)
 GROUP_MIN_TILES = 512   # below this many 64x64 output tiles in total the problems stay separate (they need split-K)
 
 

@@ -16,6 +16,9 @@ import torch
 
 from . import engine
 from . import kernels as k
+from .knobs import knob
+
+LATE_BLOCKS = knob("TOIST_LATE_BLOCKS", 0)     # workgroups of a late group's update launch (0 = one per 8192-element chunk)
 
 _TENSOR_DT = np.dtype([("p", "<i8"), ("m", "<i8"), ("v", "<i8"), ("ema", "<i8"), ("w", "<i8"), ("row_scale", "<i8"),
                        ("numel", "<i8"), ("row_len", "<i4"), ("group", "<i4")])
@@ -42,6 +45,15 @@ class FusedClipAdamWEMA:
     group dicts are kept in `self.param_groups` so `adjust_learning_rate` (util/optim.py:29-90) can assign
     `group["lr"]` as it does for a torch optimizer.  ema: list of (source, ema) pairs or None.
     max_norm <= 0 disables clipping (engine.py:89 `if max_norm > 0`).
+
+    A parameter group with "late": True (the text encoder: 125 M of the 185 M parameters, 67 % of the tail's bytes) is updated LATE:
+    step() still sums its gradients into the clipping norm, but its AdamW + EMA + bf16-refresh launch is not issued; the next forward pass
+    issues it at the head of the text branch (engine.TEXT_PRELUDE, on the text stream), where it runs beside the ResNet forward, which
+    neither reads nor writes those tensors -- the only consumer of the late parameters is the text encoder, which follows on the same
+    stream.  The arithmetic is unchanged (same gradients, same clip coefficient, same step count: the device state of step N is not
+    touched before step N + 1's finish_norm): parameters are bit-identical to the serial tail (tests/test_gpu_optim.py).  Anything that
+    reads the late parameters outside a forward pass (state_dict, evaluation with a different module, the end of training) calls
+    finish() first.
 
     defer_ema=True takes the moving average out of step(): it only needs the updated parameters, so the loop may run it as
     `ema_update()` on a side stream beside the next forward pass (12 of the tail's 38 bytes per parameter leave the critical path).
@@ -75,6 +87,14 @@ class FusedClipAdamWEMA:
         # sources that are averaged but not optimised: frozen parameters and floating-point buffers
         self._ema_only = [(src, e) for src, e in ema if src.data_ptr() in by_ptr]
         self._group_of = [gi for gi, g in enumerate(self.param_groups) for _ in g["params"]]
+        self._late = [bool(g.get("late", False)) for g in self.param_groups for _ in g["params"]]
+        self._late_pending = False
+        self._late_grads = None
+        self._n_now = self._n_late = 0
+        if any(self._late):
+            if defer_ema:
+                raise ValueError("FusedClipAdamWEMA: late groups and defer_ema are alternatives")
+            engine.register_text_prelude(self)
         for t in params + self.exp_avg + [e for e in self._ema_of if e is not None] + [x for pr in self._ema_only for x in pr]:
             if t.dtype != torch.float32 or not _dense(t) or t.device != self.device:
                 raise TypeError("FusedClipAdamWEMA: tensors must be dense fp32 tensors on one GPU")
@@ -147,7 +167,15 @@ class FusedClipAdamWEMA:
             self._ema_grads = torch.zeros(len(erows), dtype=torch.int64, device=self.device)
             rows = rows[:len(self.params)].copy()
             rows["ema"] = 0
-        self._table, self._chunks, self._n_chunks = chunked(rows)
+        self._table, chunks, self._n_chunks = chunked(rows)
+        # launch order of the chunks: everything updated inside step() first, the late groups' chunks behind them -- sqnorm walks all,
+        # adamw_ema is launched on the two runs separately
+        late_rows = torch.tensor(self._late + [False] * len(self._ema_only), dtype=torch.bool, device=self.device)
+        is_late = late_rows[chunks[:, 0].long()]
+        self._chunks = torch.cat([chunks[~is_late], chunks[is_late]], dim=0).contiguous()
+        self._n_late = int(is_late.sum())
+        self._n_now = self._n_chunks - self._n_late
+        self._late_copies = [(ent, p_) for ent, p_ in self._copies if any(p_ is q for q, l in zip(self.params, self._late) if l)]
         self._partial = torch.empty(self._n_chunks, dtype=torch.float32, device=self.device)
         self._copy_gen = engine.COPY_GEN
 
@@ -162,6 +190,8 @@ class FusedClipAdamWEMA:
     @torch.no_grad()
     def step(self):
         capturing = torch.cuda.is_current_stream_capturing()
+        if self._late_pending:
+            self.flush_late()       # nobody ran it at the head of a text branch: the late groups must be updated before their gradients are re-read
         if self._table is None or (self._copy_gen != engine.COPY_GEN and not capturing):
             self._build_table()
         if not capturing:
@@ -190,14 +220,41 @@ class FusedClipAdamWEMA:
             self._grads_turn = turn ^ 1
         k.opt_sqnorm(self._table, self._grads_dev, self._chunks, self._n_chunks, self._partial)
         k.opt_finish_norm(self._partial, self._n_chunks, self.max_norm, self.betas[0], self.betas[1], self.state)
-        k.opt_adamw_ema(self._table, self._grads_dev, self._chunks, self._n_chunks, self._groups_dev, self.state, self.betas[0],
-                        self.betas[1], self.eps, self.ema_decay)
+        if self._n_now:
+            k.opt_adamw_ema(self._table, self._grads_dev, self._chunks, self._n_now, self._groups_dev, self.state, self.betas[0],
+                            self.betas[1], self.eps, self.ema_decay)
         self._ema_pending = self.defer_ema
         # the masters changed behind torch's version counters: every compute copy is stale except the ones just rewritten
         engine.bump_weight_epoch()
+        late_ids = {id(p_) for _, p_ in self._late_copies} if self._n_late else ()
         for ent, p in self._copies:
-            if p.grad is not None:
+            if p.grad is not None and id(p) not in late_ids:
                 ent.epoch = engine.WEIGHT_EPOCH
+        if self._n_late:
+            self._late_pending = True
+            self._late_grads = [p.grad for p, l in zip(self.params, self._late) if l]     # the pointers in the device table must stay valid
+
+    @torch.no_grad()
+    def flush_late(self):
+        """Issue the AdamW + EMA + bf16-refresh launch of the "late" groups for the last step() on the current stream (no-op when
+        nothing is pending; inside a hipGraph capture it is ALWAYS recorded, since the captured step leaves one pending for every
+        replay -- the update of the step before the capture is then applied by the first replay)."""
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not self._n_late or not (self._late_pending or capturing):
+            return
+        k.opt_adamw_ema(self._table, self._grads_dev, self._chunks[self._n_now:], self._n_late, self._groups_dev, self.state, self.betas[0],
+                        self.betas[1], self.eps, self.ema_decay, max_blocks=LATE_BLOCKS)
+        for ent, p in self._late_copies:
+            ent.epoch = engine.WEIGHT_EPOCH
+        if not capturing:
+            self._late_pending = False
+            self._late_grads = None
+
+    def finish(self):
+        """complete every deferred piece of the last step (late groups, deferred EMA): call before reading parameters outside a forward pass"""
+        self.flush_late()
+        if self._ema_pending:
+            self.ema_update()
 
     @torch.no_grad()
     def ema_update(self):
@@ -223,6 +280,7 @@ class FusedClipAdamWEMA:
         """torch.optim.AdamW's layout ({"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [{..., "params": [i, ...]}]}),
         so the 'optimizer' entry of a reference checkpoint (main.py:511-513, 645) resumes here and vice versa.  The step count is one
         device counter shared by every parameter (all parameters of the hot path receive a gradient every step)."""
+        self.finish()
         step = self.device_state()["step"]
         state = {i: {"step": torch.tensor(float(step)), "exp_avg": self.exp_avg[i].clone(), "exp_avg_sq": self.exp_avg_sq[i].clone()}
                  for i in range(len(self.params))} if step > 0 else {}

@@ -13,7 +13,7 @@ from types import SimpleNamespace
 import torch
 from torch import nn
 
-from . import engine, functions
+from . import engine, functions, tlayer
 from . import kernels as k
 
 BF16 = torch.bfloat16
@@ -236,6 +236,9 @@ class Transformer(nn.Module):
     # ---- text -------------------------------------------------------------------------------------
     def encode_text(self, tokenized):
         """RoBERTa + FeatureResizer -> bf16 tokens [B*L, d] (batch-major)."""
+        # late optimizer groups of the previous step (toist_amd.optim: the text encoder's AdamW + EMA launch) are issued here, on the
+        # stream of the text branch -- beside the ResNet forward when the branch is forked -- before RoBERTa reads its weights
+        engine.run_text_prelude()
         ids = tokenized["input_ids"]
         att = tokenized["attention_mask"]
         B, L = ids.shape
@@ -336,6 +339,8 @@ class Transformer(nn.Module):
             return [x], None
 
         def prog(tape, ps, x):
+            if tlayer.supported(d, H, S):      # row-complete sub-layer kernels: LayerNorm fused into the GEMM that feeds it, both directions
+                return tlayer.encoder_program(tape, ps, x, pos, key_pad, B, S, H, n_layers)
             if engine.FUSED_BLOCKS and d // H == 32 and S <= 480:
                 return prog_fused(tape, ps, x)
             for i in range(n_layers):
@@ -436,6 +441,8 @@ class Transformer(nn.Module):
             return [hs], None
 
         def prog(tape, ps, mem, qe):
+            if tlayer.supported(d, H, max(S, Q)):
+                return tlayer.decoder_program(tape, ps, mem, qe, pos, key_pad, B, S, Q, H, n_layers)
             if engine.FUSED_BLOCKS and d // H == 32 and S <= 480 and Q <= 480:
                 return prog_fused(tape, ps, mem, qe)
             qpos_data = qe.data.to(BF16).unsqueeze(0).expand(B, Q, d).reshape(B * Q, d).contiguous()

@@ -5,7 +5,12 @@ dropout 0.1) captured in a hipGraph and replayed.  GPU only.
 
 FLOP accounting: cores 4*Sq*Sk*d, projections 2*(2*Sq + 2*Sk)*d*d per image, x3 for forward + backward.
 Next to every case: the number of kernel launches of the replayed graph, the time the same number of EMPTY launches takes
-(the launch-latency floor of this launch count) and the utilisation that floor alone would allow."""
+(the launch-latency floor of this launch count) and the utilisation that floor alone would allow.
+
+Round 4: the default path is the product path of toist_amd.tlayer -- attn2 cores (csrc/attn2.hip), out_proj + dropout + residual +
+LayerNorm as one row-complete launch, and in the backward pass [in_proj data gradient + fold of the key-split dQ shares + residual
+gradient + LayerNorm backward] as one launch (csrc/tlayer.hip).  A block here therefore ALSO contains one LayerNorm forward and one
+LayerNorm backward that the round-3 block (`--v1`: toist_amd.engine blocks) left to separate launches."""
 import json
 import os
 import sys
@@ -17,6 +22,7 @@ from toist_amd import engine, kernels as k  # noqa: E402
 
 dev = torch.device("cuda")
 BF = torch.bfloat16
+V1 = "--v1" in sys.argv
 B, d, H, L = 8, 256, 8, 6
 PEAK = 2500.0
 
@@ -63,7 +69,8 @@ class Counter:
         from toist_amd import _lib
         self.lib = _lib.lib()
         self.saved = {}
-        for name in ("toist_gemm_bf16", "toist_attn_fwd", "toist_attn_bwd", "toist_add_bf16", "toist_splitk_reduce_batch", "toist_group_fill", "toist_layernorm_fwd"):
+        for name in ("toist_gemm_bf16", "toist_attn_fwd", "toist_attn_bwd", "toist_add_bf16", "toist_splitk_reduce_batch", "toist_group_fill", "toist_layernorm_fwd",
+                     "toist_attn2_fwd", "toist_attn2_bwd", "toist_rowgemm", "toist_layernorm_bwd"):
             fn = getattr(self.lib, name)
             self.saved[name] = fn
 
@@ -119,6 +126,59 @@ def run(name, Sq, Sk, kind):
             outs.append(o)
         tape.backward()
 
+    def step2():
+        """the same blocks on toist_amd.tlayer's kernels: [q|k|v GEMM] [attn2 forward] [out_proj + dropout + residual + LayerNorm] forward;
+        [out_proj dgrad] [attn2 backward] [in_proj dgrad + dQ fold + residual gradient + LayerNorm backward] + grouped weight gradients"""
+        from toist_amd import ops, tlayer
+        tape = engine.Tape(training=True, drop_p=float(os.environ.get("TOIST_BENCH_ATTN_DROP", "0.1")), seed=1, group_wgrads=True)
+        p = tape.drop_p
+        M = B * Sq
+        if kind == "cross":
+            m = engine.Var(mem)
+            mem_e = torch.empty_like(mem)
+            k.add(mem, pos, mem_e)
+            kv, dkv = engine.cross_kv_projections(tape, m, mem_e, [(q_[0], q_[1]) for q_ in P])
+        saved = []
+        for i, (Wi, bi, Wo, bo) in enumerate(P):
+            xe = torch.empty_like(x)
+            k.add(x, e, xe)
+            if kind == "cross":
+                qb = ops.linear(xe, Wi.rows(0, d).w, bi.rows(0, d).f32)
+                kb, vb = kv[:, i * 2 * d:i * 2 * d + d], kv[:, i * 2 * d + d:(i + 1) * 2 * d]
+            else:
+                qkv = tlayer._qkv(xe, x, Wi, bi, M, d)
+                qb, kb, vb = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            ctx = torch.empty(M, d, dtype=BF, device=dev)
+            core = tlayer._core(tape, qb, kb, vb, key_pad if kind != "dec" else None, B, Sq, Sk, H, ctx, p, tape.next_seed())
+            ln = tlayer._ln_fwd(ctx, Wo, bo, x, LN[0], LN[1], tape)
+            saved.append((xe, ctx, core, ln, Wi, bi, Wo, bo))
+        prev = None
+        for i in reversed(range(L)):
+            xe, ctx, core, ln, Wi, bi, Wo, bo = saved[i]
+            if prev is None:
+                tlayer._ln_bwd_alone(ln, ones, p)           # the gradient of the last block's output arrives from outside
+            dctx = tlayer._outproj_bwd(tape, ln, ctx, Wo, bo, p)
+            if kind == "cross":
+                dq = torch.empty(M, d, dtype=BF, device=dev)
+                part = core(dctx, dq, dkv[:, i * 2 * d:i * 2 * d + d], dkv[:, i * 2 * d + d:(i + 1) * 2 * d])
+                a, w, Kk = dq, Wi.rows(0, d).w, d
+                tape.linear_wgrad(dq, xe, Wi.rows(0, d), bi.rows(0, d))
+            else:
+                dqkv = torch.empty(M, 3 * d, dtype=BF, device=dev)
+                part = core(dctx, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:])
+                a, w, Kk = dqkv, Wi.w, 3 * d
+                tape.linear_wgrad(dqkv[:, :2 * d], xe, Wi.rows(0, 2 * d), bi.rows(0, 2 * d))
+                tape.linear_wgrad(dqkv[:, 2 * d:], x, Wi.rows(2 * d, 3 * d), bi.rows(2 * d, 3 * d))
+            below = saved[i - 1][3] if i > 0 else saved[L - 1][3]      # a LayerNorm to run backward through (the block below's; any at the bottom)
+            tlayer._ln_bwd_fused(below, a, w, p, res=ln.dz, fold=part, fold_cols=d, K=Kk)
+            prev = ln
+        tape.backward()
+
+    if not V1:
+        g_ = torch.ones(d, device=dev)
+        LN = (engine.ParamView(None, torch.zeros(d, device=dev), g_), engine.ParamView(None, torch.zeros(d, device=dev), torch.zeros(d, device=dev)))
+        ones = torch.ones(B * Sq, d, device=dev).to(BF)
+        step = step2
     with Counter() as c:
         step()
     launches = c.n
@@ -134,6 +194,7 @@ rows = [run("encoder self-attention (S=416)", 416, 416, "enc"), run("decoder cro
         run("decoder self-attention (Q=100)", 100, 100, "dec")]
 tot_us = 6 * sum(r["us_fwd_bwd"] for r in rows)
 tot_fl = 6 * sum(r["gflop"] for r in rows)
-print(json.dumps({"batch": B, "layers": "6+6", "dropout": 0.1, "launch": "hipGraph replay", "path": "engine.self_attention_block / cross_attention_block / cross_kv_projections",
+print(json.dumps({"batch": B, "layers": "6+6", "dropout": 0.1, "launch": "hipGraph replay", "path": "engine.self_attention_block / cross_attention_block / cross_kv_projections (round-3 blocks)" if V1 else
+                  "toist_amd.tlayer: attn2 cores + row-complete out_proj / in_proj-dgrad launches (each block also holds one LayerNorm forward + backward)",
                   "cases": rows, "all_attention_per_step": {"ms": round(tot_us / 1e3, 3), "tflops": round(tot_fl / tot_us * 1e3, 1),
                                                             "mfma_frac": round(tot_fl / tot_us * 1e3 / PEAK, 4)}}, indent=1))
