@@ -54,8 +54,8 @@ def parse():
     ap.add_argument("--torch-optimizer", action="store_true", help="diagnostic: torch clip_grad_norm_ + fused AdamW + foreach EMA instead of the HIP tail")
     ap.add_argument("--defer-ema", action="store_true", help="diagnostic: run the EMA update beside the next forward pass instead of inside the optimizer tail "
                                                              "(measured slower: 504 vs 514 images/s, the forward pass is HBM-sensitive)")
-    ap.add_argument("--serial-tail", action="store_true", help="diagnostic: the whole clip + AdamW + EMA tail inside the step (default: the text encoder's share is "
-                    "issued at the head of the next step's text branch, beside the ResNet forward)")
+    ap.add_argument("--late-text-tail", action="store_true", help="diagnostic: the text encoder's share of the clip + AdamW + EMA tail is issued at the head of the "
+                    "next step's text branch, beside the ResNet forward (measured slower: profiles/r04_late_tail_ab.txt)")
     ap.add_argument("--no-contrastive", action="store_true", help="drop loss_contrastive_align (the round-1 configuration; the reference's detection recipe has it on, "
                     "main.py:179-184)")
     ap.add_argument("--bf16-grads", action="store_true", help="N > 1: gradients cross the xGMI links as bfloat16 (half the bytes; the reference reduces in fp32)")
@@ -291,7 +291,7 @@ def bench_mixed_sizes(a, dev):
     src = [v for v in model.state_dict().values() if v.is_floating_point()]
     opt = FusedClipAdamWEMA(groups, lr=args.lr, weight_decay=args.weight_decay, max_norm=args.clip_max_norm, ema=list(zip(src, [v.detach().clone() for v in src])),
                             ema_decay=0.9998)
-    cap = harness.CapturedTrainStep(model, criterion, opt, weight_dict, batch=a.batch, max_targets_per_image=10, pad_hw=64, pad_tokens=8, max_graphs=4)
+    cap = harness.CapturedTrainStep(model, criterion, opt, weight_dict, batch=a.batch, max_targets_per_image=10, pad_hw=64, max_graphs=4)
     sizes = ((640, 640), (576, 704), (512, 768))
     from toist_amd.matcher import StaticTargets
     packer = StaticTargets(a.batch, 10, args.num_queries, 256, dev)      # same arena layout as the buckets' own (batch, capacity, queries, K)
@@ -372,9 +372,10 @@ def main():
     groups = [
         {"params": [p for n, p in named if "backbone" not in n and "text_encoder" not in n]},
         {"params": [p for n, p in named if "backbone" in n], "lr": args.lr_backbone},
-        # "late": the text encoder's share of the optimizer tail (67 % of its bytes) is issued at the head of the next step's text branch,
-        # beside the ResNet forward (toist_amd.optim.FusedClipAdamWEMA); every replay still applies exactly one update per group
-        {"params": [p for n, p in named if "text_encoder" in n], "lr": args.text_encoder_lr, "late": not a.serial_tail and not a.torch_optimizer and not a.defer_ema},
+        # "late" (--late-text-tail): the text encoder's share of the optimizer tail (67 % of its bytes) is issued at the head of the next step's
+        # text branch, beside the ResNet forward (toist_amd.optim.FusedClipAdamWEMA).  Measured NEGATIVE (profiles/r04_late_tail_ab.txt:
+        # 12.48 -> 13.3 ms per step; the forward pass is sensitive to the 4.7 GB of HBM traffic beside it), so it is off by default.
+        {"params": [p for n, p in named if "text_encoder" in n], "lr": args.text_encoder_lr, "late": a.late_text_tail and not a.torch_optimizer and not a.defer_ema},
     ]
     from toist_amd import engine as _engine
     _engine.REUSE_GRAD_BUFFERS = True   # this loop never keeps a gradient across optimizer.zero_grad()

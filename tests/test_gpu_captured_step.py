@@ -125,3 +125,36 @@ def test_captured_step_lru_evicts_the_oldest_bucket(dev):
         assert len(cap._buckets) == 2 and (64, 64, 8) in cap._buckets and (128, 64, 8) in cap._buckets and cap.captures == 4
     finally:
         engine.REUSE_GRAD_BUFFERS = old_reuse
+
+
+def test_caption_length_is_not_padded_by_default(dev):
+    """extra pad tokens enter loss_contrastive_align (the reference takes its log-sum-exp over every token column, mdetr.py:646-663),
+    so the default bucket keeps the batch's own caption length; only the image sides are rounded up.  The loss dict of a captured step on
+    a 10-token batch then equals the eager criterion on the UNPADDED batch, contrastive term included."""
+    import toist_amd
+    from toist_amd import harness, kernels
+    from toist_amd.optim import FusedClipAdamWEMA
+    args = harness.default_args(device="cuda", enc_layers=1, dec_layers=2, num_queries=20, dropout=0.0, contrastive_align_loss=True)
+    torch.manual_seed(0)
+    model, criterion, _, weight_dict = toist_amd.build_model(args)
+    model.to(dev).train()
+    model.transformer.text_encoder.config.hidden_dropout_prob = 0.0
+    model.transformer.text_encoder.config.attention_probs_dropout_prob = 0.0
+    kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    opt = FusedClipAdamWEMA([{"params": [p for _, p in named], "lr": 0.0}], weight_decay=0.0, max_norm=0.1)      # lr 0: the weights stay put
+    cap = harness.CapturedTrainStep(model, criterion, opt, weight_dict, batch=2, max_targets_per_image=6)
+    samples, tok, targets, pmap = harness.synthetic_batch(2, 128, 128, tokens=10, seed=3, max_targets=4)
+    assert cap.bucket_of(samples, tok) == (128, 128, 10)
+    t_dev = [{k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in t.items()} for t in targets]
+    # no_grad: a grad-enabled forward that is never followed by backward() keeps its AccumulateGrad nodes pinned to the stream it ran
+    # on; the backward pass captured later on the step's own stream then drags that stream into the capture (torch warns "the
+    # AccumulateGrad node's stream does not match ..." and hipStreamEndCapture fails) -- evaluation between training steps belongs
+    # under no_grad, as in the reference's evaluate() (engine.py:104 @torch.no_grad)
+    with torch.no_grad():
+        mc = model(samples.to(dev), tok.to(dev), encode_and_save=True)
+        out = model(samples.to(dev), tok.to(dev), encode_and_save=False, memory_cache=mc)
+        want = float(toist_amd.weighted_total(criterion(mc, out, t_dev, pmap.to(dev), None), weight_dict))
+    got = [float(cap.step(samples, tok, targets, pmap)) for _ in range(3)]          # eager first step, capture, replay
+    for g in got:
+        assert abs(g - want) <= 2e-3 * abs(want), (got, want)

@@ -117,22 +117,27 @@ def test_reference_ddp_wrap_and_step_sequence(dev):
             assert cos_ > 0.995 and 0.97 < lo and hi < 1.03, out[r]
 
 
-def test_bench_two_ranks_on_one_gpu_gloo(dev):
-    """The N > 1 control flow of bench.py (four hipGraphs: forward + transformer backward | text backward || backbone backward | tail,
-    flat-buffer gradient all-reduces in between, num_boxes all-reduce, max-over-ranks timing) with two ranks sharing this GPU over
-    gloo -- RCCL needs one GPU per rank, which the test box does not have; the launch line is the driver's."""
+@pytest.mark.parametrize("world,steps", [(2, 2), (4, 3)])
+def test_bench_ranks_on_one_gpu_gloo(dev, world, steps):
+    """The N > 1 control flow of bench.py (six hipGraphs: forward + transformer backward | text backward || backbone layer 4 | layer 3 |
+    layer 2 | tail, flat-buffer gradient all-reduces in between, num_boxes all-reduce, max-over-ranks timing) with two and with FOUR ranks
+    sharing this GPU over gloo -- RCCL needs one GPU per rank, which the test box does not have; the launch line is the driver's.  Asserted:
+    the graph structure, one collective per backward segment in the order the segments finish, their sizes, and bit-identical
+    parameters on every rank after the timed steps (three at four ranks)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TOIST_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and lines, out.stderr[-3000:]
     res = json.loads(lines[-1])
-    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 16 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["n_gpus"] == world and res["config"]["global_batch"] == 8 * world and res["value"] > 0 and res["scaling"] == "weak" and res["steps"] == steps
+    assert list(res["collectives"]) == ["transformer+heads", "text_encoder", "backbone stage 1 of 3 (layer4 first)", "backbone stage 2 of 3 (layer4 first)",
+                                        "backbone stage 3 of 3 (layer4 first)"], list(res["collectives"])        # the order the segments are enqueued in
     assert "6 hipGraphs" in res["config"]["launch"], res["config"]["launch"]
     # one collective per backward segment: the backbone's gradients travel per stage (layer4 first), under the stages below
     assert set(res["collectives"]) == {"transformer+heads", "text_encoder", "backbone stage 1 of 3 (layer4 first)", "backbone stage 2 of 3 (layer4 first)",

@@ -248,3 +248,57 @@ def test_text_weight_pack_survives_a_long_caption_first(dev):
         ref.transformer.__dict__.pop("_text_packs", None)
         d, _ = ref.transformer.encode_text(tok_short.to(dev))
     assert torch.equal(c, d), "after an optimizer step the packed copies differ from freshly cast ones"
+
+
+def test_reference_validation_resolution_stays_on_the_fused_cores(dev):
+    """The reference validates at 800 x <= 1333 pixels (datasets/tdod.py:304-306, 327-333): 25 x 42 image tokens + the caption = 1066
+    keys per attention row, beyond the 480 keys the first-generation cores could hold in LDS (the model then fell back to three
+    launches that materialise the scores).  The flash-style cores of csrc/attn2.hip walk the keys in blocks: this test runs the
+    model at that size -- forward values against the oracle, and a backward pass whose attention launches are counted -- and asserts
+    that not one score-shaped launch (toist_attn_fwd / softmax / batched score GEMMs) ran."""
+    import toist_amd
+    from oracle import model_ref
+    from toist_amd import _lib, harness
+    torch.manual_seed(0)
+    args = harness.default_args(device="cuda", contrastive_align_loss=True)
+    model, criterion, _, weight_dict = toist_amd.build_model(args)
+    _damp(model)
+    sd = {k_: v.detach().clone().float() for k_, v in model.state_dict().items()}
+    model.to(dev).eval()
+    samples, tok, targets, pmap = harness.synthetic_batch(1, 800, 1333, tokens=16, seed=77, max_targets=6)
+    lib = _lib.lib()
+    counts = {}
+    saved = {}
+    for name in ("toist_attn2_fwd", "toist_attn2_bwd", "toist_attn_fwd", "toist_attn_bwd", "toist_softmax_fwd", "toist_softmax_bwd"):
+        fn = getattr(lib, name)
+        saved[name] = fn
+
+        def wrap(*a, _fn=fn, _name=name):
+            counts[_name] = counts.get(_name, 0) + 1
+            return _fn(*a)
+
+        setattr(lib, name, wrap)
+    try:
+        mc = model(samples.to(dev), tok.to(dev), encode_and_save=True)
+        out = model(samples.to(dev), tok.to(dev), encode_and_save=False, memory_cache=mc)
+        t_dev = [{k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in t.items()} for t in targets]
+        losses = criterion(mc, out, t_dev, pmap.to(dev), None)
+        toist_amd.weighted_total(losses, weight_dict).backward()
+        torch.cuda.synchronize()
+    finally:
+        for name, fn in saved.items():
+            setattr(lib, name, fn)
+    S = mc["img_memory"].shape[0]
+    assert S == 25 * 42 + 16, S
+    assert counts.get("toist_attn2_fwd") == 18 and counts.get("toist_attn2_bwd") == 18, counts          # 6 encoder + 12 decoder cores, each way
+    assert not any(counts.get(n) for n in ("toist_attn_fwd", "toist_attn_bwd", "toist_softmax_fwd", "toist_softmax_bwd")), counts
+    with torch.no_grad():
+        rmc = model_ref.mdetr_encode(sd, samples.tensors, samples.mask, tok["input_ids"], tok["attention_mask"])
+        rout = model_ref.mdetr_decode(sd, rmc, contrastive_align=True)
+    rep = {"img_memory": _elem(mc["img_memory"], rmc["img_memory"]), "pred_logits": _elem(out["pred_logits"], rout["pred_logits"]),
+           "pred_boxes": _elem(out["pred_boxes"], rout["pred_boxes"])}
+    _report("800 x 1333 (S = 1066 keys) eval forward: (max abs err, worst excess over 3e-2|ref|, rel Frobenius)", {k_: [round(x, 5) for x in v] for k_, v in rep.items()})
+    assert rep["img_memory"][2] < 2e-2 and rep["pred_logits"][2] < 3e-2 and rep["pred_logits"][1] <= 3e-2 and rep["pred_boxes"][0] <= BOX_ATOL, rep
+    bad = [n for n, p in model.named_parameters() if p.grad is not None and not bool(torch.isfinite(p.grad).all())]
+    assert not bad, bad[:5]
+    assert model.transformer.encoder.layers[0].self_attn.in_proj_weight.grad is not None

@@ -104,15 +104,28 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(const bf16_t* __restrict
         const int left = Sk - k0;
         const int nkeys = left < A2_SKB ? ((left + 127) & ~127) : A2_SKB;      // rows staged: whole 128-key blocks
         if (k0 > 0) __syncthreads();                                          // every wave has consumed the previous 512 keys
-        for (int cch = tid; cch < nkeys * 4; cch += 256) {
-            const int kl = cch >> 2, ch = cch & 3, key = k0 + kl;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if (key < Sk) {
-                kv = *reinterpret_cast<const uint4*>(kmat + ((size_t)b * Sk + key) * ldk + h * DH + ch * 8);
-                vv = *reinterpret_cast<const uint4*>(v + ((size_t)b * Sk + key) * ldv + h * DH + ch * 8);
+        // 16-byte pieces of the K / V rows: eight requests in flight per thread before the first LDS store (a load -> store -> load chain of
+        // eight round trips was half of the launch time at 416 keys)
+        for (int base = 0; base < nkeys * 4; base += 1024) {
+            u32x4_t kv[4], vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cch = base + u * 256 + tid, kl = cch >> 2, ch = cch & 3, key = k0 + kl;
+                kv[u] = u32x4_t{0, 0, 0, 0};
+                vv[u] = u32x4_t{0, 0, 0, 0};
+                if (cch < nkeys * 4 && key < Sk) {
+                    kv[u] = *reinterpret_cast<const u32x4_t*>(kmat + ((size_t)b * Sk + key) * ldk + h * DH + ch * 8);
+                    vv[u] = *reinterpret_cast<const u32x4_t*>(v + ((size_t)b * Sk + key) * ldv + h * DH + ch * 8);
+                }
             }
-            *reinterpret_cast<uint4*>(sK + kl * DH + ((ch ^ ((kl >> 1) & 3)) << 3)) = kv;
-            *reinterpret_cast<uint4*>(sV + kl * DH + (ch << 3)) = vv;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cch = base + u * 256 + tid, kl = cch >> 2, ch = cch & 3;
+                if (cch < nkeys * 4) {
+                    *reinterpret_cast<u32x4_t*>(sK + kl * DH + ((ch ^ ((kl >> 1) & 3)) << 3)) = kv[u];
+                    *reinterpret_cast<u32x4_t*>(sV + kl * DH + (ch << 3)) = vv[u];
+                }
+            }
         }
         for (int kl = tid; kl < nkeys; kl += 256) sDead[kl] = (k0 + kl >= Sk || (key_pad != nullptr && key_pad[(size_t)b * Sk + k0 + kl])) ? 1 : 0;
         __syncthreads();
@@ -204,34 +217,49 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(const bf16_t* __restrict
 constexpr int A2_TS = 24;      // row stride (bf16) of a wave's [32 keys][16 queries] dS tile
 constexpr int A2_KS = 40;      // row stride (bf16) of a wave's [32 keys][32 features] K tile (start-up transpose)
 
-__global__ __launch_bounds__(256) void attn2_bwd_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ kmat, int ldk,
+constexpr int A2_NG = 2;       // query groups per workgroup: tiles are dealt round-robin to A2_NG sets of four waves (two waves per SIMD)
+
+__global__ __launch_bounds__(256 * A2_NG) void attn2_bwd_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ kmat, int ldk,
                                                         const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ ctx, int ldo,
                                                         const bf16_t* __restrict__ dctx, int lddo, const float* __restrict__ lse,
                                                         const unsigned char* __restrict__ key_pad, int H, int Sq, int Sk, int ldp, float scale,
                                                         float drop_p, unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
                                                         bf16_t* __restrict__ dq, int lddq, bf16_t* __restrict__ dk, int lddk,
                                                         bf16_t* __restrict__ dv, int lddv, bf16_t* __restrict__ dq_part, long long part_stride) {
+    // A lone wave on its SIMD issues about one instruction per five cycles, and a query tile is ~1400 dependent instructions: with four
+    // waves per workgroup and one workgroup per CU the first version of this kernel was bound by exactly that (31.8 us for the encoder
+    // shape, profiles/r04_attn_core_us.txt).  The workgroup therefore carries A2_NG groups of four waves; every group owns the SAME keys
+    // (wave w of each group: pair 4 x + w) and every A2_NG-th query tile, with its own staging buffers and dQ slabs; the groups' dK / dV
+    // sums meet in LDS once, at the end.
     constexpr int DH = 32, QT = 32;
-    __shared__ __attribute__((aligned(16))) bf16_t sQ[2][QT * DH];        // query tile (double-buffered)
-    __shared__ __attribute__((aligned(16))) bf16_t sdO[2][QT * DH];
-    __shared__ __attribute__((aligned(16))) float sD[2][QT];              // rowsum(dO o O)
-    __shared__ __attribute__((aligned(16))) float sL[2][QT * 2];          // (row maximum of the raw dot products, 1 / row sum)
-    __shared__ __attribute__((aligned(16))) bf16_t sT[4][2 * 32 * A2_TS]; // wave-private: dS of the two 16-query blocks, [key][query]
-    __shared__ __attribute__((aligned(16))) float sSlab[2][4][QT * DH];   // the waves' shares of dQ^T of a tile (double-buffered)
+    extern __shared__ __attribute__((aligned(16))) unsigned char a2_smem[];
+    bf16_t* const sQ_ = reinterpret_cast<bf16_t*>(a2_smem);                                  // [NG][2][QT * DH]
+    bf16_t* const sdO_ = sQ_ + A2_NG * 2 * QT * DH;                                          // [NG][2][QT * DH]
+    bf16_t* const sT_ = sdO_ + A2_NG * 2 * QT * DH;                                          // [NG * 4][2 * 32 * A2_TS] wave-private
+    float* const sD_ = reinterpret_cast<float*>(sT_ + A2_NG * 4 * 2 * 32 * A2_TS);           // [NG][2][QT]
+    float* const sL_ = sD_ + A2_NG * 2 * QT;                                                 // [NG][2][QT * 2]
+    float* const sSlab_ = sL_ + A2_NG * 2 * QT * 2;                                          // [NG][2][4][QT * DH]
     if (seed_dev) seed += *seed_dev;
     const unsigned s0 = (unsigned)seed, s1 = (unsigned)(seed >> 32) ^ ((unsigned)seed * 0x9E3779B9u);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int grp = wave >> 2, w4 = wave & 3, gtid = tid & 255;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int nkp = (Sk + 31) >> 5;                           // 32-key pairs of blocks in this head
-    const int kp = blockIdx.x * 4 + wave;                     // this wave's pair
+    const int kp = blockIdx.x * 4 + w4;                       // this wave's pair
     const bool active = kp < nkp;
-    const int nw = nkp - (int)blockIdx.x * 4 < 4 ? nkp - (int)blockIdx.x * 4 : 4;     // active waves of this workgroup (>= 1)
+    const int nw = nkp - (int)blockIdx.x * 4 < 4 ? nkp - (int)blockIdx.x * 4 : 4;     // active waves of a group (>= 1)
     const float c = scale * LOG2E;
     const bool dropping = drop_p > 0.f;
     const unsigned t32 = dropping ? ((unsigned)(drop_p * 65536.0f + 0.5f)) << 16 : 0u;
     const float dscale = dropping ? 1.f / (1.f - drop_p) : 1.f;
     const int par = c16 & 1;                                  // key parity = the 16-bit field of a pair hash this lane reads
     const unsigned fsh = par ? 0u : 16u;                      // field -> bits 16-31: compare (h << fsh) with t << 16
+    bf16_t* const sT = sT_ + wave * (2 * 32 * A2_TS);
+    bf16_t* const sQg = sQ_ + grp * (2 * QT * DH);
+    bf16_t* const sdOg = sdO_ + grp * (2 * QT * DH);
+    float* const sDg = sD_ + grp * (2 * QT);
+    float* const sLg = sL_ + grp * (2 * QT * 2);
+    float* const sSlabg = sSlab_ + grp * (2 * 4 * QT * DH);
 
     // ---- this wave's keys: B fragments of K and V (lane = key c16 of block kb, features 8g ..), K^T as A fragments ----
     bf16x8_t kfB[2], vfB[2], ktA[2];
@@ -247,12 +275,12 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(const bf16_t* __restrict
             kfB[kb] = *reinterpret_cast<const bf16x8_t*>(kmat + ((size_t)b * Sk + key) * ldk + h * DH + g * 8);
             vfB[kb] = *reinterpret_cast<const bf16x8_t*>(v + ((size_t)b * Sk + key) * ldv + h * DH + g * 8);
         }
-        *reinterpret_cast<bf16x8_t*>(sT[wave] + (kb * 16 + c16) * A2_KS + g * 8) = kfB[kb];       // [32 keys][32 features] for the transpose
+        *reinterpret_cast<bf16x8_t*>(sT + (kb * 16 + c16) * A2_KS + g * 8) = kfB[kb];       // [32 keys][32 features] for the transpose
     }
     const bool any_dead = __any(dead[0] || dead[1]);
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb) {          // lane (feature 16 eb + c16, group g): keys 8g .. 8g + 7 of the pair
-        const bf16_t* base = sT[wave] + (8 * g + (c16 >> 2)) * A2_KS + eb * 16 + (c16 & 3) * 4;
+        const bf16_t* base = sT + (8 * g + (c16 >> 2)) * A2_KS + eb * 16 + (c16 & 3) * 4;
         ktA[eb] = tr_pair(base, base + 4 * A2_KS);
     }
     f32x4_t accK[2][2], accV[2][2];
@@ -261,58 +289,79 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) { accK[kb][eb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accV[kb][eb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 
-    // ---- query tiles: rows of dO, O, Q (thread = query tid / 8, features 4 (tid % 8) ..) travel one tile ahead ----
+    // ---- query tiles: rows of dO, O, Q (thread = query gtid / 8, features 4 (gtid % 8) ..) travel one tile (of this group) ahead ----
     const int n_tiles = (Sq + QT - 1) / QT;
-    u32x2_t d2n = {0, 0}, o2n = {0, 0}, q2n = {0, 0};
-    float2 lsen = make_float2(0.f, 0.f);
-    auto fetch_rows = [&](int q0_) {
-        const int qi = q0_ + (tid >> 3), ch = tid & 7;
-        d2n = u32x2_t{0, 0}; o2n = u32x2_t{0, 0}; q2n = u32x2_t{0, 0};
-        lsen = make_float2(0.f, 0.f);
+    const int n_iter = (n_tiles + A2_NG - 1) / A2_NG;
+    struct Rows { u32x2_t d2, o2, q2; float2 ls; };       // one thread's piece of a tile's dO / O / Q rows + (row maximum, 1 / row sum)
+    Rows ra, rb;                                           // loaded TWO iterations ahead: a tile's loads have a whole iteration to land
+    // row pointers of this thread's query in the group's first tile, advanced by A2_NG tiles per fetch: no multiplications inside the loop
+    const int qrow0 = grp * QT + (gtid >> 3);
+    const bf16_t* pd = dctx + ((size_t)b * Sq + qrow0) * lddo + h * DH + (gtid & 7) * 4;
+    const bf16_t* po = ctx + ((size_t)b * Sq + qrow0) * ldo + h * DH + (gtid & 7) * 4;
+    const bf16_t* pq = q + ((size_t)b * Sq + qrow0) * ldq + h * DH + (gtid & 7) * 4;
+    const float* pl = lse + 2 * ((size_t)bh * Sq + qrow0);
+    const size_t sd = (size_t)A2_NG * QT * lddo, so = (size_t)A2_NG * QT * ldo, sq_ = (size_t)A2_NG * QT * ldq;
+    // where this thread's 4 features of query gtid / 8 of dQ go: the workgroup's share (key splits) or dq itself
+    const int ldout = dq_part != nullptr ? H * DH : lddq;
+    bf16_t* pout = (dq_part != nullptr ? dq_part + (size_t)blockIdx.x * part_stride : dq) + ((size_t)b * Sq + qrow0) * ldout + h * DH + (gtid & 7) * 4;
+    const size_t sout = (size_t)A2_NG * QT * ldout;
+    auto fetch_rows = [&](Rows& r, int q0_) {
+        const int qi = q0_ + (gtid >> 3), ch = gtid & 7;
+        r.d2 = u32x2_t{0, 0}; r.o2 = u32x2_t{0, 0}; r.q2 = u32x2_t{0, 0};
+        r.ls = make_float2(0.f, 0.f);
         if (qi < Sq) {
-            d2n = *reinterpret_cast<const u32x2_t*>(dctx + ((size_t)b * Sq + qi) * lddo + h * DH + ch * 4);
-            o2n = *reinterpret_cast<const u32x2_t*>(ctx + ((size_t)b * Sq + qi) * ldo + h * DH + ch * 4);
-            q2n = *reinterpret_cast<const u32x2_t*>(q + ((size_t)b * Sq + qi) * ldq + h * DH + ch * 4);
-            if (ch == 0) lsen = *reinterpret_cast<const float2*>(lse + 2 * ((size_t)bh * Sq + qi));
+            r.d2 = *reinterpret_cast<const u32x2_t*>(pd);
+            r.o2 = *reinterpret_cast<const u32x2_t*>(po);
+            r.q2 = *reinterpret_cast<const u32x2_t*>(pq);
+            if (ch == 0) r.ls = *reinterpret_cast<const float2*>(pl);
         }
+        pd += sd; po += so; pq += sq_; pl += 2 * A2_NG * QT;
     };
-    auto stage_rows = [&](int buf) {
-        const int qq = tid >> 3, ch = tid & 7;
+    auto stage_rows = [&](const Rows& r, int buf) {
+        const int qq = gtid >> 3, ch = gtid & 7;
         float part = 0.f;
 #pragma unroll
         for (int w2 = 0; w2 < 2; ++w2) {
-            const unsigned dw = d2n[w2], ow = o2n[w2];
+            const unsigned dw = r.d2[w2], ow = r.o2[w2];
             part += __uint_as_float(dw << 16) * __uint_as_float(ow << 16) + __uint_as_float(dw & 0xffff0000u) * __uint_as_float(ow & 0xffff0000u);
         }
-        *reinterpret_cast<u32x2_t*>(sdO[buf] + qq * DH + ch * 4) = d2n;
-        *reinterpret_cast<u32x2_t*>(sQ[buf] + qq * DH + ch * 4) = q2n;
+        *reinterpret_cast<u32x2_t*>(sdOg + buf * (QT * DH) + qq * DH + ch * 4) = r.d2;
+        *reinterpret_cast<u32x2_t*>(sQg + buf * (QT * DH) + qq * DH + ch * 4) = r.q2;
         part += __shfl_xor(part, 1, 64);
         part += __shfl_xor(part, 2, 64);
         part += __shfl_xor(part, 4, 64);
         if (ch == 0) {
-            sD[buf][qq] = part;
-            sL[buf][2 * qq] = (lsen.x == -INFINITY) ? 0.f : lsen.x;
-            sL[buf][2 * qq + 1] = lsen.y;
+            sDg[buf * QT + qq] = part;
+            sLg[buf * (QT * 2) + 2 * qq] = (r.ls.x == -INFINITY) ? 0.f : r.ls.x;
+            sLg[buf * (QT * 2) + 2 * qq + 1] = r.ls.y;
         }
     };
-    fetch_rows(0);
-    stage_rows(0);
+    fetch_rows(ra, grp * QT);                               // iteration 0 (staged now)
+    fetch_rows(rb, grp * QT + A2_NG * QT);                  // iteration 1 (staged at the end of iteration 0)
+    stage_rows(ra, 0);
     __syncthreads();
 
     const unsigned hl = (unsigned)(ldp >> 1);                        // pairs per score row
-    for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1, q0 = t * QT;
-        if (t + 1 < n_tiles) fetch_rows(q0 + QT);
-        if (active) {
+    // pair index of this lane's element (query 4g + 2 par of tile 0, key of block 0): + (q0 + 16 blk) hl + 8 kb per (tile, query block, key block)
+    const unsigned pair_lane = ((unsigned)bh * (unsigned)Sq + (unsigned)(4 * g + 2 * par)) * hl + (unsigned)((kp * 32 + c16) >> 1);
+    auto iteration = [&](const int it, Rows& r_next, Rows& r_next2) {      // r_next: rows of iteration it + 1 (in flight since it - 1); r_next2 <- it + 2
+        const int t = it * A2_NG + grp;
+        const int buf = it & 1, q0 = t * QT;
+        const bool valid = t < n_tiles;
+        if (it + 2 < n_iter) fetch_rows(r_next2, q0 + 2 * A2_NG * QT);        // r_next2 was staged one iteration ago: free
+        const bf16_t* const sQ = sQg + buf * (QT * DH);
+        const bf16_t* const sdO = sdOg + buf * (QT * DH);
+        float* const slab = sSlabg + (buf * 4 + w4) * (QT * DH);
+        if (active && valid) {
             // ---- scores and dP with lane = key: rows (queries) 4g .. 4g + 3 of each 16-query block ----
             unsigned ds_pk[2][2][2], pd_pk[2][2][2];       // [query block][key block][pair of queries]
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(sQ[buf] + (blk * 16 + c16) * DH + g * 8);
-                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(sdO[buf] + (blk * 16 + c16) * DH + g * 8);
-                const float4 D4 = *reinterpret_cast<const float4*>(sD[buf] + blk * 16 + 4 * g);
-                const float4 La = *reinterpret_cast<const float4*>(sL[buf] + 2 * (blk * 16 + 4 * g));
-                const float4 Lb = *reinterpret_cast<const float4*>(sL[buf] + 2 * (blk * 16 + 4 * g) + 4);
+                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(sQ + (blk * 16 + c16) * DH + g * 8);
+                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(sdO + (blk * 16 + c16) * DH + g * 8);
+                const float4 D4 = *reinterpret_cast<const float4*>(sDg + buf * QT + blk * 16 + 4 * g);
+                const float4 La = *reinterpret_cast<const float4*>(sLg + buf * (QT * 2) + 2 * (blk * 16 + 4 * g));
+                const float4 Lb = *reinterpret_cast<const float4*>(sLg + buf * (QT * 2) + 2 * (blk * 16 + 4 * g) + 4);
                 const float Dq[4] = {D4.x, D4.y, D4.z, D4.w}, mcq[4] = {La.x, La.z, Lb.x, Lb.z}, rsq[4] = {La.y, La.w, Lb.y, Lb.w};
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
@@ -322,8 +371,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(const bf16_t* __restrict
                     unsigned hh[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
                     if (dropping) {
                         // the lanes of an (even, odd) key pair share their hashes: each computes two of the four queries, a DPP swap delivers the rest
-                        const int key = kp * 32 + kb * 16 + c16;
-                        const unsigned pair0 = ((unsigned)bh * (unsigned)Sq + (unsigned)(q0 + blk * 16 + 4 * g + 2 * par)) * hl + (unsigned)(key >> 1);
+                        const unsigned pair0 = pair_lane + (unsigned)(q0 + blk * 16) * hl + (unsigned)(kb * 8);
                         const unsigned m0 = pair_hash(pair0, s0, s1), m1 = pair_hash(pair0 + hl, s0, s1);
                         const unsigned o0 = (unsigned)__builtin_amdgcn_mov_dpp((int)m0, 0xB1, 0xf, 0xf, true);      // quad_perm [1, 0, 3, 2]
                         const unsigned o1 = (unsigned)__builtin_amdgcn_mov_dpp((int)m1, 0xB1, 0xf, 0xf, true);
@@ -345,7 +393,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(const bf16_t* __restrict
                     ds_pk[blk][kb][1] = pack2bf(dsv[2], dsv[3]);
                     pd_pk[blk][kb][0] = pack2bf(pdv[0], pdv[1]);
                     pd_pk[blk][kb][1] = pack2bf(pdv[2], pdv[3]);
-                    *reinterpret_cast<u32x2_t*>(sT[wave] + blk * (32 * A2_TS) + (kb * 16 + c16) * A2_TS + 4 * g) = u32x2_t{ds_pk[blk][kb][0], ds_pk[blk][kb][1]};
+                    *reinterpret_cast<u32x2_t*>(sT + blk * (32 * A2_TS) + (kb * 16 + c16) * A2_TS + 4 * g) = u32x2_t{ds_pk[blk][kb][0], ds_pk[blk][kb][1]};
                 }
             }
             // ---- dK^T += Q^T dS, dV^T += dO^T Pd (reduction over the tile's 32 queries: slot 8g + r <-> query 4g + r, 8g + 4 + r <-> 16 + 4g + r) ----
@@ -354,8 +402,8 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(const bf16_t* __restrict
                 bf16x8_t qT[2], oT[2];
 #pragma unroll
                 for (int eb = 0; eb < 2; ++eb) {
-                    qT[eb] = tr_pair(sQ[buf] + q_lo * DH + eb * 16 + col4, sQ[buf] + (q_lo + 16) * DH + eb * 16 + col4);
-                    oT[eb] = tr_pair(sdO[buf] + q_lo * DH + eb * 16 + col4, sdO[buf] + (q_lo + 16) * DH + eb * 16 + col4);
+                    qT[eb] = tr_pair(sQ + q_lo * DH + eb * 16 + col4, sQ + (q_lo + 16) * DH + eb * 16 + col4);
+                    oT[eb] = tr_pair(sdO + q_lo * DH + eb * 16 + col4, sdO + (q_lo + 16) * DH + eb * 16 + col4);
                 }
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
@@ -371,49 +419,68 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(const bf16_t* __restrict
             // ---- this wave's share of dQ^T = K^T dS^T: dS read back transposed (lane = query c16, keys 8g .. 8g + 7 of the pair) ----
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                const bf16_t* base = sT[wave] + blk * (32 * A2_TS) + (8 * g + (c16 >> 2)) * A2_TS + (c16 & 3) * 4;
+                const bf16_t* base = sT + blk * (32 * A2_TS) + (8 * g + (c16 >> 2)) * A2_TS + (c16 & 3) * 4;
                 const bf16x8_t sb = tr_pair(base, base + 4 * A2_TS);
 #pragma unroll
                 for (int eb = 0; eb < 2; ++eb) {
                     const f32x4_t r4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktA[eb], sb, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    *reinterpret_cast<float4*>(&sSlab[buf][wave][(blk * 16 + c16) * DH + eb * 16 + 4 * g]) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+                    *reinterpret_cast<float4*>(slab + (blk * 16 + c16) * DH + eb * 16 + 4 * g) = make_float4(r4[0], r4[1], r4[2], r4[3]);
                 }
             }
         }
-        if (t + 1 < n_tiles) stage_rows(buf ^ 1);
-        __syncthreads();     // the tile's dQ shares are complete; the next tile's rows are staged
-        {   // dQ of the tile (this workgroup's keys): sum of the active waves' shares
-            const int qq = tid >> 3, e4 = (tid & 7) * 4, qi = q0 + qq;
-            float4 a = *reinterpret_cast<const float4*>(&sSlab[buf][0][qq * DH + e4]);
+        if (it + 1 < n_iter) stage_rows(r_next, buf ^ 1);
+        __syncthreads();     // the tiles' dQ shares are complete; the next tiles' rows are staged
+        {   // dQ of this group's tile (this workgroup's keys): sum of the active waves' shares
+            const int qq = gtid >> 3, e4 = (gtid & 7) * 4, qi = q0 + qq;
+            const float* sl = sSlabg + buf * (4 * QT * DH) + qq * DH + e4;
+            float4 a = *reinterpret_cast<const float4*>(sl);
             for (int w2 = 1; w2 < nw; ++w2) {
-                const float4 o = *reinterpret_cast<const float4*>(&sSlab[buf][w2][qq * DH + e4]);
+                const float4 o = *reinterpret_cast<const float4*>(sl + w2 * (QT * DH));
                 a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
             }
-            if (qi < Sq) {
-                const u32x2_t out = {pack2bf(a.x * scale, a.y * scale), pack2bf(a.z * scale, a.w * scale)};
-                if (dq_part != nullptr)
-                    *reinterpret_cast<u32x2_t*>(dq_part + (size_t)blockIdx.x * part_stride + ((size_t)b * Sq + qi) * (H * DH) + h * DH + e4) = out;
-                else
-                    *reinterpret_cast<u32x2_t*>(dq + ((size_t)b * Sq + qi) * lddq + h * DH + e4) = out;
-            }
+            if (valid && qi < Sq) *reinterpret_cast<u32x2_t*>(pout) = u32x2_t{pack2bf(a.x * scale, a.y * scale), pack2bf(a.z * scale, a.w * scale)};
+            pout += sout;
         }
+    };
+    for (int it = 0; it < n_iter; it += 2) {
+        iteration(it, rb, ra);                       // even: stages rb (rows of it + 1), refills ra with the rows of it + 2
+        if (it + 1 < n_iter) iteration(it + 1, ra, rb);
     }
-    if (active) {
+    // ---- dK / dV: the groups' sums meet in LDS (the slabs are free after the last tile's reduction) ----
+    __syncthreads();
+    float* const xch = sSlab_ + w4 * (2 * 2 * 2 * 64 * 4);          // [w4][K | V][kb][eb][lane][4]
+    if (grp > 0 && active) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) {
+                *reinterpret_cast<float4*>(xch + (((0 * 2 + kb) * 2 + eb) * 64 + lane) * 4) = make_float4(accK[kb][eb][0], accK[kb][eb][1], accK[kb][eb][2], accK[kb][eb][3]);
+                *reinterpret_cast<float4*>(xch + (((1 * 2 + kb) * 2 + eb) * 64 + lane) * 4) = make_float4(accV[kb][eb][0], accV[kb][eb][1], accV[kb][eb][2], accV[kb][eb][3]);
+            }
+    }
+    __syncthreads();
+    if (grp == 0 && active) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const int key = kp * 32 + kb * 16 + c16;
-            if (key < Sk) {
 #pragma unroll
-                for (int eb = 0; eb < 2; ++eb) {
+            for (int eb = 0; eb < 2; ++eb) {
+                const float4 xk = *reinterpret_cast<const float4*>(xch + (((0 * 2 + kb) * 2 + eb) * 64 + lane) * 4);
+                const float4 xv = *reinterpret_cast<const float4*>(xch + (((1 * 2 + kb) * 2 + eb) * 64 + lane) * 4);
+                const float k4[4] = {accK[kb][eb][0] + xk.x, accK[kb][eb][1] + xk.y, accK[kb][eb][2] + xk.z, accK[kb][eb][3] + xk.w};
+                const float v4[4] = {accV[kb][eb][0] + xv.x, accV[kb][eb][1] + xv.y, accV[kb][eb][2] + xv.z, accV[kb][eb][3] + xv.w};
+                if (key < Sk) {
                     *reinterpret_cast<u32x2_t*>(dk + ((size_t)b * Sk + key) * lddk + h * DH + eb * 16 + g * 4) =
-                        u32x2_t{pack2bf(accK[kb][eb][0] * scale, accK[kb][eb][1] * scale), pack2bf(accK[kb][eb][2] * scale, accK[kb][eb][3] * scale)};
-                    *reinterpret_cast<u32x2_t*>(dv + ((size_t)b * Sk + key) * lddv + h * DH + eb * 16 + g * 4) =
-                        u32x2_t{pack2bf(accV[kb][eb][0], accV[kb][eb][1]), pack2bf(accV[kb][eb][2], accV[kb][eb][3])};
+                        u32x2_t{pack2bf(k4[0] * scale, k4[1] * scale), pack2bf(k4[2] * scale, k4[3] * scale)};
+                    *reinterpret_cast<u32x2_t*>(dv + ((size_t)b * Sk + key) * lddv + h * DH + eb * 16 + g * 4) = u32x2_t{pack2bf(v4[0], v4[1]), pack2bf(v4[2], v4[3])};
                 }
             }
         }
     }
 }
+
+constexpr size_t A2_BWD_LDS = (size_t)A2_NG * 2 * 32 * 32 * 2 * 2 + (size_t)A2_NG * 4 * 2 * 32 * A2_TS * 2 + (size_t)A2_NG * 2 * 32 * 4 + (size_t)A2_NG * 2 * 64 * 4 +
+                              (size_t)A2_NG * 2 * 4 * 32 * 32 * 4;
 
 }  // namespace toist
 
@@ -455,7 +522,12 @@ extern "C" int toist_attn2_bwd(const void* q, int ldq, const void* kmat, int ldk
     TOIST_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "toist_attn2_bwd: bad dropout p");
     const int ldp = (Sk + 7) / 8 * 8;
     TOIST_REQUIRE((long long)B * H * Sq * ldp < (1ll << 32), "toist_attn2_bwd: B * H * Sq * round8(Sk) must stay below 2^32 (dropout element index)");
-    hipLaunchKernelGGL(attn2_bwd_kernel, dim3(splits, B * H), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, ldq, (const bf16_t*)kmat, ldk,
+    static std::atomic<unsigned long long> done{0};
+    if (!lds_attr_once_flag(done, [] { return hipFuncSetAttribute((const void*)attn2_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; })) {
+        set_last_error("toist_attn2_bwd: cannot raise the dynamic LDS limit");
+        return TOIST_EHIP;
+    }
+    hipLaunchKernelGGL(attn2_bwd_kernel, dim3(splits, B * H), dim3(256 * A2_NG), A2_BWD_LDS, (hipStream_t)stream, (const bf16_t*)q, ldq, (const bf16_t*)kmat, ldk,
                        (const bf16_t*)v, ldv, (const bf16_t*)ctx, ldo, (const bf16_t*)dctx, lddo, lse, key_pad, H, Sq, Sk, ldp, scale, drop_p,
                        (unsigned long long)seed, (const unsigned long long*)seed_dev, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv,
                        splits > 1 ? (bf16_t*)dq_part : (bf16_t*)nullptr, (long long)B * Sq * H * 32);

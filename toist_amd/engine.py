@@ -64,15 +64,17 @@ SIDE_PRIORITY = knob("TOIST_SIDE_PRIORITY", 0)   # -1 = high: the small kernels 
 _TEXT_PRELUDE = []
 
 
-def register_text_prelude(opt):
-    _TEXT_PRELUDE[:] = [r for r in _TEXT_PRELUDE if r() is not None]
-    _TEXT_PRELUDE.append(weakref.ref(opt))
+def register_text_prelude(opt, late_params):
+    """opt.flush_late() will run at the head of every text branch whose encoder owns one of `late_params` (other models are not touched)"""
+    _TEXT_PRELUDE[:] = [(r, ids) for r, ids in _TEXT_PRELUDE if r() is not None]
+    _TEXT_PRELUDE.append((weakref.ref(opt), frozenset(id(p) for p in late_params)))
 
 
-def run_text_prelude():
-    for r in _TEXT_PRELUDE:
+def run_text_prelude(param):
+    """`param`: any parameter of the text encoder about to run"""
+    for r, ids in _TEXT_PRELUDE:
         opt = r()
-        if opt is not None:
+        if opt is not None and id(param) in ids:
             opt.flush_late()
 
 

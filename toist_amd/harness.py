@@ -208,10 +208,14 @@ class CapturedTrainStep:
     replayed from hipGraphs, one per input-shape BUCKET, with real variable-size batches.
 
     The reference resizes images to 480..800 x <= 1333 (datasets/tdod.py:305-319) and pads a batch to its largest image
-    (util/misc.py:185-209); captions are padded to the longest of the batch.  A captured graph has static shapes, so a batch is padded a
-    little further -- height / width up to multiples of `pad_hw`, tokens up to a multiple of `pad_tokens` -- with the padding masked out
-    exactly as the reference masks its own padding (NestedTensor.mask, attention_mask): the results are those of the eager step on the
-    same (more generously padded) batch.  One graph is captured per bucket (Hp, Wp, Lp) on first use and kept in an LRU of `max_graphs`;
+    (util/misc.py:185-209); captions are padded to the longest of the batch.  A captured graph has static shapes, so the IMAGES are padded a
+    little further -- height / width up to multiples of `pad_hw` -- with the padding masked out exactly as the reference masks its own
+    padding (NestedTensor.mask): extra masked pixels change no result.  Caption length is NOT rounded up by default (`pad_tokens=1`):
+    padded token positions are masked in every attention, but `loss_contrastive_align` takes its log-sum-exp over EVERY token column
+    without an attention mask (/root/reference/models/mdetr.py:646-663), so extra pad tokens would change that loss and its gradients.
+    `pad_tokens > 1` is an explicit trade: fewer graphs for captions of mixed lengths, and the contrastive term then equals the
+    reference's on a batch whose longest caption has the padded length (the detection losses are unaffected).
+    One graph is captured per bucket (Hp, Wp, Lp) on first use and kept in an LRU of `max_graphs`;
     targets travel through matcher.StaticTargets (fixed-address device image, any number of targets per image up to
     `max_targets_per_image`), dropout masks change per replay through the device seed word, learning rates are re-read from the
     optimizer's device table (`optimizer.sync_hyperparams()` after changing them).
@@ -219,9 +223,11 @@ class CapturedTrainStep:
     step(samples, tokenized, targets, positive_map) -> total loss (device scalar, valid until the next step of the same bucket).
     The FIRST step of a new bucket runs eagerly (it is a real training step) and the graph is captured right after it, without
     executing anything; later steps of that bucket are one host-to-device copy of the inputs + one graph launch.
-    Single process per GPU; with torch.distributed active the step falls back to the eager path (collectives are not captured)."""
+    Single process per GPU; with torch.distributed active the step falls back to the eager path (collectives are not captured).
+    Forward passes made between steps (validation) must run under torch.no_grad(): a grad-enabled forward that never sees backward()
+    leaves AccumulateGrad nodes bound to the stream it ran on, and torch's autograd engine would pull that stream into the next capture."""
 
-    def __init__(self, model, criterion, optimizer, weight_dict, *, batch, max_targets_per_image=16, pad_hw=64, pad_tokens=8, max_graphs=4,
+    def __init__(self, model, criterion, optimizer, weight_dict, *, batch, max_targets_per_image=16, pad_hw=64, pad_tokens=1, max_graphs=4,
                  contrastive=None, device=None):
         from collections import OrderedDict
         from . import kernels

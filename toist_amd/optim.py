@@ -89,12 +89,13 @@ class FusedClipAdamWEMA:
         self._group_of = [gi for gi, g in enumerate(self.param_groups) for _ in g["params"]]
         self._late = [bool(g.get("late", False)) for g in self.param_groups for _ in g["params"]]
         self._late_pending = False
+        self._late_captured = False
         self._late_grads = None
         self._n_now = self._n_late = 0
         if any(self._late):
             if defer_ema:
                 raise ValueError("FusedClipAdamWEMA: late groups and defer_ema are alternatives")
-            engine.register_text_prelude(self)
+            engine.register_text_prelude(self, [p for p, l in zip(params, self._late) if l])
         for t in params + self.exp_avg + [e for e in self._ema_of if e is not None] + [x for pr in self._ema_only for x in pr]:
             if t.dtype != torch.float32 or not _dense(t) or t.device != self.device:
                 raise TypeError("FusedClipAdamWEMA: tensors must be dense fp32 tensors on one GPU")
@@ -115,6 +116,8 @@ class FusedClipAdamWEMA:
         self._grads_last = None
         self._grads_dev = torch.zeros(n_t, dtype=torch.int64, device=self.device)
         self._table = None
+        self._chunks = self._partial = self._ema_table = self._ema_chunks = self._ema_grads = None
+        self._retired = []
         self.defer_ema = bool(defer_ema) and (any(e is not None for e in self._ema_of) or bool(self._ema_only))
         self._ema_pending = False
         self._copy_gen = -1
@@ -159,24 +162,40 @@ class FusedClipAdamWEMA:
             ch = np.ascontiguousarray(np.stack([tens, idx], axis=1).astype(np.int32))
             return torch.from_numpy(rr.view(np.uint8).copy()).to(self.device), torch.from_numpy(ch).to(self.device), int(ch.shape[0])
 
+        def keep(name, new):
+            """A rebuilt table takes the ADDRESS of the one it replaces when the shape allows: captured hipGraphs hold these pointers (a
+            rebuild is triggered by any new compute copy in the process, e.g. a second model's first forward pass; replacing the tensors
+            freed memory that a graph captured earlier still read -- a write through a garbage row faulted in
+            tests/test_gpu_captured_step.py).  A table of another shape retires the old one instead of freeing it."""
+            cur = getattr(self, name, None)
+            if cur is not None and cur.shape == new.shape and cur.dtype == new.dtype:
+                cur.copy_(new)
+                return
+            if cur is not None:
+                self._retired.append(cur)
+            setattr(self, name, new)
+
         if self.defer_ema:
             # the average gets its own table (source, average, size only): no gradient, no moments, no compute copy
             erows = rows[rows["ema"] != 0].copy()
             erows["m"], erows["v"], erows["w"], erows["row_scale"] = 0, 0, 0, 0
-            self._ema_table, self._ema_chunks, self._n_ema_chunks = chunked(erows)
-            self._ema_grads = torch.zeros(len(erows), dtype=torch.int64, device=self.device)
+            et, ec, self._n_ema_chunks = chunked(erows)
+            keep("_ema_table", et)
+            keep("_ema_chunks", ec)
+            keep("_ema_grads", torch.zeros(len(erows), dtype=torch.int64, device=self.device))
             rows = rows[:len(self.params)].copy()
             rows["ema"] = 0
-        self._table, chunks, self._n_chunks = chunked(rows)
+        table, chunks, self._n_chunks = chunked(rows)
+        keep("_table", table)
         # launch order of the chunks: everything updated inside step() first, the late groups' chunks behind them -- sqnorm walks all,
         # adamw_ema is launched on the two runs separately
         late_rows = torch.tensor(self._late + [False] * len(self._ema_only), dtype=torch.bool, device=self.device)
         is_late = late_rows[chunks[:, 0].long()]
-        self._chunks = torch.cat([chunks[~is_late], chunks[is_late]], dim=0).contiguous()
+        keep("_chunks", torch.cat([chunks[~is_late], chunks[is_late]], dim=0).contiguous())
         self._n_late = int(is_late.sum())
         self._n_now = self._n_chunks - self._n_late
         self._late_copies = [(ent, p_) for ent, p_ in self._copies if any(p_ is q for q, l in zip(self.params, self._late) if l)]
-        self._partial = torch.empty(self._n_chunks, dtype=torch.float32, device=self.device)
+        keep("_partial", torch.empty(self._n_chunks, dtype=torch.float32, device=self.device))
         self._copy_gen = engine.COPY_GEN
 
     # ---- torch.optim-like surface ---------------------------------------------------------------------------
@@ -190,8 +209,9 @@ class FusedClipAdamWEMA:
     @torch.no_grad()
     def step(self):
         capturing = torch.cuda.is_current_stream_capturing()
-        if self._late_pending:
+        if self._late_pending and not self._late_captured:
             self.flush_late()       # nobody ran it at the head of a text branch: the late groups must be updated before their gradients are re-read
+        self._late_captured = False
         if self._table is None or (self._copy_gen != engine.COPY_GEN and not capturing):
             self._build_table()
         if not capturing:
@@ -249,6 +269,8 @@ class FusedClipAdamWEMA:
         if not capturing:
             self._late_pending = False
             self._late_grads = None
+        else:
+            self._late_captured = True      # recorded at the head of this capture's text branch: the captured step() must not record it again
 
     def finish(self):
         """complete every deferred piece of the last step (late groups, deferred EMA): call before reading parameters outside a forward pass"""

@@ -27,7 +27,8 @@ BF16 = torch.bfloat16
 ENABLED = knob("TOIST_ROWS", True)          # tests flip this to compare with the per-op path of toist_amd.engine
 
 
-FUSE_FWD_MAX_K = knob("TOIST_ROWS_FWD_MAX_K", 768)      # forward sub-layers with a longer reduction run as GEMM + LayerNorm launch
+FUSE_FWD_MAX_K = knob("TOIST_ROWS_FWD_MAX_K", 768)      # forward sub-layers with a longer reduction run as GEMM + LayerNorm launch ...
+FUSE_FWD_MAX_M = knob("TOIST_ROWS_FWD_MAX_M", 1024)     # ... unless they have few rows (the decoder's 800 queries)
 ATTN2 = knob("TOIST_ATTN2", True)           # second-generation attention cores (csrc/attn2.hip): no key-count limit, key-owning backward
 
 
@@ -68,12 +69,13 @@ def _ln_fwd(ctx_in, W, b, res, gamma, beta, tape, add=None, y=None, eps=1e-5):
     s.mean = torch.empty(M, dtype=torch.float32, device=dev)
     s.rstd = torch.empty(M, dtype=torch.float32, device=dev)
     s.gamma, s.beta = gamma, beta
-    if ctx_in.shape[1] <= FUSE_FWD_MAX_K:
+    if ctx_in.shape[1] <= FUSE_FWD_MAX_K or M <= FUSE_FWD_MAX_M:
         k.rowgemm(ctx_in, W.w, s.y, b_kind=k.B_ROWK, epi=k.ROW_LN_FWD, bias=b.f32, res=res, drop_p=p, drop_seed=s.seed, gamma=gamma.f32, beta=beta.f32,
                   eps=eps, z=s.z, mean=s.mean, rstd=s.rstd, add=add, out2=s.y2)
     else:
         # deep reductions (linear2, K = 2048): a row-complete block streams the whole 1 MB weight through ONE CU (~18 us whatever the row
-        # count, profiles/r04_rowgemm_us.txt); the tiled GEMM spreads that stream over the chip, so GEMM + LayerNorm launch stay ahead
+        # count, profiles/r04_rowgemm_us.txt); at 3328 rows the tiled GEMM spreads that stream over the chip and GEMM + LayerNorm launch
+        # stay ahead (19.4 vs 22.0 us); at 800 rows (decoder) the tiled path is split-K GEMM + fold + LayerNorm = three launches for 18.4
         kw = dict(drop_where=1, drop_p=p, drop_seed=s.seed) if p > 0 else {}
         ops.linear(ctx_in, W.w, b.f32, res=res, out=s.z, **kw)
         k.layernorm_fwd(s.z, gamma.f32, beta.f32, eps, s.y, s.mean, s.rstd, add=add, y2=s.y2)

@@ -238,7 +238,7 @@ class Transformer(nn.Module):
         """RoBERTa + FeatureResizer -> bf16 tokens [B*L, d] (batch-major)."""
         # late optimizer groups of the previous step (toist_amd.optim: the text encoder's AdamW + EMA launch) are issued here, on the
         # stream of the text branch -- beside the ResNet forward when the branch is forked -- before RoBERTa reads its weights
-        engine.run_text_prelude()
+        engine.run_text_prelude(self.text_encoder.embeddings.word_embeddings.weight)
         ids = tokenized["input_ids"]
         att = tokenized["attention_mask"]
         B, L = ids.shape

@@ -150,7 +150,7 @@ def run(name, Sq, Sk, kind):
                 qb, kb, vb = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
             ctx = torch.empty(M, d, dtype=BF, device=dev)
             core = tlayer._core(tape, qb, kb, vb, key_pad if kind != "dec" else None, B, Sq, Sk, H, ctx, p, tape.next_seed())
-            ln = tlayer._ln_fwd(ctx, Wo, bo, x, LN[0], LN[1], tape)
+            ln = tlayer._ln_fwd(ctx, Wo, bo, x, LN[i][0], LN[i][1], tape)
             saved.append((xe, ctx, core, ln, Wi, bi, Wo, bo))
         prev = None
         for i in reversed(range(L)):
@@ -175,8 +175,9 @@ def run(name, Sq, Sk, kind):
         tape.backward()
 
     if not V1:
-        g_ = torch.ones(d, device=dev)
-        LN = (engine.ParamView(None, torch.zeros(d, device=dev), g_), engine.ParamView(None, torch.zeros(d, device=dev), torch.zeros(d, device=dev)))
+        # one LayerNorm per block, as in the model (shared parameters would force a fold of the d gamma / d beta partials per block)
+        LN = [(engine.ParamView(None, torch.zeros(d, device=dev), torch.ones(d, device=dev)), engine.ParamView(None, torch.zeros(d, device=dev), torch.zeros(d, device=dev)))
+              for _ in range(L)]
         ones = torch.ones(B * Sq, d, device=dev).to(BF)
         step = step2
     with Counter() as c:
