@@ -63,6 +63,10 @@ def parse():
                     "batch (images, captions, number of targets per image) through fixed-address input buffers, the same captured graph")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 PMC passes that measure the roofline kernel's HBM traffic (the committed passes are quoted instead)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
+    ap.add_argument("--dump-graph", default=None, help="diagnostic: write the captured step's hipGraph (nodes + dependency edges) as a DOT file to this path")
+    ap.add_argument("--stamps", action="store_true", help="diagnostic: one-thread clock kernels at the fork / join points of the step (captured into the graph); prints (stderr) "
+                    "when each branch of the LAST replayed step started and ended, in microseconds from the step's first kernel, no profiler attached")
+    ap.add_argument("--host-times", action="store_true", help="diagnostic: print (stderr) the host microseconds spent inside each run_step() call of the first timed region")
     ap.add_argument("--split-graph", action="store_true", help="force the multi-GPU structure (graph: fwd+bwd | eager all-reduce | graph: clip+AdamW+EMA) on one GPU")
     return ap.parse_args()
 
@@ -433,7 +437,11 @@ def main():
 
     cut_state = {}
 
+    if a.stamps:
+        kernels.STAMPS = {"buf": torch.zeros(64, dtype=torch.int64, device=dev), "names": []}
+
     def fwd_bwd():
+        kernels.stamp("step.start")
         kernels.SEED_DEV.add_(1000003)
         if ema_stream is not None:          # EMA of the previous step's parameters, beside this forward / backward
             ema_stream.wait_stream(torch.cuda.current_stream())
@@ -454,7 +462,9 @@ def main():
 
     def optimize():
         if not a.torch_optimizer:
+            kernels.stamp("opt.start")
             opt.step()
+            kernels.stamp("opt.end")
             return
         torch.nn.utils.clip_grad_norm_(all_params, args.clip_max_norm, foreach=True)
         opt.step()
@@ -498,9 +508,13 @@ def main():
                 opt.zero_grad(set_to_none=True)
                 if not split_graph:
                     graph = torch.cuda.CUDAGraph()
+                    if a.dump_graph:
+                        graph.enable_debug_mode()
                     with torch.cuda.graph(graph, stream=side):
                         static_loss = fwd_bwd()
                         optimize()
+                    if a.dump_graph:
+                        graph.debug_dump(a.dump_graph)
                 else:
                     # no collective inside a capture: the hook only collects the flat gradient buffers of each segment
                     functions.GRAD_SYNC = lambda f: flats.append(f) if f is not None else None
@@ -592,10 +606,21 @@ def main():
     barrier()
     kernels.PROFILE = prof
     t0 = time.perf_counter()
+    host_us = []
     for _ in range(a.steps):
+        th = time.perf_counter()
         last = run_step()
+        host_us.append(1e6 * (time.perf_counter() - th))
     barrier()
     dt = time.perf_counter() - t0
+    if a.stamps and rank == 0:
+        st_ = kernels.STAMPS
+        vals = st_["buf"][:len(st_["names"])].tolist()
+        t00 = vals[st_["names"].index("step.start")] if "step.start" in st_["names"] else min(vals)
+        print("[bench] stamps of the last step (us from step.start; 100 MHz device clock): " +
+              ", ".join(f"{n} {0.01 * (v - t00):.0f}" for n, v in sorted(zip(st_["names"], vals), key=lambda nv: nv[1])), file=sys.stderr)
+    if a.host_times and rank == 0:
+        print("[bench] host us inside each run_step() call: " + " ".join(f"{u:.0f}" for u in host_us) + f" | region {1e3 * dt:.2f} ms", file=sys.stderr)
     kernels.PROFILE = None
     loss_val = float(last)
     # the same K-step region again (replayed graphs only: nothing is instrumented there): boxes of the pool differ by +- 8 % and one

@@ -218,6 +218,9 @@ TOIST_API int toist_dropout_bf16(const void* x, int64_t n, float p, uint64_t see
 TOIST_API int toist_pack_image(const float* nchw, int N, int C, int H, int W, void* nhwc8, void* stream);
 TOIST_API int toist_maxpool3x3s2(const void* in, int N, int H, int W, int C, void* out, void* stream);
 TOIST_API int toist_unpack_nhwc(const void* nhwc, int N, int HW, int C, float* nchw, void* stream);
+/* diagnostic: slots[idx] = the device's constant-rate clock (100 MHz ticks) when everything ordered before this launch on `stream` is done
+ * (dates the branches of a replayed hipGraph without a profiler: bench.py --stamps; no reference counterpart) */
+TOIST_API int toist_stamp(uint64_t* slots, int idx, void* stream);
 
 /* ResNet stem in one launch (torchvision ResNet.conv1 / bn1 / relu / maxpool as used by /root/reference/models/backbone.py:64-91; frozen there):
  * image f32 NCHW [N, C <= 8, H, W] -> conv 7x7 / stride 2 / pad 3 with `weight` bf16 [64][7][7][8] (KRSC, channels padded to 8, FrozenBN scale

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "toist_maxpool3x3s2": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_stem_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_unpack_nhwc": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
+    "toist_stamp": ([c_void_p, c_int32, c_void_p], ctypes.c_int),
     "toist_sine_position": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_embed_fwd": ([c_void_p] * 5 + [c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_embed_bwd": ([c_void_p] * 3 + [c_int32, c_int32, c_int64] + [c_void_p] * 4, ctypes.c_int),

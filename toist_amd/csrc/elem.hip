@@ -137,6 +137,17 @@ extern "C" int toist_unpack_nhwc(const void* nhwc, int N, int HW, int C, float* 
     return check_launch("toist_unpack_nhwc");
 }
 
+// Diagnostic: the constant-rate device clock (100 MHz, s_memrealtime) at the moment this one-thread kernel runs, i.e. when everything
+// ordered before it on its stream has finished.  Captured into the step's hipGraph it dates the branches of a replayed step without a
+// profiler attached (bench.py --stamps).
+__global__ void stamp_kernel(unsigned long long* __restrict__ slots, int idx) { slots[idx] = wall_clock64(); }
+
+extern "C" int toist_stamp(uint64_t* slots, int idx, void* stream) {
+    TOIST_REQUIRE(slots != nullptr && idx >= 0, "toist_stamp: bad args");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)slots, idx);
+    return check_launch("toist_stamp");
+}
+
 extern "C" int toist_sine_position(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, void* out_tok,
                                    float* out_nchw, void* stream) {
     TOIST_REQUIRE(B > 0 && H > 0 && W > 0 && num_pos_feats > 0 && (num_pos_feats % 2) == 0, "toist_sine_position: bad shape");

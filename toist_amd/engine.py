@@ -976,3 +976,4 @@ def bottleneck(tape, x, W, bn, stride, has_down, train):
 
     tape.record(bwd)
     return out
+

@@ -15,7 +15,7 @@ Parameter gradients leave a program in one of two ways (PARAM_GRADS):
 """
 import torch
 
-from . import engine
+from . import engine, kernels
 
 # Optional callable(flat_grad_buffer or None) invoked when a program's backward has produced all of its
 # parameter gradients (set by toist_amd.parallel.GradSync / DistributedDataParallel).
@@ -65,6 +65,7 @@ class _TapeFn(torch.autograd.Function):
         else:
             tape.steps = []
         ctx.n_in = n_in
+        ctx.label = names[0].split(".")[0] if names else "program"
         ctx.n_par = len(params)
         ctx.extra = extra
         non_diff = [v.data for v in out_vars if not v.needs_grad]
@@ -75,12 +76,16 @@ class _TapeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         tape, ps = ctx.tape, ctx.ps
+        if kernels.STAMPS is not None:
+            kernels.stamp("bwd." + ctx.label + ".start")
         for v, g in zip(ctx.out_vars, grads):
             if g is not None and v.needs_grad:
                 if g.dtype != v.data.dtype:
                     g = g.to(v.data.dtype)
                 v.grad = g.contiguous()
         tape.backward()
+        if kernels.STAMPS is not None:
+            kernels.stamp("bwd." + ctx.label + ".end")
         in_grads = []
         for v in ctx.in_vars:
             if v is None or not v.needs_grad:

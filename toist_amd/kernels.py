@@ -399,6 +399,24 @@ def add(a, b, out, b_period=None):
                                   _p(out, torch.bfloat16), _stream()), "toist_add_bf16")
 
 
+STAMPS = None      # diagnostic (bench.py --stamps): {"buf": int64 device tensor, "names": [...]}: stamp(name) dates a point of the step on its stream
+
+
+def stamp(name):
+    st = STAMPS
+    if st is None:
+        return
+    names = st["names"]
+    if name in names:
+        idx = names.index(name)
+    else:
+        idx = len(names)
+        if idx >= st["buf"].numel():
+            return
+        names.append(name)
+    _lib.check(_lib.lib().toist_stamp(_p(st["buf"], torch.int64), idx, _stream()), "toist_stamp")
+
+
 def dropout(x, p, seed, out):
     _lib.check(_lib.lib().toist_dropout_bf16(_p(x, torch.bfloat16), x.numel(), p, seed, _p(SEED_DEV), _p(out, torch.bfloat16), _stream()),
                "toist_dropout_bf16")

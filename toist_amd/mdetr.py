@@ -206,12 +206,15 @@ class MDETR(nn.Module):
             if fork:
                 main = torch.cuda.current_stream()
                 side = engine.side_stream(samples.tensors.device, "text")
+                k.stamp("fwd.fork")
                 side.wait_stream(main)
                 functions.REJOIN = main
             try:
                 with torch.cuda.stream(side if fork else torch.cuda.current_stream()):
+                    k.stamp("fwd.text.start")
                     tokenized = self.transformer._tokenize(captions, samples.tensors.device)
                     flat, _ = self.transformer.encode_text(tokenized)
+                    k.stamp("fwd.text.end")
             finally:
                 functions.REJOIN = None
             if cut_on and flat.requires_grad:
@@ -220,9 +223,12 @@ class MDETR(nn.Module):
                 flat = leaf
             captions = EncodedText(tokenized, flat)
         stage_cuts = [] if cut_on else None          # data-parallel: the ResNet body runs as three programs with cuts between them
+        k.stamp("fwd.backbone.start")
         feats = body.forward_native(samples.tensors, levels, premasked=(len(levels) - 1,), stage_cuts=stage_cuts)
+        k.stamp("fwd.backbone.end")
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+        k.stamp("fwd.join")
         # Data-parallel jobs may cut the autograd graph at the outputs of the backbone and of the text encoder
         # (toist_amd.parallel.enable_backward_cuts): loss.backward() then stops there and the two long leaf programs are
         # run by backward_cut(memory_cache, name), so each gradient all-reduce can start as soon as its segment is done

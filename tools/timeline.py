@@ -28,9 +28,11 @@ def short(name):
 
 
 rows = []
+META = {}
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+        META[(int(r["Start_Timestamp"]), r["Kernel_Name"])] = (r.get("Queue_Id", "?"), r.get("Stream_Id", "?"), r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?"))
 rows.sort()
 marks = [i for i, r in enumerate(rows) if "matcher_kernel" in r[2]]
 assert len(marks) >= 3, "need at least 3 steps in the trace"
@@ -91,4 +93,5 @@ if None not in (i_bb_bwd, i_opt, i_opt_end, i_pos):
 if len(sys.argv) > 3:                      # optional: dump the kernel sequence (name, us) of the analysed step
     with open(sys.argv[3], "w") as f:
         for s, e, n in step:
-            f.write(f"{1e-3 * (s - t0):9.1f} {1e-3 * (e - s):7.1f} {short(n)}\n")
+            qid, sid, gx, wx = META.get((s, n), ("?", "?", "?", "?"))
+            f.write(f"{1e-3 * (s - t0):9.1f} {1e-3 * (e - s):7.1f} q{qid} s{sid} g{gx}/{wx} {short(n)}\n")
