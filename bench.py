@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 PMC passes that measure the roofline kernel's HBM traffic (the committed passes are quoted instead)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a captured hipGraph")
     ap.add_argument("--dump-graph", default=None, help="diagnostic: write the captured step's hipGraph (nodes + dependency edges) as a DOT file to this path")
+    ap.add_argument("--glue-report", action="store_true", help="diagnostic: one EAGER step under torch.profiler; prints (stderr) every source line of toist_amd / bench.py that "
+                    "launches torch (non-toist) device kernels, with the number of kernels and their device time, then exits")
     ap.add_argument("--stamps", action="store_true", help="diagnostic: one-thread clock kernels at the fork / join points of the step (captured into the graph); prints (stderr) "
                     "when each branch of the LAST replayed step started and ended, in microseconds from the step's first kernel, no profiler attached")
     ap.add_argument("--host-times", action="store_true", help="diagnostic: print (stderr) the host microseconds spent inside each run_step() call of the first timed region")
@@ -490,6 +492,56 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    if a.glue_report:
+        import collections
+        import traceback
+        from torch.utils._python_dispatch import TorchDispatchMode
+        NO_KERNEL = ("aten.empty", "aten.new_empty", "aten.empty_like", "aten.empty_strided", "aten.resize_", "aten.set_", "aten.record_stream", "aten._local_scalar_dense",
+                     "aten.lift_fresh", "aten.is_", "aten.sym_", "aten._has_compatible", "aten.is_pinned")
+
+        def launches(func, out):
+            name = str(func)
+            if any(name.startswith(v) for v in NO_KERNEL):
+                return False
+            try:        # a pure view: the result aliases an argument without writing it
+                rets = func._schema.returns
+                if rets and all(r.alias_info is not None and not r.alias_info.is_write for r in rets):
+                    return False
+            except Exception:
+                pass
+            return True
+
+        agg = collections.OrderedDict()
+
+        class Glue(TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                out = func(*args, **(kwargs or {}))
+                name = str(func)
+                if not launches(func, out):
+                    return out
+                on_dev = any(torch.is_tensor(x) and x.is_cuda for x in list(args) + list((kwargs or {}).values()) + ([out] if torch.is_tensor(out) else []))
+                if not on_dev:
+                    return out
+                fr = "(no toist frame)"
+                for f in reversed(traceback.extract_stack()[:-1]):
+                    if ("toist_amd/" in f.filename or f.filename.endswith("bench.py")) and not f.filename.endswith("kernels.py"):
+                        fr = f"{'toist_amd/' + f.filename.split('toist_amd/')[-1] if 'toist_amd/' in f.filename else 'bench.py'}:{f.lineno} {f.name}"
+                        break
+                ent = agg.setdefault((fr, name), [0])
+                ent[0] += 1
+                return out
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        with Glue():
+            step()
+        torch.cuda.synchronize()
+        print(f"[bench] torch operators on device tensors in one eager step (views excluded): {sum(v[0] for v in agg.values())}", file=sys.stderr)
+        for (frame, name), (calls,) in agg.items():
+            print(f"  {calls:3d} x {name:34s} {frame}", file=sys.stderr)
+        return
 
     if use_graph:
         # The step (forward, criterion, backward, clip, AdamW, EMA: ~1500 kernel launches) is captured once into
