@@ -218,6 +218,9 @@ TOIST_API int toist_dropout_bf16(const void* x, int64_t n, float p, uint64_t see
 TOIST_API int toist_pack_image(const float* nchw, int N, int C, int H, int W, void* nhwc8, void* stream);
 TOIST_API int toist_maxpool3x3s2(const void* in, int N, int H, int W, int C, void* out, void* stream);
 TOIST_API int toist_unpack_nhwc(const void* nhwc, int N, int HW, int C, float* nchw, void* stream);
+/* RoBERTa position ids (cumsum(id != pad) * (id != pad) + pad) and key-padding bytes (attention_mask != 1) of a tokenized batch [B, L] in one launch
+ * (HF create_position_ids_from_input_ids / the text branch of transformer.py:129-138) */
+TOIST_API int toist_text_prep(const int64_t* ids, const int64_t* attention_mask, int B, int L, int64_t pad_id, int64_t* pos_ids, uint8_t* key_pad, void* stream);
 /* diagnostic: slots[idx] = the device's constant-rate clock (100 MHz ticks) when everything ordered before this launch on `stream` is done
  * (dates the branches of a replayed hipGraph without a profiler: bench.py --stamps; no reference counterpart) */
 TOIST_API int toist_stamp(uint64_t* slots, int idx, void* stream);
@@ -233,6 +236,10 @@ TOIST_API int toist_stem_fwd(const float* image, const void* weight, const float
  * [B, 2*num_pos_feats, H, W] (either output may be NULL). */
 TOIST_API int toist_sine_position(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, void* out_tok,
                         float* out_nchw, void* stream);
+/* the same encoding as the token-major bf16 rows of a [B, rows_per_image, 2F] sequence buffer, rows_per_image >= H*W: the rows behind an image's
+ * H*W tokens (the caption tokens of the cross-modal encoder input) are zero (transformer.py:139 torch.zeros_like(text_memory_resized)) */
+TOIST_API int toist_sine_position_seq(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, void* out_tok, int rows_per_image,
+                                      void* stream);
 
 /* RoBERTa input embeddings (HF RobertaEmbeddings, called at transformer.py:130):
  * out[t] = word[ids[t]] + type0 + pos[pos_ids[t]] (f32 tables -> bf16 [n,D]); bwd scatter-adds the

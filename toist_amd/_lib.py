@@ -82,7 +82,9 @@ _SIGNATURES = {
     "toist_stem_fwd": ([c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_unpack_nhwc": ([c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_stamp": ([c_void_p, c_int32, c_void_p], ctypes.c_int),
+    "toist_text_prep": ([c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_sine_position": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_sine_position_seq": ([c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_int32, c_void_p], ctypes.c_int),
     "toist_embed_fwd": ([c_void_p] * 5 + [c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_embed_bwd": ([c_void_p] * 3 + [c_int32, c_int32, c_int64] + [c_void_p] * 4, ctypes.c_int),
     "toist_criterion_fwd": ([c_void_p] * 9 + [c_int32] * 4 + [c_float, c_void_p, c_void_p, c_void_p], ctypes.c_int),

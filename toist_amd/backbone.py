@@ -301,13 +301,21 @@ class BackboneBase(nn.Module):
         return out
 
 
+_NEAREST_IDX = {}
+
+
 def nearest_mask(mask, hw):
-    """F.interpolate(mask[None].float(), size=hw).bool()[0] (backbone.py:78) as an index gather."""
+    """F.interpolate(mask[None].float(), size=hw).bool()[0] (backbone.py:78) as ONE index gather; the source rows / columns of a
+    (size, device) pair are computed once on the host."""
     H, W = mask.shape[-2:]
     h, w = hw
-    iy = torch.div(torch.arange(h, device=mask.device) * H, h, rounding_mode="floor")
-    ix = torch.div(torch.arange(w, device=mask.device) * W, w, rounding_mode="floor")
-    return mask[:, iy][:, :, ix]
+    key = (H, W, h, w, str(mask.device))
+    idx = _NEAREST_IDX.get(key)
+    if idx is None:
+        iy = torch.div(torch.arange(h) * H, h, rounding_mode="floor")
+        ix = torch.div(torch.arange(w) * W, w, rounding_mode="floor")
+        idx = _NEAREST_IDX[key] = ((iy[:, None] * W + ix[None, :]).reshape(-1).to(mask.device),)
+    return mask.reshape(mask.shape[0], H * W).index_select(1, idx[0]).view(mask.shape[0], h, w)
 
 
 class Backbone(BackboneBase):

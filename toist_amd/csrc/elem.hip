@@ -75,10 +75,21 @@ __global__ __launch_bounds__(256) void unpack_nhwc_kernel(const bf16_t* __restri
 // mask [B,H,W] u8 (1 = padding) -> pos bf16 [B, H*W, 2*F] (token-major, y half then x half) and/or
 // f32 [B, 2*F, H, W] (the reference layout).  One thread per (b, y, x, feature pair).
 __global__ __launch_bounds__(256) void sine_pos_kernel(const unsigned char* __restrict__ mask, int B, int H, int W, int F,
-                                                        float temperature, bf16_t* __restrict__ out_tok, float* __restrict__ out_nchw) {
+                                                        float temperature, bf16_t* __restrict__ out_tok, float* __restrict__ out_nchw, int S) {
+    // out_tok holds S >= H * W rows per image: rows beyond the image's tokens (the caption's tokens behind them in the cross-modal
+    // encoder's sequence) get a zero encoding (transformer.py:139)
     const int half = F >> 1;
-    const long long total = (long long)B * H * W * half;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long total = (long long)B * H * W * half, tail = (long long)B * (S - H * W) * half;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total + tail; i += (long long)gridDim.x * 256) {
+        if (i >= total) {
+            const long long t = i - total;
+            const int j = (int)(t % half);
+            const long long r = t / half;
+            const int b = (int)(r / (S - H * W)), row = H * W + (int)(r % (S - H * W));
+            bf16_t* o = out_tok + ((long long)b * S + row) * (2 * F);
+            o[2 * j] = 0; o[2 * j + 1] = 0; o[F + 2 * j] = 0; o[F + 2 * j + 1] = 0;
+            continue;
+        }
         const int j = (int)(i % half);
         long long p = i / half;
         const int x = (int)(p % W); p /= W;
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(256) void sine_pos_kernel(const unsigned char* __re
         const float dim_t = powf(temperature, (2.f * (float)j) / (float)F);
         const float vy0 = sinf(ye / dim_t), vy1 = cosf(ye / dim_t);
         const float vx0 = sinf(xe / dim_t), vx1 = cosf(xe / dim_t);
-        const long long tok = ((long long)b * H + y) * W + x;
+        const long long tok = (long long)b * S + (long long)y * W + x;
         if (out_tok) {
             bf16_t* o = out_tok + tok * (2 * F);
             o[2 * j] = f2bf(vy0); o[2 * j + 1] = f2bf(vy1);
@@ -137,6 +148,28 @@ extern "C" int toist_unpack_nhwc(const void* nhwc, int N, int HW, int C, float* 
     return check_launch("toist_unpack_nhwc");
 }
 
+// RoBERTa's position ids and the key-padding bytes of a tokenized batch in one launch: position = cumsum(id != pad) * (id != pad) + pad
+// (HF create_position_ids_from_input_ids, reached through /root/reference/models/transformer.py:129-133), key_pad = (attention_mask != 1).
+__global__ __launch_bounds__(64) void text_prep_kernel(const long long* __restrict__ ids, const long long* __restrict__ att, int B, int L, long long pad_id,
+                                                       long long* __restrict__ pos_ids, unsigned char* __restrict__ key_pad) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    long long run = 0;
+    for (int t = 0; t < L; ++t) {
+        const long long keep = ids[(size_t)b * L + t] != pad_id ? 1 : 0;
+        run += keep;
+        pos_ids[(size_t)b * L + t] = run * keep + pad_id;
+        key_pad[(size_t)b * L + t] = att[(size_t)b * L + t] != 1 ? 1 : 0;
+    }
+}
+
+extern "C" int toist_text_prep(const int64_t* ids, const int64_t* attention_mask, int B, int L, int64_t pad_id, int64_t* pos_ids, uint8_t* key_pad, void* stream) {
+    TOIST_REQUIRE(ids && attention_mask && pos_ids && key_pad && B > 0 && L > 0, "toist_text_prep: bad args");
+    hipLaunchKernelGGL(text_prep_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const long long*)ids, (const long long*)attention_mask, B, L,
+                       (long long)pad_id, (long long*)pos_ids, key_pad);
+    return check_launch("toist_text_prep");
+}
+
 // Diagnostic: the constant-rate device clock (100 MHz, s_memrealtime) at the moment this one-thread kernel runs, i.e. when everything
 // ordered before it on its stream has finished.  Captured into the step's hipGraph it dates the branches of a replayed step without a
 // profiler attached (bench.py --stamps).
@@ -148,12 +181,22 @@ extern "C" int toist_stamp(uint64_t* slots, int idx, void* stream) {
     return check_launch("toist_stamp");
 }
 
-extern "C" int toist_sine_position(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, void* out_tok,
-                                   float* out_nchw, void* stream) {
-    TOIST_REQUIRE(B > 0 && H > 0 && W > 0 && num_pos_feats > 0 && (num_pos_feats % 2) == 0, "toist_sine_position: bad shape");
-    long long total = (long long)B * H * W * (num_pos_feats / 2);
+static int sine_position(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, void* out_tok, float* out_nchw, int S,
+                         void* stream, const char* who) {
+    TOIST_REQUIRE(B > 0 && H > 0 && W > 0 && num_pos_feats > 0 && (num_pos_feats % 2) == 0 && S >= H * W && (S == H * W || out_tok != nullptr), "%s: bad shape", who);
+    long long total = (long long)B * S * (num_pos_feats / 2);
     int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(sine_pos_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, B, H, W, num_pos_feats, temperature,
-                       (bf16_t*)out_tok, out_nchw);
-    return check_launch("toist_sine_position");
+                       (bf16_t*)out_tok, out_nchw, S);
+    return check_launch(who);
+}
+
+extern "C" int toist_sine_position(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, void* out_tok,
+                                   float* out_nchw, void* stream) {
+    return sine_position(mask, B, H, W, num_pos_feats, temperature, out_tok, out_nchw, H * W, stream, "toist_sine_position");
+}
+
+extern "C" int toist_sine_position_seq(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, void* out_tok, int rows_per_image,
+                                       void* stream) {
+    return sine_position(mask, B, H, W, num_pos_feats, temperature, out_tok, nullptr, rows_per_image, stream, "toist_sine_position_seq");
 }

@@ -452,6 +452,23 @@ def sine_position(mask_u8, num_pos_feats, temperature, out_tok=None, out_nchw=No
                                               _p(out_nchw, torch.float32), _stream()), "toist_sine_position")
 
 
+def text_prep(ids, attention_mask, pad_id):
+    """-> (position ids int64 [B, L], key_pad uint8 [B, L]) of a tokenized batch"""
+    B, L = ids.shape
+    pos_ids = torch.empty(B, L, dtype=torch.int64, device=ids.device)
+    key_pad = torch.empty(B, L, dtype=torch.uint8, device=ids.device)
+    _lib.check(_lib.lib().toist_text_prep(_p(ids, torch.int64), _p(attention_mask, torch.int64), B, L, pad_id, _p(pos_ids), _p(key_pad), _stream()),
+               "toist_text_prep")
+    return pos_ids, key_pad
+
+
+def sine_position_seq(mask_u8, num_pos_feats, temperature, out_tok):
+    """out_tok bf16 [B, S, 2F], S >= H*W: rows H*W .. S-1 of every image are zero"""
+    B, H, W = mask_u8.shape
+    _lib.check(_lib.lib().toist_sine_position_seq(_p(mask_u8, torch.uint8), B, H, W, num_pos_feats, temperature, _p(out_tok, torch.bfloat16),
+                                                  out_tok.shape[1], _stream()), "toist_sine_position_seq")
+
+
 def embed_fwd(ids, pos_ids, word, pos, type0, out):
     n, D = out.shape
     _lib.check(_lib.lib().toist_embed_fwd(_p(ids, torch.int64), _p(pos_ids, torch.int64), _p(word, torch.float32), _p(pos, torch.float32),

@@ -80,11 +80,13 @@ class MDETR(nn.Module):
     def _text_tokens(self, memory_cache, B):
         """bf16 [B*Lt, d] text rows of the encoder output (memory_cache["text_memory"], batch-major)."""
         native = memory_cache.get("_native")
+        lazy = getattr(memory_cache, "is_lazy", None)
+        if native is not None and ((lazy is not None and lazy("img_memory") and lazy("text_memory")) or
+                                   (native.get("img_memory_ref") is not None and native.get("img_memory_ref") is memory_cache.get("img_memory"))):
+            mem, Lt = native["memory"], native["L"]     # nobody replaced (or even read) the fp32 copies: the encoder's own bf16 rows
+            return mem.view(B, native["S"], -1)[:, native["S"] - Lt:, :].reshape(B * Lt, -1)
         tm = memory_cache["text_memory"]
         Lt = tm.shape[0]
-        if native is not None and native.get("img_memory_ref") is memory_cache.get("img_memory"):
-            mem = native["memory"]
-            return mem.view(B, native["S"], -1)[:, native["S"] - Lt:, :].reshape(B * Lt, -1)
         return tm.permute(1, 0, 2).to(BF16).reshape(B * Lt, -1)
 
     def _heads(self, stack, B, text_tok=None):
@@ -123,13 +125,14 @@ class MDETR(nn.Module):
             outs.append(logits)
             # --- box head: last layer padded from 4 to 8 outputs (16-byte rows), sigmoid in the epilogue ---
             W2, b2 = ps["bbox_embed.layers.2.weight"], ps["bbox_embed.layers.2.bias"]
-            w2p = torch.zeros(8, d, dtype=BF16, device=hs.data.device)
-            w2p[:4] = W2.w
-            b2p = torch.zeros(8, dtype=torch.float32, device=hs.data.device)
-            b2p[:4] = b2.f32
+            w2p = box_pad_w                   # [8, d] bf16, rows 4-7 zero; rows 0-3 ARE W2's compute copy (engine.packed_cast: refreshed in place)
+            assert W2.w.data_ptr() == w2p.data_ptr()
+            b2p = box_pad_b
+            b2p[:4].copy_(b2.f32)
             need = W2.g is not None
-            g2w = torch.zeros(8, d, dtype=torch.float32, device=hs.data.device) if need else None
-            g2b = torch.zeros(8, dtype=torch.float32, device=hs.data.device) if need else None
+            gpad = torch.zeros(8 * d + 8, dtype=torch.float32, device=hs.data.device) if need else None
+            g2w = gpad[:8 * d].view(8, d) if need else None
+            g2b = gpad[8 * d:] if need else None
 
             def pad_bwd():
                 if need:
@@ -170,9 +173,16 @@ class MDETR(nn.Module):
                 outs.append(ptxt)
             return outs, None
 
+        # the box head's last layer runs padded from 4 to 8 outputs: its bf16 compute copy lives in rows 0-3 of a zero [8, d] buffer
+        pads = self.__dict__.setdefault("_box_pad", {})
+        key_dev = str(stack.device)
+        if key_dev not in pads or pads[key_dev][2] != id(self):      # id: a deepcopy of the module gets its own buffers
+            buf = torch.zeros(8, d, dtype=BF16, device=stack.device)
+            pads[key_dev] = (buf, torch.zeros(8, dtype=torch.float32, device=stack.device), id(self), {"bbox_embed.layers.2.weight": engine.packed_cast(buf[:4])})
+        box_pad_w, box_pad_b, _, transforms = pads[key_dev]
         once = {"class_embed.weight", "bbox_embed.layers.0.weight", "bbox_embed.layers.1.weight", "cimg.weight", "ctxt.weight"}   # not the padded last box layer
         res = functions.run_program(prog, named, [stack] + ([text_tok] if want_proj else []), cache=self._cache_heads, training=self.training,
-                                    store_once=lambda n, t: n in once)
+                                    store_once=lambda n, t: n in once, transforms=transforms)
         K = res[0].shape[-1]
         logits = res[0].view(L, B, Q, K)
         boxes = res[1][:, :4].reshape(L, B, Q, 4)
@@ -201,7 +211,8 @@ class MDETR(nn.Module):
         cut_on = getattr(self, "split_backward", False) and torch.is_grad_enabled()
         pre_encoded = isinstance(captions, tuple) and len(captions) == 3 and torch.is_tensor(captions[0])
         fork = not pre_encoded and samples.tensors.is_cuda and engine.overlap_enabled()
-        if fork or (cut_on and not pre_encoded):
+        tail = captions[1].shape[0] if pre_encoded else 0           # caption tokens behind the image tokens of the cross-modal sequence
+        if not pre_encoded and samples.tensors.is_cuda:
             from .transformer import EncodedText
             if fork:
                 main = torch.cuda.current_stream()
@@ -213,7 +224,7 @@ class MDETR(nn.Module):
                 with torch.cuda.stream(side if fork else torch.cuda.current_stream()):
                     k.stamp("fwd.text.start")
                     tokenized = self.transformer._tokenize(captions, samples.tensors.device)
-                    flat, _ = self.transformer.encode_text(tokenized)
+                    flat, key_pad_text = self.transformer.encode_text(tokenized)
                     k.stamp("fwd.text.end")
             finally:
                 functions.REJOIN = None
@@ -221,7 +232,8 @@ class MDETR(nn.Module):
                 leaf = flat.detach().requires_grad_(True)
                 cuts["text"] = ([flat], [leaf])
                 flat = leaf
-            captions = EncodedText(tokenized, flat)
+            captions = EncodedText(tokenized, flat, key_pad_text)
+            tail = tokenized["input_ids"].shape[1]
         stage_cuts = [] if cut_on else None          # data-parallel: the ResNet body runs as three programs with cuts between them
         k.stamp("fwd.backbone.start")
         feats = body.forward_native(samples.tensors, levels, premasked=(len(levels) - 1,), stage_cuts=stage_cuts)
@@ -243,7 +255,7 @@ class MDETR(nn.Module):
         c5 = feats[-1]
         B, h, w, _ = c5.shape
         mask = nearest_mask(samples.mask, (h, w))
-        pos_tok = self.backbone[1].tokens(mask) if hasattr(self.backbone[1], "tokens") else \
+        pos_tok = self.backbone[1].tokens(mask, tail=tail) if hasattr(self.backbone[1], "tokens") else \
             self.backbone[1](NestedTensor(c5.permute(0, 3, 1, 2), mask)).flatten(2).permute(0, 2, 1).to(BF16).contiguous()
         tok = self._project(c5).view(B, h * w, -1)
         mc = self.transformer.encode_native(tok, pos_tok, mask.flatten(1), self.query_embed.weight, captions)
@@ -256,8 +268,13 @@ class MDETR(nn.Module):
     def decode(self, memory_cache):
         native = memory_cache.get("_native")
         key = "img_memory_mod" if (self.args is not None and getattr(self.args, "cluster", False)) else "img_memory"
-        stack = self.transformer.decode_native(memory_cache[key], memory_cache["pos_embed"], memory_cache["mask"],
-                                               memory_cache["query_embed"], native=native)
+        lazy = getattr(memory_cache, "is_lazy", None)
+        if native is not None and lazy is not None and lazy(key):
+            # the fp32 API copies were never read, let alone replaced: decode straight from the encoder's bf16 buffers
+            stack = self.transformer.decode_native(None, None, None, native["query_embed"], native=native)
+        else:
+            stack = self.transformer.decode_native(memory_cache[key], memory_cache["pos_embed"], memory_cache["mask"],
+                                                   memory_cache["query_embed"], native=native)
         B = memory_cache["mask"].shape[0]
         text_tok = self._text_tokens(memory_cache, B) if self.contrastive_align_loss else None
         logits, boxes, proj, proj_text = self._heads(stack, B, text_tok)
@@ -710,7 +727,7 @@ def weighted_total(loss_dict, weight_dict):
             for i, v in key[2]:
                 host[i] = v
             w = _WEIGHT_VECTORS[key] = host.to(flat.device)
-        term = (flat * w).sum()
+        term = torch.dot(flat.float(), w)
         total = term if total is None else total + term
         covered.update(index)
     for k_, v in loss_dict.items():

@@ -22,14 +22,20 @@ class PositionEmbeddingSine(nn.Module):
         mask = tensor_list.mask
         B, H, W = mask.shape
         out = torch.empty(B, 2 * self.num_pos_feats, H, W, dtype=torch.float32, device=mask.device)
-        k.sine_position(mask.to(torch.uint8).contiguous(), self.num_pos_feats, self.temperature, out_nchw=out)
+        m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
+        k.sine_position(m8, self.num_pos_feats, self.temperature, out_nchw=out)
         return out
 
-    def tokens(self, mask):
-        """bf16 [B, H*W, 2F] token-major encoding for the native encoder path."""
+    def tokens(self, mask, tail=0):
+        """bf16 [B, H*W + tail, 2F] token-major encoding for the native encoder path; the `tail` rows behind every image's tokens (the
+        caption tokens of the cross-modal sequence) are zero."""
         B, H, W = mask.shape
-        out = torch.empty(B, H * W, 2 * self.num_pos_feats, dtype=torch.bfloat16, device=mask.device)
-        k.sine_position(mask.to(torch.uint8).contiguous(), self.num_pos_feats, self.temperature, out_tok=out)
+        out = torch.empty(B, H * W + tail, 2 * self.num_pos_feats, dtype=torch.bfloat16, device=mask.device)
+        m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
+        if tail:
+            k.sine_position_seq(m8, self.num_pos_feats, self.temperature, out)
+        else:
+            k.sine_position(m8, self.num_pos_feats, self.temperature, out_tok=out)
         return out
 
 

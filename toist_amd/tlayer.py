@@ -199,7 +199,9 @@ def decoder_program(tape, ps, mem, qe, pos, key_pad, B, S, Q, H, n_layers):
     all layer outputs; returns [hs] with hs [L, B*Q, 256] bf16 (transformer.py:225-267, 362-408)."""
     d, M, p, L_ = 256, B * Q, tape.drop_p, n_layers
     dev = mem.data.device
-    qpos = qe.data.to(BF16).unsqueeze(0).expand(B, Q, d).reshape(M, d).contiguous()
+    qpos = torch.empty(B, Q, d, dtype=BF16, device=dev)
+    qpos.copy_(qe.data.unsqueeze(0).expand(B, Q, d))          # cast + broadcast over the batch in one launch
+    qpos = qpos.view(M, d)
     Wself = [(ps[f"layers.{i}.self_attn.in_proj_weight"], ps[f"layers.{i}.self_attn.in_proj_bias"]) for i in range(L_)]
     Wcross = [(ps[f"layers.{i}.cross_attn_image.in_proj_weight"], ps[f"layers.{i}.cross_attn_image.in_proj_bias"]) for i in range(L_)]
     need = qe.needs_grad or mem.needs_grad or Wself[0][0].g is not None

@@ -141,13 +141,78 @@ class RobertaTextEncoder(nn.Module):
             p.requires_grad_(False)
 
 
+class MemoryCache(dict):
+    """The reference's memory_cache dict (transformer.py:146-157).  Entries registered through `lazy` -- the fp32, sequence-first copies
+    of tensors the native path keeps in bf16 batch-major form (img_memory, text_memory, pos_embed, text_memory_resized, query_embed) --
+    are materialised when somebody READS them: the training step never does, an API consumer (distillation, evaluation scripts)
+    pays one conversion launch on first access.  Assigning to a key drops its thunk, as with a plain dict."""
+
+    def __init__(self, *args, lazy=None, **kw):
+        super().__init__(*args, **kw)
+        self._lazy = dict(lazy or {})
+
+    def is_lazy(self, key):
+        return key in self._lazy
+
+    def _force(self, key):
+        f = self._lazy.pop(key, None)
+        if f is not None:
+            dict.__setitem__(self, key, f())
+
+    def _force_all(self):
+        for key in list(self._lazy):
+            self._force(key)
+
+    def __getitem__(self, key):
+        self._force(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._force(key)
+        return dict.get(self, key, default)
+
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)
+        dict.__setitem__(self, key, value)
+
+    def __contains__(self, key):
+        return key in self._lazy or dict.__contains__(self, key)
+
+    def __iter__(self):
+        self._force_all()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._lazy)
+
+    def keys(self):
+        self._force_all()
+        return dict.keys(self)
+
+    def values(self):
+        self._force_all()
+        return dict.values(self)
+
+    def items(self):
+        self._force_all()
+        return dict.items(self)
+
+    def pop(self, key, *default):
+        self._force(key)
+        return dict.pop(self, key, *default)
+
+    def copy(self):
+        self._force_all()
+        return MemoryCache(dict.copy(self))
+
+
 class EncodedText:
     """RoBERTa + resizer output produced ahead of the image branch (see MDETR.encode)."""
 
-    __slots__ = ("tokenized", "flat")
+    __slots__ = ("tokenized", "flat", "key_pad")
 
-    def __init__(self, tokenized, flat):
-        self.tokenized, self.flat = tokenized, flat
+    def __init__(self, tokenized, flat, key_pad=None):
+        self.tokenized, self.flat, self.key_pad = tokenized, flat, key_pad      # key_pad: uint8 [B, L], 1 = padding token
 
 
 class TokenizedText(dict):
@@ -244,10 +309,14 @@ class Transformer(nn.Module):
         B, L = ids.shape
         te, cfg = self.text_encoder, self.text_encoder.config
         H = cfg.num_attention_heads
-        keep = ids.ne(cfg.pad_token_id).to(torch.int64)
-        pos_ids = (torch.cumsum(keep, dim=1) * keep + cfg.pad_token_id).contiguous()
-        ids_flat = ids.contiguous().view(-1)
-        key_pad = att.ne(1).to(torch.uint8).contiguous()
+        ids = ids.contiguous()
+        if ids.dtype == torch.int64 and att.dtype == torch.int64:
+            pos_ids, key_pad = k.text_prep(ids, att.contiguous(), cfg.pad_token_id)
+        else:
+            keep = ids.ne(cfg.pad_token_id).to(torch.int64)
+            pos_ids = (torch.cumsum(keep, dim=1) * keep + cfg.pad_token_id).contiguous()
+            key_pad = att.ne(1).to(torch.uint8).contiguous()
+        ids_flat = ids.view(-1)
         def _named():
             d = OrderedDict(("text_encoder." + n, p) for n, p in te.named_parameters())
             d.update(("resizer." + n, p) for n, p in self.resizer.named_parameters())
@@ -529,34 +598,47 @@ class Transformer(nn.Module):
             text_tok = text_memory_resized.permute(1, 0, 2).to(BF16)
             L = text_tok.shape[1]
         else:
+            key_pad_text = None
             if isinstance(text, EncodedText):  # already launched on the text stream by the caller (and joined)
-                tokenized, flat = text.tokenized, text.flat
+                tokenized, flat, key_pad_text = text.tokenized, text.flat, text.key_pad
             else:
                 tokenized = self._tokenize(text, dev)
                 flat, key_pad_text = self.encode_text(tokenized)
             L = tokenized["input_ids"].shape[1]
             text_tok = flat.view(B, L, d)
-            text_attention_mask = tokenized["attention_mask"].ne(1).bool()
-            text_memory_resized = text_tok.permute(1, 0, 2).float()
+            text_attention_mask = key_pad_text.view(torch.bool) if key_pad_text is not None else tokenized["attention_mask"].ne(1).bool()
+            text_memory_resized = None
         S = HW + L
         tokens = torch.cat([tokens_img, text_tok], dim=1).reshape(B * S, d)
-        pos = torch.cat([pos_img, torch.zeros(B, L, d, dtype=BF16, device=dev)], dim=1).reshape(B * S, d).contiguous()
+        if pos_img.shape[1] == S:      # the caller's encoding already has the zero rows of the caption tokens (PositionEmbeddingSine.tokens(tail=L))
+            pos = pos_img.reshape(B * S, d)
+        else:
+            pos = torch.cat([pos_img, torch.zeros(B, L, d, dtype=BF16, device=dev)], dim=1).reshape(B * S, d).contiguous()
         mask = torch.cat([mask_img, text_attention_mask], dim=1)
-        key_pad = mask.to(torch.uint8).contiguous()
+        key_pad = mask.view(torch.uint8)
         mem = self.encode_tokens(tokens, pos, key_pad, B, S)
         mem3 = mem.view(B, S, d)
-        img_memory = mem3.permute(1, 0, 2).float()
-        q = query_embed.unsqueeze(1).repeat(1, B, 1)
-        return {
-            "text_memory_resized": text_memory_resized, "text_memory": img_memory[-L:], "img_memory": img_memory,
-            "text_pooled_op": None, "img_pooled_op": None, "mask": mask, "text_attention_mask": text_attention_mask,
-            "pos_embed": pos.view(B, S, d).permute(1, 0, 2).float(), "query_embed": q, "tokenized": tokenized,
-            "_native": {"memory": mem, "pos": pos, "key_pad": key_pad, "B": B, "S": S, "img_memory_ref": img_memory},
-        }
+        native = {"memory": mem, "pos": pos, "key_pad": key_pad, "B": B, "S": S, "L": L, "img_memory_ref": None, "query_embed": query_embed}
+
+        def img_memory():
+            t = mem3.permute(1, 0, 2).float()
+            native["img_memory_ref"] = t
+            return t
+
+        out = MemoryCache({"text_pooled_op": None, "img_pooled_op": None, "mask": mask, "text_attention_mask": text_attention_mask, "tokenized": tokenized,
+                           "_native": native},
+                          lazy={"img_memory": img_memory, "pos_embed": lambda: pos.view(B, S, d).permute(1, 0, 2).float(),
+                                "query_embed": lambda: query_embed.unsqueeze(1).repeat(1, B, 1)})
+        out._lazy["text_memory"] = lambda: out["img_memory"][-L:]
+        if text_memory_resized is not None:
+            out["text_memory_resized"] = text_memory_resized
+        else:
+            out._lazy["text_memory_resized"] = lambda: text_tok.permute(1, 0, 2).float()
+        return out
 
     def decode_native(self, img_memory, pos_embed, mask, query_embed, native=None):
         """-> hs fp32 [L, B, Q, d] (the reference returns hs.transpose(1, 2))."""
-        if native is not None and native.get("img_memory_ref") is img_memory:
+        if native is not None and (img_memory is None or native.get("img_memory_ref") is img_memory):
             mem, pos, key_pad, B, S = native["memory"], native["pos"], native["key_pad"], native["B"], native["S"]
         else:
             S, B, d = img_memory.shape
