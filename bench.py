@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--dump-graph", default=None, help="diagnostic: write the captured step's hipGraph (nodes + dependency edges) as a DOT file to this path")
     ap.add_argument("--glue-report", action="store_true", help="diagnostic: one EAGER step under torch.profiler; prints (stderr) every source line of toist_amd / bench.py that "
                     "launches torch (non-toist) device kernels, with the number of kernels and their device time, then exits")
+    ap.add_argument("--no-early-norm", action="store_true", help="A/B: sum the squares of the text encoder's gradients inside the optimizer tail instead of at the end of "
+                    "the text branch's backward pass (beside the ResNet backward)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic: one-thread clock kernels at the fork / join points of the step (captured into the graph); prints (stderr) "
                     "when each branch of the LAST replayed step started and ended, in microseconds from the step's first kernel, no profiler attached")
     ap.add_argument("--host-times", action="store_true", help="diagnostic: print (stderr) the host microseconds spent inside each run_step() call of the first timed region")
@@ -381,7 +383,8 @@ def main():
         # "late" (--late-text-tail): the text encoder's share of the optimizer tail (67 % of its bytes) is issued at the head of the next step's
         # text branch, beside the ResNet forward (toist_amd.optim.FusedClipAdamWEMA).  Measured NEGATIVE (profiles/r04_late_tail_ab.txt:
         # 12.48 -> 13.3 ms per step; the forward pass is sensitive to the 4.7 GB of HBM traffic beside it), so it is off by default.
-        {"params": [p for n, p in named if "text_encoder" in n], "lr": args.text_encoder_lr, "late": a.late_text_tail and not a.torch_optimizer and not a.defer_ema},
+        {"params": [p for n, p in named if "text_encoder" in n], "lr": args.text_encoder_lr, "late": a.late_text_tail and not a.torch_optimizer and not a.defer_ema,
+         "early_norm": not a.no_early_norm},
     ]
     from toist_amd import engine as _engine
     _engine.REUSE_GRAD_BUFFERS = True   # this loop never keeps a gradient across optimizer.zero_grad()

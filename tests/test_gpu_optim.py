@@ -231,3 +231,61 @@ def test_late_text_group_is_bit_identical_to_the_serial_tail(dev):
               "p.transformer.resizer.fc.weight", "p.transformer.encoder.layers.0.linear1.weight", "p.backbone.0.body.layer3.5.conv2.weight"):
         de, dg = float((a[n] - init[n]).norm()), float((b[n] - init[n]).norm())
         assert de > 0 and abs(dg - de) <= 0.25 * de, (n, de, dg)
+
+
+@pytest.mark.gpu
+def test_early_norm_group_gives_the_same_clip_and_parameters(dev):
+    """A parameter group marked "early_norm" (the text encoder) has the squares of its gradients summed by the AFTER_BACKWARD hook at the end of
+    the text program's backward pass; step() sums only the rest.  Same per-chunk partial sums => the total norm, the clip coefficient and every
+    parameter / moment equal the serial tail's bit for bit (up to the fp32-atomic tensors, as in the late-group test).  The hook is really taken
+    once the gradient buffers are reused, and is skipped (full sum in step()) while their addresses still change."""
+    import copy
+    import toist_amd
+    from toist_amd import engine, harness, kernels
+    from toist_amd.optim import FusedClipAdamWEMA
+    args = harness.default_args(device="cuda", enc_layers=1, dec_layers=2, num_queries=20, dropout=0.0)
+    torch.manual_seed(0)
+    model0, criterion, _, weight_dict = toist_amd.build_model(args)
+    model0.to(dev).train()
+    samples, tok, targets, pmap = harness.synthetic_batch(2, 128, 160, tokens=12, seed=5, device=dev, max_targets=4)
+    kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+    saved = engine.REUSE_GRAD_BUFFERS
+    engine.REUSE_GRAD_BUFFERS = True
+    try:
+        def make(model, early):
+            named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+            opt = FusedClipAdamWEMA([{"params": [p for n, p in named if "text_encoder" not in n], "lr": 1e-4},
+                                     {"params": [p for n, p in named if "text_encoder" in n], "lr": 5e-5, "early_norm": early}], weight_decay=1e-4, max_norm=0.1)
+            taken = []
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                mc = model(samples, tok, encode_and_save=True)
+                out = model(samples, tok, encode_and_save=False, memory_cache=mc)
+                losses = criterion(mc, out, targets, pmap, None)
+                total = sum(losses[k_] * weight_dict[k_] for k_ in losses if k_ in weight_dict)
+                total.backward()
+                taken.append(opt._early_done)
+                opt.step()
+                return total.detach(), opt.device_state()["grad_norm"], opt.device_state()["clip_coef"]
+            return opt, step, taken
+
+        ser, ear = copy.deepcopy(model0), copy.deepcopy(model0)
+        o_s, step_s, _ = make(ser, False)
+        o_e, step_e, taken = make(ear, True)
+        assert o_e._early_ids and not o_s._early_ids
+        rs = [step_s() for _ in range(4)]
+        re_ = [step_e() for _ in range(4)]
+        assert taken[0] is False and taken[-1] is True, taken          # first step: no table yet; steady state: the hook summed the text group
+        assert 0 < o_e._e_lo < o_e._e_hi == o_e._n_now
+        for (ls, ns, cs), (le, ne, ce) in zip(rs, re_):
+            assert float(ls) == float(le) and ns == ne and cs == ce, (rs, re_)
+        torch.cuda.synchronize()
+        a = {n: p.detach() for n, p in ser.named_parameters()}
+        b = {n: p.detach() for n, p in ear.named_parameters()}
+        bad = [n for n in a if not torch.equal(a[n], b[n])]
+        assert len(bad) <= len(a) // 3, f"{len(bad)} of {len(a)} tensors differ, e.g. {bad[:6]}"
+        for n in bad:
+            torch.testing.assert_close(b[n], a[n], rtol=2e-4, atol=1e-6)
+    finally:
+        engine.REUSE_GRAD_BUFFERS = saved

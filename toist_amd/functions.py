@@ -21,6 +21,10 @@ from . import engine, kernels
 # parameter gradients (set by toist_amd.parallel.GradSync / DistributedDataParallel).
 GRAD_SYNC = None
 
+# Callables(params tuple) invoked on the program's stream when a program's backward has attached all of its parameter gradients
+# (toist_amd.optim.FusedClipAdamWEMA: the squared gradient norm of an "early_norm" group is taken right there, beside the rest of the backward pass).
+AFTER_BACKWARD = []
+
 # Stream the programs launched right now were forked from (set by MDETR.encode around the text branch).
 # Their parameter gradients are attached to .grad directly, not through AccumulateGrad nodes, so the
 # autograd engine does not know it has to join their stream at the end of backward(): each forked
@@ -114,6 +118,9 @@ class _TapeFn(torch.autograd.Function):
                 ps.flat = None  # accumulated into an older buffer: GradSync.finish() reduces those gradients one by one
         if GRAD_SYNC is not None:
             GRAD_SYNC(ps.flat)      # None: this program accumulated into older gradients (the hook still learns that a backward ran)
+        elif AFTER_BACKWARD:        # (a gradient all-reduce would change the values after this point)
+            for hook in AFTER_BACKWARD:
+                hook(ctx.params)
         if ctx.rejoin is not None:
             ctx.rejoin.wait_stream(torch.cuda.current_stream())
         ctx.tape = ctx.ps = ctx.in_vars = ctx.out_vars = ctx.params = None

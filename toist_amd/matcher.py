@@ -102,11 +102,13 @@ class StaticTargets:
         host, sizes = packed
         self.sizes = list(sizes)
         self._dev.copy_(host, non_blocking=True)
-        self.num_boxes.copy_(self._nb_local)
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            self.num_boxes.copy_(self._nb_local)
             torch.distributed.all_reduce(self.num_boxes)
             self.num_boxes.div_(torch.distributed.get_world_size())
-        self.num_boxes.clamp_(min=1)
+            self.num_boxes.clamp_(min=1)
+        else:
+            torch.clamp(self._nb_local, min=1, out=self.num_boxes)
         return self
 
     def load(self, targets, positive_map, token_masks=None):

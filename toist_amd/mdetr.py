@@ -150,7 +150,9 @@ class MDETR(nn.Module):
             def boxes_bwd():
                 if boxes.grad is not None:
                     y = boxes.data
-                    boxes.grad = (boxes.grad * y * (1 - y)).to(BF16)
+                    gb = torch.empty(y.shape, dtype=BF16, device=y.device)
+                    torch.mul(boxes.grad, torch.addcmul(y, y, y, value=-1.0), out=gb)      # sigmoid': y (1 - y) = y - y^2; two launches
+                    boxes.grad = gb
 
             tape.record(boxes_bwd)
             outs.append(boxes)

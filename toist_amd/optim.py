@@ -55,6 +55,12 @@ class FusedClipAdamWEMA:
     reads the late parameters outside a forward pass (state_dict, evaluation with a different module, the end of training) calls
     finish() first.
 
+    A parameter group with "early_norm": True (again the text encoder) has the squares of its gradients summed as soon as the program that owns
+    them has finished its backward pass (functions.AFTER_BACKWARD hook, on that program's stream -- the text branch, beside the ResNet
+    backward): step() then reads only the other gradients (a third of the bytes) before finish_norm.  Same per-chunk partial sums, same
+    total: bit-identical.  Used only while the gradient addresses are the ones of the previous step (REUSE_GRAD_BUFFERS / hipGraph replay);
+    otherwise step() sums everything as before.
+
     defer_ema=True takes the moving average out of step(): it only needs the updated parameters, so the loop may run it as
     `ema_update()` on a side stream beside the next forward pass (12 of the tail's 38 bytes per parameter leave the critical path).
     The average is the same sequence of values; step() applies a still-pending update itself before it changes the parameters
@@ -88,6 +94,24 @@ class FusedClipAdamWEMA:
         self._ema_only = [(src, e) for src, e in ema if src.data_ptr() in by_ptr]
         self._group_of = [gi for gi, g in enumerate(self.param_groups) for _ in g["params"]]
         self._late = [bool(g.get("late", False)) for g in self.param_groups for _ in g["params"]]
+        self._early = [bool(g.get("early_norm", False)) and not bool(g.get("late", False)) for g in self.param_groups for _ in g["params"]]
+        self._early_ids = frozenset(id(p) for p, e in zip(params, self._early) if e)
+        self._early_idx = [i for i, e in enumerate(self._early) if e]
+        self._early_done = False
+        self._e_lo = self._e_hi = 0
+        if self._early_ids:
+            import weakref
+            from . import functions
+            ref = weakref.ref(self)
+
+            def hook(prog_params, _ref=ref):
+                o = _ref()
+                if o is not None:
+                    o._maybe_norm_early(prog_params)
+
+            functions.AFTER_BACKWARD[:] = [h for h in functions.AFTER_BACKWARD if getattr(h, "_owner", lambda: None)() is not None]
+            hook._owner = ref
+            functions.AFTER_BACKWARD.append(hook)
         self._late_pending = False
         self._late_captured = False
         self._late_grads = None
@@ -190,10 +214,15 @@ class FusedClipAdamWEMA:
         # launch order of the chunks: everything updated inside step() first, the late groups' chunks behind them -- sqnorm walks all,
         # adamw_ema is launched on the two runs separately
         late_rows = torch.tensor(self._late + [False] * len(self._ema_only), dtype=torch.bool, device=self.device)
+        early_rows = torch.tensor(self._early + [False] * len(self._ema_only), dtype=torch.bool, device=self.device)
         is_late = late_rows[chunks[:, 0].long()]
-        keep("_chunks", torch.cat([chunks[~is_late], chunks[is_late]], dim=0).contiguous())
+        is_early = early_rows[chunks[:, 0].long()]
+        # [updated in step(), norm in step()] [updated in step(), norm taken early] [late]
+        keep("_chunks", torch.cat([chunks[~is_late & ~is_early], chunks[is_early], chunks[is_late]], dim=0).contiguous())
         self._n_late = int(is_late.sum())
         self._n_now = self._n_chunks - self._n_late
+        self._e_hi = self._n_now
+        self._e_lo = self._n_now - int(is_early.sum())
         self._late_copies = [(ent, p_) for ent, p_ in self._copies if any(p_ is q for q, l in zip(self.params, self._late) if l)]
         keep("_partial", torch.empty(self._n_chunks, dtype=torch.float32, device=self.device))
         self._copy_gen = engine.COPY_GEN
@@ -238,7 +267,15 @@ class FusedClipAdamWEMA:
                 self._grads_event[turn] = ev
             self._grads_last = gh.copy()
             self._grads_turn = turn ^ 1
-        k.opt_sqnorm(self._table, self._grads_dev, self._chunks, self._n_chunks, self._partial)
+        if self._early_done and self._e_hi > self._e_lo:
+            # partial[e_lo:e_hi] were written by norm_early() of this step (the text branch, joined before the tail)
+            if self._e_lo:
+                k.opt_sqnorm(self._table, self._grads_dev, self._chunks, self._e_lo, self._partial)
+            if self._n_chunks > self._e_hi:
+                k.opt_sqnorm(self._table, self._grads_dev, self._chunks[self._e_hi:], self._n_chunks - self._e_hi, self._partial[self._e_hi:])
+        else:
+            k.opt_sqnorm(self._table, self._grads_dev, self._chunks, self._n_chunks, self._partial)
+        self._early_done = False
         k.opt_finish_norm(self._partial, self._n_chunks, self.max_norm, self.betas[0], self.betas[1], self.state)
         if self._n_now:
             k.opt_adamw_ema(self._table, self._grads_dev, self._chunks, self._n_now, self._groups_dev, self.state, self.betas[0],
@@ -253,6 +290,24 @@ class FusedClipAdamWEMA:
         if self._n_late:
             self._late_pending = True
             self._late_grads = [p.grad for p, l in zip(self.params, self._late) if l]     # the pointers in the device table must stay valid
+
+    @torch.no_grad()
+    def _maybe_norm_early(self, prog_params):
+        """AFTER_BACKWARD hook: a program has attached its gradients.  If it owns the early-norm parameters and their gradients sit at the
+        addresses the device table already holds (those of the previous step), sum their squares now, on the current stream."""
+        if not self._early_ids or self._early_done or self._table is None or self._grads_last is None or self._e_hi <= self._e_lo:
+            return
+        if self._copy_gen != engine.COPY_GEN and not torch.cuda.is_current_stream_capturing():
+            return                          # step() is about to rebuild the tables
+        if not any(id(p) in self._early_ids for p in prog_params):
+            return
+        last = self._grads_last
+        for i in self._early_idx:
+            g = self.params[i].grad
+            if (0 if g is None else g.data_ptr()) != int(last[i]):
+                return                      # fresh gradient buffers: the table is uploaded in step(), which then sums everything
+        k.opt_sqnorm(self._table, self._grads_dev, self._chunks[self._e_lo:], self._e_hi - self._e_lo, self._partial[self._e_lo:])
+        self._early_done = True
 
     @torch.no_grad()
     def flush_late(self):

@@ -28,7 +28,7 @@ ENABLED = knob("TOIST_ROWS", True)          # tests flip this to compare with th
 
 
 FUSE_FWD_MAX_K = knob("TOIST_ROWS_FWD_MAX_K", 768)      # forward sub-layers with a longer reduction run as GEMM + LayerNorm launch ...
-FUSE_FWD_MAX_M = knob("TOIST_ROWS_FWD_MAX_M", 1024)     # ... unless they have few rows (the decoder's 800 queries)
+FUSE_FWD_MAX_M = knob("TOIST_ROWS_FWD_MAX_M", 0)        # ... (a row-count exception for the decoder's 800 queries was measured and dropped, see _ln_fwd)
 ATTN2 = knob("TOIST_ATTN2", True)           # second-generation attention cores (csrc/attn2.hip): no key-count limit, key-owning backward
 
 
@@ -74,8 +74,8 @@ def _ln_fwd(ctx_in, W, b, res, gamma, beta, tape, add=None, y=None, eps=1e-5):
                   eps=eps, z=s.z, mean=s.mean, rstd=s.rstd, add=add, out2=s.y2)
     else:
         # deep reductions (linear2, K = 2048): a row-complete block streams the whole 1 MB weight through ONE CU (~18 us whatever the row
-        # count, profiles/r04_rowgemm_us.txt); at 3328 rows the tiled GEMM spreads that stream over the chip and GEMM + LayerNorm launch
-        # stay ahead (19.4 vs 22.0 us); at 800 rows (decoder) the tiled path is split-K GEMM + fold + LayerNorm = three launches for 18.4
+        # count, profiles/r04_rowgemm_us.txt); the tiled GEMM spreads that stream over the chip and GEMM + LayerNorm launch stay ahead:
+        # 19.4 vs 22.6 us at 3328 rows, 14.8 vs 18.6 us at the decoder's 800 rows (in the step: -33 us of forward, profiles/r04_rowgemm_us.txt)
         kw = dict(drop_where=1, drop_p=p, drop_seed=s.seed) if p > 0 else {}
         ops.linear(ctx_in, W.w, b.f32, res=res, out=s.z, **kw)
         k.layernorm_fwd(s.z, gamma.f32, beta.f32, eps, s.y, s.mean, s.rstd, add=add, y2=s.y2)
