@@ -203,3 +203,28 @@ def test_store_once_row_ranges_are_tracked_on_the_root_view():
     nested = ParamView(None, torch.zeros(12, 4), fresh=True)
     nested.rows(4, 12).rows(2, 4).mark_written()                         # rows 6..8 of the root
     assert nested.unwritten_rows() == [(0, 6), (8, 12)]
+
+
+def test_memory_cache_materialises_lazy_entries_on_read():
+    """transformer.MemoryCache: the fp32 API copies of memory_cache are thunks until somebody reads them; reads, membership, iteration and
+    assignment behave like the plain dict of the reference (transformer.py:146-157)."""
+    from toist_amd.transformer import MemoryCache
+    calls = []
+
+    def thunk(name, value):
+        def f():
+            calls.append(name)
+            return value
+        return f
+
+    mc = MemoryCache({"mask": 1}, lazy={"img_memory": thunk("img", torch.ones(2)), "pos_embed": thunk("pos", torch.zeros(2))})
+    mc._lazy["text_memory"] = lambda: mc["img_memory"][-1:]
+    assert "img_memory" in mc and mc.is_lazy("img_memory") and len(mc) == 4 and calls == []
+    assert mc["mask"] == 1 and calls == []
+    assert torch.equal(mc["text_memory"], torch.ones(1)) and calls == ["img"] and not mc.is_lazy("img_memory")
+    assert mc["img_memory"] is mc["img_memory"] and calls == ["img"]              # materialised once
+    mc["pos_embed"] = "replaced"                                                  # assignment drops the thunk
+    assert mc.get("pos_embed") == "replaced" and "pos" not in calls
+    mc2 = MemoryCache({}, lazy={"a": thunk("a", 5)})
+    assert dict(mc2.items()) == {"a": 5} and calls[-1] == "a" and list(mc2) == ["a"]
+    assert mc2.get("missing", 7) == 7 and mc2.pop("a") == 5 and "a" not in mc2
