@@ -142,7 +142,7 @@ def test_bench_ranks_on_one_gpu_gloo(dev, world, steps):
     # one collective per backward segment: the backbone's gradients travel per stage (layer4 first), under the stages below
     assert set(res["collectives"]) == {"transformer+heads", "text_encoder", "backbone stage 1 of 3 (layer4 first)", "backbone stage 2 of 3 (layer4 first)",
                                        "backbone stage 3 of 3 (layer4 first)"}, sorted(res["collectives"])
-    assert all(c["busbw_GBps"] > 0 for c in res["collectives"].values())
+    assert all(c["ms"] > 0 and c["busbw_GBps"] >= 0 for c in res["collectives"].values())       # (gloo on a loaded box: the rate may round to 0.0)
     sizes = [res["collectives"]["backbone stage %d of 3 (layer4 first)" % i]["bytes"] for i in (1, 2, 3)]
     assert sizes[0] > 50e6 and sizes[1] > 90e6 and sizes[2] < 10e6, sizes       # layer4 ~ 60 MB, layer3 ~ 104 MB, layer2 ~ 5 MB of fp32 gradients
     assert res["config"]["parameters_identical_across_ranks"] is True
