@@ -283,7 +283,7 @@ class BackboneBase(nn.Module):
                                          store_once=lambda n, t: t.dim() == 4)
             if not is_last and y.requires_grad:
                 leaf = y.detach().requires_grad_(True)
-                stage_cuts.append((y, leaf))
+                stage_cuts.append((f"backbone.layer{last}", y, leaf))      # named by the stage that produced it (the cut sits at layer `last`'s output)
                 y = leaf
             x = y
         return (x,)

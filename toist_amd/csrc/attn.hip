@@ -678,12 +678,13 @@ extern "C" int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk,
     } while (0)
     if (variant == 0) variant = (Sq > 128 && Sk > 128) ? 2 : 1;
     if (variant == 2) {
+        if (q_splits > 1)       // checked BEFORE the rows kernel runs: an invalid call does no work
+            TOIST_REQUIRE((lddk % 8) == 0 && (lddv % 8) == 0 && ((((size_t)dk) | ((size_t)dv)) & 15) == 0,
+                          "toist_attn_bwd: query splits fold into 16-byte chunks of dk / dv (row strides %% 8, 16-byte aligned bases)");
         if (Sk <= 128) TOIST_ATTN_BWD_ROWS(8);
         else if (Sk <= 256) TOIST_ATTN_BWD_ROWS(16);
         else TOIST_ATTN_BWD_ROWS(32);
         if (q_splits > 1) {
-            TOIST_REQUIRE((lddk % 8) == 0 && (lddv % 8) == 0 && ((((size_t)dk) | ((size_t)dv)) & 15) == 0,
-                          "toist_attn_bwd: query splits fold into 16-byte chunks of dk / dv (row strides %% 8, 16-byte aligned bases)");
             const int rc2 = check_launch("toist_attn_bwd");
             if (rc2 != TOIST_OK) return rc2;
             const long long rows = (long long)B * Sk, n8 = rows * (H * 32 / 8);

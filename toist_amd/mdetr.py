@@ -252,7 +252,7 @@ class MDETR(nn.Module):
             cuts["backbone"] = (list(feats), leaves)
             feats = leaves
             # backward order: "backbone" (layer4, or the whole body when it ran as one program), then layer3, then stem .. layer2
-            for name, (y, leaf) in zip(("backbone.layer2", "backbone.layer3"), stage_cuts or ()):
+            for name, y, leaf in stage_cuts or ():      # "backbone.layer2", "backbone.layer3": only the stages that produced a differentiable output
                 cuts[name] = ([y], [leaf])
         c5 = feats[-1]
         B, h, w, _ = c5.shape
