@@ -321,6 +321,8 @@ class CapturedTrainStep:
         if ent["graph"] is not None:
             ent["graph"].replay()
             self.replays += 1
+            if hasattr(self.optimizer, "note_replayed_step"):
+                self.optimizer.note_replayed_step()      # copies of the weights that the captured tail does not rewrite are stale now
             return ent["loss"]
         # first batch of this bucket: a real, eager training step, launched on the object's own stream -- the stream the graph is captured
         # on right afterwards, so that every per-stream cache of the launchers (split-K scratch, reduction arena) exists before the

@@ -291,6 +291,16 @@ class FusedClipAdamWEMA:
             self._late_pending = True
             self._late_grads = [p.grad for p, l in zip(self.params, self._late) if l]     # the pointers in the device table must stay valid
 
+    def note_replayed_step(self):
+        """Host-side bookkeeping of ONE replay of a hipGraph that holds this optimizer's step(): the replay rewrote the masters and the bf16 compute
+        copies in the tail's table, but no Python ran -- every OTHER cached copy of a parameter (another program cache of the same module, an
+        evaluation-time transform) must be seen as stale, exactly as after an eager step()."""
+        engine.bump_weight_epoch()
+        late_ids = {id(p_) for _, p_ in self._late_copies} if self._n_late else ()
+        for ent, p in self._copies:
+            if p.grad is not None and id(p) not in late_ids:
+                ent.epoch = engine.WEIGHT_EPOCH
+
     @torch.no_grad()
     def _maybe_norm_early(self, prog_params):
         """AFTER_BACKWARD hook: a program has attached its gradients.  If it owns the early-norm parameters and their gradients sit at the
