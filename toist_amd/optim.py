@@ -305,7 +305,8 @@ class FusedClipAdamWEMA:
     def _maybe_norm_early(self, prog_params):
         """AFTER_BACKWARD hook: a program has attached its gradients.  If it owns the early-norm parameters and their gradients sit at the
         addresses the device table already holds (those of the previous step), sum their squares now, on the current stream."""
-        if not self._early_ids or self._early_done or self._table is None or self._grads_last is None or self._e_hi <= self._e_lo:
+        # (a second backward pass before step() -- gradient accumulation -- simply sums again: the launch reads the accumulated gradients)
+        if not self._early_ids or self._table is None or self._grads_last is None or self._e_hi <= self._e_lo:
             return
         if self._copy_gen != engine.COPY_GEN and not torch.cuda.is_current_stream_capturing():
             return                          # step() is about to rebuild the tables
