@@ -16,6 +16,11 @@ import os
 import pytest
 import torch
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# mask-branch gradients of the frozen recipe against fp32 autograd through the oracle (measured: profiles/r04_small_shape_grad_parity.json)
+MASK_GRAD_COS_MIN = 0.985     # measured minimum 0.9912 (bbox_attention.q_linear.weight)
+MASK_GRAD_RATIO = (0.97, 1.03)   # measured 0.998 .. 1.005
+
 pytestmark = pytest.mark.gpu
 
 
@@ -193,7 +198,10 @@ def test_frozen_segmentation_recipe(dev):
         g, r = params[n].grad.float().cpu(), sdr[n].grad
         cos = float(torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0))
         worst[n] = (round(cos, 4), round(float(g.norm() / (r.norm() + 1e-20)), 3))
-    bad = {n: v for n, v in worst.items() if v[0] < 0.97 or not (0.8 < v[1] < 1.25)}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "frozen_mask_grad_parity.json"), "w") as f:
+        json.dump(worst, f, indent=1)
+    bad = {n: v for n, v in worst.items() if v[0] < MASK_GRAD_COS_MIN or not (MASK_GRAD_RATIO[0] < v[1] < MASK_GRAD_RATIO[1])}
     assert not bad, f"frozen recipe: mask-branch gradient mismatch (cos, norm ratio): {bad}\nall: {worst}"
 
 

@@ -72,6 +72,20 @@ def test_backbone_and_encode_decode(dev, setup):
         assert rel_err(a["pred_logits"], r["pred_logits"]) < 5e-2
 
 
+# measured (160 x 192, B = 2, eval mode; profiles/r04_small_shape_grad_parity.json): the bounds sit just below the worst tensor
+GRAD_COS_MIN = 0.985          # measured minimum 0.9937 (backbone layer2.0.conv1, the deepest gradient path), everything else >= 0.9988
+GRAD_RATIO = (0.95, 1.06)     # measured 0.998 .. 1.035
+
+
+def _dump_measured(name, worst):
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, name), "w") as f:
+        json.dump(worst, f, indent=1)
+
+
 def test_criterion_and_gradients(dev, setup):
     from oracle import model_ref
     from toist_amd import harness
@@ -133,7 +147,8 @@ def test_criterion_and_gradients(dev, setup):
         cos = float(torch.nn.functional.cosine_similarity(g.float().cpu().flatten(), r.flatten(), dim=0))
         ratio = float(g.float().norm().cpu() / (r.norm() + 1e-20))
         worst[n] = (round(cos, 4), round(ratio, 3))
-    bad = {n: v for n, v in worst.items() if v[0] < 0.97 or not (0.8 < v[1] < 1.25)}
+    _dump_measured("model_grad_parity.json", worst)
+    bad = {n: v for n, v in worst.items() if v[0] < GRAD_COS_MIN or not (GRAD_RATIO[0] < v[1] < GRAD_RATIO[1])}
     assert not bad, f"gradient mismatch (cos, norm ratio): {bad}\nall: {worst}"
     frozen = params["backbone.0.body.layer1.0.conv1.weight"]
     assert frozen.grad is None and not frozen.requires_grad
