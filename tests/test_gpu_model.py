@@ -73,7 +73,7 @@ def test_backbone_and_encode_decode(dev, setup):
 
 
 # measured (160 x 192, B = 2, eval mode; profiles/r04_small_shape_grad_parity.json): the bounds sit just below the worst tensor
-GRAD_COS_MIN = 0.985          # measured minimum 0.9937 (backbone layer2.0.conv1, the deepest gradient path), everything else >= 0.9988
+GRAD_COS_MIN = 0.985          # measured minimum 0.9926 (the deepest gradient paths: backbone layer2.0.conv1 0.9937), most tensors >= 0.9988
 GRAD_RATIO = (0.95, 1.06)     # measured 0.998 .. 1.035
 
 
