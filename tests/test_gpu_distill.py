@@ -114,6 +114,88 @@ def test_distillation_step_end_to_end(dev):
     assert float(g_s.abs().sum()) > 0 and float(g_n.abs().sum()) > 0 and float(g_t.abs().sum()) > 0
 
 
+def test_distillation_step_replayed_from_a_hipgraph(dev):
+    """The whole distillation step -- both encodes, the memory-bank update + k-means + prototype substitution, both decodes, the paired criterion with
+    softkd / nsthl2 / cluster losses, backward through both models and the two fused optimizer tails -- captured ONCE into a hipGraph and replayed
+    (bench.py --distill).  The step reads no host data once the caption-driven tables of the batch are cached on the device (toist_amd.distill._TABLES,
+    the matcher / softkd index caches) and synchronises nowhere (LSAP status checks are deferred); the graph is the batch's own.  Replays continue the
+    eager trajectory of an identical copy: same losses step by step (bf16 / atomics noise), banks and centres move the same way."""
+    import copy
+    import toist_amd
+    from toist_amd import engine, harness, kernels
+    from toist_amd.matcher import check_lsap_pending
+    from toist_amd.optim import FusedClipAdamWEMA
+    args = harness.default_args(device="cuda", distillation=True, cluster=True, nsthl2_loss=True, softkd_loss=True, cluster_memory_size=32,
+                                num_queries=20, enc_layers=1, dec_layers=2, dropout=0.0)
+    torch.manual_seed(0)
+    model0, criterion, cluster0, weight_dict = toist_amd.build_model(args)
+    noun0, _, _, _ = toist_amd.build_model(args)
+    model0.to(dev).train()
+    noun0.to(dev).train()
+    for m_ in (model0, noun0):          # RoBERTa's own dropout off as well: its host-side seed is frozen into a captured step, so only a dropout-free step
+        m_.transformer.text_encoder.config.hidden_dropout_prob = 0.0      # can be compared replay by replay with the eager loop
+        m_.transformer.text_encoder.config.attention_probs_dropout_prob = 0.0
+    cluster0.to(dev)
+    cluster0.full_label.fill_(1)
+    batch = harness.synthetic_distill_batch(2, 128, 160, tokens=16, seed=3, device=dev, max_targets=4)
+    kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+    saved = engine.REUSE_GRAD_BUFFERS
+    engine.REUSE_GRAD_BUFFERS = True
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    try:
+        def make():
+            m, n, c = copy.deepcopy(model0), copy.deepcopy(noun0), copy.deepcopy(cluster0)
+            c.sync_host_state()
+            # (a tiny learning rate: Adam's first updates are +-lr per weight whatever the gradient's size, so bf16 noise in near-zero gradients would
+            # otherwise pull the two runs apart by more than the comparison below can tell from a real defect)
+            opts = [FusedClipAdamWEMA([{"params": [p for p in x.parameters() if p.requires_grad]}], lr=1e-6, weight_decay=1e-4, max_norm=0.1) for x in (m, n)]
+
+            def step():
+                for o in opts:
+                    o.zero_grad(set_to_none=True)
+                total, _ = harness.distillation_step(m, n, criterion, c, weight_dict, batch)
+                total.backward()
+                for o in opts:
+                    o.step()
+                return total.detach()
+            return m, n, c, opts, step
+
+        with torch.cuda.stream(side):
+            _, _, c_e, _, step_e = make()
+            eager = [float(step_e()) for _ in range(5)]
+            m_g, n_g, c_g, opts_g, step_g = make()
+            first = [float(step_g()) for _ in range(3)]
+            for o in opts_g:
+                o.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with kernels.tables_beside_graph(), torch.cuda.graph(graph, stream=side):
+                static_loss = step_g()
+            replayed = []
+            for _ in range(2):
+                graph.replay()
+                replayed.append(float(static_loss))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        check_lsap_pending()
+        # the eager loop is deterministic run to run; the replays continue it (fp32 atomics in a few gradient sums: 1e-4)
+        assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(eager[:3], first)), (eager, first)
+        assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(eager[3:], replayed)), (eager, replayed)
+        assert replayed[0] != replayed[1]                      # the replays really update the models and the banks
+        # the banks: five steps x two samples pushed into the same tasks' banks by nearest replacement -- the same rows are replaced in both runs (a row
+        # whose replacement flipped between near-tied neighbours would show as two unequal rows: allow one), by features that agree to bf16 noise
+        changed_e = (c_e.feature_bank != cluster0.feature_bank).any(-1)
+        changed_g = (c_g.feature_bank != cluster0.feature_bank).any(-1)
+        assert int(changed_e.sum()) > 0 and int(changed_e.sum()) == int(changed_g.sum()), (int(changed_e.sum()), int(changed_g.sum()))
+        assert int((changed_e != changed_g).sum()) <= 2, int((changed_e != changed_g).sum())
+        both = changed_e & changed_g
+        assert torch.allclose(c_e.feature_bank[both], c_g.feature_bank[both], rtol=1e-3, atol=1e-3), float((c_e.feature_bank[both] - c_g.feature_bank[both]).abs().max())
+        assert torch.allclose(c_e.cluster_centers, c_g.cluster_centers, rtol=1e-3, atol=1e-3), float((c_e.cluster_centers - c_g.cluster_centers).abs().max())
+    finally:
+        engine.REUSE_GRAD_BUFFERS = saved
+
+
 def test_device_kmeans_matches_host_loop(dev):
     """csrc/kmeans.hip (all samples of a batch in one launch, no host read) against the per-sample Lloyd loop that restates
     models/kmeans.py (toist_amd.distill.kmeans, itself pinned to the reference's ClusterCriterion by distill.npz): same centres (fp32

@@ -7,6 +7,8 @@ replacement assignment (mdetr.py:98-103) runs on the HIP LSAP kernel instead of 
 is a handful of device tensor ops per iteration ([1024, 256] bank, 3 centres), and nothing calls `.cpu()`.
 Buffer names and shapes equal the reference's, so a reference checkpoint of the criterion loads unchanged.
 """
+import collections
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -50,19 +52,61 @@ def span_positions(tokenized, batch_index, spans, length):
     return hit.nonzero().reshape(-1)
 
 
+# Caption-driven index tables of a batch (token weights, substitution masks, task columns) are built once on the host and kept on the device while the
+# batch's objects are alive: the steps that use them issue no host -> device copy and read nothing back, so the launch queue never drains inside a
+# training step (every small pageable upload is a stream synchronisation).  Keyed by object identity; the entry holds the objects, so an id cannot be reused.
+_TABLES = collections.OrderedDict()
+
+
+def _tok_ref(tokenized):
+    """the object whose identity stands for a tokenized batch: its input_ids tensor when there is one (Transformer._tokenize wraps the caller's dict in a
+    new TokenizedText on every call, the tensors inside stay the same objects), else the tokenized object itself"""
+    try:
+        ids = tokenized["input_ids"]
+        if torch.is_tensor(ids):
+            return ids
+    except Exception:
+        pass
+    return tokenized
+
+
+def _cached_table(kind, refs, extra, make):
+    key = (kind, tuple(id(r) for r in refs), extra)
+    ent = _TABLES.get(key)
+    if ent is not None:
+        _TABLES.move_to_end(key)
+        return ent[1]
+    val = make()
+    _TABLES[key] = (refs, val)
+    while len(_TABLES) > 64:
+        _TABLES.popitem(last=False)
+    return val
+
+
+def noun_token_weights(tokenized, targets, L, device):
+    """fp32 [B, L]: w[i, l] = sum over the boxes of image i of [token l belongs to the box's noun spans] / (tokens of the box x boxes of the image), so that
+    w @ text_feature[i] is the reference's mean over boxes of the mean over each box's noun tokens (mdetr.py:112-145, 684-711).  A box without any token
+    makes the reference average an empty set: the row is NaN, as there."""
+    def make():
+        W = np.zeros((len(targets), L), dtype=np.float32)
+        for i, tgt in enumerate(targets):
+            boxes = tgt["noun_tokens_positive"]
+            for spans in boxes:
+                pos = span_positions(tokenized, i, spans, L).numpy()
+                if len(pos) == 0:
+                    W[i, :] = np.nan
+                else:
+                    W[i, pos] += np.float32(1.0 / (len(pos) * len(boxes)))
+        return torch.from_numpy(W).to(device)
+    return _cached_table("noun_w", (_tok_ref(tokenized), *targets), (L, str(device)), make)
+
+
 def noun_token_features(text_feature, tokenized, targets):
     """[B, d]: per image, the mean over its boxes of the mean text feature of each box's noun tokens
-    (mdetr.py:112-145, 684-711); zero rows for images without boxes."""
+    (mdetr.py:112-145, 684-711); zero rows for images without boxes.  One weighted sum over the tokens with host-built, device-cached weights."""
     B, L, d = text_feature.shape
-    out = torch.zeros(B, d, device=text_feature.device, dtype=text_feature.dtype)
-    for i, tgt in enumerate(targets):
-        per_box = []
-        for spans in tgt["noun_tokens_positive"]:
-            pos = span_positions(tokenized, i, spans, L).to(text_feature.device)
-            per_box.append(text_feature[i][pos].mean(0))
-        if per_box:
-            out[i] = torch.stack(per_box, 0).mean(0)
-    return out
+    W = noun_token_weights(tokenized, targets, L, text_feature.device).to(text_feature.dtype)
+    return (W.unsqueeze(-1) * text_feature).sum(1)
 
 
 def task_index(dataset_name):
@@ -125,19 +169,37 @@ class ClusterCriterion(nn.Module):
         self.feature_bank /= world
         self.cluster_centers /= world
 
-    def update_memory_queue(self, feature_idx):
+    _MEMBERS = {}
+
+    @staticmethod
+    def _members(tasks, t, device):
+        """int64 device indices of the rows whose task is t, cached per task signature (no upload in steady state)"""
+        key = (tuple(tasks), t, str(device))
+        ent = ClusterCriterion._MEMBERS.get(key)
+        if ent is None:
+            if len(ClusterCriterion._MEMBERS) > 512:
+                ClusterCriterion._MEMBERS.clear()
+            ent = ClusterCriterion._MEMBERS[key] = torch.tensor([i for i, x in enumerate(tasks) if x == t], dtype=torch.int64, device=device)
+        return ent
+
+    def update_memory_queue(self, feature_idx, tasks_host=None):
         """feature_idx [B, d+1]: feature | task index (-1 = none).  All ranks' rows enter every rank's bank in rank
-        order (mdetr.py:63-103): FIFO until a task's bank has been filled, then FIFO or nearest-replacement."""
+        order (mdetr.py:63-103): FIFO until a task's bank has been filled, then FIFO or nearest-replacement.
+        tasks_host: the task column as a host list when the caller knows it (one rank: the targets' dataset names) -- nothing is read back then."""
         world = self._world()
         if world > 1:
             parts = [torch.zeros_like(feature_idx) for _ in range(world)]
             torch.distributed.all_gather(parts, feature_idx)
             feature_idx = torch.cat(parts, 0)
-        tasks = feature_idx[:, -1].round().to(torch.int64).tolist()   # one host read per step; the values are small integers
+            tasks_host = None
+        if tasks_host is not None:
+            tasks = [int(t) for t in tasks_host]
+        else:
+            tasks = feature_idx[:, -1].round().to(torch.int64).tolist()   # one host read per step; the values are small integers
         full = self._full_host()
         count = self.__dict__["_count_mirror"]
         for t in sorted(set(tasks) - {-1}):
-            new = feature_idx[[i for i, x in enumerate(tasks) if x == t], :-1]
+            new = feature_idx.index_select(0, self._members(tasks, t, feature_idx.device))[:, :-1]
             n = new.shape[0]
             bank = self.feature_bank[t]
             filling = not full[t]
@@ -150,7 +212,7 @@ class ClusterCriterion(nn.Module):
                     self.update_count[t] += n
                     count[t] += n
             else:   # replace the entries closest (L1) to the new features: one LSAP on the device
-                (rows, cols), = linear_sum_assignment_batch([torch.cdist(new, bank, p=1)])
+                (rows, cols), = linear_sum_assignment_batch([torch.cdist(new, bank, p=1)], defer_status=True)
                 bank[cols] = new[rows]
 
     # ---- device path: every sample of the batch in ONE launch, no host read (csrc/kmeans.hip) -------------------------------
@@ -223,54 +285,72 @@ class ClusterCriterion(nn.Module):
         tokens of the teacher's text memory by their prototype."""
         text = memory_cache_noun["text_memory"].permute(1, 0, 2)
         B, L, d = text.shape
+        dev = text.device
         tokenized = memory_cache_noun["tokenized"]
         feats = noun_token_features(text, tokenized, targets_noun)
         empty = [len(t["boxes"]) == 0 for t in targets_noun]
-        rows = torch.zeros(B, d + 1, device=text.device)
-        rows[:, -1] = -1
-        for i, tgt in enumerate(targets_noun):
-            if not empty[i]:
-                rows[i, :-1] = feats[i].detach()
-                rows[i, -1] = task_index(tgt["dataset_name"])
-        self.update_memory_queue(rows)
-        memory_cache_noun["img_memory_mod"] = memory_cache_noun["img_memory"].clone()
         tasks = [None if empty[i] else task_index(t["dataset_name"]) for i, t in enumerate(targets_noun)]
+
+        def make():     # task column of the queue rows and the [L, B] mask of the noun tokens that receive the prototype
+            col = torch.tensor([-1.0 if t is None else float(t) for t in tasks], dtype=torch.float32)
+            mask = torch.zeros(L, B, dtype=torch.bool)
+            for i, tgt in enumerate(targets_noun):
+                if not empty[i]:
+                    mask[span_positions(tokenized, i, [s for box in tgt["noun_tokens_positive"] for s in box], L), i] = True
+            return col.to(dev), mask.to(dev)
+        task_col, sub_mask = _cached_table("noun_meta", (_tok_ref(tokenized), *targets_noun), (L, str(dev)), make)
+        rows = torch.cat([feats.detach().float(), task_col[:, None]], dim=1)          # rows of images without boxes: zero feature, task -1
+        self.update_memory_queue(rows, tasks_host=[-1 if t is None else t for t in tasks])
+        memory_cache_noun["img_memory_mod"] = memory_cache_noun["img_memory"].clone()
         batch = self.cluster_batch(feats, tasks)
-        for i, tgt in enumerate(targets_noun):
-            if empty[i]:
-                continue
-            spans = [s for box in tgt["noun_tokens_positive"] for s in box]
-            pos = span_positions(tokenized, i, spans, L)
-            if batch is not None:
-                memory_cache_noun["img_memory_mod"][-L:, i, :][pos.to(text.device)] = batch[1][i]
-            else:
-                self._substitute(memory_cache_noun, i, pos, tasks[i], feats[i])
+        if batch is not None:
+            mod = memory_cache_noun["img_memory_mod"]
+            mod[-L:] = torch.where(sub_mask[:, :, None], batch[1][None].to(mod.dtype), mod[-L:])
+        else:
+            for i, tgt in enumerate(targets_noun):
+                if empty[i]:
+                    continue
+                spans = [s for box in tgt["noun_tokens_positive"] for s in box]
+                self._substitute(memory_cache_noun, i, span_positions(tokenized, i, spans, L), tasks[i], feats[i])
         memory_cache_noun["full_label"], memory_cache_noun["update_count"] = self.full_label, self.update_count
         return memory_cache_noun
 
     def _something(self, memory_cache, names, captions, with_loss):
         text = memory_cache["text_memory"].permute(1, 0, 2)
         B, L, _ = text.shape
+        dev = text.device
         tokenized = memory_cache["tokenized"]
         memory_cache["img_memory_mod"] = memory_cache["img_memory"].clone()
-        loss_feature = torch.zeros((), device=text.device)
-        positions, features = [], []
-        for i in range(B):
-            beg = captions[i].find("something")
-            pos = torch.arange(tokenized.char_to_token(i, beg), tokenized.char_to_token(i, beg + len("something") - 1) + 1)
-            positions.append(pos)
-            features.append(text[i][pos.to(text.device)].mean(0))
+
+        def make():     # tokens of the pronoun "something" per caption: mean weights [B, L], substitution mask [L, B], host positions
+            W = torch.zeros(B, L, dtype=torch.float32)
+            mask = torch.zeros(L, B, dtype=torch.bool)
+            positions = []
+            for i in range(B):
+                beg = captions[i].find("something")
+                pos = torch.arange(tokenized.char_to_token(i, beg), tokenized.char_to_token(i, beg + len("something") - 1) + 1)
+                positions.append(pos)
+                W[i, pos] = 1.0 / max(len(pos), 1) if len(pos) else float("nan")
+                mask[pos, i] = True
+            if any(len(p_) == 0 for p_ in positions):       # the reference averages an empty set there: NaN
+                for i, p_ in enumerate(positions):
+                    if len(p_) == 0:
+                        W[i, :] = float("nan")
+            return W.to(dev), mask.to(dev), positions
+        W, sub_mask, positions = _cached_table("sth_meta", (_tok_ref(tokenized),), (tuple(captions), L, str(dev)), make)
+        features = (W.to(text.dtype).unsqueeze(-1) * text).sum(1)                      # [B, d]: text[i][pos].mean(0)
         tasks = [task_index(n) for n in names]
-        batch = self.cluster_batch(torch.stack(features), tasks) if B else None
-        for i in range(B):
-            if batch is not None:
-                center = batch[1][i]
-                L = len(memory_cache["text_memory"])
-                memory_cache["img_memory_mod"][-L:, i, :][positions[i].to(center.device)] = center
-            else:
+        batch = self.cluster_batch(features, tasks) if B else None
+        if batch is not None:
+            mod = memory_cache["img_memory_mod"]
+            mod[-L:] = torch.where(sub_mask[:, :, None], batch[1][None].to(mod.dtype), mod[-L:])
+            loss_feature = ((features - batch[1].to(features.dtype)) ** 2).mean(1).sum() if with_loss else torch.zeros((), device=dev)
+        else:
+            loss_feature = torch.zeros((), device=dev)
+            for i in range(B):
                 center = self._substitute(memory_cache, i, positions[i], tasks[i], features[i])
-            if with_loss:
-                loss_feature = loss_feature + F.mse_loss(features[i], center)
+                if with_loss:
+                    loss_feature = loss_feature + F.mse_loss(features[i], center)
         return memory_cache, loss_feature / max(B, 1)
 
     def forward(self, memory_cache_sth, targets_sth, captions_sth):

@@ -216,13 +216,46 @@ def _lsap_meta(shapes, offsets, dev):
     return ent
 
 
-def check_lsap_status(status):
-    """Raise like SciPy for invalid / infeasible matrices (reads the device: call once per step, not per launch)."""
-    st = status.cpu()
+_LSAP_PENDING = []      # (pinned host copy of a status vector, event recorded behind the copy)
+
+
+def _raise_on(st):
     if bool((st == 1).any()):
         raise ValueError("matrix contains invalid numeric entries")
     if bool((st == 2).any()):
         raise ValueError("cost matrix is infeasible")
+
+
+def check_lsap_status(status, defer=False):
+    """Raise like SciPy for invalid / infeasible matrices.  defer=False reads the device now (a host sync).  defer=True stages the status words in
+    pinned host memory behind an event and raises for the launches of EARLIER calls whose copies have arrived (the training step's paths: the
+    error of a poisoned cost matrix surfaces one call later instead of stalling the launch queue every step, as SetCriterion._note_status
+    does for the matcher); check_lsap_pending() waits for everything still in flight."""
+    if not defer or not status.is_cuda:
+        _raise_on(status.cpu())
+        return
+    if torch.cuda.is_current_stream_capturing():      # (an event recorded on this stream before the capture may not even be queried now)
+        return
+    check_lsap_pending(wait=False)
+    host = torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
+    host.copy_(status, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _LSAP_PENDING.append((host, ev))
+
+
+def check_lsap_pending(wait=True):
+    keep = []
+    try:
+        while _LSAP_PENDING:
+            host, ev = _LSAP_PENDING.pop(0)
+            if not wait and not ev.query():
+                keep.append((host, ev))
+                continue
+            ev.synchronize()
+            _raise_on(host)
+    finally:
+        _LSAP_PENDING[:0] = keep
 
 
 def lsap_blocks(cost, shapes, offsets, ld):
@@ -241,7 +274,7 @@ def lsap_blocks(cost, shapes, offsets, ld):
     return ri, ci, out_off, pairs, status
 
 
-def linear_sum_assignment_batch(costs):
+def linear_sum_assignment_batch(costs, defer_status=False):
     """scipy.optimize.linear_sum_assignment for a list of 2-D fp32 device cost matrices, solved in one launch of the
     HIP LSAP kernel (csrc/matcher.hip).  Returns a list of (row_ind, col_ind) int64 device tensors (rows ascending, as
     SciPy returns them).  Raises ValueError on NaN / -inf entries or an infeasible matrix, like SciPy."""
@@ -251,5 +284,5 @@ def linear_sum_assignment_batch(costs):
     sizes = [r * c for r, c in shapes]
     flat = torch.cat([c.reshape(-1).float() for c in costs]) if sum(sizes) else torch.zeros(1, device=costs[0].device)
     ri, ci, out_off, pairs, status = lsap_blocks(flat.contiguous(), shapes, [sum(sizes[:i]) for i in range(len(sizes))], 0)
-    check_lsap_status(status)
+    check_lsap_status(status, defer=defer_status)
     return [(ri[o:o + n], ci[o:o + n]) for o, n in zip(out_off, pairs)]

@@ -575,7 +575,7 @@ class SetCriterion(nn.Module):
         keep = [i for i, c in enumerate(match_sth.counts) if c > 0]
         if not keep:
             return torch.zeros((), device=feats[0].device)
-        idx = torch.as_tensor(keep, device=feats[0].device)
+        idx = _cached(("keep", tuple(keep), str(feats[0].device)), lambda: torch.as_tensor(keep, device=feats[0].device))
         per_image = ((feats[1][idx] - feats[0][idx].detach()) ** 2).mean(1)     # F.mse_loss per image
         return per_image.sum() / len(keep)
 
@@ -600,7 +600,7 @@ class SetCriterion(nn.Module):
             free = torch.ones(L, B, Q, dtype=torch.int8, device=dev)
             if m.src.shape[1]:
                 b_of = _pair_image_index(tuple(m.counts), dev)                                         # [Mtot]
-                free[torch.arange(L, device=dev)[:, None], b_of[None, :], m.src] = 0
+                free.view(L, B * Q).scatter_(1, b_of[None, :] * Q + m.src, 0)        # (scatter: advanced-index assignment synchronises the host)
             return torch.sort(free, dim=-1, descending=True, stable=True).indices
 
         p_n, p_s = binarise(lg_n).detach(), binarise(lg_s)
@@ -629,11 +629,14 @@ class SetCriterion(nn.Module):
         kl_tp = _kl_rows(by_target(p_n, m_n), by_target(p_s, m_s))                                      # [L, Mtot]
         # per image: batchmean over its (matched + assigned unmatched) rows; then mean over images
         n_rows = [c + (Q - c) for c in m_n.counts]
-        w_tp = torch.tensor([1.0 / (n_rows[i] * B) for i, c in enumerate(m_n.counts) for _ in range(c)] or [0.0], device=dev)
-        w_fp = torch.tensor([1.0 / (n_rows[i] * B) for _ in range(L) for i, c in enumerate(m_n.counts) for _ in range(Q - c)] or [0.0], device=dev)
+        counts = tuple(m_n.counts)
+        w_tp = _cached(("w_tp", counts, Q, B, str(dev)),
+                       lambda: torch.tensor([1.0 / (n_rows[i] * B) for i, c in enumerate(counts) for _ in range(c)] or [0.0], device=dev))
+        w_fp = _cached(("w_fp", counts, L, Q, B, str(dev)),
+                       lambda: torch.tensor([1.0 / (n_rows[i] * B) for _ in range(L) for i, c in enumerate(counts) for _ in range(Q - c)] or [0.0], device=dev))
         per_layer = (kl_tp * w_tp[None, :kl_tp.shape[1]]).sum(1) if m_n.src.shape[1] else torch.zeros(L, device=dev)
         per_layer = per_layer + (kl_fp * w_fp[:kl_fp.shape[0]]).view(L, -1).sum(1)
-        check_lsap_status(status)
+        check_lsap_status(status, defer=True)      # an invalid cost block raises at the next call (no host sync inside the step)
         return per_layer
 
 
