@@ -158,6 +158,8 @@ def secondary_legs():
             d = json.loads(line)
             out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "launch": d["config"].get("launch"),
                          "mfma_frac_whole_step": d["config"].get("mfma_frac_whole_step"), "workload": d["config"]["workload"]}
+            if "eager_pairs_per_s" in d["config"]:
+                out[name]["eager_pairs_per_s"] = d["config"]["eager_pairs_per_s"]
         except Exception as e:
             out[name] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
     return out
