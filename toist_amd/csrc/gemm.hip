@@ -2937,11 +2937,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_tall_kernel(const ReduceBat
     const int sl = threadIdx.x >> 4, c = threadIdx.x & 15;
     const long long e = (long long)(blockIdx.x - b0) * RT_ELEMS + c * 4;
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < total)
-        for (int k = sl; k < d.splits; k += 16) {
+    if (e < total) {
+        // four slices in flight per thread (a 208-slice stack was a chain of 13 dependent-latency loads: 13 us for 0.4 MB); the sum keeps its order
+        int k = sl;
+        for (; k + 48 < d.splits; k += 64) {
+            const float4 t0 = *reinterpret_cast<const float4*>(d.ws + (size_t)k * total + e);
+            const float4 t1 = *reinterpret_cast<const float4*>(d.ws + (size_t)(k + 16) * total + e);
+            const float4 t2 = *reinterpret_cast<const float4*>(d.ws + (size_t)(k + 32) * total + e);
+            const float4 t3 = *reinterpret_cast<const float4*>(d.ws + (size_t)(k + 48) * total + e);
+            s4.x += t0.x; s4.y += t0.y; s4.z += t0.z; s4.w += t0.w;
+            s4.x += t1.x; s4.y += t1.y; s4.z += t1.z; s4.w += t1.w;
+            s4.x += t2.x; s4.y += t2.y; s4.z += t2.z; s4.w += t2.w;
+            s4.x += t3.x; s4.y += t3.y; s4.z += t3.z; s4.w += t3.w;
+        }
+        for (; k < d.splits; k += 16) {
             const float4 t = *reinterpret_cast<const float4*>(d.ws + (size_t)k * total + e);
             s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w;
         }
+    }
     red[sl][c] = s4;
     __syncthreads();
     if (sl == 0 && e < total) {
