@@ -445,6 +445,68 @@ typedef struct toist_rowgemm_desc {
 TOIST_API int toist_rowgemm_blocks(int M);
 TOIST_API int toist_rowgemm(const toist_rowgemm_desc* d, void* stream);
 
+/* ---- XCD-resident decoder stack, forward (/root/reference/models/transformer.py:225-267 TransformerDecoder.forward, :362-408
+ * TransformerDecoderLayer.forward_post): ALL L post-norm decoder layers of d_model 256 / 8 heads / dim_feedforward 2048 in ONE launch.
+ * Images are independent from the first decoder layer to the last, and an MI355X has 8 XCDs of 32 CUs with one L2 each: the launch is
+ * 256 workgroups of 512 threads (one per CU); every workgroup reads its XCC id from the hardware register, takes a ticket on that XCD's
+ * counter, and the 32 workgroups that read the same id form the group of image b = xcc (+ 8, + 16 ... for B > 8).  A group exchanges
+ * activations only through its own L2 (plain stores, `s_waitcnt vmcnt(0)`, an L2-scope atomic arrival counter polled by one lane, sc1
+ * loads that bypass the reader's L1): 0.84 us per synchronisation point (profiles/r05_xcd_barrier.txt), four per layer:
+ *   P1  q | k | v = [x + query_pos | x] W_in^T + b_in             column tiles over the 32 CUs                      -> barrier
+ *   A   a CU owns 4 query rows: self-attention of its rows (wave = head), out_proj + dropout + residual + norm1, the cross-attention
+ *       query projection, cross-attention into the pre-projected memory K / V (wave = head, flash over 128-key blocks), out_proj +
+ *       dropout + residual + norm3 -- all inside the workgroup                                                     -> barrier
+ *   P6  a CU owns 64 of the 2048 hidden units: ReLU(y3 W1^T + b1) with dropout, and ITS partial sum of linear2    -> barrier
+ *   P7  the row owners add the 32 partials, bias, dropout, residual, norm4 (and y4 + query_pos for the next layer) -> barrier
+ * Every tensor the existing backward launches read (csrc/attn2.hip toist_attn2_bwd, csrc/tlayer.hip toist_rowgemm LN_BWD, the grouped
+ * weight gradients) is written with the layouts, (maximum, 1 / sum) statistics and dropout hashes of the per-op forward kernels, so
+ * the backward pass is unchanged.  Limits: Q <= 128, S <= 512, L <= 8, the device must expose 8 XCDs x 32 CUs.
+ * ctl: 1024 uint32 of caller scratch, zeroed once by the caller; the launch function re-zeroes words 0 .. 1022 (a memset node under
+ * capture).  ctl[1023] is sticky: != 0 = a bounded spin expired in some launch (a group was not co-resident) and that launch's
+ * results are invalid. */
+enum { TOIST_XDEC_MAX_LAYERS = 8, TOIST_XDEC_CTL_WORDS = 1024 };
+
+typedef struct toist_xdec_layer {
+    const void* w_in;  const float* b_in;      /* self_attn.in_proj_weight bf16 [768, 256] / bias f32 [768] */
+    const void* w_os;  const float* b_os;      /* self_attn.out_proj */
+    const float* g1;   const float* be1;       /* norm1 */
+    const void* w_q;   const float* b_q;       /* cross_attn_image.in_proj rows 0 .. 255 (the query projection) */
+    const void* w_oc;  const float* b_oc;      /* cross_attn_image.out_proj */
+    const float* g3;   const float* be3;       /* norm3 */
+    const void* w1;    const float* b1;        /* linear1 bf16 [2048, 256] */
+    const void* w2;    const float* b2;        /* linear2 bf16 [256, 2048] */
+    const float* g4;   const float* be4;       /* norm4 */
+    uint64_t seed[6];                          /* dropout seeds: self-attention, norm1 branch, cross-attention, norm3 branch, hidden, norm4 branch */
+} toist_xdec_layer;
+
+typedef struct toist_xdec_desc {
+    int32_t B, Q, S, L;
+    const void* x0;            /* bf16 [B*Q, 256]: tgt entering layer 0 (zeros in the reference) */
+    const void* qpos;          /* bf16 [B*Q, 256]: query_pos broadcast over the batch */
+    const void* kv;            /* bf16 [B*S, ldkv]: memory K (with pos) / V projections of layer l at columns l*512 / l*512 + 256 */
+    int32_t ldkv, reserved;
+    const uint8_t* key_pad;    /* [B, S] 1 = padding, or NULL */
+    float drop_p, eps;
+    const uint64_t* seed_dev;  /* optional device word added to every seed (graph replay) */
+    /* stacked per-layer outputs, layer l at + l * B*Q * width elements */
+    void* qkv;                 /* bf16 [L][B*Q][768] */
+    void* ctx_s;               /* bf16 [L][B*Q][256] self-attention context */
+    float* lse_s;              /* f32  [L][B*8][Q][2] */
+    void* z1; void* y1; void* y1e; float* mean1; float* rstd1;          /* norm1: pre-norm sum, output, output + query_pos */
+    void* qc;                  /* bf16 [L][B*Q][256] cross-attention queries */
+    void* ctx_c;               /* bf16 [L][B*Q][256] */
+    float* lse_c;              /* f32  [L][B*8][Q][2] */
+    void* z3; void* y3; float* mean3; float* rstd3;                      /* norm3 */
+    void* h;                   /* bf16 [L][B*Q][2048] dropout(relu(linear1)) */
+    void* z4; void* y4; void* y4e; float* mean4; float* rstd4;          /* norm4: y4 = the layer output (tgt_stack), y4e = y4 + query_pos */
+    void* part;                /* bf16 [B][32][128][256] scratch: linear2 partial sums */
+    uint32_t* ctl;             /* TOIST_XDEC_CTL_WORDS words of scratch */
+    toist_xdec_layer layer[TOIST_XDEC_MAX_LAYERS];
+} toist_xdec_desc;
+
+TOIST_API int toist_xdec_supported(int B, int Q, int S, int L);      /* 1 when toist_xdec_fwd takes the shape on the current device */
+TOIST_API int toist_xdec_fwd(const toist_xdec_desc* d, void* stream);
+
 /* ---- k-means of the distillation step on the device (models/kmeans.py:21-96 as mdetr.py:213-234 calls it).  One workgroup per
  * distinct task of the batch: group g covers samples members[group_off[g] .. group_off[g+1]) (batch order), all of task
  * group_task[g]; for each sample: Lloyd iterations over banks[task] ([N, D] f32, stride bank_stride elements) from

@@ -1,0 +1,82 @@
+"""XCD-resident decoder stack (csrc/xdec.hip, toist_xdec_fwd): ONE launch for the six decoder layers of
+/root/reference/models/transformer.py:225-267, 362-408 against the per-op launches of toist_amd.tlayer on the same model and batch.
+
+Both paths draw their dropout seeds in the same order and use the same hashes, so they are compared IN TRAINING MODE, dropout on:
+outputs agree to bf16 rounding, every gradient (the backward pass is the per-op one in both cases and consumes what the forward saved:
+q | k | v, contexts, (max, 1 / sum), pre-norm sums, statistics, hidden activations) to cosine > 0.995."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _model(dev):
+    import toist_amd
+    from toist_amd import harness
+    torch.manual_seed(0)
+    args = harness.default_args(device="cuda", contrastive_align_loss=True)
+    model, _, _, _ = toist_amd.build_model(args)
+    for n, b in model.named_buffers():
+        if n.endswith("bn3.weight"):
+            b.mul_(0.3)
+    return model.to(dev)
+
+
+def _run(model, dev, samples, tok, w, fused, train):
+    from toist_amd import kernels as k
+    from toist_amd import tlayer
+    calls = []
+    real = k.xdec_fwd
+    k.xdec_fwd = lambda *a, **kw: (calls.append(a[:3]), real(*a, **kw))[1]
+    old = tlayer.XDEC
+    tlayer.XDEC = fused
+    try:
+        model.train(train)
+        model.transformer._step = 0          # both runs draw the same seeds
+        model.zero_grad(set_to_none=True)
+        mc = model(samples.to(dev), tok.to(dev), encode_and_save=True)
+        out = model(samples.to(dev), tok.to(dev), encode_and_save=False, memory_cache=mc)
+        st = out["_stacked"]
+        loss = (st["pred_logits"] * w[0]).sum() + 30 * (st["pred_boxes"] * w[1]).sum() + (st["proj_queries"] * w[2]).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        k.xdec_check()
+    finally:
+        tlayer.XDEC = old
+        k.xdec_fwd = real
+    grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+    return st["pred_logits"].detach().float().clone(), st["pred_boxes"].detach().float().clone(), float(loss), grads, calls
+
+
+@pytest.mark.parametrize("B,hw,train", [(2, (160, 192), True), (8, (96, 128), True), (10, (64, 96), True), (3, (128, 160), False)])
+def test_xcd_resident_decoder_matches_the_per_op_launches(dev, B, hw, train):
+    from toist_amd import harness
+    from toist_amd import kernels as k
+    model = _model(dev)
+    samples, tok, _, _ = harness.synthetic_batch(B, hw[0], hw[1], tokens=16, seed=6 + B, max_targets=6)
+    g = torch.Generator().manual_seed(3)
+    w = [torch.randn(6, B, 100, n, generator=g).to(dev) for n in (256, 4, 64)]
+    S = (hw[0] // 32) * (hw[1] // 32) + 16
+    if not k.xdec_supported(B, 100, S, 6):
+        pytest.skip("device without 8 XCDs x 32 CUs")
+    lg_a, bx_a, loss_a, g_a, calls_a = _run(model, dev, samples, tok, w, True, train)
+    lg_b, bx_b, loss_b, g_b, calls_b = _run(model, dev, samples, tok, w, False, train)
+    assert len(calls_a) == 1 and calls_a[0][:2] == (B, 100) and not calls_b           # the fused launch really ran (once: all six layers)
+    rel = float((lg_a - lg_b).norm() / lg_b.norm())
+    assert rel < 1.5e-2, rel                                                            # six layers of bf16 activations; same dropout masks
+    assert float((bx_a - bx_b).abs().max()) < 2e-2
+    assert set(g_a) == set(g_b)
+    worst = {}
+    for n in g_b:
+        if g_b[n].norm() == 0 or "decoder.layers.0.self_attn.in_proj" in n or n.endswith("attention.self.key.bias"):
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(g_a[n].flatten(), g_b[n].flatten(), dim=0))
+        ratio = float(g_a[n].norm() / g_b[n].norm())
+        if cos < 0.995 or not (0.97 < ratio < 1.03):
+            worst[n] = (round(cos, 5), round(ratio, 4))
+    assert not worst, f"{len(worst)} gradients differ between the XCD-resident and the per-op decoder forward: {dict(list(worst.items())[:12])}"

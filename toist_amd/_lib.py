@@ -59,6 +59,24 @@ class RowGemm(Structure):
     ]
 
 
+XDEC_MAX_LAYERS, XDEC_CTL_WORDS = 8, 1024
+
+
+class XdecLayer(Structure):
+    """toist_xdec_layer (include/toist_hip.h)"""
+    _fields_ = [(n, c_void_p) for n in ("w_in", "b_in", "w_os", "b_os", "g1", "be1", "w_q", "b_q", "w_oc", "b_oc", "g3", "be3", "w1", "b1", "w2", "b2", "g4", "be4")] + \
+               [("seed", c_uint64 * 6)]
+
+
+class Xdec(Structure):
+    """toist_xdec_desc (include/toist_hip.h): the XCD-resident decoder stack of csrc/xdec.hip"""
+    _fields_ = [("B", c_int32), ("Q", c_int32), ("S", c_int32), ("L", c_int32), ("x0", c_void_p), ("qpos", c_void_p), ("kv", c_void_p), ("ldkv", c_int32),
+                ("reserved", c_int32), ("key_pad", c_void_p), ("drop_p", c_float), ("eps", c_float), ("seed_dev", c_void_p)] + \
+               [(n, c_void_p) for n in ("qkv", "ctx_s", "lse_s", "z1", "y1", "y1e", "mean1", "rstd1", "qc", "ctx_c", "lse_c", "z3", "y3", "mean3", "rstd3", "h", "z4", "y4",
+                                        "y4e", "mean4", "rstd4", "part", "ctl")] + \
+               [("layer", XdecLayer * XDEC_MAX_LAYERS)]
+
+
 class ReduceDesc(Structure):
     _fields_ = [("ws", c_void_p), ("out", c_void_p), ("rscale", c_void_p), ("splits", c_int32), ("M", c_int32), ("N", c_int32),
                 ("ldc", c_int32), ("alpha", c_float), ("accumulate", c_int32)]
@@ -115,6 +133,8 @@ _SIGNATURES = {
                         [c_float, c_float, c_uint64, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_rowgemm_blocks": ([c_int32], ctypes.c_int),
     "toist_rowgemm": ([POINTER(RowGemm), c_void_p], ctypes.c_int),
+    "toist_xdec_supported": ([c_int32] * 4, ctypes.c_int),
+    "toist_xdec_fwd": ([POINTER(Xdec), c_void_p], ctypes.c_int),
     "toist_kmeans": ([c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_float, c_int32,
                      c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_attn_small_fwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 4 + [c_float, c_float, c_uint64, c_void_p, c_void_p,

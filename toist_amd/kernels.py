@@ -716,6 +716,62 @@ def rowgemm(a, w, out, *, b_kind, epi, K=None, bias=None, res=None, res2=None, d
 ROW_PLAIN, ROW_LN_FWD, ROW_LN_BWD = _lib.ROW_PLAIN, _lib.ROW_LN_FWD, _lib.ROW_LN_BWD
 
 
+# ---- XCD-resident decoder stack (csrc/xdec.hip) ------------------------------------------------------------------------------------------
+_XDEC_CTL = {}      # (device, stream) -> int32[1024] control words (tickets, arrival counters, sticky status)
+
+
+def xdec_supported(B, Q, S, L):
+    return bool(_lib.lib().toist_xdec_supported(B, Q, S, L))
+
+
+def xdec_fwd(B, Q, S, x0, qpos, kv, key_pad, drop_p, eps, out, layers, part):
+    """All decoder layers in one launch (include/toist_hip.h: toist_xdec_fwd).  `out` = dict of the stacked per-layer tensors named as the
+    descriptor's fields; `layers` = one dict per layer with the 18 parameter tensors + "seed" (6 ints)."""
+    d = _lib.Xdec()
+    d.B, d.Q, d.S, d.L = B, Q, S, len(layers)
+    d.x0, d.qpos, d.kv, d.ldkv = _p(x0, torch.bfloat16), _p(qpos, torch.bfloat16), _p(kv, torch.bfloat16), kv.stride(0)
+    d.key_pad = _p(key_pad, torch.uint8) if key_pad is not None else None
+    d.drop_p, d.eps = drop_p, eps
+    d.seed_dev = _p(SEED_DEV) if drop_p > 0 else None
+    for name in ("qkv", "ctx_s", "z1", "y1", "y1e", "qc", "ctx_c", "z3", "y3", "h", "z4", "y4", "y4e"):
+        t = out[name]
+        assert t.is_contiguous()
+        setattr(d, name, _p(t, torch.bfloat16))
+    for name in ("lse_s", "mean1", "rstd1", "lse_c", "mean3", "rstd3", "mean4", "rstd4"):
+        t = out[name]
+        assert t.is_contiguous()
+        setattr(d, name, _p(t, torch.float32))
+    assert part.is_contiguous() and part.numel() >= B * 32 * 128 * 256
+    d.part = _p(part, torch.bfloat16)
+    key = (x0.device, _raw_stream())
+    ctl = _XDEC_CTL.get(key)
+    if ctl is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("toist_amd.kernels.xdec_fwd: run one eager step on this stream before capturing (the control words are allocated on first use)")
+        ctl = _XDEC_CTL[key] = torch.zeros(_lib.XDEC_CTL_WORDS, dtype=torch.int32, device=x0.device)
+    d.ctl = ctl.data_ptr()
+    for i, ly in enumerate(layers):
+        e = d.layer[i]
+        for name in ("w_in", "w_os", "w_q", "w_oc", "w1", "w2"):
+            t = ly[name]
+            assert t.is_contiguous()
+            setattr(e, name, _p(t, torch.bfloat16))
+        for name in ("b_in", "b_os", "g1", "be1", "b_q", "b_oc", "g3", "be3", "b1", "b2", "g4", "be4"):
+            t = ly[name]
+            assert t.is_contiguous()
+            setattr(e, name, _p(t, torch.float32))
+        for j in range(6):
+            e.seed[j] = ly["seed"][j]
+    _lib.check(_lib.lib().toist_xdec_fwd(ctypes.byref(d), _stream()), "toist_xdec_fwd")
+
+
+def xdec_check():
+    """Raises when a bounded spin of an XCD-resident launch expired (synchronises: call it from tests / at the end of a run)."""
+    for key, ctl in _XDEC_CTL.items():
+        if int(ctl[_lib.XDEC_CTL_WORDS - 1].item()) != 0:
+            raise RuntimeError("toist_xdec: a workgroup gave up waiting for its XCD group (the 32 workgroups of an image were not co-resident); results are invalid")
+
+
 def kmeans(banks, centers, group_task, group_off, members, features, tol, max_iter, pick, chosen_center, iters=None):
     """banks [T, N, D] f32, centers [T, K, D] f32 (updated in place); see toist_kmeans."""
     T, N, D = banks.shape

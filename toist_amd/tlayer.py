@@ -29,6 +29,7 @@ ENABLED = knob("TOIST_ROWS", True)          # tests flip this to compare with th
 
 FUSE_FWD_MAX_K = knob("TOIST_ROWS_FWD_MAX_K", 768)      # forward sub-layers with a longer reduction run as GEMM + LayerNorm launch ...
 FUSE_FWD_MAX_M = knob("TOIST_ROWS_FWD_MAX_M", 0)        # ... (a row-count exception for the decoder's 800 queries was measured and dropped, see _ln_fwd)
+XDEC = knob("TOIST_XDEC", True)             # decoder forward as ONE XCD-resident launch (csrc/xdec.hip) when the shape and the device allow it
 ATTN2 = knob("TOIST_ATTN2", True)           # second-generation attention cores (csrc/attn2.hip): no key-count limit, key-owning backward
 
 
@@ -46,6 +47,13 @@ def _core(tape, qb, kb, vb, key_pad, B, Sq, Sk, H, ctx, p, seed_p):
     scale = 1.0 / math.sqrt(dh)
     lse = torch.empty(B * H, Sq, 2, dtype=torch.float32, device=qb.device)
     k.attn2_fwd(qb, kb, vb, key_pad, B, H, Sq, Sk, dh, scale, p, seed_p, ctx, lse)
+    return _core_bwd_of(qb, kb, vb, key_pad, B, Sq, Sk, H, ctx, p, seed_p, lse)
+
+
+def _core_bwd_of(qb, kb, vb, key_pad, B, Sq, Sk, H, ctx, p, seed_p, lse):
+    """backward closure of an attn2-convention forward that has already run (attn2_fwd above, or the XCD-resident decoder launch)"""
+    dh = qb.shape[1] // H
+    scale = 1.0 / math.sqrt(dh)
     splits = k.attn2_splits(Sk)
 
     def core_bwd(dctx, dq, dk, dv):
@@ -194,6 +202,51 @@ def encoder_program(tape, ps, x, pos, key_pad, B, S, H, n_layers):
 
 
 # ------------------------------------------------------------------------------------------------------------------ decoder
+def _decoder_layers_xcd(tape, ps, Wself, Wcross, x0, qpos, kv, key_pad, tgt_stack, B, S, Q, H, L_):
+    """Forward of all decoder layers as ONE launch (csrc/xdec.hip: one image per XCD, XCD-local barriers); returns the per-layer records the
+    backward steps of decoder_program read -- every saved tensor has the layout / statistics / dropout hash of the per-op launches, so the
+    backward pass is the same code.  Seeds are drawn in the order of the per-op path (tests compare the two paths WITH dropout)."""
+    d, M, p = 256, B * Q, tape.drop_p
+    dev = x0.device
+    bf = lambda *shape: torch.empty(*shape, dtype=BF16, device=dev)
+    f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    out = dict(qkv=bf(L_, M, 3 * d), ctx_s=bf(L_, M, d), lse_s=f32(L_, B * H, Q, 2), z1=bf(L_, M, d), y1=bf(L_, M, d), y1e=bf(L_, M, d), mean1=f32(L_, M), rstd1=f32(L_, M),
+               qc=bf(L_, M, d), ctx_c=bf(L_, M, d), lse_c=f32(L_, B * H, Q, 2), z3=bf(L_, M, d), y3=bf(L_, M, d), mean3=f32(L_, M), rstd3=f32(L_, M),
+               h=bf(L_, M, 2048), z4=bf(L_, M, d), y4=tgt_stack, y4e=bf(L_, M, d), mean4=f32(L_, M), rstd4=f32(L_, M))
+    part = bf(B * 32 * 128 * 256)
+    recs, table = [], []
+    for i in range(L_):
+        lp = f"layers.{i}."
+        L = SimpleNamespace(i=i, x_in=x0 if i == 0 else out["y4"][i - 1], xe_in=qpos if i == 0 else out["y4e"][i - 1])
+        L.Ws, L.bs = Wself[i]
+        L.Wc, L.bc = Wcross[i]
+        L.Wq, L.bq = L.Wc.rows(0, d), L.bc.rows(0, d)
+        L.Wos, L.bos = ps[lp + "self_attn.out_proj.weight"], ps[lp + "self_attn.out_proj.bias"]
+        L.Woc, L.boc = ps[lp + "cross_attn_image.out_proj.weight"], ps[lp + "cross_attn_image.out_proj.bias"]
+        L.W1, L.b1, L.W2, L.b2 = ps[lp + "linear1.weight"], ps[lp + "linear1.bias"], ps[lp + "linear2.weight"], ps[lp + "linear2.bias"]
+        norms = [(ps[lp + f"norm{j}.weight"], ps[lp + f"norm{j}.bias"]) for j in (1, 3, 4)]
+        seeds = [tape.next_seed() if p > 0 else 0 for _ in range(6)]      # self-attention, norm1, cross-attention, norm3, hidden, norm4
+        qkv = out["qkv"][i]
+        L.ctx_s, L.ctx_c, L.h, L.col = out["ctx_s"][i], out["ctx_c"][i], out["h"][i], i * 2 * d
+        L.core_s = _core_bwd_of(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], None, B, Q, Q, H, L.ctx_s, p, seeds[0], out["lse_s"][i])
+        L.core_c = _core_bwd_of(out["qc"][i], kv[:, L.col:L.col + d], kv[:, L.col + d:L.col + 2 * d], key_pad, B, Q, S, H, L.ctx_c, p, seeds[2], out["lse_c"][i])
+        last = i + 1 == L_
+        L.ln1 = SimpleNamespace(seed=seeds[1], z=out["z1"][i], y=out["y1"][i], y2=out["y1e"][i], mean=out["mean1"][i], rstd=out["rstd1"][i], gamma=norms[0][0],
+                                beta=norms[0][1], dz=None, dzd=None)
+        L.ln3 = SimpleNamespace(seed=seeds[3], z=out["z3"][i], y=out["y3"][i], y2=None, mean=out["mean3"][i], rstd=out["rstd3"][i], gamma=norms[1][0],
+                                beta=norms[1][1], dz=None, dzd=None)
+        L.ln4 = SimpleNamespace(seed=seeds[5], z=out["z4"][i], y=out["y4"][i], y2=None if last else out["y4e"][i], mean=out["mean4"][i], rstd=out["rstd4"][i],
+                                gamma=norms[2][0], beta=norms[2][1], dz=None, dzd=None)
+        L.out = engine.Var(L.ln4.y)
+        table.append(dict(w_in=L.Ws.w, b_in=L.bs.f32, w_os=L.Wos.w, b_os=L.bos.f32, g1=norms[0][0].f32, be1=norms[0][1].f32, w_q=L.Wq.w, b_q=L.bq.f32, w_oc=L.Woc.w,
+                          b_oc=L.boc.f32, g3=norms[1][0].f32, be3=norms[1][1].f32, w1=L.W1.w, b1=L.b1.f32, w2=L.W2.w, b2=L.b2.f32, g4=norms[2][0].f32,
+                          be4=norms[2][1].f32, seed=seeds))
+        recs.append(L)
+    k.xdec_fwd(B, Q, S, x0, qpos, kv, key_pad, p, 1e-5, out, table, part)
+    tape.keep.append((out, part))
+    return recs
+
+
 def decoder_program(tape, ps, mem, qe, pos, key_pad, B, S, Q, H, n_layers):
     """6 decoder layers (self-attention over the queries, cross-attention into the encoder memory, FFN) + the shared final LayerNorm over
     all layer outputs; returns [hs] with hs [L, B*Q, 256] bf16 (transformer.py:225-267, 362-408)."""
@@ -223,7 +276,10 @@ def decoder_program(tape, ps, mem, qe, pos, key_pad, B, S, Q, H, n_layers):
     cur = torch.zeros(M, d, dtype=BF16, device=dev)
     cur_e = qpos
     layers = []
-    for i in range(L_):
+    fused = XDEC and ATTN2 and k.xdec_supported(B, Q, S, L_)
+    if fused:
+        layers = _decoder_layers_xcd(tape, ps, Wself, Wcross, cur, qpos, kv, key_pad, tgt_stack, B, S, Q, H, L_)
+    for i in range(0 if not fused else L_, L_):
         lp = f"layers.{i}."
         L = SimpleNamespace(i=i, x_in=cur, xe_in=cur_e)
         L.Ws, L.bs = Wself[i]
