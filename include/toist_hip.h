@@ -501,6 +501,7 @@ typedef struct toist_xdec_desc {
     void* z4; void* y4; void* y4e; float* mean4; float* rstd4;          /* norm4: y4 = the layer output (tgt_stack), y4e = y4 + query_pos */
     void* part;                /* bf16 [B][32][128][256] scratch: linear2 partial sums */
     uint32_t* ctl;             /* TOIST_XDEC_CTL_WORDS words of scratch */
+    uint64_t* prof;            /* diagnostics, normally NULL: [256 workgroups][L][16] device-clock stamps (100 MHz) at the phase boundaries of image 0 .. 7 */
     toist_xdec_layer layer[TOIST_XDEC_MAX_LAYERS];
 } toist_xdec_desc;
 

@@ -85,6 +85,38 @@ def test_cluster_criterion_full_bank(dev):
     assert ms["img_memory"].grad is not None
 
 
+def test_invalid_bank_update_leaves_the_bank_untouched(dev):
+    """the nearest-replacement bank update defers its LSAP status check; a NaN feature (invalid cost matrix: SciPy raises at
+    mdetr.py:100 before touching the bank) must not overwrite bank rows in the meantime -- the write is gated on the device, and the ValueError
+    surfaces at the next drain (check_lsap_pending / state_dict)."""
+    import types
+    from toist_amd.distill import ClusterCriterion
+    from toist_amd.matcher import check_lsap_pending
+    D, MEM = 16, 12
+    args = types.SimpleNamespace(train_batch_size=2, fifo_memory=False)
+    cc = ClusterCriterion(feature_dim=D, memory_size=MEM, cluster_num=3, task_count=4, args=args).to(dev)
+    g = torch.Generator().manual_seed(1)
+    cc.feature_bank.copy_(torch.randn(4, MEM, D, generator=g))
+    cc.full_label.fill_(1)
+    cc.update_count.fill_(100)
+    cc.sync_host_state()
+    check_lsap_pending()
+    before = cc.feature_bank.clone()
+    good = torch.cat([torch.randn(2, D, generator=g), torch.tensor([[1.0], [1.0]])], 1).to(dev)
+    cc.update_memory_queue(good, tasks_host=[1, 1])
+    check_lsap_pending()
+    assert not torch.equal(cc.feature_bank[1], before[1]) and torch.equal(cc.feature_bank[0], before[0])
+    mid = cc.feature_bank.clone()
+    bad = good.clone()
+    bad[0, 3] = float("nan")
+    cc.update_memory_queue(bad, tasks_host=[1, 1])
+    torch.cuda.synchronize()
+    assert torch.equal(cc.feature_bank, mid)                    # nothing was written, no NaN entered the bank
+    with pytest.raises(ValueError):
+        cc.state_dict()
+    check_lsap_pending()                                       # drained: the next call is clean
+
+
 def test_distillation_step_end_to_end(dev):
     """Teacher + student double forward with the cluster criterion and the paired criterion (engine.py:152-204) on
     synthetic (noun, pronoun) pairs: every reference loss key is produced, the loss is finite, and the backward pass

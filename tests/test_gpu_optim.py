@@ -136,6 +136,39 @@ def test_deferred_ema_is_the_same_average(dev):
         assert torch.equal(x, y)
 
 
+def test_late_group_survives_in_place_zero_grad(dev):
+    """zero_grad(set_to_none=False) zeroes the gradient tensors a pending late-group launch still has to read -- the launch is
+    issued first.  Three steps of a loop that zeroes in place: the late run's text-encoder weights equal the serial tail's."""
+    import copy
+    import toist_amd
+    from toist_amd import harness, kernels
+    from toist_amd.optim import FusedClipAdamWEMA
+    args = harness.default_args(device="cuda", enc_layers=1, dec_layers=1, num_queries=20, dropout=0.0)
+    torch.manual_seed(0)
+    model0, criterion, _, weight_dict = toist_amd.build_model(args)
+    model0.to(dev).train()
+    samples, tok, targets, pmap = harness.synthetic_batch(2, 128, 160, tokens=12, seed=5, device=dev, max_targets=4)
+    kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+    res = {}
+    for late in (False, True):
+        model = copy.deepcopy(model0)
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        opt = FusedClipAdamWEMA([{"params": [p for n, p in named if "text_encoder" not in n], "lr": 1e-4},
+                                 {"params": [p for n, p in named if "text_encoder" in n], "lr": 5e-5, "late": late}], weight_decay=1e-4, max_norm=0.1)
+        for _ in range(3):
+            opt.zero_grad(set_to_none=False)
+            mc = model(samples, tok, encode_and_save=True)
+            out = model(samples, tok, encode_and_save=False, memory_cache=mc)
+            losses = criterion(mc, out, targets, pmap, None)
+            sum(losses[k_] * weight_dict[k_] for k_ in losses if k_ in weight_dict).backward()
+            opt.step()
+        opt.finish()
+        torch.cuda.synchronize()
+        res[late] = model.transformer.text_encoder.encoder.layer[0].output.dense.weight.detach().clone()
+    torch.testing.assert_close(res[True], res[False], rtol=2e-4, atol=1e-6)
+    assert not torch.equal(res[True], model0.transformer.text_encoder.encoder.layer[0].output.dense.weight)
+
+
 def test_late_text_group_is_bit_identical_to_the_serial_tail(dev):
     """A parameter group marked "late" (the text encoder) is updated at the head of the NEXT forward pass's text branch instead of
     inside step() (toist_amd.optim / engine.run_text_prelude): same gradients, same clip coefficient, same step count -- after five

@@ -73,7 +73,7 @@ class Xdec(Structure):
     _fields_ = [("B", c_int32), ("Q", c_int32), ("S", c_int32), ("L", c_int32), ("x0", c_void_p), ("qpos", c_void_p), ("kv", c_void_p), ("ldkv", c_int32),
                 ("reserved", c_int32), ("key_pad", c_void_p), ("drop_p", c_float), ("eps", c_float), ("seed_dev", c_void_p)] + \
                [(n, c_void_p) for n in ("qkv", "ctx_s", "lse_s", "z1", "y1", "y1e", "mean1", "rstd1", "qc", "ctx_c", "lse_c", "z3", "y3", "mean3", "rstd3", "h", "z4", "y4",
-                                        "y4e", "mean4", "rstd4", "part", "ctl")] + \
+                                        "y4e", "mean4", "rstd4", "part", "ctl", "prof")] + \
                [("layer", XdecLayer * XDEC_MAX_LAYERS)]
 
 

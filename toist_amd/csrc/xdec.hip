@@ -53,13 +53,13 @@ constexpr int L_SC = L_SQ + 4 * XAS * 2;                  // [4][XCS] f32: accum
 constexpr int L_DEADC = L_SC + 4 * XCS * 4;               // [512] u8: memory keys that are padding or beyond S
 constexpr int L_DEADS = L_DEADC + 512;                    // [128] u8: query keys beyond Q
 constexpr int L_INFO = L_DEADS + 128;                     // [16] u32
-constexpr int L_SV = L_INFO + 64;                         // [8 waves][128 keys][32] bf16: V of the key block in progress, wave-private
+constexpr int L_SV = L_INFO + 64;                         // [8 waves][64 keys][32] bf16: V of the key block in progress, wave-private (32 KB; P7's sums need as much)
 constexpr int L_RED = L_SV;                               // P7: [8][4][256] f32 (the V tiles are idle then)
-constexpr int L_W1 = L_SV + 8 * 128 * XDH * 2;            // [64 hidden][XAS] bf16: this CU's rows of linear1
+constexpr int L_W1 = L_SV + 8 * 64 * XDH * 2;            // [64 hidden][XAS] bf16: this CU's rows of linear1
 constexpr int L_W2 = L_W1 + 64 * XAS * 2;                 // [256 n][XW2S] bf16: this CU's columns of linear2
 constexpr int L_TOTAL = L_W2 + XD * XW2S * 2;
 static_assert(L_TOTAL <= 160 * 1024, "xdec: LDS budget");
-static_assert(8 * 4 * XD * 4 <= 8 * 128 * XDH * 2, "xdec: the P7 sums alias the V tiles");
+static_assert(8 * 4 * XD * 4 <= 8 * 64 * XDH * 2, "xdec: the P7 sums alias the V tiles");
 
 template <int N, typename F>
 __device__ __forceinline__ void unrolled(F&& f) {
@@ -151,6 +151,10 @@ __device__ __forceinline__ void xcd_barrier(XSync& sy) {
     __syncthreads();
 }
 
+__device__ __forceinline__ void xstamp(uint64_t* prof, int wg, int L, int layer, int phase) {
+    if (prof != nullptr && threadIdx.x == 0) prof[((size_t)wg * L + layer) * 16 + phase] = wall_clock64();
+}
+
 // ---- weights of a 256 -> 256 projection as MFMA B fragments, straight from global memory --------------------------------------------------
 // wave w owns output columns 32 w .. 32 w + 31 (two 16-column blocks); a lane (column c16, k group g) takes 32 contiguous bytes per 64-deep
 // k-step (k = 64 s + 16 g .. + 15): the four k groups of a row read one whole 128-byte line, and the A fragments use the same k order.
@@ -187,133 +191,130 @@ __device__ __forceinline__ void acc_to_lds(const f32x4_t* acc, float* sC, int wa
     }
 }
 
-// ---- row epilogue of one wave: lane = (row lane >> 4, column pieces lane & 15 and (lane & 15) + 16), 8 columns per piece ----------------
-// v (in)  : accumulator rows in LDS;  resid (in): the residual rows (f32 values of the bf16 tensor), (out): this LayerNorm's output rows
-struct LnArgs {
-    const float* bias;
-    const float* gamma;
-    const float* beta;
-    const bf16_t* add;     // rows of query_pos (global, image rows), or nullptr
-    bf16_t* z;             // global outputs, already offset to the image's first row
+
+// ---- row epilogue: ONE WAVE PER ROW, a lane owns 4 consecutive columns (4 lane .. 4 lane + 3) ------------------------------------------------
+// The operands that do not depend on the GEMM (bias, affine parameters, query_pos) are requested early (ln_prefetch) so that they are not queued
+// behind a weight stream when the row is ready (vmcnt retires in order).
+struct LnPre {
+    float4 bias, gamma, beta;
+    uint2 add;
+};
+__device__ __forceinline__ LnPre ln_prefetch(const float* bias, const float* gamma, const float* beta, const bf16_t* add_row, int lane) {
+    LnPre o;
+    o.bias = *reinterpret_cast<const float4*>(bias + 4 * lane);
+    o.gamma = *reinterpret_cast<const float4*>(gamma + 4 * lane);
+    o.beta = *reinterpret_cast<const float4*>(beta + 4 * lane);
+    o.add = add_row != nullptr ? *reinterpret_cast<const uint2*>(add_row + 4 * lane) : make_uint2(0u, 0u);
+    return o;
+}
+__device__ __forceinline__ void unpack4f(const uint2 u, float* v) {
+    v[0] = __uint_as_float(u.x << 16);
+    v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16);
+    v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+struct LnOut {
+    bf16_t* z;             // global row pointers (this wave's row), or nullptr
     bf16_t* y;
-    bf16_t* y2;            // or nullptr
+    bf16_t* y2;
     float* mean;
     float* rstd;
-    bf16_t* sOut;          // LDS [4][XAS]: receives y2 (or y when there is no add), or nullptr
-    unsigned long long seed;
-    float drop_p, eps;
+    bf16_t* sOut;          // LDS row: receives y2 (y when the row has no addend), or nullptr
 };
-__device__ __forceinline__ void ln_rows(const float* sC, const LnArgs& a, float (&resid)[2][8], int lane, int row_img, bool live, size_t grow) {
-    const int r = lane >> 4, pl = lane & 15;
-    float v[2][8];
+// sCrow: the row's 256 accumulators (f32, LDS); resid (in): the residual row, (out): this LayerNorm's output row (f32 values of the bf16 numbers)
+__device__ __forceinline__ void ln_row(const float* sCrow, const LnPre& o, float (&resid)[4], unsigned long long seed, float drop_p, float eps, size_t grow, bool live,
+                                       bool has_add, const LnOut& out, int lane) {
+    const float4 a = *reinterpret_cast<const float4*>(sCrow + 4 * lane);
+    float v[4] = {a.x + o.bias.x, a.y + o.bias.y, a.z + o.bias.z, a.w + o.bias.w};
+    if (drop_p > 0.f) {
+        const unsigned thresh = (unsigned)(drop_p * 4294967296.0);
+        const float dscale = 1.f / (1.f - drop_p);
+        const unsigned long long idx = (unsigned long long)grow * XD + 4 * lane;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int c0 = (pl + 16 * h) * 8;
-        const float4 lo = *reinterpret_cast<const float4*>(sC + r * XCS + c0), hi = *reinterpret_cast<const float4*>(sC + r * XCS + c0 + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(a.bias + c0), b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 4);
-        v[h][0] = lo.x + b0.x; v[h][1] = lo.y + b0.y; v[h][2] = lo.z + b0.z; v[h][3] = lo.w + b0.w;
-        v[h][4] = hi.x + b1.x; v[h][5] = hi.y + b1.y; v[h][6] = hi.z + b1.z; v[h][7] = hi.w + b1.w;
+        for (int q = 0; q < 4; ++q) v[q] = dropout_keep(seed, idx + q, thresh) ? v[q] * dscale : 0.f;
     }
-    if (a.drop_p > 0.f) {
-        const unsigned thresh = (unsigned)(a.drop_p * 4294967296.0);
-        const float dscale = 1.f / (1.f - a.drop_p);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const unsigned long long idx = (unsigned long long)grow * XD + (pl + 16 * h) * 8 + q;
-                v[h][q] = dropout_keep(a.seed, idx, thresh) ? v[h][q] * dscale : 0.f;
-            }
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[h][q] += resid[h][q];
-        const uint4 zp = pack8f(v[h]);
-        if (live) *reinterpret_cast<uint4*>(a.z + (size_t)row_img * XD + (pl + 16 * h) * 8) = zp;
-        unpack8f(zp, v[h]);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += v[h][q];
-    }
-    const float mean = group16_sum(s) * (1.f / XD);
+    for (int q = 0; q < 4; ++q) v[q] += resid[q];
+    const uint2 zp = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+    if (live && out.z != nullptr) *reinterpret_cast<uint2*>(out.z + 4 * lane) = zp;
+    unpack4f(zp, v);                                     // the statistics are those of the ROUNDED row (what the backward pass reads)
+    const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / XD);
     float qq = 0.f;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { const float d = v[h][q] - mean; qq += d * d; }
-    const float rstd = rsqrtf(group16_sum(qq) * (1.f / XD) + a.eps);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int c0 = (pl + 16 * h) * 8;
-        float gm[8], bt[8], o[8];
-        *reinterpret_cast<float4*>(gm) = *reinterpret_cast<const float4*>(a.gamma + c0);
-        *reinterpret_cast<float4*>(gm + 4) = *reinterpret_cast<const float4*>(a.gamma + c0 + 4);
-        *reinterpret_cast<float4*>(bt) = *reinterpret_cast<const float4*>(a.beta + c0);
-        *reinterpret_cast<float4*>(bt + 4) = *reinterpret_cast<const float4*>(a.beta + c0 + 4);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = (v[h][q] - mean) * rstd * gm[q] + bt[q];
-        uint4 yo = pack8f(o);
-        if (live) *reinterpret_cast<uint4*>(a.y + (size_t)row_img * XD + c0) = yo;
-        unpack8f(yo, resid[h]);
-        if (a.add != nullptr) {
-            float a8[8], y8[8];
-            unpack8f(live ? *reinterpret_cast<const uint4*>(a.add + (size_t)row_img * XD + c0) : make_uint4(0, 0, 0, 0), a8);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) y8[q] = resid[h][q] + a8[q];
-            yo = pack8f(y8);
-            if (live && a.y2 != nullptr) *reinterpret_cast<uint4*>(a.y2 + (size_t)row_img * XD + c0) = yo;
-        }
-        if (a.sOut != nullptr) *reinterpret_cast<uint4*>(a.sOut + r * XAS + c0) = yo;
+    for (int q = 0; q < 4; ++q) { const float d = v[q] - mean; qq += d * d; }
+    const float rstd = rsqrtf(wave_sum(qq) * (1.f / XD) + eps);
+    const float y0 = (v[0] - mean) * rstd * o.gamma.x + o.beta.x, y1 = (v[1] - mean) * rstd * o.gamma.y + o.beta.y;
+    const float y2 = (v[2] - mean) * rstd * o.gamma.z + o.beta.z, y3 = (v[3] - mean) * rstd * o.gamma.w + o.beta.w;
+    uint2 yo = make_uint2(pack2bf(y0, y1), pack2bf(y2, y3));
+    if (live) *reinterpret_cast<uint2*>(out.y + 4 * lane) = yo;
+    unpack4f(yo, resid);
+    if (has_add) {
+        float a4[4];
+        unpack4f(o.add, a4);
+        yo = make_uint2(pack2bf(resid[0] + a4[0], resid[1] + a4[1]), pack2bf(resid[2] + a4[2], resid[3] + a4[3]));
+        if (live && out.y2 != nullptr) *reinterpret_cast<uint2*>(out.y2 + 4 * lane) = yo;
     }
-    if (live && pl == 0) {
-        a.mean[row_img] = mean;
-        a.rstd[row_img] = rstd;
+    if (out.sOut != nullptr) *reinterpret_cast<uint2*>(out.sOut + 4 * lane) = yo;
+    if (live && lane == 0) {
+        *out.mean = mean;
+        *out.rstd = rstd;
     }
 }
 
-// ---- attention of 4 query rows against Sk keys, one wave = one head (the loop body is attn2_fwd_kernel's) ------------------------------
-// sQ: LDS rows [4][XAS] of the projected queries (all heads); K / V: buffer + byte offset of (key 0, this head's first feature) and the row
-// stride in bytes; FRESH = the buffer was written in this launch.  Writes ctx rows into sX (LDS) and to global memory, (max, 1 / sum) to lse.
+// ---- attention of 4 query rows against Sk keys, one wave = one head (the block body is attn2_fwd_kernel's) -----------------------------
+// qf: this lane's query fragment (query c16 & 3, features 8 g .. 8 g + 7 of the head); K / V: buffer + byte offset of (key 0, this head's first
+// feature) and the row stride in bytes; FRESH = the buffer was written in this launch.  The loads of key block i + 1 are in flight while block i
+// is computed; `between` runs once, right after the first block's loads have been issued (the caller's prefetch of the next weight stream).
+// Writes the context rows into sX (LDS) and to global memory, (max, 1 / sum) to lse.
+constexpr int XKB = 64;        // keys per block of the attention loop (128 as in attn2.hip keeps 64 more registers live next to the prefetched weight stream: spills)
+struct KVBlock {
+    bf16x8_t kf[XKB / 16];
+    uint4 vv[XKB / 16];
+};
 template <bool FRESH>
-__device__ __forceinline__ void attn_rows(const bf16_t* sQ, rsrc_t rsK, unsigned offK, rsrc_t rsV, unsigned offV, unsigned ldb, int Sk,
-                                          const unsigned char* sDead, bf16_t* sVw, int h, int lane, float c, float drop_p, unsigned long long seed,
-                                          unsigned row, bool qlive, bf16_t* sX, bf16_t* ctx_row, float* lse_row) {
+__device__ __forceinline__ void kv_load(KVBlock& t, rsrc_t rsK, unsigned offK, rsrc_t rsV, unsigned offV, unsigned ldb, int Sk, int k0, int lane) {
+    const int g = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int j = 0; j < XKB / 16; ++j) {
+        const int key = k0 + j * 16 + c16;
+        t.kf[j] = ld16<FRESH>(rsK, key < Sk ? offK + (unsigned)key * ldb + (unsigned)(g * 16) : XOOB);
+    }
+#pragma unroll
+    for (int u = 0; u < XKB / 16; ++u) {
+        const int pc = u * 64 + lane, key = k0 + (pc >> 2);
+        t.vv[u] = ld16u<FRESH>(rsV, key < Sk ? offV + (unsigned)key * ldb + (unsigned)((pc & 3) * 16) : XOOB);
+    }
+}
+template <bool FRESH, typename Between>
+__device__ __forceinline__ void attn_rows(const bf16x8_t qf, rsrc_t rsK, unsigned offK, rsrc_t rsV, unsigned offV, unsigned ldb, int Sk, const unsigned char* sDead,
+                                          bf16_t* sVw, int h, int lane, float c, float drop_p, unsigned long long seed, unsigned row, bool qlive, bf16_t* sX,
+                                          bf16_t* ctx_row, float* lse_row, Between&& between) {
+    constexpr int NJ = XKB / 16;
     const int g = lane >> 4, c16 = lane & 15;
     const bool dropping = drop_p > 0.f;
     const unsigned t16 = dropping ? (unsigned)(drop_p * 65536.0f + 0.5f) : 0u;
     const unsigned s0 = (unsigned)seed, s1 = (unsigned)(seed >> 32) ^ ((unsigned)seed * 0x9E3779B9u);
     const int ldp = (Sk + 7) & ~7;
     const unsigned pair_row = row * (unsigned)(ldp >> 1);
-    const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(sQ + (c16 & 3) * XAS + h * XDH + g * 8);
     float m = -INFINITY, l = 0.f;
     f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-    for (int k0 = 0; k0 < Sk; k0 += 128) {
-        // K fragments (lane = key 16 j + c16, features 8 g .. 8 g + 7) and the V rows of the block (16-byte pieces -> wave-private LDS tile)
-        bf16x8_t kf[8];
-        uint4 vv[8];
+    KVBlock cur;
+    kv_load<FRESH>(cur, rsK, offK, rsV, offV, ldb, Sk, 0, lane);
+    between();
+    for (int k0 = 0; k0 < Sk; k0 += XKB) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int key = k0 + j * 16 + c16;
-            kf[j] = ld16<FRESH>(rsK, key < Sk ? offK + (unsigned)key * ldb + (unsigned)(g * 16) : XOOB);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int pc = u * 64 + lane, key = k0 + (pc >> 2);
-            vv[u] = ld16u<FRESH>(rsV, key < Sk ? offV + (unsigned)key * ldb + (unsigned)((pc & 3) * 16) : XOOB);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NJ; ++u) {
             const int pc = u * 64 + lane;
-            *reinterpret_cast<uint4*>(sVw + (pc >> 2) * XDH + (pc & 3) * 8) = vv[u];
+            *reinterpret_cast<uint4*>(sVw + (pc >> 2) * XDH + (pc & 3) * 8) = cur.vv[u];
         }
-        f32x4_t s[8];
+        f32x4_t s[NJ];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j], qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        const unsigned short dd = *reinterpret_cast<const unsigned short*>(sDead + k0 + lane * 2);
+        for (int j = 0; j < NJ; ++j) s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.kf[j], qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (k0 + XKB < Sk) kv_load<FRESH>(cur, rsK, offK, rsV, offV, ldb, Sk, k0 + XKB, lane);          // the next block's rows travel during this block's arithmetic
+        const unsigned char dd = sDead[k0 + lane];
         if (__any(dd != 0)) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const unsigned dead4 = *reinterpret_cast<const unsigned*>(sDead + k0 + j * 16 + g * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -322,7 +323,7 @@ __device__ __forceinline__ void attn_rows(const bf16_t* sQ, rsrc_t rsK, unsigned
         }
         float bm = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bm = fmaxf(fmaxf(bm, fmaxf(s[j][0], s[j][1])), fmaxf(s[j][2], s[j][3]));
+        for (int j = 0; j < NJ; ++j) bm = fmaxf(fmaxf(bm, fmaxf(s[j][0], s[j][1])), fmaxf(s[j][2], s[j][3]));
         bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
         bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
         const float mn = fmaxf(m, bm);
@@ -330,9 +331,9 @@ __device__ __forceinline__ void attn_rows(const bf16_t* sQ, rsrc_t rsK, unsigned
         const float alpha = __builtin_amdgcn_exp2f((m - msafe) * c);
         m = mn;
         float psum = 0.f;
-        unsigned pk[8][2];
+        unsigned pk[NJ][2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             float p[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -356,7 +357,7 @@ __device__ __forceinline__ void attn_rows(const bf16_t* sQ, rsrc_t rsK, unsigned
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[nb][r] *= alpha;
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
+        for (int cc = 0; cc < NJ / 2; ++cc) {
             const bf16x8_t pa = frag_of(pk[2 * cc][0], pk[2 * cc][1], pk[2 * cc + 1][0], pk[2 * cc + 1][1]);
             const int k_lo = 32 * cc + 4 * g + (c16 >> 2), k_hi = k_lo + 16;
 #pragma unroll
@@ -382,6 +383,14 @@ __device__ __forceinline__ void attn_rows(const bf16_t* sQ, rsrc_t rsK, unsigned
     }
 }
 
+// pulls `bytes` (a multiple of 128) at `base` into this XCD's L2: thread idx of n touches every n-th line.  The sum keeps the loads alive.
+__device__ __forceinline__ unsigned l2_touch(const void* base, size_t bytes, int idx, int n) {
+    unsigned acc = 0;
+    const unsigned* w = reinterpret_cast<const unsigned*>(base);
+    for (size_t line = idx; line < bytes / 128; line += n) acc ^= w[line * 32];
+    return acc;
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) {
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) 
     bf16_t* const sW2 = reinterpret_cast<bf16_t*>(smem + L_W2);
     const int tid0 = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    bf16_t* const sVw = reinterpret_cast<bf16_t*>(smem + L_SV) + wave * (128 * XDH);
+    bf16_t* const sVw = reinterpret_cast<bf16_t*>(smem + L_SV) + wave * (64 * XDH);
 
     // ---- group formation: the XCD is read from the hardware, the slot is a ticket of that XCD ----
     if (tid0 == 0) {
@@ -417,9 +426,11 @@ __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) 
     const int MT = (Q + 15) >> 4;                  // 16-row tiles of an image
     const int RB = (Q + 3) >> 2;                   // 4-row blocks of an image: block `slot` belongs to this CU
     const bool rowner = slot < RB;
+    const int n_idle = XWG - RB;                   // CUs without rows: they pull the coming weights into the L2 while the row owners work
     const float cexp = 0.17677669529663687f * LOG2E;     // head dim 32: 1 / sqrt(32)
     const float drop_p = p.drop_p;
     const unsigned long long seed_add = p.seed_dev ? *p.seed_dev : 0ull;
+    unsigned touched = 0;
 
     for (int b = xcd; b < p.B; b += 8) {
         int tid = tid0;
@@ -430,97 +441,115 @@ __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) 
         for (int i = tid; i < 512; i += XNT) sDeadC[i] = (i >= S || (p.key_pad != nullptr && p.key_pad[(size_t)b * S + i])) ? 1 : 0;
         if (tid < 128) sDeadS[tid] = tid >= Q ? 1 : 0;
         const size_t row0 = (size_t)b * Q;             // first row of the image in the [B*Q, .] tensors
-        const int my_row = 4 * slot + (lane >> 4);     // wave 0's row in the row epilogues
-        const bool my_live = rowner && my_row < Q;
-        float resid[2][8];                              // wave 0: the residual stream of this CU's rows (f32 of the bf16 values)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) resid[hh][q] = 0.f;
-        if (wave == 0 && my_live) {
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-                unpack8f(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.x0) + (row0 + my_row) * XD + ((lane & 15) + 16 * hh) * 8), resid[hh]);
+        const int my_row = 4 * slot + wave;            // waves 0 .. 3: the row this wave normalises
+        const bool my_live = rowner && wave < 4 && my_row < Q;
+        float resid[4] = {0.f, 0.f, 0.f, 0.f};          // waves 0 .. 3: the residual stream of the row (f32 of the bf16 values), 4 columns per lane
+        if (my_live) unpack4f(*reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.x0) + (row0 + my_row) * XD + 4 * lane), resid);
+        if (b == xcd) {
+            // layer 0's weights into this XCD's L2 (every CU takes a 32nd); later layers are fetched by the idle CUs one phase ahead
+            const toist_xdec_layer& l0 = p.layer[0];
+            const int idx = slot * XNT + tid, n = XWG * XNT;
+            touched ^= l2_touch(l0.w_os, XD * XD * 2, idx, n) ^ l2_touch(l0.w_q, XD * XD * 2, idx, n) ^ l2_touch(l0.w_oc, XD * XD * 2, idx, n) ^
+                       l2_touch(l0.w1, (size_t)XFF * XD * 2, idx, n) ^ l2_touch(l0.w2, (size_t)XFF * XD * 2, idx, n);
         }
         __syncthreads();
 
         for (int layer = 0; layer < p.L; ++layer) {
             // per-lane offsets are re-derived in every layer: hoisted out of the loop they are a few hundred live registers (128 spills)
-            asm volatile("" : "+v"(tid));
-            lane = tid & 63;
-            const int g = lane >> 4, c16 = lane & 15;
+            // (and again at the head of every phase: XD_REDERIVE)
+            int g, c16;
+#define XD_REDERIVE()                   \
+    do {                                \
+        asm volatile("" : "+v"(tid));   \
+        lane = tid & 63;                \
+        g = lane >> 4;                  \
+        c16 = lane & 15;                \
+    } while (0)
+            XD_REDERIVE();
             const toist_xdec_layer& ly = p.layer[layer];
             const size_t lrow = (size_t)layer * M + row0;        // row offset of (layer, image) in the stacked outputs
             const bf16_t* const x_img = layer == 0 ? reinterpret_cast<const bf16_t*>(p.x0) + row0 * XD : reinterpret_cast<const bf16_t*>(p.y4) + (lrow - M) * XD;
             const bf16_t* const xe_img = layer == 0 ? reinterpret_cast<const bf16_t*>(p.qpos) + row0 * XD : reinterpret_cast<const bf16_t*>(p.y4e) + (lrow - M) * XD;
             bf16_t* const qkv_img = reinterpret_cast<bf16_t*>(p.qkv) + lrow * (3 * XD);
+            const bf16_t* const qpos_img = reinterpret_cast<const bf16_t*>(p.qpos) + row0 * XD;
+            const bool last = layer + 1 == p.L;
 
-            // ================= P1: q | k | v column tiles: CU `slot` computes 16-column tiles slot and slot + 32, wave = 16-row tile =================
+            const int wgid = xcd * XWG + slot;
+            xstamp(p.prof, wgid, p.L, layer, 0);
+            // ================= P1: q | k | v column tiles (16 columns each): CUs 0 .. 15 compute tiles slot and slot + 16 (q, k: both read x + query_pos,
+            // one set of A fragments), CUs 16 .. 31 tile slot + 16 (v: reads x); wave = 16-row tile =================
             if (wave < MT) {
                 const int mrow = wave * 16 + c16;
                 const unsigned aoff = mrow < Q ? (unsigned)((mrow * XD + 16 * g) * 2) : XOOB;
                 const rsrc_t rsW = mkrs(ly.w_in);
-                for (int nt = slot; nt < 48; nt += XWG) {
-                    const rsrc_t rsA = mkrs(nt < 32 ? xe_img : x_img);        // q, k from x + query_pos; v from x
-                    const unsigned woff = (unsigned)(((nt * 16 + c16) * XD + 16 * g) * 2);
-                    bf16x8_t af[8], wf[8];
-                    if (layer == 0) {
+                const bool two = slot < 16;
+                const rsrc_t rsA = mkrs(two ? xe_img : x_img);
+                const int nt0 = two ? slot : slot + 16, nt1 = slot + 16;
+                bf16x8_t af[8], wf[8], wf2[8];
+                const unsigned woff = (unsigned)(((nt0 * 16 + c16) * XD + 16 * g) * 2), woff2 = (unsigned)(((nt1 * 16 + c16) * XD + 16 * g) * 2);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) af[i] = ld16<false>(rsA, aoff + (unsigned)((64 * (i >> 1) + 8 * (i & 1)) * 2));
-                    } else {
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned ko = (unsigned)((64 * (i >> 1) + 8 * (i & 1)) * 2);
+                    af[i] = layer == 0 ? ld16<false>(rsA, aoff + ko) : ld16<true>(rsA, aoff + ko);
+                    wf[i] = ld16<false>(rsW, woff + ko);
+                    wf2[i] = ld16<false>(rsW, two ? woff2 + ko : XOOB);
+                }
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) af[i] = ld16<true>(rsA, aoff + (unsigned)((64 * (i >> 1) + 8 * (i & 1)) * 2));
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) wf[i] = ld16<false>(rsW, woff + (unsigned)((64 * (i >> 1) + 8 * (i & 1)) * 2));
-                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[i], acc, 0, 0, 0);   // [n = 4 g + r][m = c16]
-                    const float4 bb = *reinterpret_cast<const float4*>(ly.b_in + nt * 16 + 4 * g);
-                    if (mrow < Q)
-                        *reinterpret_cast<uint2*>(qkv_img + (size_t)mrow * (3 * XD) + nt * 16 + 4 * g) =
-                            make_uint2(pack2bf(acc[0] + bb.x, acc[1] + bb.y), pack2bf(acc[2] + bb.z, acc[3] + bb.w));
+                for (int i = 0; i < 8; ++i) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[i], acc, 0, 0, 0);       // [n = 4 g + r][m = c16]
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[i], af[i], acc2, 0, 0, 0);
+                }
+                const float4 bb = *reinterpret_cast<const float4*>(ly.b_in + nt0 * 16 + 4 * g), b2 = *reinterpret_cast<const float4*>(ly.b_in + nt1 * 16 + 4 * g);
+                if (mrow < Q) {
+                    *reinterpret_cast<uint2*>(qkv_img + (size_t)mrow * (3 * XD) + nt0 * 16 + 4 * g) =
+                        make_uint2(pack2bf(acc[0] + bb.x, acc[1] + bb.y), pack2bf(acc[2] + bb.z, acc[3] + bb.w));
+                    if (two)
+                        *reinterpret_cast<uint2*>(qkv_img + (size_t)mrow * (3 * XD) + nt1 * 16 + 4 * g) =
+                            make_uint2(pack2bf(acc2[0] + b2.x, acc2[1] + b2.y), pack2bf(acc2[2] + b2.z, acc2[3] + b2.w));
                 }
             }
+            xstamp(p.prof, wgid, p.L, layer, 1);
             xcd_barrier(sy);
+            xstamp(p.prof, wgid, p.L, layer, 2);
 
             // ================= A: the row owners: self-attention, norm1, cross-attention, norm3 for rows 4 slot .. 4 slot + 3 =================
+            XD_REDERIVE();
             if (rowner) {
                 const int q0 = 4 * slot;
                 const int qi = q0 + (c16 & 3);
                 const bool qlive = qi < Q;
                 WFrag wf;
-                // queries of the self-attention: q columns of qkv (all heads) -> LDS rows
-                if (tid < 128) {
-                    const int r = tid >> 5, pc = tid & 31;
-                    const rsrc_t rsq = mkrs(qkv_img);
-                    const uint4 v = ld16u<true>(rsq, q0 + r < Q ? (unsigned)(((q0 + r) * (3 * XD) + pc * 8) * 2) : XOOB);
-                    *reinterpret_cast<uint4*>(sQ + r * XAS + pc * 8) = v;
-                }
-                __syncthreads();
+                LnPre pre;
+                f32x4_t acc[2];
                 {
                     const rsrc_t rsk = mkrs(qkv_img);
+                    const bf16x8_t qf = ld16<true>(rsk, qlive ? (unsigned)((qi * (3 * XD) + wave * XDH + g * 8) * 2) : XOOB);
                     const unsigned long long seed = ly.seed[0] + seed_add;
                     const unsigned row = (unsigned)((b * XH + wave) * Q + (qlive ? qi : 0));
-                    attn_rows<true>(sQ, rsk, (unsigned)((XD + wave * XDH) * 2), rsk, (unsigned)((2 * XD + wave * XDH) * 2), (unsigned)(3 * XD * 2), Q, sDeadS,
-                                    sVw, wave, lane, cexp, drop_p, seed, row, qlive, sX,
-                                    reinterpret_cast<bf16_t*>(p.ctx_s) + (lrow + (qlive ? qi : 0)) * XD,
-                                    p.lse_s + ((size_t)layer * p.B * XH * Q + (size_t)row) * 2);
+                    attn_rows<true>(qf, rsk, (unsigned)((XD + wave * XDH) * 2), rsk, (unsigned)((2 * XD + wave * XDH) * 2), (unsigned)(3 * XD * 2), Q, sDeadS, sVw, wave,
+                                    lane, cexp, drop_p, seed, row, qlive, sX, reinterpret_cast<bf16_t*>(p.ctx_s) + (lrow + (qlive ? qi : 0)) * XD,
+                                    p.lse_s + ((size_t)layer * p.B * XH * Q + (size_t)row) * 2, [&]() {
+                                        // behind the K / V requests: norm1's operands, then the out-projection weights (they stream during the softmax)
+                                        if (wave < 4) pre = ln_prefetch(ly.b_os, ly.g1, ly.be1, my_live ? qpos_img + (size_t)my_row * XD : nullptr, lane);
+                                        wload(wf, ly.w_os, wave, c16, g);
+                                    });
                 }
-                wload(wf, ly.w_os, wave, c16, g);
+                xstamp(p.prof, wgid, p.L, layer, 8);
                 __syncthreads();                                   // sX complete (all heads)
-                f32x4_t acc[2];
+                xstamp(p.prof, wgid, p.L, layer, 9);
                 rgemm(wf, sX, c16, g, acc);
                 acc_to_lds(acc, sC, wave, c16, g);
-                wload(wf, ly.w_q, wave, c16, g);                    // streams while wave 0 normalises
                 __syncthreads();
-                if (wave == 0) {
-                    LnArgs a{ly.b_os, ly.g1, ly.be1, reinterpret_cast<const bf16_t*>(p.qpos) + row0 * XD,
-                             reinterpret_cast<bf16_t*>(p.z1) + lrow * XD, reinterpret_cast<bf16_t*>(p.y1) + lrow * XD, reinterpret_cast<bf16_t*>(p.y1e) + lrow * XD,
-                             p.mean1 + lrow, p.rstd1 + lrow, sY, ly.seed[1] + seed_add, drop_p, p.eps};
-                    ln_rows(sC, a, resid, lane, my_row, my_live, row0 + my_row);
+                if (wave < 4) {
+                    const LnOut o{reinterpret_cast<bf16_t*>(p.z1) + (lrow + my_row) * XD, reinterpret_cast<bf16_t*>(p.y1) + (lrow + my_row) * XD,
+                                  reinterpret_cast<bf16_t*>(p.y1e) + (lrow + my_row) * XD, p.mean1 + lrow + my_row, p.rstd1 + lrow + my_row, sY + wave * XAS};
+                    ln_row(sC + wave * XCS, pre, resid, ly.seed[1] + seed_add, drop_p, p.eps, row0 + my_row, my_live, true, o, lane);
+                    pre = ln_prefetch(ly.b_oc, ly.g3, ly.be3, nullptr, lane);        // norm3's operands: ahead of the next weight streams
                 }
+                wload(wf, ly.w_q, wave, c16, g);
                 __syncthreads();                                   // sY = norm1 output + query_pos
+                xstamp(p.prof, wgid, p.L, layer, 10);
                 rgemm(wf, sY, c16, g, acc);
                 acc_to_lds(acc, sC, wave, c16, g);
                 __syncthreads();
@@ -536,28 +565,42 @@ __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) 
                     if (q0 + r < Q) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.qc) + (lrow + q0 + r) * XD + pc * 8) = o;
                 }
                 __syncthreads();
+                xstamp(p.prof, wgid, p.L, layer, 11);
+                XD_REDERIVE();
                 {
                     const bf16_t* kv_img = reinterpret_cast<const bf16_t*>(p.kv) + (size_t)b * S * p.ldkv;
                     const rsrc_t rsk = mkrs(kv_img);
+                    const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(sQ + (c16 & 3) * XAS + wave * XDH + g * 8);
                     const unsigned long long seed = ly.seed[2] + seed_add;
                     const unsigned row = (unsigned)((b * XH + wave) * Q + (qlive ? qi : 0));
-                    attn_rows<false>(sQ, rsk, (unsigned)((layer * 2 * XD + wave * XDH) * 2), rsk, (unsigned)((layer * 2 * XD + XD + wave * XDH) * 2),
+                    attn_rows<false>(qf, rsk, (unsigned)((layer * 2 * XD + wave * XDH) * 2), rsk, (unsigned)((layer * 2 * XD + XD + wave * XDH) * 2),
                                      (unsigned)(p.ldkv * 2), S, sDeadC, sVw, wave, lane, cexp, drop_p, seed, row, qlive, sX,
                                      reinterpret_cast<bf16_t*>(p.ctx_c) + (lrow + (qlive ? qi : 0)) * XD,
-                                     p.lse_c + ((size_t)layer * p.B * XH * Q + (size_t)row) * 2);
+                                     p.lse_c + ((size_t)layer * p.B * XH * Q + (size_t)row) * 2, [&]() { wload(wf, ly.w_oc, wave, c16, g); });
                 }
-                wload(wf, ly.w_oc, wave, c16, g);
+                xstamp(p.prof, wgid, p.L, layer, 12);
                 __syncthreads();
+                xstamp(p.prof, wgid, p.L, layer, 13);
                 rgemm(wf, sX, c16, g, acc);
                 acc_to_lds(acc, sC, wave, c16, g);
                 __syncthreads();
-                if (wave == 0) {
-                    LnArgs a{ly.b_oc, ly.g3, ly.be3, nullptr,
-                             reinterpret_cast<bf16_t*>(p.z3) + lrow * XD, reinterpret_cast<bf16_t*>(p.y3) + lrow * XD, nullptr,
-                             p.mean3 + lrow, p.rstd3 + lrow, nullptr, ly.seed[3] + seed_add, drop_p, p.eps};
-                    ln_rows(sC, a, resid, lane, my_row, my_live, row0 + my_row);
+                if (wave < 4) {
+                    const LnOut o{reinterpret_cast<bf16_t*>(p.z3) + (lrow + my_row) * XD, reinterpret_cast<bf16_t*>(p.y3) + (lrow + my_row) * XD, nullptr,
+                                  p.mean3 + lrow + my_row, p.rstd3 + lrow + my_row, nullptr};
+                    ln_row(sC + wave * XCS, pre, resid, ly.seed[3] + seed_add, drop_p, p.eps, row0 + my_row, my_live, false, o, lane);
+                }
+            } else {
+                // idle CUs: this layer's FFN weights and the next layer's projections into the L2, a phase ahead of their readers
+                const int idx = (slot - RB) * XNT + tid, n = n_idle * XNT;
+                if (layer > 0) touched ^= l2_touch(ly.w1, (size_t)XFF * XD * 2, idx, n) ^ l2_touch(ly.w2, (size_t)XFF * XD * 2, idx, n);
+                if (!last) {
+                    const toist_xdec_layer& nx = p.layer[layer + 1];
+                    touched ^= l2_touch(nx.w_in, 3 * XD * XD * 2, idx, n) ^ l2_touch(nx.w_os, XD * XD * 2, idx, n) ^ l2_touch(nx.w_q, XD * XD * 2, idx, n) ^
+                               l2_touch(nx.w_oc, XD * XD * 2, idx, n);
                 }
             }
+            xstamp(p.prof, wgid, p.L, layer, 3);
+            XD_REDERIVE();
             // this CU's slices of linear1 / linear2 -> LDS (requested before the barrier, they land while the group gathers)
             {
                 uint4 w1v[4], w2v[4];
@@ -577,8 +620,12 @@ __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) 
                 }
             }
             __syncthreads();
+            xstamp(p.prof, wgid, p.L, layer, 4);
 
             // ================= P6: hidden units 64 slot .. 64 slot + 63: h = dropout(relu(y3 W1^T + b1)), partial sums of linear2 =================
+            XD_REDERIVE();
+            LnPre pre4;
+            if (my_live) pre4 = ln_prefetch(ly.b2, ly.g4, ly.be4, last ? nullptr : qpos_img + (size_t)my_row * XD, lane);       // norm4's operands, a phase early
             if (wave < MT) {
                 const int mrow = wave * 16 + c16;
                 const bool mlive = mrow < Q;
@@ -634,9 +681,12 @@ __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) 
                             make_uint4(pack2bf(o[0][0], o[0][1]), pack2bf(o[0][2], o[0][3]), pack2bf(o[1][0], o[1][1]), pack2bf(o[1][2], o[1][3]));
                 }
             }
+            xstamp(p.prof, wgid, p.L, layer, 5);
             xcd_barrier(sy);
+            xstamp(p.prof, wgid, p.L, layer, 6);
 
             // ================= P7: the row owners add the 32 partial sums: + bias, dropout, residual, norm4 =================
+            XD_REDERIVE();
             if (rowner) {
                 {
                     const rsrc_t rsp = mkrs(reinterpret_cast<const bf16_t*>(p.part) + (size_t)b * XWG * XPR * XD);
@@ -669,31 +719,25 @@ __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) 
                     }
                 }
                 __syncthreads();
-                if (wave == 0) {
-                    const int r = lane >> 4, pl = lane & 15;
+                if (wave < 4) {                                     // wave = row: the eight waves' sums in a fixed order, then the row epilogue
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int w = 0; w < 8; ++w) {
-                            const float* src = sRed + (w * 4 + r) * XD + (pl + 16 * hh) * 8;
-                            const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
-                            t[0] += lo.x; t[1] += lo.y; t[2] += lo.z; t[3] += lo.w; t[4] += hi.x; t[5] += hi.y; t[6] += hi.z; t[7] += hi.w;
-                        }
-                        float* dst = sC + r * XCS + (pl + 16 * hh) * 8;
-                        *reinterpret_cast<float4*>(dst) = make_float4(t[0], t[1], t[2], t[3]);
-                        *reinterpret_cast<float4*>(dst + 4) = make_float4(t[4], t[5], t[6], t[7]);
+                    for (int w = 0; w < 8; ++w) {
+                        const float4 s4 = *reinterpret_cast<const float4*>(sRed + (w * 4 + wave) * XD + 4 * lane);
+                        t.x += s4.x; t.y += s4.y; t.z += s4.z; t.w += s4.w;
                     }
-                    const bool last = layer + 1 == p.L;
-                    LnArgs a{ly.b2, ly.g4, ly.be4, last ? nullptr : reinterpret_cast<const bf16_t*>(p.qpos) + row0 * XD,
-                             reinterpret_cast<bf16_t*>(p.z4) + lrow * XD, reinterpret_cast<bf16_t*>(p.y4) + lrow * XD,
-                             last ? nullptr : reinterpret_cast<bf16_t*>(p.y4e) + lrow * XD, p.mean4 + lrow, p.rstd4 + lrow, nullptr, ly.seed[5] + seed_add, drop_p, p.eps};
-                    ln_rows(sC, a, resid, lane, my_row, my_live, row0 + my_row);
+                    *reinterpret_cast<float4*>(sC + wave * XCS + 4 * lane) = t;      // (same lane reads it back: no barrier needed)
+                    const LnOut o{reinterpret_cast<bf16_t*>(p.z4) + (lrow + my_row) * XD, reinterpret_cast<bf16_t*>(p.y4) + (lrow + my_row) * XD,
+                                  last ? nullptr : reinterpret_cast<bf16_t*>(p.y4e) + (lrow + my_row) * XD, p.mean4 + lrow + my_row, p.rstd4 + lrow + my_row, nullptr};
+                    ln_row(sC + wave * XCS, pre4, resid, ly.seed[5] + seed_add, drop_p, p.eps, row0 + my_row, my_live, !last, o, lane);
                 }
             }
+            xstamp(p.prof, wgid, p.L, layer, 7);
             if (layer + 1 < p.L || b + 8 < p.B) xcd_barrier(sy);
+#undef XD_REDERIVE
         }
     }
+    if (touched == 0x9E3779B9u) __hip_atomic_store(p.ctl + 1000, touched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // keeps the L2 touches alive
 }
 
 }  // namespace toist

@@ -212,8 +212,11 @@ class ClusterCriterion(nn.Module):
                     self.update_count[t] += n
                     count[t] += n
             else:   # replace the entries closest (L1) to the new features: one LSAP on the device
-                (rows, cols), = linear_sum_assignment_batch([torch.cdist(new, bank, p=1)], defer_status=True)
-                bank[cols] = new[rows]
+                # SciPy raises on an invalid matrix (mdetr.py:100) BEFORE the bank is touched.  The status check here is deferred (no host
+                # sync per step), so the write itself is gated on the device: an invalid / infeasible problem leaves the bank as it was
+                # and the ValueError surfaces at the next deferred check (or state_dict() / check_lsap_pending()).
+                ((rows, cols),), status = linear_sum_assignment_batch([torch.cdist(new, bank, p=1)], defer_status=True, with_status=True)
+                bank[cols] = torch.where(status[0] == 0, new[rows], bank[cols])
 
     # ---- device path: every sample of the batch in ONE launch, no host read (csrc/kmeans.hip) -------------------------------
     _INDEX_TABLES = {}
@@ -258,6 +261,11 @@ class ClusterCriterion(nn.Module):
             m = self.__dict__["_full_mirror"] = [bool(v) for v in self.full_label.detach().cpu().tolist()]
             self.__dict__["_count_mirror"] = [float(v) for v in self.update_count.detach().cpu().tolist()]
         return m
+
+    def state_dict(self, *a, **kw):
+        from .matcher import check_lsap_pending
+        check_lsap_pending()        # a deferred LSAP error of the bank update (invalid cost matrix) must not be saved silently
+        return super().state_dict(*a, **kw)
 
     def sync_host_state(self):
         self.__dict__.pop("_full_mirror", None)

@@ -717,6 +717,7 @@ ROW_PLAIN, ROW_LN_FWD, ROW_LN_BWD = _lib.ROW_PLAIN, _lib.ROW_LN_FWD, _lib.ROW_LN
 
 
 # ---- XCD-resident decoder stack (csrc/xdec.hip) ------------------------------------------------------------------------------------------
+XDEC_PROF = None
 _XDEC_CTL = {}      # (device, stream) -> int32[1024] control words (tickets, arrival counters, sticky status)
 
 
@@ -750,6 +751,7 @@ def xdec_fwd(B, Q, S, x0, qpos, kv, key_pad, drop_p, eps, out, layers, part):
             raise RuntimeError("toist_amd.kernels.xdec_fwd: run one eager step on this stream before capturing (the control words are allocated on first use)")
         ctl = _XDEC_CTL[key] = torch.zeros(_lib.XDEC_CTL_WORDS, dtype=torch.int32, device=x0.device)
     d.ctl = ctl.data_ptr()
+    d.prof = XDEC_PROF.data_ptr() if XDEC_PROF is not None else None      # diagnostics (tools/r5/xdec_bench.py): int64 [256, L, 8]
     for i, ly in enumerate(layers):
         e = d.layer[i]
         for name in ("w_in", "w_os", "w_q", "w_oc", "w1", "w2"):

@@ -274,7 +274,7 @@ def lsap_blocks(cost, shapes, offsets, ld):
     return ri, ci, out_off, pairs, status
 
 
-def linear_sum_assignment_batch(costs, defer_status=False):
+def linear_sum_assignment_batch(costs, defer_status=False, with_status=False):
     """scipy.optimize.linear_sum_assignment for a list of 2-D fp32 device cost matrices, solved in one launch of the
     HIP LSAP kernel (csrc/matcher.hip).  Returns a list of (row_ind, col_ind) int64 device tensors (rows ascending, as
     SciPy returns them).  Raises ValueError on NaN / -inf entries or an infeasible matrix, like SciPy."""
@@ -285,4 +285,5 @@ def linear_sum_assignment_batch(costs, defer_status=False):
     flat = torch.cat([c.reshape(-1).float() for c in costs]) if sum(sizes) else torch.zeros(1, device=costs[0].device)
     ri, ci, out_off, pairs, status = lsap_blocks(flat.contiguous(), shapes, [sum(sizes[:i]) for i in range(len(sizes))], 0)
     check_lsap_status(status, defer=defer_status)
-    return [(ri[o:o + n], ci[o:o + n]) for o, n in zip(out_off, pairs)]
+    res = [(ri[o:o + n], ci[o:o + n]) for o, n in zip(out_off, pairs)]
+    return (res, status) if with_status else res      # status (int32 per problem, device): lets a deferred caller gate its writes on the device

@@ -732,7 +732,7 @@ def weighted_total(loss_dict, weight_dict):
             for i, v in key[2]:
                 host[i] = v
             w = _WEIGHT_VECTORS[key] = host.to(flat.device)
-        term = torch.dot(flat.float(), w)
+        term = (flat.float() * w).sum()        # (torch.dot would put a rocBLAS launch into the replayed step)
         total = term if total is None else total + term
         covered.update(index)
     for k_, v in loss_dict.items():

@@ -229,6 +229,11 @@ class FusedClipAdamWEMA:
 
     # ---- torch.optim-like surface ---------------------------------------------------------------------------
     def zero_grad(self, set_to_none=True):
+        # a pending late-group launch reads the gradient VALUES through the pointers kept in _late_grads: it must run before they are zeroed
+        # in place (set_to_none=False) or their storage is handed back to the allocator
+        if not set_to_none:
+            self.flush_late()           # (set_to_none=True keeps the tensors alive through _late_grads: the launch may still wait for the next text branch)
+        self._early_done = False        # partial sums of gradients that are going away
         for p in self.params:
             if set_to_none:
                 p.grad = None
@@ -308,10 +313,13 @@ class FusedClipAdamWEMA:
         # (a second backward pass before step() -- gradient accumulation -- simply sums again: the launch reads the accumulated gradients)
         if not self._early_ids or self._table is None or self._grads_last is None or self._e_hi <= self._e_lo:
             return
-        if self._copy_gen != engine.COPY_GEN and not torch.cuda.is_current_stream_capturing():
-            return                          # step() is about to rebuild the tables
         if not any(id(p) in self._early_ids for p in prog_params):
             return
+        # from here on the early parameters' gradients have just changed: sums taken by an earlier backward pass (a step() that was skipped)
+        # are stale unless this call replaces them
+        self._early_done = False
+        if self._copy_gen != engine.COPY_GEN and not torch.cuda.is_current_stream_capturing():
+            return                          # step() is about to rebuild the tables
         last = self._grads_last
         for i in self._early_idx:
             g = self.params[i].grad
@@ -326,7 +334,7 @@ class FusedClipAdamWEMA:
         nothing is pending; inside a hipGraph capture it is ALWAYS recorded, since the captured step leaves one pending for every
         replay -- the update of the step before the capture is then applied by the first replay)."""
         capturing = torch.cuda.is_current_stream_capturing()
-        if not self._n_late or not (self._late_pending or capturing):
+        if not self._n_late or not (self._late_pending or capturing) or (capturing and self._late_captured):
             return
         k.opt_adamw_ema(self._table, self._grads_dev, self._chunks[self._n_now:], self._n_late, self._groups_dev, self.state, self.betas[0],
                         self.betas[1], self.eps, self.ema_decay, max_blocks=LATE_BLOCKS)
@@ -382,6 +390,7 @@ class FusedClipAdamWEMA:
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
+        self.finish()       # a pending late update belongs to the OLD moments
         if "state" not in sd and "exp_avg" in sd:      # round-1 layout of this class
             sd = {"state": {i: {"step": sd["step"], "exp_avg": a, "exp_avg_sq": b} for i, (a, b) in enumerate(zip(sd["exp_avg"], sd["exp_avg_sq"]))},
                   "param_groups": sd.get("param_groups", [])}

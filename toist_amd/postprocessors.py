@@ -23,13 +23,8 @@ class PostProcess(nn.Module):
         boxes = box_ops.box_cxcywh_to_xyxy(out_bbox.float())
         img_h, img_w = target_sizes.unbind(1)
         boxes = boxes * torch.stack([img_w, img_h, img_w, img_h], dim=1)[:, None, :]
-        results = [{"scores": s, "labels": l, "boxes": b} for s, l, b in zip(scores, labels, boxes)]
-        if "pred_isfinal" in outputs:
-            is_final = outputs["pred_isfinal"].sigmoid()
-            refexp = scores * is_final.view_as(scores)
-            for i in range(len(results)):
-                results[i]["scores_refexp"] = refexp[i]
-        return results
+        # (the reference also forwards an MDETR "pred_isfinal" head; no TOIST model produces that key)
+        return [{"scores": s, "labels": l, "boxes": b} for s, l, b in zip(scores, labels, boxes)]
 
 
 class PostProcessSegm(nn.Module):

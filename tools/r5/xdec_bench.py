@@ -1,0 +1,80 @@
+"""Decoder forward (6 layers, B = 8, 100 queries, 416 memory tokens) as the per-op launches of toist_amd.tlayer vs the ONE XCD-resident launch of
+csrc/xdec.hip: time per forward under hipGraph replay, and the in-kernel phase stamps of the fused launch (toist_xdec_desc.prof).
+Usage (GPU box): python tools/r5/xdec_bench.py [--train]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import toist_amd  # noqa: E402
+from toist_amd import harness, tlayer  # noqa: E402
+from toist_amd import kernels as k  # noqa: E402
+from tools.bench_gemm import timeit  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--train", action="store_true")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--tokens", type=int, default=416)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    args = harness.default_args(device="cuda", contrastive_align_loss=True)
+    model, _, _, _ = toist_amd.build_model(args)
+    model.to(dev).train(a.train)
+    tr = model.transformer
+    B, S, Q, d = a.batch, a.tokens, 100, 256
+    g = torch.Generator().manual_seed(1)
+    memory = torch.randn(B * S, d, generator=g).to(dev).to(BF)
+    pos = torch.randn(B * S, d, generator=g).to(dev).to(BF)
+    key_pad = torch.zeros(B, S, dtype=torch.uint8, device=dev)
+    key_pad[:, S - 5:] = 1
+    qe = model.query_embed.weight
+    k.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def fwd():
+        with torch.no_grad():
+            return tr.decode_tokens(memory, pos, key_pad, qe, B, S)
+
+    res = {}
+    for flag in (False, True):
+        tlayer.XDEC = flag
+        tr._step = 0
+        out = fwd().float()
+        torch.cuda.synchronize()
+        res[flag] = (timeit(fwd, 10) * 1000.0, out)
+    k.xdec_check()
+    rel = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
+    print(f"decoder forward, B={B} Q={Q} S={S} train={a.train}: per-op launches {res[False][0]:.1f} us, XCD-resident launch {res[True][0]:.1f} us, outputs differ by {rel:.2e} (relative Frobenius)")
+    # phase stamps of one eager fused forward
+    L = 6
+    k.XDEC_PROF = torch.zeros(256, L, 16, dtype=torch.int64, device=dev)
+    tlayer.XDEC = True
+    fwd()
+    torch.cuda.synchronize()
+    st = k.XDEC_PROF.cpu().double() * 0.01      # us
+    k.XDEC_PROF = None
+    live = st[:, 0, 0] > 0
+    st = st[live]
+    t0 = st[:, 0, 0].min()
+    names = ["P1 q|k|v", "wait", "A rows (attn, norm1, cross, norm3)", "FFN weights + wait", "P6 hidden + linear2 partials", "wait", "P7 fold + norm4"]
+    print(f"{int(live.sum())} workgroups stamped; whole launch {float(st[:, L - 1, 7].max() - t0):.1f} us between the first P1 and the last P7 stamp")
+    own = st[:, 0, 8] > 0
+    a = st[own]
+    for layer in (0, 3):
+        ch = [("q rows + self-attention", 2, 8), ("W_os stream + sync", 8, 9), ("out_proj + norm1", 9, 10), ("query projection", 10, 11), ("cross-attention", 11, 12),
+              ("W_oc stream + sync", 12, 13), ("out_proj + norm3", 13, 3)]
+        print(f"layer {layer} phase A of the {int(own.sum())} row owners: " + " | ".join(f"{n} {float((a[:, layer, j] - a[:, layer, i]).mean()):.2f}" for n, i, j in ch))
+    for layer in range(L):
+        seg = st[:, layer, 1:8] - st[:, layer, :7]
+        row = " | ".join(f"{n} {float(seg[:, i].mean()):.2f} (max {float(seg[:, i].max()):.2f})" for i, n in enumerate(names))
+        print(f"layer {layer}: start +{float(st[:, layer, 0].min() - t0):.1f} us | {row}")
+
+
+if __name__ == "__main__":
+    main()
