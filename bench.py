@@ -391,13 +391,15 @@ def main():
     import toist_amd
     from toist_amd import harness, kernels, parallel
     from toist_amd.mdetr import weighted_total
-    # the roofline kernel = the kernel with the largest share of the step's kernel time (profiles/r02_timeline_graph_step.txt): the
-    # short-K panel kernel (csrc/gemm.hip panel_kernel, dispatcher tile code 135) -- the 1x1 convolutions of the backbone with K <= 256 and
-    # their data gradients, 81 launches per step.  ~100 flop per algorithmic byte, below the ridge (2500 TFLOP/s / 8 TB/s = 312): HBM-bound.
+    # Three GEMM kernel families are timed launch by launch (HIP events on the launch stream) -- together ~50 % of the step's kernel time:
+    #   tile code 65   gemm_kernel<64,64,64,...>: the generic 64 x 64 tile -- the transformer's and the text encoder's linears, their data and weight
+    #                  gradients, small convolutions (15 template instantiations; the largest family by summed time in round 4, untimed until round 5)
+    #   tile code 135  panel2_kernel: 1x1 convolutions / linears with K <= 256 and their data gradients (HBM-bound: ~100 flop per algorithmic byte,
+    #                  below the ridge 2500 TFLOP/s / 8 TB/s = 312)
+    #   tile code 136  gemm128_kernel: 3x3 convolutions of ResNet layers 2-4, their data gradients, 1x1 / linear launches with K >= 768
+    # `roofline` = the family with the largest summed time in THIS run.
     global ROOFLINE_KEYS
-    ROOFLINE_KEYS = frozenset({(135, kernels.A_ROWK, kernels.B_ROWK), (135, kernels.A_ROWK, kernels.B_KROW),       # hbm: the short-K panel kernel
-                               (136, kernels.A_CONV, kernels.B_ROWK), (136, kernels.A_CONVT, kernels.B_KROW),      # mfma: gemm128_kernel, 3x3 gathers ...
-                               (136, kernels.A_ROWK, kernels.B_ROWK), (136, kernels.A_ROWK, kernels.B_KROW)})      # ... and its deep-K 1x1 / linear launches
+    ROOFLINE_KEYS = lambda key: key[0] in (65, 135, 136)
     if a.distill:
         return bench_distillation(a, dev, rank, world)
     if a.mixed_sizes:
@@ -796,16 +798,21 @@ def main():
                 res["config"]["parameters_differing"] = {"count": len(params_differing), "first": params_differing[:12]}
             res["config"]["gradient_wire_dtype"] = "bf16" if a.bf16_grads else "f32"
         if prof is not None and prof["records"] and prof["key"] is not None:
-            # Two kernel families are timed launch by launch (HIP events on the launch stream, the eager steps): the short-K panel kernel
-            # (tile code 135, HBM-bound) and gemm128_kernel (tile code 136: the 3x3 convolutions of layers 2-4, their data gradients and the
-            # deep 1x1 launches, MFMA-bound).  `roofline` is the family with the LARGER share of the step's kernel time in THIS run; the
-            # other one is reported under its own name.  Both carry `traffic` from one pair of rocprofv3 PMC passes.
-            fams = {"hbm": [r for r in prof["records"] if r[3][0] == 135], "mfma": [r for r in prof["records"] if r[3][0] == 136]}
+            # Three kernel families are timed launch by launch (HIP events on the launch stream, the eager steps): the generic 64 x 64 tile
+            # (tile code 65), the short-K panel kernel (135, HBM-bound) and gemm128_kernel (136, MFMA-bound).  `roofline` is the family with the
+            # LARGEST share of the step's kernel time in THIS run; each one is also reported under its own name, with `traffic` from one pair
+            # of rocprofv3 PMC passes.
+            FAMS = {"generic": (65, ("gemm_kernel<64, 64, 64",)), "hbm": (135, ("panel_kernel", "panel2_kernel")),
+                    "mfma": (136, ("gemm128_kernel",))}
+            fams = {fam: [r for r in prof["records"] if r[3][0] == code] for fam, (code, _) in FAMS.items()}
             pmc, why = {}, "PMC passes skipped (--no-pmc / N > 1)"
             if world == 1 and not a.no_pmc:
-                pmc, why = pmc_traffic_live({"hbm": ("panel_kernel", "panel2_kernel"), "mfma": ("gemm128_kernel",)})
+                pmc, why = pmc_traffic_live({fam: subs for fam, (_, subs) in FAMS.items()})
             pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            pname = next((n_ for n_ in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(pdir, n_))), None)
+            pname = next((n_ for n_ in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(pdir, n_))), None)
+            KERNEL_TEXT = {"generic": "gemm_kernel<64,64,64,A kind,B kind,ring slots,lean epilogue> (tile code 65: the generic 64x64x64 tile -- linears of the cross-modal transformer and of RoBERTa, their data and weight gradients, small convolutions)",
+                           "hbm": "panel2_kernel<{B_ROWK,B_KROW},act,BM> (tile code 135: 1x1 convolutions / linears with K <= 256 and their data gradients)",
+                           "mfma": "gemm128_kernel<A kind, B kind, NS> (tile code 136: 3x3 convolutions of ResNet layers 2-4, their data gradients, 1x1 / linear launches with K >= 768; 128x128 tiles, 64x64 wave tiles)"}
             entries, fam_ms = {}, {}
             for fam, recs in fams.items():
                 if not recs:
@@ -814,7 +821,7 @@ def main():
                 fl, nb, n = sum(r[2] for r in recs), sum(r[5] for r in recs), len(recs)
                 fam_ms[fam] = ms / a.steps
                 tfl, gbs = fl / (ms * 1e-3) / 1e12, nb / (ms * 1e-3) / 1e9
-                subs = ("panel_kernel", "panel2_kernel") if fam == "hbm" else ("gemm128_kernel",)
+                subs = FAMS[fam][1]
                 traffic, traffic_src = None, None
                 if fam in pmc:
                     traffic = pmc[fam][0]
@@ -832,19 +839,20 @@ def main():
                           "algorithmic_bytes_per_launch": round(nb / n), "launches": n, "launches_per_step": n // a.steps, "ms_per_step": round(ms / a.steps, 3),
                           "avg_launch_us": round(1000 * ms / n, 2), "avg_gflop_per_launch": round(fl / n / 1e9, 3),
                           "timed": "HIP events around each launch, %d eager steps %s" % (a.steps, "after the graph-replayed timed region" if use_graph else "inside the timed region")}
-                if fam == "hbm":
+                # which roofline bounds the family: flop per algorithmic byte against the ridge (dense bf16 MFMA peak / HBM peak = 312)
+                bound = "hbm" if fam == "hbm" or (fam == "generic" and fl / max(nb, 1) < PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS) else "mfma"
+                if bound == "hbm":
                     entries[fam] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 5),
-                                    "kernel": "panel2_kernel<{B_ROWK,B_KROW},act,BM> (tile code 135: 1x1 convolutions / linears with K <= 256 and their data gradients)",
-                                    "tflops": round(tfl, 2), "mfma_frac": round(tfl / PEAK_BF16_TFLOPS, 5)}
+                                    "kernel": KERNEL_TEXT[fam], "tflops": round(tfl, 2), "mfma_frac": round(tfl / PEAK_BF16_TFLOPS, 5), "flop_per_byte": round(fl / max(nb, 1), 1)}
                 else:
                     entries[fam] = {"bound": "mfma", "achieved": round(tfl, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / PEAK_BF16_TFLOPS, 5),
-                                    "kernel": "gemm128_kernel<A kind, B kind, NS> (tile code 136: 3x3 convolutions of ResNet layers 2-4, their data gradients, 1x1 / linear launches with K >= 768; 128x128 tiles, 64x64 wave tiles)",
-                                    "algorithmic_gbs": round(gbs, 1)}
+                                    "kernel": KERNEL_TEXT[fam], "algorithmic_gbs": round(gbs, 1), "flop_per_byte": round(fl / max(nb, 1), 1)}
                 entries[fam].update(common)
             if entries:
+                NAME = {"generic": "gemm_kernel<64,64,64>", "hbm": "panel2_kernel", "mfma": "gemm128_kernel"}
                 top = max(fam_ms, key=fam_ms.get)
-                res["roofline"] = dict(entries[top], why_this_kernel="largest share of the step's kernel time among the timed families in this run: " +
-                                       ", ".join("%s %.2f ms/step" % (("panel2_kernel" if f_ == "hbm" else "gemm128_kernel"), v) for f_, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])))
+                res["roofline"] = dict(entries[top], why_this_kernel="largest summed time per step among the three timed GEMM families in this run: " +
+                                       ", ".join("%s %.2f ms/step" % (NAME[f_], v) for f_, v in sorted(fam_ms.items(), key=lambda kv: -kv[1])))
                 for fam, ent in entries.items():
                     res["roofline_" + fam] = ent
         elif prof is not None and prof["records"]:

@@ -168,6 +168,48 @@ def _ddp_worker(rank, world, port, out):
     g4 = grads(m4)
     res["unused_on_one_rank"] = "extra" in g4 and torch.allclose(g4["extra"], torch.tensor([0.5, 1.0, 1.5])) and \
         close({k: v for k, v in g4.items() if k != "extra"}, want)
+    # 6. the same gradient in a flat program buffer on rank 0 and stand-alone on rank 1 (the ranks ran different schedules): EVERY rank raises
+    # (round 3 / 4: rank 0 skipped the stand-alone reduction rank 1 entered -- a hang)
+    w = torch.nn.Parameter(torch.ones(4))
+    holder = torch.nn.Module()
+    holder.register_parameter("w", w)
+    flat = torch.full((4,), float(rank + 1))
+    w.grad = flat if rank == 0 else torch.full((4,), 5.0)
+    sync6 = parallel.GradSync(holder)
+    sync6._launch(flat)                      # both ranks issue the flat collective; only rank 0's covers w.grad
+    try:
+        sync6.finish()
+        res["conflict_raises_everywhere"] = False
+    except RuntimeError as e:
+        res["conflict_raises_everywhere"] = "flat program buffer" in str(e)
+    dist.barrier()
+    # 7. static_set=True: the agreement of the first step is kept -- the second finish() issues no agreement collective
+    torch.manual_seed(0)
+    m7 = _Toy()
+    extra7 = torch.nn.Parameter(torch.ones(3))
+    m7.register_parameter("extra", extra7)
+    sync7 = parallel.GradSync(m7, static_set=True)
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **kw):
+        calls.append(tuple(t.shape))
+        return real(t, *a, **kw)
+
+    counts = []
+    for step in range(2):
+        m7.zero_grad(set_to_none=True)
+        calls.clear()
+        dist.all_reduce = counting
+        try:
+            with sync7:
+                (m7(xs[rank]) + (extra7 * torch.tensor([1.0, 2.0, 3.0])).sum()).backward()
+                sync7.finish()
+        finally:
+            dist.all_reduce = real
+        counts.append(sum(1 for sh in calls if len(sh) == 2 and sh[1] == 3))        # the [n_params, 3] one-hot agreement
+    g7 = grads(m7)
+    res["static_set"] = counts == [1, 0] and torch.allclose(g7["extra"], torch.tensor([1.0, 2.0, 3.0])) and close({k: v for k, v in g7.items() if k != "extra"}, want)
     out[rank] = res
     dist.barrier()
     dist.destroy_process_group()
@@ -179,4 +221,5 @@ def test_ddp_wrapping_delivers_averaged_gradients():
     out = mgr.dict()
     mp.spawn(_ddp_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     for r in range(world):
-        assert out[r] == {"torch_ddp": True, "toist_ddp": True, "no_sync_local": True, "gradsync": True, "accumulate": True, "unused_on_one_rank": True}, out[r]
+        assert out[r] == {"torch_ddp": True, "toist_ddp": True, "no_sync_local": True, "gradsync": True, "accumulate": True, "unused_on_one_rank": True,
+                          "conflict_raises_everywhere": True, "static_set": True}, out[r]

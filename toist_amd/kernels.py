@@ -22,7 +22,7 @@ __all__ = [
 ]
 
 
-# bench.py sets this to {"key": (tile, a_kind, b_kind) | None, "records": [], "other": {}} to time GEMM
+# bench.py sets this to {"key": (tile, a_kind, b_kind) | set of such | predicate(key) | None, "records": [], "other": {}} to time GEMM
 # launches with HIP events on the launch stream (roofline accounting); None = no instrumentation.
 PROFILE = None
 # Optional int64[1] device tensor added to every dropout seed inside the kernels.  A training loop that
@@ -315,7 +315,7 @@ def gemm(M, N, K, a_kind, a, b_kind, b, c, ldc, *, batch=1, batch_inner=1, cs_ou
     t = int(_lib.lib().toist_gemm_pick_tile(ctypes.byref(d)))
     key = (t, a_kind, b_kind)
     want = prof["key"]
-    if want is not None and key != want and not (isinstance(want, (set, frozenset)) and key in want):
+    if want is not None and not (want(key) if callable(want) else (key == want or (isinstance(want, (set, frozenset)) and key in want))):
         _lib.check(_lib.lib().toist_gemm_bf16(ctypes.byref(d), _stream()), "toist_gemm_bf16")
         prof["other"][key] = prof["other"].get(key, 0) + flops
         return

@@ -18,9 +18,18 @@ class GradSync:
     its backward has finished; finish() joins them and then reduces whatever the flat buffers did not cover: parameters
     differentiated by plain autograd, and programs that accumulated into gradients kept from an earlier backward (gradient
     accumulation: wrap only the LAST micro-step, like DDP.no_sync() around the others).  Without `model` only flat buffers are
-    reduced (the round-1 behaviour)."""
+    reduced (the round-1 behaviour).
 
-    def __init__(self, model=None, process_group=None):
+    Which stand-alone gradients exist may differ between ranks (a conditionally used module, an empty micro-batch: the reference wraps
+    its model with find_unused_parameters=True, main.py:335-337).  Every rank must nevertheless issue the same collectives, so the ranks
+    agree on the set first: one small SUM all-reduce of per-parameter one-hot counts (no gradient | in a flat buffer | stand-alone).
+      * stand-alone on any rank           -> every rank reduces it stand-alone (a rank without a gradient contributes zeros)
+      * flat on one rank, stand-alone on another -> RuntimeError on EVERY rank (the flat buffer has already been averaged with a slot that
+        does not hold the other rank's gradient; all ranks see the same counts, so none is left waiting in a collective)
+    static_set=True: the agreement of the first finish() is kept -- no collective and no host read in later steps; a rank whose own
+    states change raises.  Use it when every rank runs the same programs every step (the training loop of engine.py:54-101)."""
+
+    def __init__(self, model=None, process_group=None, static_set=False):
         if model is not None and not isinstance(model, (torch.nn.Module, list, tuple)):      # GradSync(process_group) of round 1
             model, process_group = None, model
         self.models = [] if model is None else (list(model) if isinstance(model, (list, tuple)) else [model])
@@ -28,6 +37,8 @@ class GradSync:
         self.pending = []
         self.ranges = []
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.static_set = static_set
+        self._agreed = None          # (local states, indices of the parameters every rank reduces stand-alone)
 
     def __enter__(self):
         if self.world > 1:
@@ -46,6 +57,39 @@ class GradSync:
         self.pending.append((work, flat, op))
         self.ranges.append((flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()))
 
+    def _local_states(self, params):
+        state = []
+        for p in params:
+            g = p.grad
+            if g is None:
+                state.append(0)
+            else:
+                a = g.data_ptr()
+                state.append(1 if any(lo <= a < hi for lo, hi in self.ranges) else 2)
+        return state
+
+    def _agree(self, params, state):
+        """indices of the parameters that every rank reduces stand-alone; raises on every rank for a flat / stand-alone conflict"""
+        if self.static_set and self._agreed is not None:
+            if self._agreed[0] != state:
+                raise RuntimeError("GradSync(static_set=True): this rank's gradient states changed since the first step; use the default (agreement every step)")
+            return self._agreed[1]
+        dev = next((p.grad.device for p in params if p.grad is not None), params[0].device)
+        onehot = torch.zeros(len(params), 3, dtype=torch.int32)
+        onehot[torch.arange(len(params)), torch.tensor(state, dtype=torch.int64)] = 1
+        counts = onehot.to(dev)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
+        counts = counts.cpu()
+        conflict = ((counts[:, 1] > 0) & (counts[:, 2] > 0)).nonzero().flatten().tolist()
+        if conflict:
+            raise RuntimeError("GradSync: %d parameter gradient(s) travelled in a flat program buffer on some ranks and stand-alone on others "
+                               "(first index %d): the ranks ran different backward schedules; zero the gradients on every rank before the step "
+                               "or accumulate on all of them" % (len(conflict), conflict[0]))
+        alone = (counts[:, 2] > 0).nonzero().flatten().tolist()
+        if self.static_set:
+            self._agreed = (list(state), alone)
+        return alone
+
     def finish(self):
         """Wait for every outstanding all-reduce, then reduce the gradients no flat buffer carried (call after loss.backward(),
         before clipping)."""
@@ -55,29 +99,16 @@ class GradSync:
                 flat.div_(self.world)
         rest = []
         if self.world > 1 and self.models:
-            # Every rank must issue the SAME sequence of collectives.  A parameter differentiated by plain autograd may have a gradient on
-            # one rank and none on another (a conditionally used module, an empty micro-batch): the ranks first agree on the set with one
-            # small MAX all-reduce of a per-parameter state (0 no gradient, 1 travelled in a flat buffer, 2 needs its own reduction),
-            # a rank without a gradient contributes zeros -- what torch DDP does under find_unused_parameters=True.
             params = [q for m in self.models for q in m.parameters() if q.requires_grad]
-            state = []
-            for p in params:
-                g = p.grad
-                if g is None:
-                    state.append(0)
-                else:
-                    a = g.data_ptr()
-                    state.append(1 if any(lo <= a < hi for lo, hi in self.ranges) else 2)
             if params:
-                dev = next((p.grad.device for p in params if p.grad is not None), params[0].device)
-                st = torch.tensor(state, dtype=torch.int32, device=dev)
-                dist.all_reduce(st, op=dist.ReduceOp.MAX, group=self.group)
-                agreed = st.tolist()
-                for p, mine, glob in zip(params, state, agreed):
-                    if glob == 2 and mine != 1:
+                try:
+                    for i in self._agree(params, self._local_states(params)):
+                        p = params[i]
                         if p.grad is None:
                             p.grad = torch.zeros_like(p)
                         rest.append(p.grad)
+                finally:
+                    self.pending, self.ranges = [], []
         if rest:
             all_reduce_mean(rest, self.group)
         self.pending, self.ranges = [], []

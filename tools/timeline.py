@@ -12,9 +12,11 @@ import sys
 
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
-    m = re.match(r"void toist::gemm_kernel<([^>]*)>", name)
+    # every template family is ONE row (its instantiations are summed), like gemm128_kernel / panel2_kernel: round 4 listed the 15 instantiations
+    # of the generic tile separately, which hid that the family was the largest of the step
+    m = re.match(r"void toist::gemm_kernel<(\d+), (\d+), (\d+),", name)
     if m:
-        return "gemm<" + m.group(1).replace(" ", "") + ">"
+        return "gemm_kernel<%s,%s,%s,...>" % m.groups()
     m = re.search(r"toist::(\w+)", name)
     if m:
         return m.group(1)
