@@ -300,6 +300,7 @@ TOIST_API int toist_l2norm_bwd(const float* x, const float* dy, int rows, int D,
  *  mask_loss: bilinear (align_corners=False) upsample of pred[pred_row[t]] [h,w] f32 to [TH,TW], sigmoid focal
  *      (alpha, gamma=2) + dice sums against gt[gt_row[t]] u8 [TH,TW] (mdetr.py:827-853, segmentation.py:276-319):
  *      sums[t] += {focal, p*t, p, t}; bwd scatters coef[0]*dfocal + coef[1]*ddice into dpred (f32 atomics).
+ *      pred_row[t] < 0 = an unused slot of a fixed-capacity pair table: skipped by both kernels (sums stay 0).
  */
 TOIST_API int toist_attnmap_softmax_fwd(const void* scores, const uint8_t* key_pad, int B, int Q, int H, int HW, int ld, void* out, void* stream);
 TOIST_API int toist_attnmap_softmax_bwd(const void* prob, const void* dprob, int BQ, int H, int HW, int ld, void* dscores, void* stream);

@@ -158,3 +158,62 @@ def test_caption_length_is_not_padded_by_default(dev):
     got = [float(cap.step(samples, tok, targets, pmap)) for _ in range(3)]          # eager first step, capture, replay
     for g in got:
         assert abs(g - want) <= 2e-3 * abs(want), (got, want)
+
+
+def test_captured_step_with_mask_losses(dev):
+    """configs[2] through CapturedTrainStep: the ground-truth masks travel in StaticTargets(mask_hw=...), the mask losses run on a
+    fixed-capacity pair table whose live slots / image indices are computed on the device (segmentation.mask_losses_static), so ONE graph serves
+    batches with different numbers of targets.  Each step is compared with the same step launched eagerly through the LIST-of-dicts criterion path
+    (segmentation.mask_losses: an independent implementation of the pair tables) from the same weights."""
+    import toist_amd
+    from toist_amd import engine, harness, kernels
+    from toist_amd.optim import FusedClipAdamWEMA
+    args = harness.default_args(device="cuda", enc_layers=1, dec_layers=2, num_queries=20, dropout=0.0, masks=True, mask_model="smallconv")
+    torch.manual_seed(0)
+    model0, criterion, _, weight_dict = toist_amd.build_model(args)
+    assert "masks" in criterion.losses
+    model0.to(dev).train()
+    det = model0.detr
+    det.transformer.text_encoder.config.hidden_dropout_prob = 0.0
+    det.transformer.text_encoder.config.attention_probs_dropout_prob = 0.0
+    criterion.train()
+    kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+    old_reuse = engine.REUSE_GRAD_BUFFERS
+
+    def opt_of(model):
+        return FusedClipAdamWEMA([{"params": [p for p in model.parameters() if p.requires_grad], "lr": 1e-4}], weight_decay=1e-4, max_norm=0.1)
+
+    try:
+        cap_model, eag_model = copy.deepcopy(model0), copy.deepcopy(model0)
+        cap = harness.CapturedTrainStep(cap_model, criterion, opt_of(cap_model), weight_dict, batch=2, max_targets_per_image=6, pad_hw=64, pad_tokens=1)
+        assert cap.masks
+        eag_opt = opt_of(eag_model)
+        cap_opt = cap.optimizer
+        # one bucket (128 x 192, 12 tokens: sides are multiples of pad_hw, so the padded batch IS the batch), 0 .. 5 targets per image
+        stream = [harness.synthetic_batch(2, 128, 192, tokens=12, seed=70 + i, max_targets=mt, with_masks=True) for i, mt in enumerate((4, 5, 0, 2, 5, 3))]
+        got, ref = [], []
+        for samples, tok, targets, pmap in stream:
+            with torch.no_grad():
+                for p_e, p_c in zip(eag_model.parameters(), cap_model.parameters()):
+                    p_e.copy_(p_c)
+                for a_e, a_c in zip(eag_opt.exp_avg + eag_opt.exp_avg_sq, cap_opt.exp_avg + cap_opt.exp_avg_sq):
+                    a_e.copy_(a_c)
+                eag_opt.state.copy_(cap_opt.state)
+            engine.bump_weight_epoch()
+            got.append(float(cap.step(samples.to(dev), tok.to(dev), targets, pmap).detach()))
+            t_dev = [{k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in t.items()} for t in targets]
+            eag_opt.zero_grad(set_to_none=True)
+            mc = eag_model(samples.to(dev), tok.to(dev), encode_and_save=True)
+            out = eag_model(samples.to(dev), tok.to(dev), encode_and_save=False, memory_cache=mc)
+            losses = criterion(mc, out, t_dev, pmap.to(dev), None)
+            assert "loss_mask" in losses and "loss_dice" in losses
+            total = toist_amd.weighted_total(losses, weight_dict)
+            total.backward()
+            eag_opt.step()
+            ref.append(float(total.detach()))
+        assert cap.captures == 1 and cap.replays == len(stream) - 1
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert abs(a - b) <= 3e-3 * abs(b) + 1e-4, (i, got, ref)
+        assert len(set(round(v, 3) for v in got)) > 3
+    finally:
+        engine.REUSE_GRAD_BUFFERS = old_reuse

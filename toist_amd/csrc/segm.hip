@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256) void mask_loss_fwd_kernel(const float* __restr
                                                              int h, int w, int TH, int TW, float alpha, float* __restrict__ sums) {
     __shared__ float red[4];
     const int t = blockIdx.y;
+    if (pred_row[t] < 0) return;          // an unused slot of a fixed-capacity pair table (matcher.StaticTargets): its sums stay 0 -> both losses 0
     const float* pm = pred + (size_t)pred_row[t] * h * w;
     const unsigned char* gm = gt + (size_t)gt_row[t] * TH * TW;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restr
                                                              const float* __restrict__ coef, float* __restrict__ dpred) {
     __shared__ float acc[MLB_SRC * MLB_SRC];
     const int t = blockIdx.y;
+    if (pred_row[t] < 0) return;          // unused slot
     const float* pm = pred + (size_t)pred_row[t] * h * w;
     float* dp = dpred + (size_t)pred_row[t] * h * w;
     const unsigned char* gm = gt + (size_t)gt_row[t] * TH * TW;

@@ -238,6 +238,11 @@ class CapturedTrainStep:
         det = getattr(model, "detr", model)
         self.num_queries = det.query_embed.weight.shape[0]
         self.contrastive = bool(getattr(det, "contrastive_align_loss", False)) if contrastive is None else bool(contrastive)
+        # configs[2]: the ground-truth masks travel in the bucket's StaticTargets, zero-padded to the bucket's (Hp, Wp) -- the reference pads them to the
+        # batch's largest image (util/misc.py:185-209) and resizes the predicted masks to that size (mdetr.py:843): with image sides that are
+        # multiples of pad_hw the two coincide; otherwise the padded margin enters the mask losses as background (targets 0), like the margin
+        # of a smaller image inside a reference batch
+        self.masks = "masks" in getattr(criterion, "losses", ())
         self._buckets = OrderedDict()          # (Hp, Wp, Lp) -> dict(graph, images, mask, ids, att, targets, loss)
         self._side = torch.cuda.Stream(device=self.device)
         if kernels.SEED_DEV is None:
@@ -264,7 +269,8 @@ class CapturedTrainStep:
         ent = {"samples": NestedTensor(torch.zeros(self.batch, 3, Hp, Wp, device=dev), torch.ones(self.batch, Hp, Wp, dtype=torch.bool, device=dev)),
                "tok": TokenizedText({"input_ids": torch.full((self.batch, Lp), pad_id, dtype=torch.int64, device=dev),
                                      "attention_mask": torch.zeros(self.batch, Lp, dtype=torch.int64, device=dev)}),
-               "targets": StaticTargets(self.batch, self.max_t, self.num_queries, 256, dev), "graph": None, "loss": None, "pad_id": pad_id}
+               "targets": StaticTargets(self.batch, self.max_t, self.num_queries, 256, dev, mask_hw=(Hp, Wp) if self.masks else None),
+               "graph": None, "loss": None, "pad_id": pad_id}
         return ent
 
     def _fill(self, ent, samples, tokenized, targets, positive_map, packed):

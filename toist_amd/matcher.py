@@ -48,8 +48,15 @@ class StaticTargets:
     Layout of the arena (bytes): boxes f32 [cap,4] | positive_map f32 [cap,K] | token masks i64 [cap,2] | tgt_off i32 [B+1] |
     match_off i32 [B+1] | num_boxes f32 [1] (local sum of targets; the world mean, clamped to >= 1, is formed on the device)."""
 
-    def __init__(self, batch, max_per_image, num_queries, K=256, device="cuda"):
+    def __init__(self, batch, max_per_image, num_queries, K=256, device="cuda", mask_hw=None):
         self.B, self.max_per_image, self.Q, self.K = batch, max_per_image, num_queries, K
+        # mask_hw = (TH, TW): the ground-truth masks of the targets travel too (uint8 [cap, TH, TW], zero-padded to the padded batch size like
+        # NestedTensor.from_tensor_list, util/misc.py:185-209) -- the mask losses of configs[2] then replay from the same graph as the detection losses
+        self.mask_hw = None if mask_hw is None else (int(mask_hw[0]), int(mask_hw[1]))
+        self.masks = self._mask_host = None
+        if self.mask_hw is not None:
+            self.masks = torch.zeros(batch * max_per_image, *self.mask_hw, dtype=torch.uint8, device=device)
+            self._mask_host = torch.zeros(batch * max_per_image, *self.mask_hw, dtype=torch.uint8).pin_memory()
         self.cap = cap = batch * max_per_image
         self.device = torch.device(device)
         sizes = [cap * 4 * 4, cap * K * 4, cap * TOKEN_MASK_WORDS * 8, (batch + 1) * 4, (batch + 1) * 4, 4]
@@ -94,14 +101,31 @@ class StaticTargets:
             acc_m += min(self.Q, sz)
             hto[i + 1], hmo[i + 1] = acc_t, acc_m
         hnb[0] = float(tot)
-        return host, sizes
+        if self.mask_hw is None:
+            return host, sizes
+        TH, TW = self.mask_hw
+        mh = self._mask_host if out is not None else torch.zeros(self.cap, TH, TW, dtype=torch.uint8).pin_memory()
+        row = 0
+        for t in targets:
+            m = t["masks"].to(torch.uint8).cpu()
+            n, h, w = m.shape
+            if h > TH or w > TW:
+                raise ValueError(f"StaticTargets(mask_hw={self.mask_hw}) got a {h} x {w} mask")
+            mh[row:row + n].zero_()
+            mh[row:row + n, :h, :w] = m
+            row += n
+        return host, sizes, mh
 
     def load_packed(self, packed):
         """One asynchronous H2D copy of a pack()ed batch + the device-side num_boxes (mdetr.py:997-1001: all-reduce, / world, clamp >= 1);
         no host sync.  Call between replays of the captured step, on the stream that replays it."""
-        host, sizes = packed
+        host, sizes = packed[0], packed[1]
         self.sizes = list(sizes)
         self._dev.copy_(host, non_blocking=True)
+        if self.mask_hw is not None:
+            tot = sum(sizes)
+            if tot:
+                self.masks[:tot].copy_(packed[2][:tot], non_blocking=True)
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             self.num_boxes.copy_(self._nb_local)
             torch.distributed.all_reduce(self.num_boxes)

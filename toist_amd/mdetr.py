@@ -520,9 +520,7 @@ class SetCriterion(nn.Module):
     def _forward_static(self, outputs, logits, boxes, st, L):
         """Detection losses on a StaticTargets image (matcher.StaticTargets): no shape, pointer or launch parameter depends on the
         batch's target counts -- the captured step is replayed for any batch after st.load(...).  labels / boxes / cardinality /
-        contrastive_align; the mask losses keep the per-batch path."""
-        if "masks" in self.losses:
-            raise NotImplementedError("StaticTargets covers the detection losses (BASELINE configs[1]); mask losses take lists of target dicts")
+        contrastive_align / masks (StaticTargets(mask_hw=...) carries the ground-truth masks)."""
         match = self.matcher.match_layers_static(logits.detach(), boxes.detach(), st)
         self.last_match = match
         losses = self._detection_losses(logits, boxes, match, None, st.positive_map, st.num_boxes)
@@ -535,6 +533,9 @@ class SetCriterion(nn.Module):
                 out[key], index[key] = vals[l], l
             out.groups.append((vals, index))
             losses.merge(out)
+        if "masks" in self.losses:
+            from .segmentation import mask_losses_static
+            losses.update(mask_losses_static(outputs, st, match, L - 1, L))
         return losses
 
     # ---- distillation: [teacher (noun), student (pronoun)] -------------------------------------------------------

@@ -337,6 +337,36 @@ def _match_offsets(counts, sizes, dev):
     return ent
 
 
+_ARANGE = {}
+
+
+def mask_losses_static(outputs, st, match, layer, L):
+    """mask_losses on a matcher.StaticTargets image: the pair table has the fixed capacity st.cap; which slots are live, which image a
+    pair belongs to and where layer `layer`'s pairs start (the matcher packs the layers with stride match_off[B]) are all computed ON THE
+    DEVICE from st.match_off / st.tgt_off, so the launches are the same for every batch (hipGraph replay)."""
+    pred = outputs["pred_masks"].float().contiguous()                      # [B,Q,hm,wm]
+    B, Q = pred.shape[:2]
+    dev = pred.device
+    cap = st.cap
+    if st.masks is None:
+        raise ValueError("mask losses on StaticTargets need StaticTargets(mask_hw=(H, W))")
+    TH, TW = st.mask_hw
+    j = _ARANGE.get((cap, str(dev)))
+    if j is None:
+        j = _ARANGE[(cap, str(dev))] = torch.arange(cap, dtype=torch.int64, device=dev)
+    mo = st.match_off.to(torch.int64)
+    mtot = mo[B]
+    live = j < mtot
+    pos = (layer * mtot + j).clamp(max=L * cap - 1)
+    src = match.src.reshape(-1).gather(0, pos)
+    tgt = match.tgt.reshape(-1).gather(0, pos)
+    img = torch.bucketize(j, mo[1:], right=True).clamp(max=B - 1)        # pair j belongs to the image whose run [match_off[i], match_off[i+1]) holds it
+    pred_row = torch.where(live, img * Q + src, torch.full_like(src, -1)).to(torch.int32)
+    gt_row = torch.where(live, st.tgt_off.to(torch.int64)[img] + tgt, torch.zeros_like(tgt)).to(torch.int32)
+    vals = _MaskLossFn.apply(pred.view(B * Q, pred.shape[-2], pred.shape[-1]), pred_row.contiguous(), st.masks, gt_row.contiguous(), st.num_boxes.reshape(()).float(), TH, TW)
+    return {"loss_mask": vals[0], "loss_dice": vals[1]}
+
+
 def mask_losses(outputs, targets, match, layer, num_boxes):
     """SetCriterion.loss_masks (mdetr.py:827-853) on the device-resident assignment of `layer`."""
     pred = outputs["pred_masks"].float().contiguous()                      # [B,Q,hm,wm]
