@@ -22,8 +22,8 @@ pytestmark = pytest.mark.gpu
 # bounds set from the measured values (profiles/r05_masks_grad_parity.json)
 MASK_LOGIT_EXCESS = 1e-1        # |a - b| <= 1e-1 + 5e-2 |b| (the stated deviation of DESIGN.md section 5: five bf16 3x3 convolutions + GroupNorms)
 MASK_LOGIT_FRO = 3e-2
-GRAD_COS_MIN = 0.985
-GRAD_RATIO = (0.97, 1.03)
+GRAD_COS_MIN = 0.998            # measured minimum 0.99927 (bbox_attention.q_linear.weight)
+GRAD_RATIO = (0.99, 1.01)       # measured 0.9957 .. 1.0066
 
 
 def test_config2_b8_mask_logits_and_mask_branch_gradients(dev):
