@@ -509,6 +509,62 @@ typedef struct toist_xdec_desc {
 TOIST_API int toist_xdec_supported(int B, int Q, int S, int L);      /* 1 when toist_xdec_fwd takes the shape on the current device */
 TOIST_API int toist_xdec_fwd(const toist_xdec_desc* d, void* stream);
 
+/* ---- XCD-resident decoder stack, backward: the data-gradient chain of ALL L decoder layers in one launch, consuming what toist_xdec_fwd saved
+ * (same grouping: one image per XCD, 32 workgroups of 512 threads, XCD-local barriers; six per layer):
+ *   R0  row owners: norm4 backward of their 4 rows (gradient of the layer output = next layer's input gradient + the shared final norm's share)
+ *   H   CU = 64 hidden units: dh = (dzd4 W2) masked by h > 0, and ITS partial sum of dh W1
+ *   C   row owners: fold the 32 partials + residual gradient, norm3 backward, gradient of the cross-attention context (x W_oc)
+ *   D   CU = (head, key split): cross-attention backward (the body of toist_attn2_bwd: dk / dv of the memory written once, dq shares)
+ *   E   row owners: fold dq, x W_q + residual gradient, norm1 backward, gradient of the self-attention context (x W_os)
+ *   F   CU = head: self-attention backward (dq | dk | dv of the layer's q | k | v)
+ *   G   row owners: [dq | dk | dv] W_in + residual gradient + the final norm's share of the layer below = the next R0's input
+ * Weight gradients are NOT formed here: every operand they need (dzd4, dh, dzd3, dq, dzd1, dq | dk | dv) is left in the output tensors for the
+ * grouped weight-gradient launches, and the LayerNorm parameter gradients leave as per-row-block partial sums (ln_part) for
+ * toist_splitk_reduce_batch.  Limits as toist_xdec_fwd. */
+typedef struct toist_xdec_bwd_layer {
+    const void* w_in;          /* bf16 weights, read in place as k-major operands */
+    const void* w_os;
+    const void* w_q;
+    const void* w_oc;
+    const void* w1;
+    const void* w2;
+    const float* g1;           /* LayerNorm gammas */
+    const float* g3;
+    const float* g4;
+    uint64_t seed[6];          /* the forward's seeds */
+} toist_xdec_bwd_layer;
+
+typedef struct toist_xdec_bwd_desc {
+    int32_t B, Q, S, L;
+    const void* kv;            /* as toist_xdec_desc */
+    int32_t ldkv, ldsink, lddkv, reserved;
+    const uint8_t* key_pad;
+    float drop_p, reserved2;
+    const uint64_t* seed_dev;
+    /* saved by the forward launch (stacked per layer) */
+    const void* qkv; const void* ctx_s; const float* lse_s; const void* z1; const float* mean1; const float* rstd1;
+    const void* qc; const void* ctx_c; const float* lse_c; const void* z3; const float* mean3; const float* rstd3;
+    const void* h; const void* z4; const float* mean4; const float* rstd4;
+    const void* g_out;         /* bf16 [L][B*Q][256]: gradient of the shared final norm w.r.t. every layer's output */
+    /* outputs */
+    void* gb4;                 /* bf16 [L][B*Q][256]: (dropout-masked) gradient of norm4's input = dy of linear2 */
+    void* dh;                  /* bf16 [L][B*Q][2048]: gradient of linear1's output */
+    void* go3;                 /* bf16 [L][B*Q][256]: dy of cross_attn out_proj */
+    void* go1;                 /* bf16 [L][B*Q][256]: dy of self_attn out_proj */
+    void* sink;                /* bf16 [B*Q][ldsink]: per layer l at columns l*1024: [dq_s | dk_s | dv_s | dq_c] */
+    void* dkv;                 /* bf16 [B*S][lddkv]: dk / dv of the memory projections, layer l at columns l*512 / l*512 + 256 */
+    float* ln_part;            /* f32 [L][3][2][B*ceil(Q/4)][256]: (sum v*xhat, sum v) per row block for norm1 / norm3 / norm4 */
+    /* scratch */
+    void* dctx;                /* bf16 [2][B*Q][256] */
+    void* part;                /* bf16 [B][32][128][256] */
+    void* dq_part;             /* bf16 [4][B*Q][256] */
+    uint32_t* ctl;
+    uint64_t* prof;
+    toist_xdec_bwd_layer layer[TOIST_XDEC_MAX_LAYERS];
+} toist_xdec_bwd_desc;
+
+TOIST_API int toist_xdec_bwd(const toist_xdec_bwd_desc* d, void* stream);
+
 /* ---- k-means of the distillation step on the device (models/kmeans.py:21-96 as mdetr.py:213-234 calls it).  One workgroup per
  * distinct task of the batch: group g covers samples members[group_off[g] .. group_off[g+1]) (batch order), all of task
  * group_task[g]; for each sample: Lloyd iterations over banks[task] ([N, D] f32, stride bank_stride elements) from

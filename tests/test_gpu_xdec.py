@@ -27,14 +27,17 @@ def _model(dev):
     return model.to(dev)
 
 
-def _run(model, dev, samples, tok, w, fused, train):
+def _run(model, dev, samples, tok, w, fused, train, fused_bwd=False):
     from toist_amd import kernels as k
     from toist_amd import tlayer
     calls = []
     real = k.xdec_fwd
     k.xdec_fwd = lambda *a, **kw: (calls.append(a[:3]), real(*a, **kw))[1]
-    old = tlayer.XDEC
-    tlayer.XDEC = fused
+    old, old_b = tlayer.XDEC, tlayer.XDEC_BWD
+    tlayer.XDEC, tlayer.XDEC_BWD = fused, fused_bwd
+    bcalls = []
+    real_b = k.xdec_bwd
+    k.xdec_bwd = lambda *a, **kw: (bcalls.append(a[:3]), real_b(*a, **kw))[1]
     try:
         model.train(train)
         model.transformer._step = 0          # both runs draw the same seeds
@@ -47,14 +50,18 @@ def _run(model, dev, samples, tok, w, fused, train):
         torch.cuda.synchronize()
         k.xdec_check()
     finally:
-        tlayer.XDEC = old
+        tlayer.XDEC, tlayer.XDEC_BWD = old, old_b
         k.xdec_fwd = real
+        k.xdec_bwd = real_b
     grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
-    return st["pred_logits"].detach().float().clone(), st["pred_boxes"].detach().float().clone(), float(loss), grads, calls
+    return st["pred_logits"].detach().float().clone(), st["pred_boxes"].detach().float().clone(), float(loss.detach()), grads, (calls, bcalls)
 
 
-@pytest.mark.parametrize("B,hw,train", [(2, (160, 192), True), (8, (96, 128), True), (10, (64, 96), True), (3, (128, 160), False)])
-def test_xcd_resident_decoder_matches_the_per_op_launches(dev, B, hw, train):
+@pytest.mark.parametrize("B,hw,train,bwd", [(2, (160, 192), True, False), (2, (160, 192), True, True), (8, (96, 128), True, True), (10, (64, 96), True, True),
+                                            (3, (128, 160), False, True), (8, (416, 512), True, True)])
+def test_xcd_resident_decoder_matches_the_per_op_launches(dev, B, hw, train, bwd):
+    """bwd = the data-gradient chain of the backward pass as ONE launch too (toist_xdec_bwd); (416, 512) gives 208 + 16 memory tokens: two key splits in
+    the cross-attention backward, i.e. folded dq shares."""
     from toist_amd import harness
     from toist_amd import kernels as k
     model = _model(dev)
@@ -64,9 +71,10 @@ def test_xcd_resident_decoder_matches_the_per_op_launches(dev, B, hw, train):
     S = (hw[0] // 32) * (hw[1] // 32) + 16
     if not k.xdec_supported(B, 100, S, 6):
         pytest.skip("device without 8 XCDs x 32 CUs")
-    lg_a, bx_a, loss_a, g_a, calls_a = _run(model, dev, samples, tok, w, True, train)
-    lg_b, bx_b, loss_b, g_b, calls_b = _run(model, dev, samples, tok, w, False, train)
+    lg_a, bx_a, loss_a, g_a, (calls_a, bcalls_a) = _run(model, dev, samples, tok, w, True, train, bwd)
+    lg_b, bx_b, loss_b, g_b, (calls_b, bcalls_b) = _run(model, dev, samples, tok, w, False, train)
     assert len(calls_a) == 1 and calls_a[0][:2] == (B, 100) and not calls_b           # the fused launch really ran (once: all six layers)
+    assert len(bcalls_a) == (1 if bwd else 0) and not bcalls_b
     rel = float((lg_a - lg_b).norm() / lg_b.norm())
     assert rel < 1.5e-2, rel                                                            # six layers of bf16 activations; same dropout masks
     assert float((bx_a - bx_b).abs().max()) < 2e-2

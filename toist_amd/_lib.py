@@ -77,6 +77,20 @@ class Xdec(Structure):
                [("layer", XdecLayer * XDEC_MAX_LAYERS)]
 
 
+class XdecBwdLayer(Structure):
+    """toist_xdec_bwd_layer (include/toist_hip.h)"""
+    _fields_ = [(n, c_void_p) for n in ("w_in", "w_os", "w_q", "w_oc", "w1", "w2", "g1", "g3", "g4")] + [("seed", c_uint64 * 6)]
+
+
+class XdecBwd(Structure):
+    """toist_xdec_bwd_desc (include/toist_hip.h): backward of the XCD-resident decoder stack"""
+    _fields_ = [("B", c_int32), ("Q", c_int32), ("S", c_int32), ("L", c_int32), ("kv", c_void_p), ("ldkv", c_int32), ("ldsink", c_int32), ("lddkv", c_int32),
+                ("reserved", c_int32), ("key_pad", c_void_p), ("drop_p", c_float), ("reserved2", c_float), ("seed_dev", c_void_p)] + \
+               [(n, c_void_p) for n in ("qkv", "ctx_s", "lse_s", "z1", "mean1", "rstd1", "qc", "ctx_c", "lse_c", "z3", "mean3", "rstd3", "h", "z4", "mean4", "rstd4", "g_out",
+                                        "gb4", "dh", "go3", "go1", "sink", "dkv", "ln_part", "dctx", "part", "dq_part", "ctl", "prof")] + \
+               [("layer", XdecBwdLayer * XDEC_MAX_LAYERS)]
+
+
 class ReduceDesc(Structure):
     _fields_ = [("ws", c_void_p), ("out", c_void_p), ("rscale", c_void_p), ("splits", c_int32), ("M", c_int32), ("N", c_int32),
                 ("ldc", c_int32), ("alpha", c_float), ("accumulate", c_int32)]
@@ -135,6 +149,7 @@ _SIGNATURES = {
     "toist_rowgemm": ([POINTER(RowGemm), c_void_p], ctypes.c_int),
     "toist_xdec_supported": ([c_int32] * 4, ctypes.c_int),
     "toist_xdec_fwd": ([POINTER(Xdec), c_void_p], ctypes.c_int),
+    "toist_xdec_bwd": ([POINTER(XdecBwd), c_void_p], ctypes.c_int),
     "toist_kmeans": ([c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_float, c_int32,
                      c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_attn_small_fwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 4 + [c_float, c_float, c_uint64, c_void_p, c_void_p,

@@ -740,6 +740,462 @@ __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) 
     if (touched == 0x9E3779B9u) __hip_atomic_store(p.ctl + 1000, touched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // keeps the L2 touches alive
 }
 
+
+// =====================================================================================================================================================
+// Backward (include/toist_hip.h: toist_xdec_bwd).  Same grouping and barriers as the forward launch; the two attention backward phases run the body
+// of csrc/attn2.hip's key-owning kernel (attn2_bwd_body.h) with workgroup = (head, key split) of this XCD's image.
+#include "attn2_bwd_body.h"
+
+namespace {
+
+// LDS carve of the backward launch
+constexpr int B_SA = 0;                                   // [4][XAS] bf16: A rows of the row-local data-gradient GEMMs
+constexpr int B_SB = B_SA + 4 * XAS * 2;                  // [4][XAS] bf16
+constexpr int B_SA3 = B_SB + 4 * XAS * 2;                 // [4][3 * XD + 8] bf16: [dq | dk | dv] rows
+constexpr int B_SC = B_SA3 + 4 * (3 * XD + 8) * 2;        // [4][XCS] f32 accumulator rows
+constexpr int B_SG = B_SC + 4 * XCS * 4;                  // [2][4][XD] f32: v * xhat, v of the four rows (LayerNorm parameter gradients)
+constexpr int B_INFO = B_SG + 2 * 4 * XD * 4;             // [16] u32
+constexpr int B_U = B_INFO + 64;                          // phase-private region:
+constexpr int XKT = 64 * 40;                              //   one wave's [64 k][32 n + 8] weight tile (bf16 elements)
+constexpr int B_TILE = B_U;                               //   row-local phases: [8 waves][2][XKT] bf16 ...
+constexpr int B_RED = B_TILE + 8 * 2 * XKT * 2;           //   ... + [8][4][XD] f32 partial folds
+constexpr int B_W1 = B_U;                                 //   H: [64 hidden][XAS] bf16 ...
+constexpr int B_W2 = B_W1 + 64 * XAS * 2;                 //   ... + [256 n][XW2S] bf16
+constexpr int B_END_ROW = B_RED + 8 * 4 * XD * 4, B_END_H = B_W2 + XD * XW2S * 2, B_END_ATT = B_U + (int)a2b::A2_BWD_LDS;
+constexpr int B_TOTAL = (B_END_ROW > B_END_H ? (B_END_ROW > B_END_ATT ? B_END_ROW : B_END_ATT) : (B_END_H > B_END_ATT ? B_END_H : B_END_ATT));
+static_assert(B_TOTAL <= 160 * 1024, "xdec backward: LDS budget");
+static_assert((B_U % 16) == 0, "xdec backward: alignment");
+
+template <bool FRESH>
+__device__ __forceinline__ uint2 ld8(rsrc_t r, unsigned off) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
+    const u2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, FRESH ? 16 : 0);
+    return make_uint2(v[0], v[1]);
+}
+
+// ---- row-local data gradient: acc (this wave's 32 output columns, the 4 rows replicated) = A[4][K] W[K][256], W = an nn.Linear weight read in place
+// (its ROWS are the reduction index): 64-row chunks of the wave's 32 columns go through a wave-private LDS tile and come back transposed. ----
+template <int K>
+__device__ __forceinline__ void kgemm(const bf16_t* sA, int lda, const void* W, bf16_t* tiles, int wave, int lane, f32x4_t* acc) {
+    const int g = lane >> 4, c16 = lane & 15;
+    acc[0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    acc[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const rsrc_t rs = mkrs(W);
+    const unsigned lane_off = (unsigned)(((lane >> 2) * XD + wave * 32 + (lane & 3) * 8) * 2);       // row lane / 4 (+ 16 i), 16-byte piece lane % 4 of the wave's 64-byte row slice
+    const int wr = (lane >> 2) * 40 + (lane & 3) * 8;
+    const bf16_t* arow = sA + (c16 & 3) * lda + 4 * g;
+    for (int n0 = 0; n0 < K; n0 += 256) {                       // 256 reduction rows = four 64-row chunks = 16 requests in flight per lane
+        uint4 wv[4][4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[ch][i] = ld16u<false>(rs, lane_off + (unsigned)((n0 + ch * 64 + 16 * i) * XD * 2));
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            bf16_t* const tile = tiles + (ch & 1) * XKT;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + 16 * i * 40 + wr) = wv[ch][i];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kk = n0 + ch * 64 + 32 * u;
+                const uint2 a0 = *reinterpret_cast<const uint2*>(arow + kk), a1 = *reinterpret_cast<const uint2*>(arow + kk + 16);
+                const bf16x8_t af = frag_of(a0.x, a0.y, a1.x, a1.y);
+                const bf16_t* tb = tile + (32 * u + 4 * g + (c16 >> 2)) * 40 + (c16 & 3) * 4;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const bf16x8_t bfr = tr_pair(tb + nb * 16, tb + nb * 16 + 16 * 40);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[nb], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// ---- LayerNorm backward of one row by one wave (a lane owns 4 columns): v = gradient of the LayerNorm output (f32) ----
+// dz (out): the input gradient, rounded to bf16 like the tensor the per-op launch stores; the dropout-masked copy goes to global memory and (optionally) to LDS
+__device__ __forceinline__ void lnb_row(const float (&v_in)[4], const bf16_t* z_row, float mu, float rs, const float* gamma, unsigned long long seed, float drop_p,
+                                        size_t grow, bool live, float (&dz)[4], bf16_t* gb_row, bf16_t* sOutRow, float* sG, int row, int lane) {
+    float z4[4], v[4];
+    unpack4f(live ? *reinterpret_cast<const uint2*>(z_row + 4 * lane) : make_uint2(0u, 0u), z4);
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * lane);
+    const float gam[4] = {gm.x, gm.y, gm.z, gm.w};
+    float xh[4], gg[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v[q] = live ? v_in[q] : 0.f;
+        xh[q] = (z4[q] - mu) * rs;
+        gg[q] = v[q] * gam[q];
+        s1 += gg[q];
+        s2 += gg[q] * xh[q];
+    }
+    s1 = wave_sum(s1) * (1.f / XD);
+    s2 = wave_sum(s2) * (1.f / XD);
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = rs * (gg[q] - s1 - xh[q] * s2);
+    const uint2 dzp = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+    unpack4f(dzp, dz);
+    uint2 gbp = dzp;
+    if (drop_p > 0.f) {
+        const unsigned thresh = (unsigned)(drop_p * 4294967296.0);
+        const float dscale = 1.f / (1.f - drop_p);
+        const unsigned long long idx = (unsigned long long)grow * XD + 4 * lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = dropout_keep(seed, idx + q, thresh) ? o[q] * dscale : 0.f;
+        gbp = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+    }
+    if (live) *reinterpret_cast<uint2*>(gb_row + 4 * lane) = gbp;
+    if (sOutRow != nullptr) *reinterpret_cast<uint2*>(sOutRow + 4 * lane) = gbp;
+    *reinterpret_cast<float4*>(sG + row * XD + 4 * lane) = make_float4(v[0] * xh[0], v[1] * xh[1], v[2] * xh[2], v[3] * xh[3]);
+    *reinterpret_cast<float4*>(sG + (4 + row) * XD + 4 * lane) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(XNT) void xdec_bwd_kernel(const toist_xdec_bwd_desc p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* const sA = reinterpret_cast<bf16_t*>(smem + B_SA);
+    bf16_t* const sB = reinterpret_cast<bf16_t*>(smem + B_SB);
+    bf16_t* const sA3 = reinterpret_cast<bf16_t*>(smem + B_SA3);
+    float* const sC = reinterpret_cast<float*>(smem + B_SC);
+    float* const sG = reinterpret_cast<float*>(smem + B_SG);
+    unsigned* const sInfo = reinterpret_cast<unsigned*>(smem + B_INFO);
+    float* const sRed = reinterpret_cast<float*>(smem + B_RED);
+    bf16_t* const sW1 = reinterpret_cast<bf16_t*>(smem + B_W1);
+    bf16_t* const sW2 = reinterpret_cast<bf16_t*>(smem + B_W2);
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    bf16_t* const tiles = reinterpret_cast<bf16_t*>(smem + B_TILE) + wave * (2 * XKT);
+
+    if (tid0 == 0) {
+        const unsigned x = xcc_id() & 7u;
+        sInfo[0] = x;
+        sInfo[1] = __hip_atomic_fetch_add(p.ctl + x * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        sInfo[2] = 0u;
+    }
+    __syncthreads();
+    const int xcd = __builtin_amdgcn_readfirstlane((int)sInfo[0]);
+    const int slot = __builtin_amdgcn_readfirstlane((int)sInfo[1]);
+    if (slot >= XWG) return;
+    XSync sy{p.ctl + 256 + xcd * 32, p.ctl + (TOIST_XDEC_CTL_WORDS - 1), sInfo + 2, 0u};
+
+    const int Q = p.Q, S = p.S, M = p.B * p.Q;
+    const int MT = (Q + 15) >> 4;
+    const int RB = (Q + 3) >> 2;
+    const bool rowner = slot < RB;
+    const float drop_p = p.drop_p;
+    const unsigned long long seed_add = p.seed_dev ? *p.seed_dev : 0ull;
+    const int splits_c = ((S + 31) / 32 + 3) / 4, splits_s = ((Q + 31) / 32 + 3) / 4;      // toist_attn2_splits
+    const int wgid = xcd * XWG + slot;
+
+    for (int b = xcd; b < p.B; b += 8) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        int lane = tid & 63;
+        const size_t row0 = (size_t)b * Q;
+        const int my_row = 4 * slot + wave;
+        const bool my_live = rowner && wave < 4 && my_row < Q;
+        const int blk = b * RB + slot;                         // this CU's row block in the LayerNorm partial sums
+        const int nblk = p.B * RB;
+        float gy[4] = {0.f, 0.f, 0.f, 0.f};                     // waves 0 .. 3: gradient of the current layer's output row (f32), 4 columns per lane
+        float rdz[4] = {0.f, 0.f, 0.f, 0.f};                    // the residual gradient that travels down the layer (bf16-rounded values)
+        if (my_live) unpack4f(*reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.g_out) + ((size_t)(p.L - 1) * M + row0 + my_row) * XD + 4 * lane), gy);
+        __syncthreads();
+
+        for (int layer = p.L - 1; layer >= 0; --layer) {
+            int g, c16;
+#define XB_REDERIVE()                   \
+    do {                                \
+        asm volatile("" : "+v"(tid));   \
+        lane = tid & 63;                \
+        g = lane >> 4;                  \
+        c16 = lane & 15;                \
+    } while (0)
+            XB_REDERIVE();
+            const toist_xdec_bwd_layer& ly = p.layer[layer];
+            const size_t lrow = (size_t)layer * M + row0;
+            float* const lnp = p.ln_part + (size_t)layer * 3 * 2 * nblk * XD;          // [3 norms][2][nblk][256]
+            bf16_t* const sink_img = reinterpret_cast<bf16_t*>(p.sink) + row0 * p.ldsink + layer * 4 * XD;
+            bf16_t* const dctx_c = reinterpret_cast<bf16_t*>(p.dctx), * const dctx_s = dctx_c + (size_t)M * XD;
+            // writes this CU's LayerNorm partial rows (sum over its 4 rows of v * xhat, v) of norm `which` (0: norm1, 1: norm3, 2: norm4); call after a barrier
+            auto ln_partials = [&](int which) {
+                if (tid < XD) {
+                    float a = 0.f, c = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { a += sG[r * XD + tid]; c += sG[(4 + r) * XD + tid]; }
+                    lnp[((size_t)(which * 2 + 0) * nblk + blk) * XD + tid] = a;
+                    lnp[((size_t)(which * 2 + 1) * nblk + blk) * XD + tid] = c;
+                }
+            };
+
+            xstamp(p.prof, wgid, p.L, layer, 0);
+            // ================= R0: norm4 backward of this CU's rows =================
+            if (rowner) {
+                if (wave < 4) {
+                    const float mu = my_live ? p.mean4[lrow + my_row] : 0.f, rs = my_live ? p.rstd4[lrow + my_row] : 0.f;
+                    lnb_row(gy, reinterpret_cast<const bf16_t*>(p.z4) + (lrow + my_row) * XD, mu, rs, ly.g4, ly.seed[5] + seed_add, drop_p, row0 + my_row, my_live, rdz,
+                            reinterpret_cast<bf16_t*>(p.gb4) + (lrow + my_row) * XD, nullptr, sG, wave, lane);
+                }
+                __syncthreads();
+                ln_partials(2);
+            }
+            xstamp(p.prof, wgid, p.L, layer, 1);
+            // this CU's slices of linear1 / linear2 -> registers before the barrier, -> LDS after it
+            {
+                uint4 w1v[4], w2v[4];
+                const rsrc_t rs1 = mkrs(ly.w1), rs2 = mkrs(ly.w2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pc = tid + XNT * u;
+                    w1v[u] = ld16u<false>(rs1, (unsigned)(((slot * 64 + (pc >> 5)) * XD + (pc & 31) * 8) * 2));
+                    w2v[u] = ld16u<false>(rs2, (unsigned)(((pc >> 3) * XFF + slot * 64 + (pc & 7) * 8) * 2));
+                }
+                xcd_barrier(sy);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pc = tid + XNT * u;
+                    *reinterpret_cast<uint4*>(sW1 + (pc >> 5) * XAS + (pc & 31) * 8) = w1v[u];
+                    *reinterpret_cast<uint4*>(sW2 + (pc >> 3) * XW2S + (pc & 7) * 8) = w2v[u];
+                }
+            }
+            __syncthreads();
+            xstamp(p.prof, wgid, p.L, layer, 2);
+
+            // ================= H: hidden units 64 slot .. + 63: dh = (gb4 W2) where h > 0, partial sums of dh W1 =================
+            XB_REDERIVE();
+            if (wave < MT) {
+                const int mrow = wave * 16 + c16;
+                const bool mlive = mrow < Q;
+                const rsrc_t rsg = mkrs(reinterpret_cast<const bf16_t*>(p.gb4) + lrow * XD);
+                const unsigned goff = mlive ? (unsigned)((mrow * XD + 4 * g) * 2) : XOOB;
+                bf16x8_t gbf[8];          // k slots of block j: (g, i) <-> n = 32 j + 4 g + i, (g, 4 + i) <-> n = 32 j + 16 + 4 g + i
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint2 lo = ld8<true>(rsg, goff + (unsigned)(64 * j)), hi = ld8<true>(rsg, goff + (unsigned)(64 * j + 32));
+                    gbf[j] = frag_of(lo.x, lo.y, hi.x, hi.y);
+                }
+                const float alpha = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+                const bf16_t* const h_row = reinterpret_cast<const bf16_t*>(p.h) + (lrow + (mlive ? mrow : 0)) * XFF + slot * 64;
+                bf16_t* const dh_row = reinterpret_cast<bf16_t*>(p.dh) + (lrow + (mlive ? mrow : 0)) * XFF + slot * 64;
+                unsigned pk[4][2];
+#pragma unroll
+                for (int th = 0; th < 4; ++th) {
+                    f32x4_t a4 = {0.f, 0.f, 0.f, 0.f};
+                    const bf16_t* wt = sW2 + (4 * g + (c16 >> 2)) * XW2S + 16 * th + (c16 & 3) * 4;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bf16x8_t wfr = tr_pair(wt + 32 * j * XW2S, wt + (32 * j + 16) * XW2S);     // lane = hidden 16 th + c16
+                        a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, gbf[j], a4, 0, 0, 0);          // [hidden 16 th + 4 g + r][m = c16]
+                    }
+                    float hv[4];
+                    unpack4f(mlive ? *reinterpret_cast<const uint2*>(h_row + 16 * th + 4 * g) : make_uint2(0u, 0u), hv);
+                    float dv4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dv4[r] = hv[r] > 0.f ? a4[r] * alpha : 0.f;
+                    pk[th][0] = pack2bf(dv4[0], dv4[1]);
+                    pk[th][1] = pack2bf(dv4[2], dv4[3]);
+                    if (mlive) *reinterpret_cast<uint2*>(dh_row + 16 * th + 4 * g) = make_uint2(pk[th][0], pk[th][1]);
+                }
+                const bf16x8_t pa0 = frag_of(pk[0][0], pk[0][1], pk[1][0], pk[1][1]), pa1 = frag_of(pk[2][0], pk[2][1], pk[3][0], pk[3][1]);
+                bf16_t* const part_row = reinterpret_cast<bf16_t*>(p.part) + (((size_t)b * XWG + slot) * XPR + mrow) * XD;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    f32x4_t o[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        // result lane L holds output column 32 v + 8 (L >> 2) + 4 e + (L & 3): the ADDRESS lane X supplies the 4-column chunk 32 v + 8 (X & 3) + 4 e
+                        const bf16_t* w1t = sW1 + (4 * g + (c16 >> 2)) * XAS + 32 * v + 8 * (c16 & 3) + 4 * e;
+                        const bf16x8_t f0 = tr_pair(w1t, w1t + 16 * XAS), f1 = tr_pair(w1t + 32 * XAS, w1t + 48 * XAS);
+                        const f32x4_t t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, pa0, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        o[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, pa1, t, 0, 0, 0);
+                    }
+                    if (mlive)
+                        *reinterpret_cast<uint4*>(part_row + 32 * v + 8 * g) =
+                            make_uint4(pack2bf(o[0][0], o[0][1]), pack2bf(o[0][2], o[0][3]), pack2bf(o[1][0], o[1][1]), pack2bf(o[1][2], o[1][3]));
+                }
+            }
+            xstamp(p.prof, wgid, p.L, layer, 3);
+            xcd_barrier(sy);
+            xstamp(p.prof, wgid, p.L, layer, 4);
+
+            // ================= C: fold the partials, norm3 backward, gradient of the cross-attention context =================
+            XB_REDERIVE();
+            if (rowner) {
+                {
+                    const rsrc_t rsp = mkrs(reinterpret_cast<const bf16_t*>(p.part) + (size_t)b * XWG * XPR * XD);
+                    const int r = lane >> 4, pl = lane & 15;
+                    float sum[2][8];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) sum[hh][q] = 0.f;
+                    uint4 pv[4][2];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh)
+                            pv[u][hh] = ld16u<true>(rsp, (unsigned)((((wave * 4 + u) * XPR + 4 * slot + r) * XD + (pl + 16 * hh) * 8) * 2));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            float t8[8];
+                            unpack8f(pv[u][hh], t8);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) sum[hh][q] += t8[q];
+                        }
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        float* dst = sRed + (wave * 4 + r) * XD + (pl + 16 * hh) * 8;
+                        *reinterpret_cast<float4*>(dst) = make_float4(sum[hh][0], sum[hh][1], sum[hh][2], sum[hh][3]);
+                        *reinterpret_cast<float4*>(dst + 4) = make_float4(sum[hh][4], sum[hh][5], sum[hh][6], sum[hh][7]);
+                    }
+                }
+                __syncthreads();
+                if (wave < 4) {
+                    float v[4] = {rdz[0], rdz[1], rdz[2], rdz[3]};              // the residual branch: norm4's input gradient
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        const float4 s4 = *reinterpret_cast<const float4*>(sRed + (w * 4 + wave) * XD + 4 * lane);
+                        v[0] += s4.x; v[1] += s4.y; v[2] += s4.z; v[3] += s4.w;
+                    }
+                    const float mu = my_live ? p.mean3[lrow + my_row] : 0.f, rs = my_live ? p.rstd3[lrow + my_row] : 0.f;
+                    lnb_row(v, reinterpret_cast<const bf16_t*>(p.z3) + (lrow + my_row) * XD, mu, rs, ly.g3, ly.seed[3] + seed_add, drop_p, row0 + my_row, my_live, rdz,
+                            reinterpret_cast<bf16_t*>(p.go3) + (lrow + my_row) * XD, sA + wave * XAS, sG, wave, lane);
+                }
+                __syncthreads();
+                ln_partials(1);
+                f32x4_t acc[2];
+                kgemm<XD>(sA, XAS, ly.w_oc, tiles, wave, lane, acc);
+                acc_to_lds(acc, sC, wave, c16, g);
+                __syncthreads();
+                if (tid < 128) {
+                    const int r = tid >> 5, pc = tid & 31;
+                    float v8[8];
+                    const float4 lo = *reinterpret_cast<const float4*>(sC + r * XCS + pc * 8), hi = *reinterpret_cast<const float4*>(sC + r * XCS + pc * 8 + 4);
+                    v8[0] = lo.x; v8[1] = lo.y; v8[2] = lo.z; v8[3] = lo.w; v8[4] = hi.x; v8[5] = hi.y; v8[6] = hi.z; v8[7] = hi.w;
+                    if (4 * slot + r < Q) *reinterpret_cast<uint4*>(dctx_c + (row0 + 4 * slot + r) * XD + pc * 8) = pack8f(v8);
+                }
+            }
+            xstamp(p.prof, wgid, p.L, layer, 5);
+            xcd_barrier(sy);
+            xstamp(p.prof, wgid, p.L, layer, 6);
+
+            // ================= D: cross-attention backward, CU = (head slot / 4, key split slot % 4) =================
+            if ((slot & 3) < splits_c) {
+                const bf16_t* const kvb = reinterpret_cast<const bf16_t*>(p.kv) + layer * 2 * XD;
+                bf16_t* const dkvb = reinterpret_cast<bf16_t*>(p.dkv) + layer * 2 * XD;
+                a2b::attn2_bwd_body<true>(smem + B_U, slot & 3, b * XH + (slot >> 2), reinterpret_cast<const bf16_t*>(p.qc) + (size_t)layer * M * XD, XD, kvb, p.ldkv, kvb + XD,
+                                          p.ldkv, reinterpret_cast<const bf16_t*>(p.ctx_c) + (size_t)layer * M * XD, XD, dctx_c, XD,
+                                          p.lse_c + (size_t)layer * p.B * XH * Q * 2, p.key_pad, XH, Q, S, (S + 7) & ~7, 0.17677669529663687f, drop_p, ly.seed[2],
+                                          reinterpret_cast<const unsigned long long*>(p.seed_dev), reinterpret_cast<bf16_t*>(p.sink) + layer * 4 * XD + 3 * XD, p.ldsink, dkvb,
+                                          p.lddkv, dkvb + XD, p.lddkv, splits_c > 1 ? reinterpret_cast<bf16_t*>(p.dq_part) : nullptr, (long long)M * XD);
+            }
+            xstamp(p.prof, wgid, p.L, layer, 7);
+            xcd_barrier(sy);
+            xstamp(p.prof, wgid, p.L, layer, 8);
+
+            // ================= E: fold dq, x W_q + residual, norm1 backward, gradient of the self-attention context =================
+            XB_REDERIVE();
+            if (rowner) {
+                if (wave < 4) {
+                    uint2 dq2;
+                    if (splits_c > 1) {
+                        const rsrc_t rsq = mkrs(reinterpret_cast<const bf16_t*>(p.dq_part));
+                        float f4[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int sp = 0; sp < splits_c; ++sp) {
+                            float t4[4];
+                            unpack4f(ld8<true>(rsq, my_live ? (unsigned)((((size_t)sp * M + row0 + my_row) * XD + 4 * lane) * 2) : XOOB), t4);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) f4[q] += t4[q];
+                        }
+                        dq2 = make_uint2(pack2bf(f4[0], f4[1]), pack2bf(f4[2], f4[3]));
+                        if (my_live) *reinterpret_cast<uint2*>(sink_img + (size_t)my_row * p.ldsink + 3 * XD + 4 * lane) = dq2;     // the folded rows: dy of the query projection's weight gradient
+                    } else {
+                        const rsrc_t rsq = mkrs(sink_img);
+                        dq2 = ld8<true>(rsq, my_live ? (unsigned)(((size_t)my_row * p.ldsink + 3 * XD + 4 * lane) * 2) : XOOB);
+                    }
+                    *reinterpret_cast<uint2*>(sA + wave * XAS + 4 * lane) = dq2;
+                }
+                __syncthreads();
+                f32x4_t acc[2];
+                kgemm<XD>(sA, XAS, ly.w_q, tiles, wave, lane, acc);
+                acc_to_lds(acc, sC, wave, c16, g);
+                __syncthreads();
+                if (wave < 4) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(sC + wave * XCS + 4 * lane);
+                    const float v[4] = {a4.x + rdz[0], a4.y + rdz[1], a4.z + rdz[2], a4.w + rdz[3]};          // + norm3's input gradient (the residual branch)
+                    const float mu = my_live ? p.mean1[lrow + my_row] : 0.f, rs = my_live ? p.rstd1[lrow + my_row] : 0.f;
+                    lnb_row(v, reinterpret_cast<const bf16_t*>(p.z1) + (lrow + my_row) * XD, mu, rs, ly.g1, ly.seed[1] + seed_add, drop_p, row0 + my_row, my_live, rdz,
+                            reinterpret_cast<bf16_t*>(p.go1) + (lrow + my_row) * XD, sB + wave * XAS, sG, wave, lane);
+                }
+                __syncthreads();
+                ln_partials(0);
+                kgemm<XD>(sB, XAS, ly.w_os, tiles, wave, lane, acc);
+                acc_to_lds(acc, sC, wave, c16, g);
+                __syncthreads();
+                if (tid < 128) {
+                    const int r = tid >> 5, pc = tid & 31;
+                    float v8[8];
+                    const float4 lo = *reinterpret_cast<const float4*>(sC + r * XCS + pc * 8), hi = *reinterpret_cast<const float4*>(sC + r * XCS + pc * 8 + 4);
+                    v8[0] = lo.x; v8[1] = lo.y; v8[2] = lo.z; v8[3] = lo.w; v8[4] = hi.x; v8[5] = hi.y; v8[6] = hi.z; v8[7] = hi.w;
+                    if (4 * slot + r < Q) *reinterpret_cast<uint4*>(dctx_s + (row0 + 4 * slot + r) * XD + pc * 8) = pack8f(v8);
+                }
+            }
+            xstamp(p.prof, wgid, p.L, layer, 9);
+            xcd_barrier(sy);
+            xstamp(p.prof, wgid, p.L, layer, 10);
+
+            // ================= F: self-attention backward, CU = (head slot / 4, key split slot % 4) =================
+            if ((slot & 3) < splits_s) {
+                const bf16_t* const qkvb = reinterpret_cast<const bf16_t*>(p.qkv) + (size_t)layer * M * 3 * XD;
+                bf16_t* const sk = reinterpret_cast<bf16_t*>(p.sink) + layer * 4 * XD;
+                a2b::attn2_bwd_body<true>(smem + B_U, slot & 3, b * XH + (slot >> 2), qkvb, 3 * XD, qkvb + XD, 3 * XD, qkvb + 2 * XD, 3 * XD,
+                                          reinterpret_cast<const bf16_t*>(p.ctx_s) + (size_t)layer * M * XD, XD, dctx_s, XD, p.lse_s + (size_t)layer * p.B * XH * Q * 2, nullptr,
+                                          XH, Q, Q, (Q + 7) & ~7, 0.17677669529663687f, drop_p, ly.seed[0], reinterpret_cast<const unsigned long long*>(p.seed_dev), sk, p.ldsink,
+                                          sk + XD, p.ldsink, sk + 2 * XD, p.ldsink, splits_s > 1 ? reinterpret_cast<bf16_t*>(p.dq_part) : nullptr, (long long)M * XD);
+            }
+            xstamp(p.prof, wgid, p.L, layer, 11);
+            xcd_barrier(sy);
+            xstamp(p.prof, wgid, p.L, layer, 12);
+
+            // ================= G: [dq | dk | dv] W_in + residual gradient + the final norm's share of the layer below -> the next R0's input =================
+            XB_REDERIVE();
+            if (rowner && layer > 0) {
+                if (tid < 384) {
+                    const int r = tid / 96, pc = tid - r * 96;
+                    const rsrc_t rsd = mkrs(sink_img);
+                    uint4 v;
+                    if (splits_s > 1 && pc < 32) {        // dq of a self-attention with several key splits arrives as shares (Q > 128 is outside the launch's limits: kept for completeness)
+                        v = make_uint4(0u, 0u, 0u, 0u);
+                    } else {
+                        v = ld16u<true>(rsd, 4 * slot + r < Q ? (unsigned)(((size_t)(4 * slot + r) * p.ldsink + pc * 8) * 2) : XOOB);
+                    }
+                    *reinterpret_cast<uint4*>(sA3 + r * (3 * XD + 8) + pc * 8) = v;
+                }
+                __syncthreads();
+                f32x4_t acc[2];
+                kgemm<3 * XD>(sA3, 3 * XD + 8, ly.w_in, tiles, wave, lane, acc);
+                acc_to_lds(acc, sC, wave, c16, g);
+                __syncthreads();
+                if (wave < 4) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(sC + wave * XCS + 4 * lane);
+                    float go[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (my_live) unpack4f(*reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.g_out) + ((size_t)(layer - 1) * M + row0 + my_row) * XD + 4 * lane), go);
+                    gy[0] = a4.x + rdz[0] + go[0];
+                    gy[1] = a4.y + rdz[1] + go[1];
+                    gy[2] = a4.z + rdz[2] + go[2];
+                    gy[3] = a4.w + rdz[3] + go[3];
+                }
+                __syncthreads();
+            }
+            xstamp(p.prof, wgid, p.L, layer, 13);
+#undef XB_REDERIVE
+        }
+        if (b + 8 < p.B) xcd_barrier(sy);
+    }
+}
+
 }  // namespace toist
 
 using namespace toist;
@@ -790,4 +1246,35 @@ extern "C" int toist_xdec_fwd(const toist_xdec_desc* d, void* stream) {
     }
     hipLaunchKernelGGL(xdec_fwd_kernel, dim3(8 * XWG), dim3(XNT), L_TOTAL, st, *d);
     return check_launch("toist_xdec_fwd");
+}
+
+extern "C" int toist_xdec_bwd(const toist_xdec_bwd_desc* d, void* stream) {
+    TOIST_REQUIRE(d != nullptr, "toist_xdec_bwd: null descriptor");
+    TOIST_REQUIRE(toist_xdec_supported(d->B, d->Q, d->S, d->L), "toist_xdec_bwd: unsupported shape B=%d Q=%d S=%d L=%d", d->B, d->Q, d->S, d->L);
+    TOIST_REQUIRE(d->kv && d->qkv && d->ctx_s && d->lse_s && d->z1 && d->mean1 && d->rstd1 && d->qc && d->ctx_c && d->lse_c && d->z3 && d->mean3 && d->rstd3 && d->h && d->z4 &&
+                      d->mean4 && d->rstd4 && d->g_out && d->gb4 && d->dh && d->go3 && d->go1 && d->sink && d->dkv && d->ln_part && d->dctx && d->part && d->dq_part && d->ctl,
+                  "toist_xdec_bwd: every buffer of the descriptor is required");
+    TOIST_REQUIRE((d->ldkv % 8) == 0 && d->ldkv >= d->L * 2 * XD && (d->lddkv % 8) == 0 && d->lddkv >= d->L * 2 * XD && (d->ldsink % 8) == 0 && d->ldsink >= d->L * 4 * XD,
+                  "toist_xdec_bwd: ldkv / lddkv / ldsink must be multiples of 8 and cover L * 512 / L * 512 / L * 1024 columns");
+    TOIST_REQUIRE((long long)d->B * d->S * d->ldkv * 2 < 0x7ffffff0ll && (long long)d->L * d->B * d->Q * XFF * 2 < 0x7ffffff0ll && (long long)d->B * d->Q * d->ldsink * 2 < 0x7ffffff0ll,
+                  "toist_xdec_bwd: buffers beyond 2 GB");
+    TOIST_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "toist_xdec_bwd: bad dropout p");
+    for (int l = 0; l < d->L; ++l) {
+        const toist_xdec_bwd_layer& y = d->layer[l];
+        TOIST_REQUIRE(y.w_in && y.w_os && y.w_q && y.w_oc && y.w1 && y.w2 && y.g1 && y.g3 && y.g4, "toist_xdec_bwd: layer %d: every parameter pointer is required", l);
+        TOIST_REQUIRE(((((size_t)y.w_in) | ((size_t)y.w_os) | ((size_t)y.w_q) | ((size_t)y.w_oc) | ((size_t)y.w1) | ((size_t)y.w2) | ((size_t)y.g1) | ((size_t)y.g3) | ((size_t)y.g4)) & 15) == 0,
+                      "toist_xdec_bwd: layer %d: parameter pointers must be 16-byte aligned", l);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    static std::atomic<unsigned long long> done{0};
+    if (!lds_attr_once_flag(done, [] { return hipFuncSetAttribute((const void*)xdec_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; })) {
+        set_last_error("toist_xdec_bwd: cannot raise the dynamic LDS limit");
+        return TOIST_EHIP;
+    }
+    if (hipMemsetAsync(d->ctl, 0, (TOIST_XDEC_CTL_WORDS - 1) * sizeof(uint32_t), st) != hipSuccess) {
+        set_last_error("toist_xdec_bwd: hipMemsetAsync of the control words failed");
+        return TOIST_EHIP;
+    }
+    hipLaunchKernelGGL(xdec_bwd_kernel, dim3(8 * XWG), dim3(XNT), B_TOTAL, st, *d);
+    return check_launch("toist_xdec_bwd");
 }

@@ -767,6 +767,63 @@ def xdec_fwd(B, Q, S, x0, qpos, kv, key_pad, drop_p, eps, out, layers, part):
     _lib.check(_lib.lib().toist_xdec_fwd(ctypes.byref(d), _stream()), "toist_xdec_fwd")
 
 
+def xdec_bwd(B, Q, S, kv, key_pad, drop_p, saved, g_out, outs, layers, scratch):
+    """Data-gradient chain of all decoder layers in one launch (include/toist_hip.h: toist_xdec_bwd).  saved = the forward's stacked tensors,
+    g_out bf16 [L, B*Q, 256], outs = dict(gb4, dh, go3, go1, sink, dkv, ln_part), scratch = dict(dctx, part, dq_part)."""
+    d = _lib.XdecBwd()
+    d.B, d.Q, d.S, d.L = B, Q, S, len(layers)
+    d.kv, d.ldkv = _p(kv, torch.bfloat16), kv.stride(0)
+    d.key_pad = _p(key_pad, torch.uint8) if key_pad is not None else None
+    d.drop_p = drop_p
+    d.seed_dev = _p(SEED_DEV) if drop_p > 0 else None
+    for name in ("qkv", "ctx_s", "z1", "qc", "ctx_c", "z3", "h", "z4"):
+        assert saved[name].is_contiguous()
+        setattr(d, name, _p(saved[name], torch.bfloat16))
+    for name in ("lse_s", "mean1", "rstd1", "lse_c", "mean3", "rstd3", "mean4", "rstd4"):
+        assert saved[name].is_contiguous()
+        setattr(d, name, _p(saved[name], torch.float32))
+    assert g_out.is_contiguous() and g_out.shape == (len(layers), B * Q, 256)
+    d.g_out = _p(g_out, torch.bfloat16)
+    for name in ("gb4", "dh", "go3", "go1"):
+        assert outs[name].is_contiguous()
+        setattr(d, name, _p(outs[name], torch.bfloat16))
+    sink, dkv = outs["sink"], outs["dkv"]
+    assert sink.stride(1) == 1 and dkv.stride(1) == 1
+    d.sink, d.ldsink, d.dkv, d.lddkv = _p(sink, torch.bfloat16), sink.stride(0), _p(dkv, torch.bfloat16), dkv.stride(0)
+    d.ln_part = _p(outs["ln_part"], torch.float32)
+    for name in ("dctx", "part", "dq_part"):
+        assert scratch[name].is_contiguous()
+        setattr(d, name, _p(scratch[name], torch.bfloat16))
+    key = (kv.device, _raw_stream())
+    ctl = _XDEC_CTL.get(key)
+    if ctl is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("toist_amd.kernels.xdec_bwd: run one eager step on this stream before capturing (the control words are allocated on first use)")
+        ctl = _XDEC_CTL[key] = torch.zeros(_lib.XDEC_CTL_WORDS, dtype=torch.int32, device=kv.device)
+    d.ctl = ctl.data_ptr()
+    d.prof = XDEC_PROF.data_ptr() if XDEC_PROF is not None else None
+    for i, ly in enumerate(layers):
+        e = d.layer[i]
+        for name in ("w_in", "w_os", "w_q", "w_oc", "w1", "w2"):
+            assert ly[name].is_contiguous()
+            setattr(e, name, _p(ly[name], torch.bfloat16))
+        for name in ("g1", "g3", "g4"):
+            setattr(e, name, _p(ly[name], torch.float32))
+        for j in range(6):
+            e.seed[j] = ly["seed"][j]
+    _lib.check(_lib.lib().toist_xdec_bwd(ctypes.byref(d), _stream()), "toist_xdec_bwd")
+
+
+def queue_fold(partials, out, splits, keep=()):
+    """out[256] += sum over `splits` rows of partials [splits, 256] (f32), folded with the other deferred reductions of the current stream
+    (flush_reductions): the LayerNorm parameter gradients of the XCD-resident backward."""
+    key = (out.device, _raw_stream())
+    if any(it[0].out == out.data_ptr() for it in _PENDING.get(key, ())):
+        flush_reductions()
+    rd = _lib.ReduceDesc(partials.data_ptr(), out.data_ptr(), None, splits, 1, 256, 256, 1.0, 1)
+    _PENDING.setdefault(key, []).append((rd, (out, partials) + tuple(keep)))
+
+
 def xdec_check():
     """Raises when a bounded spin of an XCD-resident launch expired (synchronises: call it from tests / at the end of a run)."""
     for key, ctl in _XDEC_CTL.items():

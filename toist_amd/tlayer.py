@@ -29,6 +29,7 @@ ENABLED = knob("TOIST_ROWS", True)          # tests flip this to compare with th
 
 FUSE_FWD_MAX_K = knob("TOIST_ROWS_FWD_MAX_K", 768)      # forward sub-layers with a longer reduction run as GEMM + LayerNorm launch ...
 FUSE_FWD_MAX_M = knob("TOIST_ROWS_FWD_MAX_M", 0)        # ... (a row-count exception for the decoder's 800 queries was measured and dropped, see _ln_fwd)
+XDEC_BWD = knob("TOIST_XDEC_BWD", True)     # ... and the data-gradient chain of the decoder backward as one launch (toist_xdec_bwd)
 XDEC = knob("TOIST_XDEC", True)             # decoder forward as ONE XCD-resident launch (csrc/xdec.hip) when the shape and the device allow it
 ATTN2 = knob("TOIST_ATTN2", True)           # second-generation attention cores (csrc/attn2.hip): no key-count limit, key-owning backward
 
@@ -244,7 +245,44 @@ def _decoder_layers_xcd(tape, ps, Wself, Wcross, x0, qpos, kv, key_pad, tgt_stac
         recs.append(L)
     k.xdec_fwd(B, Q, S, x0, qpos, kv, key_pad, p, 1e-5, out, table, part)
     tape.keep.append((out, part))
-    return recs
+    return recs, SimpleNamespace(out=out, part=part, table=table)
+
+
+def _decoder_backward_xcd(tape, layers, fw, g_out, kv, dkv, sink, key_pad, B, S, Q, H, p):
+    """Backward of all decoder layers: ONE launch for the data-gradient chain (csrc/xdec.hip xdec_bwd_kernel), then the weight gradients exactly as
+    the per-op steps queue them (grouped launches at the program's end) and the LayerNorm parameter gradients as deferred folds of the
+    launch's per-row-block partial sums."""
+    d, M, L_ = 256, B * Q, len(layers)
+    dev = kv.device
+    bf = lambda *shape: torch.empty(*shape, dtype=BF16, device=dev)
+    nblk = B * ((Q + 3) // 4)
+    outs = dict(gb4=bf(L_, M, d), dh=bf(L_, M, 2048), go3=bf(L_, M, d), go1=bf(L_, M, d), sink=sink, dkv=dkv,
+                ln_part=torch.empty(L_, 3, 2, nblk, d, dtype=torch.float32, device=dev))
+    scratch = dict(dctx=bf(2, M, d), part=fw.part, dq_part=bf(4, M, d))
+    table = [dict(w_in=L.Ws.w, w_os=L.Wos.w, w_q=L.Wq.w, w_oc=L.Woc.w, w1=L.W1.w, w2=L.W2.w, g1=L.ln1.gamma.f32, g3=L.ln3.gamma.f32, g4=L.ln4.gamma.f32,
+                  seed=t["seed"]) for L, t in zip(layers, fw.table)]
+    k.xdec_bwd(B, Q, S, kv, key_pad, p, fw.out, g_out, outs, table, scratch)
+    for L in reversed(layers):
+        i = L.i
+        if L.W2.g is not None:
+            tape.linear_wgrad(outs["gb4"][i], L.h, L.W2, L.b2)
+        if L.W1.g is not None:
+            tape.linear_wgrad(outs["dh"][i], L.ln3.y, L.W1, L.b1)
+        if L.Woc.g is not None:
+            tape.linear_wgrad(outs["go3"][i], L.ctx_c, L.Woc, L.boc)
+        if L.Wq.g is not None:
+            tape.linear_wgrad(sink[:, i * 4 * d + 3 * d:i * 4 * d + 4 * d], L.ln1.y2, L.Wq, L.bq)
+        if L.Wos.g is not None:
+            tape.linear_wgrad(outs["go1"][i], L.ctx_s, L.Wos, L.bos)
+        if L.Ws.g is not None:
+            dqkv = sink[:, i * 4 * d:i * 4 * d + 3 * d]
+            tape.linear_wgrad(dqkv[:, :2 * d], L.xe_in, L.Ws.rows(0, 2 * d), L.bs.rows(0, 2 * d))
+            tape.linear_wgrad(dqkv[:, 2 * d:], L.x_in, L.Ws.rows(2 * d, 3 * d), L.bs.rows(2 * d, 3 * d))
+        for which, ln in ((0, L.ln1), (1, L.ln3), (2, L.ln4)):
+            if ln.gamma.g is not None:
+                k.queue_fold(outs["ln_part"][i, which, 0], ln.gamma.g, nblk, keep=(outs["ln_part"],))
+                k.queue_fold(outs["ln_part"][i, which, 1], ln.beta.g, nblk, keep=(outs["ln_part"],))
+    tape.keep.append((outs, scratch))
 
 
 def decoder_program(tape, ps, mem, qe, pos, key_pad, B, S, Q, H, n_layers):
@@ -277,8 +315,9 @@ def decoder_program(tape, ps, mem, qe, pos, key_pad, B, S, Q, H, n_layers):
     cur_e = qpos
     layers = []
     fused = XDEC and ATTN2 and k.xdec_supported(B, Q, S, L_)
+    fw = None
     if fused:
-        layers = _decoder_layers_xcd(tape, ps, Wself, Wcross, cur, qpos, kv, key_pad, tgt_stack, B, S, Q, H, L_)
+        layers, fw = _decoder_layers_xcd(tape, ps, Wself, Wcross, cur, qpos, kv, key_pad, tgt_stack, B, S, Q, H, L_)
     for i in range(0 if not fused else L_, L_):
         lp = f"layers.{i}."
         L = SimpleNamespace(i=i, x_in=cur, xe_in=cur_e)
@@ -341,8 +380,19 @@ def decoder_program(tape, ps, mem, qe, pos, key_pad, B, S, Q, H, n_layers):
             L.ln1.dz = L.ln1.dzd = L.ln3.dz = L.ln3.dzd = L.ln4.dz = L.ln4.dzd = None
         return bwd
 
-    for L in layers:
-        tape.record(make_bwd(L))
+    # one launch for the whole data-gradient chain when the forward ran as one launch, every decoder weight trains and dk / dv have a consumer
+    fused_bwd = fused and XDEC_BWD and sink is not None and dkv is not None and all(
+        v.g is not None for L in layers for v in (L.Ws, L.Wos, L.Wq, L.Woc, L.W1, L.W2, L.ln1.gamma, L.ln3.gamma, L.ln4.gamma))
+    shared = SimpleNamespace(g=None)
+    if fused_bwd:
+        def all_layers_bwd():
+            if shared.g is not None:
+                _decoder_backward_xcd(tape, layers, fw, shared.g, kv, dkv, sink, key_pad, B, S, Q, H, p)
+                shared.g = None
+        tape.record(all_layers_bwd)
+    else:
+        for L in layers:
+            tape.record(make_bwd(L))
     allv = engine.Var(tgt_stack.view(L_ * M, d))
 
     def split_bwd():    # gradient of the shared final norm -> the layer outputs (runs before the layers' own backward steps)
@@ -350,6 +400,9 @@ def decoder_program(tape, ps, mem, qe, pos, key_pad, B, S, Q, H, n_layers):
         if g is None:
             return
         g = g.view(L_, M, d)
+        if fused_bwd:
+            shared.g = g.contiguous()
+            return
         for i, L in enumerate(layers):
             L.out.grad = g[i]
 
