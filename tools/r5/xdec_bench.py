@@ -16,11 +16,46 @@ from tools.bench_gemm import timeit  # noqa: E402
 BF = torch.bfloat16
 
 
+def backward_profile(tr, memory, pos, key_pad, qe, B, S, dev):
+    """forward + backward of the decoder program: per-op backward vs the one-launch data-gradient chain, and the backward launch's phase stamps"""
+    L = 6
+    mem = memory.clone().requires_grad_(True)
+    g = torch.randn(L, B * 100, 256, device=dev).to(BF)
+
+    def fb():
+        mem.grad = None
+        out = tr.decode_tokens(mem, pos, key_pad, qe, B, S)
+        out.backward(g.view_as(out))
+
+    res = {}
+    for flag in (False, True):
+        tlayer.XDEC, tlayer.XDEC_BWD = True, flag
+        fb()
+        torch.cuda.synchronize()
+        res[flag] = timeit(fb, 10) * 1000.0
+    k.xdec_check()
+    print(f"decoder forward + backward (weight gradients included): per-op backward {res[False]:.1f} us, one-launch data-gradient chain {res[True]:.1f} us")
+    k.XDEC_PROF = torch.zeros(256, L, 16, dtype=torch.int64, device=dev)
+    tlayer.XDEC, tlayer.XDEC_BWD = True, True
+    fb()
+    torch.cuda.synchronize()
+    st = k.XDEC_PROF.cpu().double() * 0.01
+    k.XDEC_PROF = None
+    t0 = st[:, L - 1, 0].min()
+    print(f"backward launch: {float(st[:, 0, 13].max() - t0):.1f} us between the first and the last stamp")
+    names = ["R0 norm4 bwd", "wait", "H dh + partial", "wait", "C fold + norm3 bwd + x W_oc", "wait", "D cross-attn bwd", "wait", "E fold dq + x W_q + norm1 bwd + x W_os", "wait",
+             "F self-attn bwd", "wait", "G x W_in"]
+    for layer in (L - 1, 2, 0):
+        seg = st[:, layer, 1:14] - st[:, layer, :13]
+        print(f"layer {layer}: start +{float(st[:, layer, 0].min() - t0):.1f} us | " + " | ".join(f"{n} {float(seg[:, i].mean()):.2f} (max {float(seg[:, i].max()):.2f})" for i, n in enumerate(names)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--train", action="store_true")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tokens", type=int, default=416)
+    ap.add_argument("--bwd", action="store_true", help="phase stamps of the backward launch (toist_xdec_bwd) and fwd + bwd timings")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -65,11 +100,13 @@ def main():
     names = ["P1 q|k|v", "wait", "A rows (attn, norm1, cross, norm3)", "FFN weights + wait", "P6 hidden + linear2 partials", "wait", "P7 fold + norm4"]
     print(f"{int(live.sum())} workgroups stamped; whole launch {float(st[:, L - 1, 7].max() - t0):.1f} us between the first P1 and the last P7 stamp")
     own = st[:, 0, 8] > 0
-    a = st[own]
+    ao = st[own]
     for layer in (0, 3):
         ch = [("q rows + self-attention", 2, 8), ("W_os stream + sync", 8, 9), ("out_proj + norm1", 9, 10), ("query projection", 10, 11), ("cross-attention", 11, 12),
               ("W_oc stream + sync", 12, 13), ("out_proj + norm3", 13, 3)]
-        print(f"layer {layer} phase A of the {int(own.sum())} row owners: " + " | ".join(f"{n} {float((a[:, layer, j] - a[:, layer, i]).mean()):.2f}" for n, i, j in ch))
+        print(f"layer {layer} phase A of the {int(own.sum())} row owners: " + " | ".join(f"{n} {float((ao[:, layer, j] - ao[:, layer, i]).mean()):.2f}" for n, i, j in ch))
+    if a.bwd:
+        return backward_profile(tr, memory, pos, key_pad, qe, B, S, dev)
     for layer in range(L):
         seg = st[:, layer, 1:8] - st[:, layer, :7]
         row = " | ".join(f"{n} {float(seg[:, i].mean()):.2f} (max {float(seg[:, i].max()):.2f})" for i, n in enumerate(names))
