@@ -287,11 +287,17 @@ __device__ __forceinline__ int swz_k(int row, int kc) {
     return kc ^ ((row / RPL) % CPR);
 }
 // k-major tile: [BK][ROWS], chunk (krow, rc) lives in slot rc ^ 2*h(krow) (32-byte pairs stay together
-// for ds_read_b64_tr_b16), h = (krow & 3) | ((krow >> 3) & 1) << 2, limited to the pairs a row has.
+// for ds_read_b64_tr_b16).  One ds_read_b64_tr_b16 is served per 32-lane half: the half of lane groups g = 0, 1 reads k rows
+// {k0 .. k0 + 3} u {k0 + 8 .. k0 + 11}, 32 bytes each = 256 bytes, conflict-free iff the eight pieces fall on eight different 32-byte bank
+// slots.  128-row tiles (256-byte rows: every row starts on bank 0) need three hash bits: h = (krow & 3) | ((krow >> 3) & 1) << 2.
+// 64-row tiles (128-byte rows) only have four pairs = two hash bits, but the row PARITY already moves a row by half the banks, so the two
+// bits go to krow bit 1 and krow bit 3: h = ((krow >> 1) & 1) | ((krow >> 3) & 1) << 1.  (Round 4 masked the 128-row hash to two bits = krow & 3:
+// rows k and k + 8 collided -- 32-47 % of the LDS-active cycles of every k-major 64 x 64 kernel were bank conflicts,
+// profiles/r04_pmc_lds_conflicts.txt.)
 template <int ROWS>
 __device__ __forceinline__ int swz_m(int krow, int rc) {
     constexpr int PAIRS = ROWS / 16;
-    const int h = ((krow & 3) | (((krow >> 3) & 1) << 2)) & (PAIRS - 1);
+    const int h = PAIRS == 4 ? (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) : (((krow & 3) | (((krow >> 3) & 1) << 2)) & (PAIRS - 1));
     return rc ^ (h << 1);
 }
 
