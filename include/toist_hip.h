@@ -350,32 +350,7 @@ typedef struct toist_opt_state {
     int32_t reserved[3];
 } toist_opt_state;            /* 32 bytes */
 
-/* ---- fused attention core, forward (head dim 32): prob = softmax(scale * q k^T + key padding), prob_drop = dropout(prob),
- * ctx = prob_drop v, one launch (transformer.py:297,370-400 through nn.MultiheadAttention).  q / k / v / ctx are per-head
- * column slices of [B*S, ld*] buffers (row b*S + s, feature h*32 + e); prob / prob_drop are [B*H, Sq, ld] bf16, ld =
- * round8(Sk), and feed toist_softmax_bwd and the backward GEMMs; prob_drop may be NULL (no dropout: ctx uses prob).
- * Flash-style bookkeeping: with `lse` (f32 [B*H, Sq, 2]: maximum and reciprocal sum of exp(s - max) of each score row -- a split
- * log-sum-exp, exact for scores of any magnitude) given, prob and prob_drop may both be NULL --
- * nothing score-shaped reaches HBM and toist_attn_bwd re-forms the probabilities (and the dropout mask, from the same
- * (seed, element index) hash) itself. */
-TOIST_API int toist_attn_fwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const uint8_t* key_pad, int B, int H, int Sq, int Sk,
-                   int dh, int ld, float scale, void* prob, void* prob_drop, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* ctx,
-                   int ldo, float* lse, void* stream);
-
-/* ---- fused attention core, backward (head dim 32, Sk <= 512): dq = scale dS k, dk = scale dS^T q, dv = Pd^T dctx with
- * Pd = prob_drop (or prob when NULL), dP = (dctx v^T) o keep / (1 - drop_p), dS = prob o (dP - rowsum(dctx o ctx)); one launch
- * instead of four batched GEMMs and toist_softmax_bwd.  Layouts as toist_attn_fwd; ctx is the forward context, dctx its
- * gradient; dq / dk / dv are per-head column slices like q / k / v.  variant: 0 = by shape, 1 = key-major kernel (short query
- * ranges), 2 = query-major kernel (long ones).  q_splits > 1 (variant 2, dk / dv slices H*32 wide): that many workgroups share a
- * head, each a run of query tiles; their dk / dv sums meet in `workspace` (q_splits * 2 * B*Sk * H*32 floats) and a fold
- * kernel writes dk / dv.  prob == NULL selects the recomputing mode (query-major kernel): P = exp(scale q k^T - max) * rsum from the
- * forward's `lse`, key padding from `key_pad`, the keep mask from (seed + *seed_dev, row * ld + key) as in toist_attn_fwd. */
-TOIST_API int toist_attn_bwd(const void* q, int ldq, const void* kmat, int ldk, const void* v, int ldv, const void* prob, const void* prob_drop,
-                   const void* ctx, int ldo, const void* dctx, int lddo, int B, int H, int Sq, int Sk, int dh, int ld, float scale,
-                   float drop_p, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int variant, float* workspace, int q_splits,
-                   const float* lse, const uint8_t* key_pad, uint64_t seed, const uint64_t* seed_dev, void* stream);
-
-/* ---- attention cores, second generation (head dim 32; csrc/attn2.hip).  Same operands as toist_attn_fwd / toist_attn_bwd (per-head column
+/* ---- attention cores (head dim 32; csrc/attn2.hip; the first-generation toist_attn_fwd / toist_attn_bwd of rounds 1-4 were removed in round 5).  Operands: per-head column
  * slices of [B*S, ld*] bf16 buffers), flash-style only: nothing score-shaped is stored, the key count is unbounded.
  *   toist_attn2_fwd   ctx = dropout(softmax(scale q k^T + key padding)) v; lse (f32 [B*H, Sq, 2]) receives (maximum of the RAW dot
  *                     products of the row, 1 / sum of exp(scale (s - max))).  The keep mask of element (row = bh * Sq + q, key) is the

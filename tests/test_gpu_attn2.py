@@ -19,6 +19,7 @@ def pair_hash(pair, seed):
     s0 = seed & M32
     s1 = ((seed >> 32) ^ ((seed & M32) * 0x9E3779B9)) & M32
     a = (pair ^ s0) & M32
+    a = a ^ (a >> 12)
     h = ((a & 0xFFFFFF) * 0x9E3779 + s1) & M32
     h = h ^ (h >> 15)
     h = ((h & 0xFFFFFF) * 0x85EBCB + (a >> 8)) & M32

@@ -263,7 +263,7 @@ def test_reference_validation_resolution_stays_on_the_fused_cores(dev):
     keys per attention row, beyond the 480 keys the first-generation cores could hold in LDS (the model then fell back to three
     launches that materialise the scores).  The flash-style cores of csrc/attn2.hip walk the keys in blocks: this test runs the
     model at that size -- forward values against the oracle, and a backward pass whose attention launches are counted -- and asserts
-    that not one score-shaped launch (toist_attn_fwd / softmax / batched score GEMMs) ran."""
+    that not one score-shaped launch (softmax / batched score GEMMs) ran."""
     import toist_amd
     from oracle import model_ref
     from toist_amd import _lib, harness
@@ -277,7 +277,7 @@ def test_reference_validation_resolution_stays_on_the_fused_cores(dev):
     lib = _lib.lib()
     counts = {}
     saved = {}
-    for name in ("toist_attn2_fwd", "toist_attn2_bwd", "toist_attn_fwd", "toist_attn_bwd", "toist_softmax_fwd", "toist_softmax_bwd"):
+    for name in ("toist_attn2_fwd", "toist_attn2_bwd", "toist_softmax_fwd", "toist_softmax_bwd"):
         fn = getattr(lib, name)
         saved[name] = fn
 
@@ -299,7 +299,7 @@ def test_reference_validation_resolution_stays_on_the_fused_cores(dev):
     S = mc["img_memory"].shape[0]
     assert S == 25 * 42 + 16, S
     assert counts.get("toist_attn2_fwd") == 18 and counts.get("toist_attn2_bwd") == 18, counts          # 6 encoder + 12 decoder cores, each way
-    assert not any(counts.get(n) for n in ("toist_attn_fwd", "toist_attn_bwd", "toist_softmax_fwd", "toist_softmax_bwd")), counts
+    assert not any(counts.get(n) for n in ("toist_softmax_fwd", "toist_softmax_bwd")), counts
     with torch.no_grad():
         rmc = model_ref.mdetr_encode(sd, samples.tensors, samples.mask, tok["input_ids"], tok["attention_mask"])
         rout = model_ref.mdetr_decode(sd, rmc, contrastive_align=True)

@@ -135,11 +135,6 @@ _SIGNATURES = {
     "toist_mask_loss_fwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p], ctypes.c_int),
     "toist_mask_loss_bwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_dropout_bf16": ([c_void_p, c_int64, c_float, c_uint64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "toist_attn_fwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 6 + [c_float, c_void_p, c_void_p, c_float, c_uint64,
-                       c_void_p, c_void_p, c_int32, c_void_p, c_void_p], ctypes.c_int),
-    "toist_attn_bwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32] + [c_int32] * 6 +
-                       [c_float, c_float, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_uint64,
-                        c_void_p, c_void_p], ctypes.c_int),
     "toist_attn2_splits": ([c_int32], ctypes.c_int),
     "toist_attn2_fwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 5 + [c_float, c_float, c_uint64, c_void_p, c_void_p,
                         c_int32, c_void_p, c_void_p], ctypes.c_int),

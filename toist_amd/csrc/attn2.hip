@@ -39,7 +39,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 // v_mul_lo_u32 occupies the vector pipe four times as long); keep rate, field / neighbour / stride correlations measured in
 // tools/r4/hash_quality.py.
 __device__ __forceinline__ unsigned pair_hash(unsigned pair, unsigned s0, unsigned s1) {
-    const unsigned a = pair ^ s0;
+    unsigned a = pair ^ s0;
+    a ^= a >> 12;               // the 24-bit multiply below only sees bits 0-23: fold the upper bits in first (pairs 2^24 apart otherwise share 99.9 % of their masks)
     unsigned h = __umul24(a, 0x9E3779u) + s1;
     h ^= h >> 15;
     h = __umul24(h, 0x85EBCBu) + (a >> 8);

@@ -19,7 +19,8 @@ constexpr size_t A2_BWD_LDS = (size_t)A2_NG * 2 * 32 * 32 * 2 * 2 + (size_t)A2_N
                               (size_t)A2_NG * 2 * 4 * 32 * 32 * 4;
 
 __device__ __forceinline__ unsigned pair_hash(unsigned pair, unsigned s0, unsigned s1) {
-    const unsigned a = pair ^ s0;
+    unsigned a = pair ^ s0;
+    a ^= a >> 12;               // the 24-bit multiply below only sees bits 0-23: fold the upper bits in first (pairs 2^24 apart otherwise share 99.9 % of their masks)
     unsigned h = __umul24(a, 0x9E3779u) + s1;
     h ^= h >> 15;
     h = __umul24(h, 0x85EBCBu) + (a >> 8);

@@ -417,7 +417,7 @@ extern "C" int toist_rowgemm(const toist_rowgemm_desc* d, void* stream) {
         }                                                                                                                                  \
         hipLaunchKernelGGL((rowgemm_kernel<BK, EP>), grid, block, lds, st, *d);                                                            \
     } while (0)
-    // lds_attr_once keeps 8 flag words: tlayer uses slots 2 .. 7 (attn.hip has its own hipFuncSetAttribute calls)
+    // lds_attr_once keeps 8 flag words: tlayer uses slots 2 .. 7
     if (d->b_kind == TOIST_B_ROWK) {
         if (d->epi == TOIST_ROW_PLAIN) TOIST_ROWGEMM(TOIST_B_ROWK, TOIST_ROW_PLAIN, 2);
         else if (d->epi == TOIST_ROW_LN_FWD) TOIST_ROWGEMM(TOIST_B_ROWK, TOIST_ROW_LN_FWD, 3);

@@ -90,7 +90,8 @@ __device__ __forceinline__ unsigned xcc_id() {
 
 // attn2.hip's hash: one 32-bit value decides two adjacent keys of a score row
 __device__ __forceinline__ unsigned pair_hash(unsigned pair, unsigned s0, unsigned s1) {
-    const unsigned a = pair ^ s0;
+    unsigned a = pair ^ s0;
+    a ^= a >> 12;               // the 24-bit multiply below only sees bits 0-23: fold the upper bits in first (pairs 2^24 apart otherwise share 99.9 % of their masks)
     unsigned h = __umul24(a, 0x9E3779u) + s1;
     h ^= h >> 15;
     h = __umul24(h, 0x85EBCBu) + (a >> 8);

@@ -52,8 +52,7 @@ class Var:
 # GEMMs from the data-gradient chain was measured too (0 % to -6 %: those kernels already fill the chip and
 # every fork is a cross-stream edge of the graph) and is deliberately not done.
 OVERLAP = knob("TOIST_OVERLAP", "capture")   # "capture": fork the text branch inside captured graphs only; "on" / "off"
-FUSED_ATTENTION = True   # head-dim-32 attention cores run as one fused forward launch (csrc/attn.hip); False = 3 launches
-LSE_ONLY = True          # the fused cores keep only the log-sum-exp of every score row; backward re-forms P and the dropout mask
+FUSED_ATTENTION = True   # head-dim-32 attention cores run as one flash-style launch each way (csrc/attn2.hip); False = batched score GEMMs + softmax kernels
 FUSED_BLOCKS = True      # encoder / decoder layers: packed in_proj in one launch, decoder K/V of all layers grouped, LayerNorm emits y + pos
 _SIDE = {}
 SIDE_PRIORITY = knob("TOIST_SIDE_PRIORITY", 0)   # -1 = high: the small kernels of a side branch get free CU slots first
@@ -634,21 +633,14 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
     vb = ops.linear(v_in.data, Pv[0].w, Pv[1].f32)
     seed_p = tape.next_seed() if p > 0 else 0
     ctx = torch.empty(B * Sq, d, dtype=BF16, device=dev)
-    fused_core = FUSED_ATTENTION and dh == 32 and Sk <= 480
+    fused_core = FUSED_ATTENTION and dh == 32
     if fused_core:
-        # scores -> mask -> softmax -> dropout -> P V in one launch (csrc/attn.hip); the probabilities are kept for backward.
-        # Measured (tools/bench_attn_core.py, B=8): 37.2 vs 61.2 us at 416x416, 25.2 vs 30.9 us at 100x416, 9.4 vs 21.2 us at 100x100
+        # scores -> mask -> softmax -> dropout -> P V in one flash-style launch (csrc/attn2.hip): nothing score-shaped is written (22 MB of P and
+        # 22 MB of dropout(P) per encoder layer at B = 8 otherwise), only (row maximum, 1 / row sum) per score row; any key count
+        prob = prob_used = None
         ld = ops.round8(Sk)
-        lse = None
-        if LSE_ONLY:
-            # flash-style: nothing score-shaped is written (22 MB of P and 22 MB of dropout(P) per encoder layer at B = 8 otherwise)
-            prob = prob_used = None
-            lse = torch.empty(B * H, Sq, 2, dtype=torch.float32, device=dev)   # (row max, 1 / row sum)
-            k.attn_fwd(qb, kb, vb, key_pad, B, H, Sq, Sk, dh, scale, None, None, p, seed_p, ctx, lse=lse)
-        else:
-            prob = torch.empty(B * H, Sq, ld, dtype=BF16, device=dev)
-            prob_used = torch.empty_like(prob) if p > 0 else None
-            k.attn_fwd(qb, kb, vb, key_pad, B, H, Sq, Sk, dh, scale, prob, prob_used, p, seed_p, ctx)
+        lse = torch.empty(B * H, Sq, 2, dtype=torch.float32, device=dev)
+        k.attn2_fwd(qb, kb, vb, key_pad, B, H, Sq, Sk, dh, scale, p, seed_p, ctx, lse)
     else:
         s = ops.attn_scores(qb, kb, B, H, Sq, Sk, dh, scale)
         ld = s.shape[-1]
@@ -659,7 +651,6 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
         ops.attn_context(prob_used if prob_used is not None else prob, vb, B, H, Sq, Sk, dh, ctx)
     if prob_used is None:
         prob_used = prob
-    lse_only = fused_core and LSE_ONLY
     seed_o = tape.next_seed() if p > 0 else 0
     z = ops.linear(ctx, Wo.w, bo.f32, res=resid.data, drop_where=1 if p > 0 else 0, drop_p=p, drop_seed=seed_o)
     out = Var(z)
@@ -690,15 +681,12 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
             return ds
 
         if fused_core:
-            # dV, dP, softmax backward, dQ, dK in one launch (csrc/attn.hip, query-major variant; several workgroups per head when the
-            # query range is long, their dK / dV sums folded by a second small kernel).  Measured (tools/bench_attn_core.py, B=8):
-            # 11 vs 35 us at 100x100, 24 vs 41 us at 100x416, 45 vs 70 us at 416x416 (100 us with one workgroup per head)
-            if lse_only:
-                k.attn_bwd(qb, kb, vb, None, None, ctx, dctx, B, H, Sq, Sk, dh, scale, p, dq, dk, dv, variant=2, q_splits=4 if Sk > 128 else 1,
-                           lse=lse, key_pad=key_pad, seed=seed_p)
-            else:
-                k.attn_bwd(qb, kb, vb, prob, prob_used if p > 0 else None, ctx, dctx, B, H, Sq, Sk, dh, scale, p, dq, dk, dv, variant=2,
-                           q_splits=4 if Sk > 128 else 1)
+            # key-owning backward (csrc/attn2.hip): dK / dV written once, dQ directly or as one bf16 share per 128-key split
+            splits = k.attn2_splits(Sk)
+            part = torch.empty(splits, B * Sq, d, dtype=BF16, device=dev) if splits > 1 else None
+            k.attn2_bwd(qb, kb, vb, ctx, dctx, lse, key_pad, B, H, Sq, Sk, dh, scale, p, seed_p, dq if splits == 1 else None, dk, dv, dq_part=part)
+            if part is not None:
+                dq.copy_(part.float().sum(0))
         else:
             ops.attn_backward(prob_used, scale, qb, kb, vb, dctx, B, H, Sq, Sk, dh, dq, dk, dv, sm_bwd)
         if fused:
@@ -730,16 +718,20 @@ def attention(tape, q_in, k_in, v_in, Pq, Pk, Pv, Wo, bo, resid, key_pad, B, Sq,
 # The gradient w.r.t. a trainable e (the decoder's query embedding) is not formed per layer: every block leaves its dq / dk in a
 # column slice of one [rows, n] buffer (`e_sink`) and the caller multiplies that buffer once by the stacked projection weights.
 def _attn_core(tape, qb, kb, vb, key_pad, B, Sq, Sk, H, ctx, p, seed_p):
+    """attention core of the fused blocks (csrc/attn2.hip, head dim 32); returns core_bwd(dctx, dq, dk, dv)"""
     dh = qb.shape[1] // H
     scale = 1.0 / math.sqrt(dh)
-    if not (FUSED_ATTENTION and dh == 32 and Sk <= 480):
-        raise NotImplementedError("fused attention blocks need head dim 32 and at most 480 keys")
+    if not (FUSED_ATTENTION and dh == 32):
+        raise NotImplementedError("fused attention blocks need head dim 32")
     lse = torch.empty(B * H, Sq, 2, dtype=torch.float32, device=qb.device)
-    k.attn_fwd(qb, kb, vb, key_pad, B, H, Sq, Sk, dh, scale, None, None, p, seed_p, ctx, lse=lse)
+    k.attn2_fwd(qb, kb, vb, key_pad, B, H, Sq, Sk, dh, scale, p, seed_p, ctx, lse)
+    splits = k.attn2_splits(Sk)
 
     def core_bwd(dctx, dq, dk, dv):
-        k.attn_bwd(qb, kb, vb, None, None, ctx, dctx, B, H, Sq, Sk, dh, scale, p, dq, dk, dv, variant=2, q_splits=4 if Sk > 128 else 1,
-                   lse=lse, key_pad=key_pad, seed=seed_p)
+        part = torch.empty(splits, B * Sq, H * dh, dtype=BF16, device=qb.device) if splits > 1 else None
+        k.attn2_bwd(qb, kb, vb, ctx, dctx, lse, key_pad, B, H, Sq, Sk, dh, scale, p, seed_p, dq if splits == 1 else None, dk, dv, dq_part=part)
+        if part is not None:
+            dq.copy_(part.float().sum(0))
 
     return core_bwd
 

@@ -625,29 +625,6 @@ def wgrad3x3_small(dy, x, out, defer=False, accumulate=True):
         flush_reductions()
 
 
-def attn_fwd(q, kmat, v, key_pad, B, H, Sq, Sk, dh, scale, prob, prob_drop, drop_p, seed, ctx, lse=None):
-    """Fused attention core (csrc/attn.hip): q/k/v/ctx are column slices of packed [B*S, ld] bf16 buffers.  With `lse`
-    (f32 [B*H, Sq, 2]: row maximum, reciprocal row sum) the probabilities need not be stored (prob = prob_drop = None): attn_bwd re-forms them."""
-    ld = prob.shape[-1] if prob is not None else (Sk + 7) // 8 * 8
-    _lib.check(_lib.lib().toist_attn_fwd(_p(q, torch.bfloat16), q.stride(0), _p(kmat, torch.bfloat16), kmat.stride(0), _p(v, torch.bfloat16), v.stride(0),
-                                         _p(key_pad, torch.uint8), B, H, Sq, Sk, dh, ld, scale, _p(prob, torch.bfloat16),
-                                         _p(prob_drop, torch.bfloat16), drop_p, seed, _p(SEED_DEV) if drop_p > 0 else None,
-                                         _p(ctx, torch.bfloat16), ctx.stride(0), _p(lse, torch.float32), _stream()), "toist_attn_fwd")
-
-
-def attn_bwd(q, kmat, v, prob, prob_drop, ctx, dctx, B, H, Sq, Sk, dh, scale, drop_p, dq, dk, dv, variant=0, q_splits=1, lse=None, key_pad=None, seed=0):
-    """Fused attention core backward (csrc/attn.hip): all operands are column slices of packed [B*S, ld] bf16 buffers.
-    prob=None: recomputing mode from `lse`, `key_pad` and the forward's dropout `seed`."""
-    ws = _workspace(q_splits * 2 * B * Sk * H * dh, q.device) if q_splits > 1 else None
-    ld = prob.shape[-1] if prob is not None else (Sk + 7) // 8 * 8
-    _lib.check(_lib.lib().toist_attn_bwd(_p(q, torch.bfloat16), q.stride(0), _p(kmat, torch.bfloat16), kmat.stride(0), _p(v, torch.bfloat16), v.stride(0),
-                                         _p(prob, torch.bfloat16), _p(prob_drop, torch.bfloat16), _p(ctx, torch.bfloat16), ctx.stride(0),
-                                         _p(dctx, torch.bfloat16), dctx.stride(0), B, H, Sq, Sk, dh, ld, scale, drop_p,
-                                         _p(dq, torch.bfloat16), dq.stride(0), _p(dk, torch.bfloat16), dk.stride(0), _p(dv, torch.bfloat16), dv.stride(0),
-                                         variant, _p(ws, torch.float32), q_splits, _p(lse, torch.float32), _p(key_pad, torch.uint8), seed,
-                                         _p(SEED_DEV) if (prob is None and drop_p > 0) else None, _stream()), "toist_attn_bwd")
-
-
 def attn2_splits(Sk):
     return int(_lib.lib().toist_attn2_splits(Sk))
 

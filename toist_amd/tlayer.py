@@ -31,19 +31,15 @@ FUSE_FWD_MAX_K = knob("TOIST_ROWS_FWD_MAX_K", 768)      # forward sub-layers wit
 FUSE_FWD_MAX_M = knob("TOIST_ROWS_FWD_MAX_M", 0)        # ... (a row-count exception for the decoder's 800 queries was measured and dropped, see _ln_fwd)
 XDEC_BWD = knob("TOIST_XDEC_BWD", True)     # ... and the data-gradient chain of the decoder backward as one launch (toist_xdec_bwd)
 XDEC = knob("TOIST_XDEC", True)             # decoder forward as ONE XCD-resident launch (csrc/xdec.hip) when the shape and the device allow it
-ATTN2 = knob("TOIST_ATTN2", True)           # second-generation attention cores (csrc/attn2.hip): no key-count limit, key-owning backward
 
 
 def supported(d, H, Sk):
-    return ENABLED and engine.FUSED_BLOCKS and d == 256 and d // H == 32 and (ATTN2 or Sk <= 480)
+    return ENABLED and engine.FUSED_BLOCKS and d == 256 and d // H == 32
 
 
 def _core(tape, qb, kb, vb, key_pad, B, Sq, Sk, H, ctx, p, seed_p):
     """attention core forward; returns core_bwd(dctx, dq, dk, dv) -> None, or the bf16 [splits, B*Sq, 256] partial sums of dq that the
     consumer of dq must fold (kernels.rowgemm(fold=...)) when the keys of a head are owned by several workgroups"""
-    if not ATTN2:
-        old = engine._attn_core(tape, qb, kb, vb, key_pad, B, Sq, Sk, H, ctx, p, seed_p)
-        return lambda dctx, dq, dk, dv: old(dctx, dq, dk, dv)
     dh = qb.shape[1] // H
     scale = 1.0 / math.sqrt(dh)
     lse = torch.empty(B * H, Sq, 2, dtype=torch.float32, device=qb.device)
@@ -314,7 +310,7 @@ def decoder_program(tape, ps, mem, qe, pos, key_pad, B, S, Q, H, n_layers):
     cur = torch.zeros(M, d, dtype=BF16, device=dev)
     cur_e = qpos
     layers = []
-    fused = XDEC and ATTN2 and k.xdec_supported(B, Q, S, L_)
+    fused = XDEC and k.xdec_supported(B, Q, S, L_)
     fw = None
     if fused:
         layers, fw = _decoder_layers_xcd(tape, ps, Wself, Wcross, cur, qpos, kv, key_pad, tgt_stack, B, S, Q, H, L_)

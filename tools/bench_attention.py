@@ -69,13 +69,13 @@ class Counter:
         from toist_amd import _lib
         self.lib = _lib.lib()
         self.saved = {}
-        for name in ("toist_gemm_bf16", "toist_attn_fwd", "toist_attn_bwd", "toist_add_bf16", "toist_splitk_reduce_batch", "toist_group_fill", "toist_layernorm_fwd",
+        for name in ("toist_gemm_bf16", "toist_add_bf16", "toist_splitk_reduce_batch", "toist_group_fill", "toist_layernorm_fwd",
                      "toist_attn2_fwd", "toist_attn2_bwd", "toist_rowgemm", "toist_layernorm_bwd"):
             fn = getattr(self.lib, name)
             self.saved[name] = fn
 
             def wrap(*a, _fn=fn, _name=name):
-                self.n += 2 if _name == "toist_attn_bwd" else 1      # attn_bwd with query splits = core + fold
+                self.n += 1
                 return _fn(*a)
 
             setattr(self.lib, name, wrap)

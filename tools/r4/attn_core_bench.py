@@ -1,4 +1,4 @@
-"""us per launch (hipGraph replay of 20 back-to-back launches) of the attention cores: first generation (csrc/attn.hip: forward, query-major
+"""us per launch (hipGraph replay of 20 back-to-back launches) of the attention cores: (round 4 also timed the first generation, csrc/attn.hip, removed in round 5: forward, query-major
 backward with 4 query splits + fold) against second generation (csrc/attn2.hip) at the three shapes of the bench model, dropout 0.1."""
 import math
 import sys
@@ -26,11 +26,6 @@ for Sq, Sk in [(416, 416), (100, 416), (100, 100), (1066, 1066)]:
     dkv = torch.empty(B * Sk, 3 * d, dtype=BF, device=dev)
     sc = 1 / math.sqrt(dh)
     print(f"--- Sq = {Sq}, Sk = {Sk}, dropout {drop}")
-    if Sk <= 480:
-        timed(lambda: k.attn_fwd(qs, ks, vs, pad, B, H, Sq, Sk, dh, sc, None, None, drop, 7, ctx, lse=lse), "v1 forward (lse mode)")
-        qsp = 4 if Sk > 128 else 1
-        timed(lambda: k.attn_bwd(qs, ks, vs, None, None, ctx, dctx, B, H, Sq, Sk, dh, sc, drop, dqkv[:, :d], dkv[:, d:2 * d], dkv[:, 2 * d:], variant=2, q_splits=qsp,
-                                 lse=lse, key_pad=pad, seed=7), f"v1 backward (query-major, {qsp} splits{' + fold' if qsp > 1 else ''})")
     timed(lambda: k.attn2_fwd(qs, ks, vs, pad, B, H, Sq, Sk, dh, sc, drop, 7, ctx, lse), "attn2 forward")
     splits = k.attn2_splits(Sk)
     part = torch.empty(splits, B * Sq, d, dtype=BF, device=dev) if splits > 1 else None

@@ -6,11 +6,14 @@ Run: python tools/r4/hash_quality.py  (output kept in profiles/r04_hash_quality.
 import numpy as np
 
 M1, M2 = 0x9E3779, 0x85EBCB
+FOLD_HIGH_BITS = True      # round 5: a ^= a >> 12 before the first 24-bit multiply
 
 
 def pair_hash(idx, s0, s1):
     idx = idx.astype(np.uint64)
     a = (idx ^ s0) & 0xFFFFFFFF
+    if FOLD_HIGH_BITS:
+        a ^= a >> 12
     h = ((a & 0xFFFFFF) * M1 + s1) & 0xFFFFFFFF
     h ^= h >> 15
     h = ((h & 0xFFFFFF) * M2 + (a >> 8)) & 0xFFFFFFFF
@@ -32,6 +35,12 @@ def main():
         cs = [np.corrcoef(klo[:-s], klo[s:])[0, 1] for s in strides]
         print(f"seed {seed:#x}: drop rate field0 {1 - klo.mean():.5f} field1 {1 - khi.mean():.5f} (p = {p}); corr(field0, field1) {np.corrcoef(klo, khi)[0, 1]:+.4f}")
         print("    autocorrelation of the keep mask at pair strides " + ", ".join(f"{s}: {c:+.4f}" for s, c in zip(strides, cs)))
+        # pairs 2^24 apart (B * H * Sq * round8(Sk) / 2 reaches 2^24 at B = 8, H = 8, S ~ 1066): the first multiply only sees 24 bits of the index
+        base = np.arange(1 << 20, dtype=np.uint64)
+        far = pair_hash(base + (1 << 24), s0, s1)
+        near = pair_hash(base, s0, s1)
+        kf, kn = (far & 0xFFFF) >= t, (near & 0xFFFF) >= t
+        print(f"    stride 2^24: mask agreement {np.mean(kf == kn):.4f} (independent masks: {1 - 2 * p * (1 - p):.4f}), correlation {np.corrcoef(kf, kn)[0, 1]:+.4f}")
         m = klo[:208 * 20000].reshape(20000, 208)
         print(f"    [20000 x 208] mask: column-mean std {m.mean(0).std():.5f} (binomial {np.sqrt(p * (1 - p) / 20000):.5f}), "
               f"row-mean std {m.mean(1).std():.5f} (binomial {np.sqrt(p * (1 - p) / 208):.5f})")
