@@ -726,6 +726,7 @@ def main():
         print("[bench] host us inside each run_step() call: " + " ".join(f"{u:.0f}" for u in host_us) + f" | region {1e3 * dt:.2f} ms", file=sys.stderr)
     kernels.PROFILE = None
     loss_val = float(last)
+    kernels.xdec_check()        # a bounded spin of an XCD-resident decoder launch expired (its group was not co-resident): the numbers would be invalid
     # the same K-step region again (replayed graphs only: nothing is instrumented there): boxes of the pool differ by +- 8 % and one
     # 0.3 s region is one sample -- `value` stays the FIRST region, the spread is reported beside it
     region_ms = [1000 * dt / a.steps]

@@ -30,6 +30,8 @@ def finite_or_exit(loss_value, loss_dict=None, criterion=None):
     import math
     import sys
     v = float(loss_value)
+    from . import kernels
+    kernels.xdec_check()        # (the float() above synchronised) a group of an XCD-resident launch that was not co-resident gave up waiting: results invalid
     if math.isfinite(v):
         return v
     if criterion is not None:

@@ -699,6 +699,12 @@ _XDEC_CTL = {}      # (device, stream) -> int32[1024] control words (tickets, ar
 
 
 def xdec_supported(B, Q, S, L):
+    """The XCD-resident decoder launches need all 256 CUs of the device to themselves (one 147 KB workgroup per CU, 32 co-resident per image): not
+    when several ranks of one job share a GPU (the one-GPU multi-rank tests; two such launches from two processes would starve each other until their
+    bounded spins expire)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > torch.cuda.device_count():
+        return False
     return bool(_lib.lib().toist_xdec_supported(B, Q, S, L))
 
 
