@@ -695,7 +695,17 @@ ROW_PLAIN, ROW_LN_FWD, ROW_LN_BWD = _lib.ROW_PLAIN, _lib.ROW_LN_FWD, _lib.ROW_LN
 
 # ---- XCD-resident decoder stack (csrc/xdec.hip) ------------------------------------------------------------------------------------------
 XDEC_PROF = None
-_XDEC_CTL = {}      # (device, stream) -> int32[1024] control words (tickets, arrival counters, sticky status)
+_XDEC_CTL = {}      # device -> int32[1024] control words (tickets, arrival counters, sticky status)
+
+
+def _xdec_ctl(device):
+    """One set of control words per device: the launches need the whole chip, so two of them never run at the same time on one device (the forward and
+    the backward launch of a step are ordered by the stream).  Allocated on first use -- normally an eager warm-up step; a first use inside a capture
+    takes the words from the graph's pool (the fill is then replayed: the sticky status word is cleared by every replay)."""
+    ctl = _XDEC_CTL.get(device)
+    if ctl is None:
+        ctl = _XDEC_CTL[device] = torch.zeros(_lib.XDEC_CTL_WORDS, dtype=torch.int32, device=device)
+    return ctl
 
 
 def xdec_supported(B, Q, S, L):
@@ -727,13 +737,7 @@ def xdec_fwd(B, Q, S, x0, qpos, kv, key_pad, drop_p, eps, out, layers, part):
         setattr(d, name, _p(t, torch.float32))
     assert part.is_contiguous() and part.numel() >= B * 32 * 128 * 256
     d.part = _p(part, torch.bfloat16)
-    key = (x0.device, _raw_stream())
-    ctl = _XDEC_CTL.get(key)
-    if ctl is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("toist_amd.kernels.xdec_fwd: run one eager step on this stream before capturing (the control words are allocated on first use)")
-        ctl = _XDEC_CTL[key] = torch.zeros(_lib.XDEC_CTL_WORDS, dtype=torch.int32, device=x0.device)
-    d.ctl = ctl.data_ptr()
+    d.ctl = _xdec_ctl(x0.device).data_ptr()
     d.prof = XDEC_PROF.data_ptr() if XDEC_PROF is not None else None      # diagnostics (tools/r5/xdec_bench.py): int64 [256, L, 8]
     for i, ly in enumerate(layers):
         e = d.layer[i]
@@ -777,13 +781,7 @@ def xdec_bwd(B, Q, S, kv, key_pad, drop_p, saved, g_out, outs, layers, scratch):
     for name in ("dctx", "part", "dq_part"):
         assert scratch[name].is_contiguous()
         setattr(d, name, _p(scratch[name], torch.bfloat16))
-    key = (kv.device, _raw_stream())
-    ctl = _XDEC_CTL.get(key)
-    if ctl is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("toist_amd.kernels.xdec_bwd: run one eager step on this stream before capturing (the control words are allocated on first use)")
-        ctl = _XDEC_CTL[key] = torch.zeros(_lib.XDEC_CTL_WORDS, dtype=torch.int32, device=kv.device)
-    d.ctl = ctl.data_ptr()
+    d.ctl = _xdec_ctl(kv.device).data_ptr()
     d.prof = XDEC_PROF.data_ptr() if XDEC_PROF is not None else None
     for i, ly in enumerate(layers):
         e = d.layer[i]
