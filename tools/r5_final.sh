@@ -7,6 +7,7 @@ O=gpurun_out/$TAG
 mkdir -p $O
 ( time timeout 2700 python -m pytest tests -m gpu -q -p no:cacheprovider ) > $O/pytest.log 2>&1
 tail -4 $O/pytest.log | cut -c1-300
+( timeout 600 python -c 'import __graft_entry__ as g; g.smoke()' ) 2>&1 | grep -v amdgpu.ids | tail -2 | tee $O/smoke.txt
 ( time timeout 1500 python bench.py ) > $O/bench_default.log 2>&1
 grep metric $O/bench_default.log | cut -c1-400
 ( timeout 600 python bench.py --no-secondary --no-cpu-baseline --no-roofline --stamps ) > $O/bench_stamps.log 2>&1
