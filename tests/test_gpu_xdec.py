@@ -15,11 +15,11 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _model(dev):
+def _model(dev, **over):
     import toist_amd
     from toist_amd import harness
     torch.manual_seed(0)
-    args = harness.default_args(device="cuda", contrastive_align_loss=True)
+    args = harness.default_args(device="cuda", contrastive_align_loss=True, **over)
     model, _, _, _ = toist_amd.build_model(args)
     for n, b in model.named_buffers():
         if n.endswith("bn3.weight"):
@@ -88,3 +88,36 @@ def test_xcd_resident_decoder_matches_the_per_op_launches(dev, B, hw, train, bwd
         if cos < 0.995 or not (0.97 < ratio < 1.03):
             worst[n] = (round(cos, 5), round(ratio, 4))
     assert not worst, f"{len(worst)} gradients differ between the XCD-resident and the per-op decoder forward: {dict(list(worst.items())[:12])}"
+
+
+def test_xcd_resident_decoder_with_ragged_rows_and_padded_keys(dev):
+    """30 queries (the last 4-row block of an image has 2 live rows, the last 16-row tile 14), images of different sizes in one batch (key padding inside
+    the memory of the smaller ones), 5 decoder layers: both launches against the per-op path, training mode."""
+    from toist_amd import harness, misc
+    from toist_amd import kernels as k
+    model = _model(dev, num_queries=30, dec_layers=5)
+    parts = [harness.synthetic_batch(1, h, w_, tokens=11, seed=50 + i, max_targets=3) for i, (h, w_) in enumerate(((160, 224), (128, 160), (96, 224)))]
+    samples = misc.NestedTensor.from_tensor_list([p[0].tensors[0] for p in parts])
+    tok = parts[0][1]
+    tok = type(tok)({key: torch.cat([p[1][key] for p in parts]) for key in ("input_ids", "attention_mask")})
+    B = 3
+    assert bool(samples.mask.any()) and not bool(samples.mask.all())
+    g = torch.Generator().manual_seed(4)
+    w = [torch.randn(5, B, 30, n, generator=g).to(dev) for n in (256, 4, 64)]
+    S = (samples.tensors.shape[-2] // 32) * (samples.tensors.shape[-1] // 32) + 11
+    if not k.xdec_supported(B, 30, S, 5):
+        pytest.skip("device without 8 XCDs x 32 CUs")
+    lg_a, bx_a, _, g_a, (calls_a, bcalls_a) = _run(model, dev, samples, tok, w, True, True, True)
+    lg_b, bx_b, _, g_b, (calls_b, bcalls_b) = _run(model, dev, samples, tok, w, False, True)
+    assert len(calls_a) == 1 and len(bcalls_a) == 1 and not calls_b and not bcalls_b
+    assert float((lg_a - lg_b).norm() / lg_b.norm()) < 1.5e-2
+    assert float((bx_a - bx_b).abs().max()) < 2e-2
+    worst = {}
+    for n in g_b:
+        if g_b[n].norm() == 0 or "decoder.layers.0.self_attn.in_proj" in n or n.endswith("attention.self.key.bias"):
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(g_a[n].flatten(), g_b[n].flatten(), dim=0))
+        ratio = float(g_a[n].norm() / g_b[n].norm())
+        if cos < 0.995 or not (0.97 < ratio < 1.03):
+            worst[n] = (round(cos, 5), round(ratio, 4))
+    assert not worst, f"{len(worst)} gradients differ: {dict(list(worst.items())[:12])}"
