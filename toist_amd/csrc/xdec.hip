@@ -640,6 +640,12 @@ __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) 
                 const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
                 unsigned pk[4][2];
                 bf16_t* const h_row = reinterpret_cast<bf16_t*>(p.h) + (lrow + (mlive ? mrow : 0)) * XFF + slot * 64;
+                if (p.prof != nullptr) {          // diagnostics: when have the y3 fragments arrived?
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(yf[i]));
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    xstamp(p.prof, wgid, p.L, layer, 14);
+                }
 #pragma unroll
                 for (int th = 0; th < 4; ++th) {
                     f32x4_t a4 = {0.f, 0.f, 0.f, 0.f};
@@ -664,6 +670,10 @@ __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) 
                 // linear2 partial: k slots of block u: (g, i) <-> hidden 32 u + 4 g + i, (g, 4 + i) <-> hidden 32 u + 16 + 4 g + i
                 const bf16x8_t pa0 = frag_of(pk[0][0], pk[0][1], pk[1][0], pk[1][1]), pa1 = frag_of(pk[2][0], pk[2][1], pk[3][0], pk[3][1]);
                 bf16_t* const part_row = reinterpret_cast<bf16_t*>(p.part) + (((size_t)b * XWG + slot) * XPR + mrow) * XD;
+                if (p.prof != nullptr) {
+                    asm volatile("" : "+v"(pk[3][1]));
+                    xstamp(p.prof, wgid, p.L, layer, 15);
+                }
 #pragma unroll
                 for (int v = 0; v < 8; ++v) {
                     f32x4_t o[2];

@@ -105,6 +105,10 @@ def main():
         ch = [("q rows + self-attention", 2, 8), ("W_os stream + sync", 8, 9), ("out_proj + norm1", 9, 10), ("query projection", 10, 11), ("cross-attention", 11, 12),
               ("W_oc stream + sync", 12, 13), ("out_proj + norm3", 13, 3)]
         print(f"layer {layer} phase A of the {int(own.sum())} row owners: " + " | ".join(f"{n} {float((ao[:, layer, j] - ao[:, layer, i]).mean()):.2f}" for n, i, j in ch))
+    w0 = st[:, :, 14] > 0
+    if bool(w0.any()):
+        print("P6 of wave 0 (workgroup mean over layers): y3 fragments arrive after %.2f us, linear1 + ReLU + dropout + h stores %.2f us, linear2 partials + stores %.2f us" % (
+            float((st[:, :, 14] - st[:, :, 4])[w0].mean()), float((st[:, :, 15] - st[:, :, 14])[w0].mean()), float((st[:, :, 5] - st[:, :, 15])[w0].mean())))
     if a.bwd:
         return backward_profile(tr, memory, pos, key_pad, qe, B, S, dev)
     for layer in range(L):
