@@ -405,6 +405,23 @@ __device__ __forceinline__ bf16x8_t fragment(const bf16_t* s, int r0, int ks, in
     return *reinterpret_cast<const bf16x8_t*>(&s[row * BK + swz_k<BK>(row, ks * 4 + g) * 8]);
 }
 
+// fragment<true, ...> with the rows of a 32-row group in the order panel2_kernel wants (row q of fragment j = row 8 (q >> 2) + 4 j + (q & 3) of the
+// group starting at r0, a multiple of 8): lane quad q & 3 of a 16-lane group transposes the four rows at element 4 j of the group's chunk (q & 3).
+template <int ROWS, int BK>
+__device__ __forceinline__ bf16x8_t fragment_perm8(const bf16_t* s, int r0, int j, int ks, int g, int c16) {
+    const int k = ks * 32 + 8 * g + (c16 >> 2);
+    const int rc = (r0 >> 3) + (c16 & 3);
+    const int sub = j * 4;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+    const bf16_t* q0 = &s[k * ROWS + swz_m<ROWS>(k, rc) * 8 + sub];
+    const bf16_t* q1 = &s[(k + 4) * ROWS + swz_m<ROWS>(k + 4, rc) * 8 + sub];
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q1));
+    union { struct { s16x4_t a, b; } h; bf16x8_t v; } u;
+    u.h.a = lo; u.h.b = hi;
+    return u.v;
+}
+
 // logical tile index -> (tile_m, tile_n): panels of 8 M tiles, M fastest inside a panel, then N, then the next panel
 __device__ __forceinline__ void tile_order(int L, int nt_m, int nt_n, int& tile_m, int& tile_n) {
     constexpr int G = 8;
@@ -2234,6 +2251,10 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
     if (rr >= groups || m_beg + rr >= m_end) return;
     const int T = (m_end - (m_beg + rr) + groups - 1) / groups;      // tiles of this workgroup: m_beg + rr + j * groups
     const int n0 = tile_n * BN;
+    // Column order of the MFMA fragments (round 5): row q of fragment j of the B operand is column 8 (q >> 2) + 4 j + (q & 3) of the wave's 32, so
+    // that the 2 x 4 values a lane holds after the MFMA -- rows 4 g .. 4 g + 3 of both fragments -- are the EIGHT consecutive columns 8 g .. 8 g + 7
+    // of one output row: one 16-byte residual / mask read and one 16-byte store per lane and row instead of two 8-byte ones.  Sums are unchanged.
+    auto pcol = [](const int j, const int q) { return 8 * (q >> 2) + 4 * j + (q & 3); };
     const bf16_t* const resp = (const bf16_t*)p.epi.res;
     const bf16_t* const auxp = (const bf16_t*)p.epi.aux;
     const bool has_res = resp != nullptr;
@@ -2255,7 +2276,7 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + c16, k = ks * 32 + g * 8;
+                const int n = n0 + wn * WN + pcol(j, c16), k = ks * 32 + g * 8;
                 const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
                 bq[ks][j] = (n < N && k < K) ? *reinterpret_cast<const bf16x8_t*>(B + (size_t)n * ldb + k) : zero;
             }
@@ -2276,7 +2297,7 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
-                bq[ks][j] = (ks < nks) ? fragment<true, BN, BK>(smem + (ks >> 1) * 64 * BK, wn * WN + j * 16, ks & 1, g, c16) : zero;
+                bq[ks][j] = (ks < nks) ? fragment_perm8<BN, BK>(smem + (ks >> 1) * 64 * BK, wn * WN, j, ks & 1, g, c16) : zero;
             }
         __syncthreads();
     }
@@ -2298,7 +2319,7 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
         x_off[it] = r_row[it] * p.epi.ldaux + cc;
     }
     const int P = PW * (kt + (has_res ? 1 : 0) + (has_aux ? 1 : 0));    // DMA instructions per wave per tile
-    constexpr int S = FM * FN;                                          // store instructions per wave per tile
+    constexpr int S = FM;                                               // store instructions per wave per tile
     // Lane offsets of a FULL tile (every row < M): loop invariants in bytes, out-of-range where the K tail / the column tail says so; the
     // tile's row offset m0 * ld travels in the buffer instruction's scalar offset -- no vector instruction per piece.  (The DMA issue
     // of a tile used to be ~90 instructions: address adds, predicates and an M0 save / restore per piece.)
@@ -2360,35 +2381,33 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
     const unsigned long long dseed = drop ? p.epi.drop_seed + (p.epi.drop_seed_dev ? *p.epi.drop_seed_dev : 0ull) : 0ull;
     const unsigned dth = (unsigned)(p.epi.drop_p * 4294967296.0);
     const float dsc = 1.f / (1.f - p.epi.drop_p);
-    int ncol[FN];                                       // first of this lane's 4 columns in fragment column j
-    bool col_ok[FN];                                    // N % 8 == 0: the 4 columns are valid or absent together
+    static_assert(FN == 2, "the fragment column order above pairs two fragments");
+    const int ncol = n0 + wn * WN + g * 8;              // first of this lane's 8 columns (fragment 0: +0..3, fragment 1: +4..7)
+    const bool col_ok = ncol < N;                       // N % 8 == 0: the 8 columns are valid or absent together
     float csc[FN][4], csh[FN][4];
 #pragma unroll
     for (int jj = 0; jj < FN; ++jj) {
-        ncol[jj] = n0 + wn * WN + jj * 16 + g * 4;
-        col_ok[jj] = ncol[jj] < N;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { csc[jj][e] = alpha; csh[jj][e] = 0.f; }
-        if (col_ok[jj]) {
+        if (col_ok) {
             if (p.epi.scale != nullptr) {
-                const float4 t4 = *reinterpret_cast<const float4*>(p.epi.scale + ncol[jj]);
+                const float4 t4 = *reinterpret_cast<const float4*>(p.epi.scale + ncol + jj * 4);
                 csc[jj][0] = alpha * t4.x; csc[jj][1] = alpha * t4.y; csc[jj][2] = alpha * t4.z; csc[jj][3] = alpha * t4.w;
             }
             if (p.epi.shift != nullptr) {
-                const float4 t4 = *reinterpret_cast<const float4*>(p.epi.shift + ncol[jj]);
+                const float4 t4 = *reinterpret_cast<const float4*>(p.epi.shift + ncol + jj * 4);
                 csh[jj][0] = t4.x; csh[jj][1] = t4.y; csh[jj][2] = t4.z; csh[jj][3] = t4.w;
             }
         }
     }
-    // residual / mask fragment (i, j) of this lane inside a stage's [BM][64] tile: row wm*WM + 16 i + c16, 8 bytes at column wn*32 + 16 j + 4 g
-    int rx_off[FM][FN];
+    // residual / mask row piece of this lane inside a stage's [BM][64] tile: row wm*WM + 16 i + c16, the 16-byte chunk wn*4 + g (stored in slot
+    // chunk ^ ((row >> 1) & 7): the 16 rows of a 16-lane read pass cover all 64 banks once)
+    int rx_off[FM];
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int jj = 0; jj < FN; ++jj) {
-            const int r = wm * WM + i * 16 + c16, c = wn * 4 + jj * 2 + (g >> 1);
-            rx_off[i][jj] = r * BN + ((c ^ ((r >> 1) & 7)) * 8) + (g & 1) * 4;
-        }
+    for (int i = 0; i < FM; ++i) {
+        const int r = wm * WM + i * 16 + c16, c = wn * 4 + g;
+        rx_off[i] = r * BN + ((c ^ ((r >> 1) & 7)) * 8);
+    }
     // The prologue's own (compiler-visible) loads end here: naming their registers as asm operands makes hipcc place ITS wait for them in
     // front of this statement instead of at their first use inside the tile loop, where it would be a vmcnt(0) per tile.  From here on
     // the wave's counter holds only what `issue` and the stores put there.
@@ -2453,48 +2472,52 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int m = tm * BM + wm * WM + i * 16 + c16;
+            float v[8];
 #pragma unroll
-            for (int jj = 0; jj < FN; ++jj) {
-                float v[4] = {acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]};
+            for (int jj = 0; jj < FN; ++jj)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] * csc[jj][e] + csh[jj][e];
-                if (drop == 1) {
-                    const unsigned long long didx = (unsigned long long)m * N + ncol[jj];
+                for (int e = 0; e < 4; ++e) v[jj * 4 + e] = acc[i][jj][e] * csc[jj][e] + csh[jj][e];
+            const unsigned long long didx = (unsigned long long)m * N + ncol;
+            if (drop == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = dropout_keep(dseed, didx + e, dth) ? v[e] * dsc : 0.f;
-                }
-                if (has_res) {
-                    const uint2 r2 = *reinterpret_cast<const uint2*>(sR + rx_off[i][jj]);
-                    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-                    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
-                }
-                if (has_aux) {
-                    const uint2 x2 = *reinterpret_cast<const uint2*>(sX + rx_off[i][jj]);
-                    v[0] = __uint_as_float(x2.x << 16) > 0.f ? v[0] : 0.f; v[1] = __uint_as_float(x2.x & 0xffff0000u) > 0.f ? v[1] : 0.f;
-                    v[2] = __uint_as_float(x2.y << 16) > 0.f ? v[2] : 0.f; v[3] = __uint_as_float(x2.y & 0xffff0000u) > 0.f ? v[3] : 0.f;
-                }
-                if (drop == 2) {
-                    if (ACT == TOIST_ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    const unsigned long long didx = (unsigned long long)m * N + ncol[jj];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = dropout_keep(dseed, didx + e, dth) ? v[e] * dsc : 0.f;
-                }
-                u32x2_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                if (ACT == TOIST_ACT_RELU && drop != 2) {
-                    // ReLU on the packed bf16 pairs (one v_pk_max_i16 per pair instead of a v_max_f32 per value): rounding is monotone and
-                    // keeps the sign, so max(round(v), 0) = round(max(v, 0)); a negative (or -0) half has its int16 sign bit set
-                    // (written as asm: hipcc's SLP pass merged two __builtin_elementwise_max calls on <2 x i16> into one and fed its result
-                    // to BOTH words -- seen in the ISA, wrong values in tools/r3/panel2.py)
-                    unsigned r0, r1;
-                    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r0) : "v"(o[0]));
-                    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r1) : "v"(o[1]));
-                    o[0] = r0; o[1] = r1;
-                }
-                store8_asm(rsC, (col_ok[jj] && m < M) ? (m * ldc + ncol[jj]) * 2 : OOB, o);
+                for (int e = 0; e < 8; ++e) v[e] = dropout_keep(dseed, didx + e, dth) ? v[e] * dsc : 0.f;
             }
+            if (has_res) {
+                const uint4 r4 = *reinterpret_cast<const uint4*>(sR + rx_off[i]);
+                v[0] += __uint_as_float(r4.x << 16); v[1] += __uint_as_float(r4.x & 0xffff0000u);
+                v[2] += __uint_as_float(r4.y << 16); v[3] += __uint_as_float(r4.y & 0xffff0000u);
+                v[4] += __uint_as_float(r4.z << 16); v[5] += __uint_as_float(r4.z & 0xffff0000u);
+                v[6] += __uint_as_float(r4.w << 16); v[7] += __uint_as_float(r4.w & 0xffff0000u);
+            }
+            if (has_aux) {
+                const uint4 x4 = *reinterpret_cast<const uint4*>(sX + rx_off[i]);
+                v[0] = __uint_as_float(x4.x << 16) > 0.f ? v[0] : 0.f; v[1] = __uint_as_float(x4.x & 0xffff0000u) > 0.f ? v[1] : 0.f;
+                v[2] = __uint_as_float(x4.y << 16) > 0.f ? v[2] : 0.f; v[3] = __uint_as_float(x4.y & 0xffff0000u) > 0.f ? v[3] : 0.f;
+                v[4] = __uint_as_float(x4.z << 16) > 0.f ? v[4] : 0.f; v[5] = __uint_as_float(x4.z & 0xffff0000u) > 0.f ? v[5] : 0.f;
+                v[6] = __uint_as_float(x4.w << 16) > 0.f ? v[6] : 0.f; v[7] = __uint_as_float(x4.w & 0xffff0000u) > 0.f ? v[7] : 0.f;
+            }
+            if (drop == 2) {
+                if (ACT == TOIST_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = dropout_keep(dseed, didx + e, dth) ? v[e] * dsc : 0.f;
+            }
+            u32x4_t o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+            if (ACT == TOIST_ACT_RELU && drop != 2) {
+                // ReLU on the packed bf16 pairs (one v_pk_max_i16 per pair instead of a v_max_f32 per value): rounding is monotone and
+                // keeps the sign, so max(round(v), 0) = round(max(v, 0)); a negative (or -0) half has its int16 sign bit set
+                // (written as asm: hipcc's SLP pass merged two __builtin_elementwise_max calls on <2 x i16> into one and fed its result
+                // to BOTH words -- seen in the ISA, wrong values in tools/r3/panel2.py)
+                unsigned r0, r1, r2, r3;
+                asm("v_pk_max_i16 %0, %1, 0" : "=v"(r0) : "v"(o[0]));
+                asm("v_pk_max_i16 %0, %1, 0" : "=v"(r1) : "v"(o[1]));
+                asm("v_pk_max_i16 %0, %1, 0" : "=v"(r2) : "v"(o[2]));
+                asm("v_pk_max_i16 %0, %1, 0" : "=v"(r3) : "v"(o[3]));
+                o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
+            }
+            store16_asm(rsC, (col_ok && m < M) ? (m * ldc + ncol) * 2 : OOB, o);
         }
         if (PROF) { t1 = cyc_now(); pc[3] += t1 - t0; t0 = t1; }
         if (++slot == ns) slot = 0;
