@@ -2447,17 +2447,41 @@ __global__ __launch_bounds__(256, 2) void panel2_kernel(const toist_gemm p, cons
 #pragma unroll
             for (int jj = 0; jj < FN; ++jj) acc[i][jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         const bf16_t* sA = ring + slot * stage;
+        // All A fragments of the tile are read before the first MFMA (round 5): with the k-step count a run-time value the compiler emitted
+        // read -> wait -> two MFMAs per step, eight LDS latencies in a row (the "mfma" phase of profiles/r03_panel2_phase_cycles.txt: 1050
+        // cycles for 16 MFMAs).  The reduction depths of the hot path (K = 256 / 128 / 64) get a straight-line body each; same MFMA order.
+        auto mma_all = [&](auto nk_tag) {
+            constexpr int NK = decltype(nk_tag)::value;
+            bf16x8_t af[NK][FM];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks < nks) {
-                bf16x8_t af[FM];
+            for (int ks = 0; ks < NK; ++ks)
 #pragma unroll
-                for (int i = 0; i < FM; ++i) af[i] = fragment<false, BM, BK>(sA + (ks >> 1) * SUB, wm * WM + i * 16, ks & 1, g, c16);
+                for (int i = 0; i < FM; ++i) af[ks][i] = fragment<false, BM, BK>(sA + (ks >> 1) * SUB, wm * WM + i * 16, ks & 1, g, c16);
+            __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks every read to its MFMA again)
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks)
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int jj = 0; jj < FN; ++jj)
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][jj], af[i], acc[i][jj], 0, 0, 0);
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][jj], af[ks][i], acc[i][jj], 0, 0, 0);
+        };
+        if (nks == 8) mma_all(std::integral_constant<int, 8>{});
+        else if (nks == 4) mma_all(std::integral_constant<int, 4>{});
+        else if (nks == 2) mma_all(std::integral_constant<int, 2>{});
+        else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks < nks) {
+                    bf16x8_t af[FM];
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) af[i] = fragment<false, BM, BK>(sA + (ks >> 1) * SUB, wm * WM + i * 16, ks & 1, g, c16);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < FN; ++jj)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks][jj], af[i], acc[i][jj], 0, 0, 0);
+                }
             }
         }
         const bf16_t* sR = sA + res_off;
