@@ -306,8 +306,9 @@ TOIST_API int toist_attnmap_softmax_fwd(const void* scores, const uint8_t* key_p
 TOIST_API int toist_attnmap_softmax_bwd(const void* prob, const void* dprob, int BQ, int H, int HW, int ld, void* dscores, void* stream);
 TOIST_API int toist_groupnorm_fwd(const void* x, const float* gamma, const float* beta, int N, int HW, int C, int G, float eps, int relu,
                         void* y, float* stats, void* stream);
-TOIST_API int toist_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, int N, int HW, int C, int G,
-                        float eps, int relu, void* dx, float* dgamma, float* dbeta, float* bstats, void* stream);
+/* y may be NULL when beta is given: the ReLU mask (y > 0) is then re-derived from x, stats, gamma and beta with the forward's arithmetic */
+TOIST_API int toist_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, const float* beta, int N, int HW,
+                        int C, int G, float eps, int relu, void* dx, float* dgamma, float* dbeta, float* bstats, void* stream);
 TOIST_API int toist_upsample_add(const void* in, const void* fpn, int BQ, int Q, int H, int W, int C, void* out, void* stream);
 TOIST_API int toist_upsample_add_bwd(const void* dout, int BQ, int H, int W, int C, void* din, void* stream);
 TOIST_API int toist_sum_queries(const void* in, int B, int Q, int64_t per, void* out, void* stream);

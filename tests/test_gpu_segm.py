@@ -97,3 +97,37 @@ def test_mask_losses(dev):
         assert abs(float(got[k_]) - float(ref[k_])) <= 1e-4 * abs(float(ref[k_])) + 1e-6, (k_, float(got[k_]), float(ref[k_]))
     err = float((p2.grad.cpu() - pred.grad).abs().max())
     assert err <= 1e-3 * float(pred.grad.abs().max()) + 1e-8, err
+
+
+@pytest.mark.parametrize("N,HW,C", [(6, 400, 264), (4, 1600, 64), (3, 6400, 16)])
+def test_groupnorm_backward_rederives_the_relu_mask(dev, N, HW, C):
+    """toist_groupnorm_bwd without y (round 5: the mask y > 0 of relu(GroupNorm(x)) re-derived from x, stats, gamma, beta -- two passes over
+    the activation fewer) against the same call with y, and against fp32 autograd of F.relu(F.group_norm(x, 8)) (segmentation.py:203-241)."""
+    from toist_amd import kernels as k
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(N * HW + C)
+    x = torch.randn(N, HW, C, generator=g).to(BF).to(dev)
+    dy = torch.randn(N, HW, C, generator=g).to(BF).to(dev)
+    gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.3 * torch.randn(C, generator=g)).to(dev)
+    y = torch.empty_like(x)
+    stats = torch.zeros(N, 8, 2, device=dev)
+    k.groupnorm_fwd(x, gamma, beta, N, HW, C, 8, 1e-5, True, y, stats)
+    outs = []
+    for with_y in (True, False):
+        dx = torch.empty_like(x)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        bstats = torch.empty(N, 8, 2, device=dev)
+        k.groupnorm_bwd(dy, y if with_y else None, x, stats, gamma, N, HW, C, 8, 1e-5, True, dx, dg, db, bstats, beta=None if with_y else beta)
+        outs.append((dx, dg, db))
+    # the two masks differ at most where the normalised value is a rounding error away from zero (a flipped element also moves its group's sums by one term)
+    for a, b in zip(outs[0], outs[1]):
+        assert (a.float() - b.float()).norm() / a.float().norm() < 2e-3
+    xr = x.float().permute(0, 2, 1).reshape(N, C, HW, 1).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.relu(torch.nn.functional.group_norm(xr, 8, gr, br, 1e-5))
+    ref.backward(dy.float().permute(0, 2, 1).reshape(N, C, HW, 1))
+    dx_ref = xr.grad.reshape(N, C, HW).permute(0, 2, 1)
+    dx = outs[1][0].float()
+    assert (dx - dx_ref).norm() / dx_ref.norm() < 1e-2
+    assert (outs[1][1] - gr.grad).norm() / gr.grad.norm() < 1e-2 and (outs[1][2] - br.grad).norm() / br.grad.norm() < 1e-2

@@ -106,17 +106,42 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
     if (pl < ppi) {
-        for (int p = p_beg + pl; p < p_end; p += ppi) {
+        // four pixels per trip: the loads of a trip are issued together (one 16-byte load in flight per thread ran this pass at 3 TB/s)
+        int p = p_beg + pl;
+        for (; p + 3 * ppi < p_end; p += 4 * ppi) {
+            uint4 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const uint4*>(x + ((size_t)n * HW + p + u * ppi) * C + cc * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[8];
+                unpack8(r[u], v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+            }
+        }
+        for (; p < p_end; p += ppi) {
             float v[8];
             unpack8(*reinterpret_cast<const uint4*>(x + ((size_t)n * HW + p) * C + cc * 8), v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
         }
+        // lanes c8 apart hold the same channels: fold them inside the wave first (with C = 16 the 32 lanes per chunk used to queue on ONE LDS
+        // address per atomic -- 32 atomics x 32-way x 22 blocks per CU were ~150 of this pass's 215 us at 160 x 160)
+        const bool pow2 = (c8 & (c8 - 1)) == 0 && c8 < 64;
+        if (pow2) {
+            for (int m = c8; m < 64; m <<= 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int g = (cc * 8 + j) / Cg;
-            atomicAdd(&acc[0][g], s[j]);
-            atomicAdd(&acc[1][g], q[j]);
+                for (int j = 0; j < 8; ++j) { s[j] += __shfl_xor(s[j], m); q[j] += __shfl_xor(q[j], m); }
+            }
+        }
+        if (!pow2 || (int)(threadIdx.x & 63) < c8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int g = (cc * 8 + j) / Cg;
+                atomicAdd(&acc[0][g], s[j]);
+                atomicAdd(&acc[1][g], q[j]);
+            }
         }
     }
     __syncthreads();
@@ -125,35 +150,32 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
         atomicAdd(stats + ((size_t)n * G + threadIdx.x) * 2 + 1, acc[1][threadIdx.x]);
     }
 }
-// y = relu((x - mean) * rstd * gamma + beta)
+// y = relu((x - mean) * rstd * gamma + beta).  Work split of the reducing kernels above (round 5): a thread keeps ONE channel chunk and walks the
+// pixels of its block's slab, so the affine coefficients y = x * a + b of its 8 channels (two statistics loads, a division and an rsqrt each) are
+// computed once -- a thread per 16-byte chunk spent most of its instructions on them (the 20 x 20 and 40 x 40 stages ran at 1.2-1.6 TB/s).
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int HW, int C, int G, float eps, int relu,
                                                         bf16_t* __restrict__ y) {
     const int n = blockIdx.y;
     const int Cg = C / G, c8 = C >> 3;
     const float cnt = (float)HW * (float)Cg;
-    const long long total = (long long)HW * c8;
-    const long long stride = (long long)gridDim.x * 256;
-    // when the grid stride is a multiple of the chunks per pixel a thread always meets the same 8 channels: their affine
-    // coefficients y = x * a + b are then computed once instead of a division, two loads and an rsqrt per element
-    const bool fixed = (stride % c8) == 0;
+    const int ppi = 256 / c8;
+    const int cc = threadIdx.x % c8, pl = threadIdx.x / c8;
+    if (pl >= ppi) return;
+    const int per = (HW + gridDim.x - 1) / gridDim.x;
+    const int p_beg = blockIdx.x * per, p_end = (p_beg + per < HW) ? p_beg + per : HW;
     float ca[8], cb[8];
-    auto coeffs = [&](int cc) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = cc * 8 + j, g = c / Cg;
-            const float mean = stats[((size_t)n * G + g) * 2] / cnt;
-            const float var = fmaxf(stats[((size_t)n * G + g) * 2 + 1] / cnt - mean * mean, 0.f);
-            ca[j] = rsqrtf(var + eps) * gamma[c];
-            cb[j] = beta[c] - mean * ca[j];
-        }
-    };
-    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (fixed) coeffs((int)(i0 % c8));
-    for (long long i = i0; i < total; i += stride) {
-        if (!fixed) coeffs((int)(i % c8));
+    for (int j = 0; j < 8; ++j) {
+        const int c = cc * 8 + j, g = c / Cg;
+        const float mean = stats[((size_t)n * G + g) * 2] / cnt;
+        const float var = fmaxf(stats[((size_t)n * G + g) * 2 + 1] / cnt - mean * mean, 0.f);
+        ca[j] = rsqrtf(var + eps) * gamma[c];
+        cb[j] = beta[c] - mean * ca[j];
+    }
+    for (int p = p_beg + pl; p < p_end; p += ppi) {
         float v[8];
-        const size_t off = ((size_t)n * HW * C) + (size_t)i * 8;
+        const size_t off = ((size_t)n * HW + p) * C + cc * 8;
         unpack8(*reinterpret_cast<const uint4*>(x + off), v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -165,7 +187,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 }
 // backward pass 1: with g = dy * (y > 0): bstats[n][g] = {sum g*gamma, sum g*gamma*xhat}; dgamma[c] += sum g*xhat; dbeta[c] += sum g
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
-                                                            const float* __restrict__ stats, const float* __restrict__ gamma, int HW, int C, int G,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C, int G,
                                                             float eps, int relu, float* __restrict__ bstats, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta) {
     extern __shared__ float sm[];  // [2][C] channel partials + [2][16] group partials
@@ -182,7 +204,10 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restr
     const int per = (HW + gridDim.x - 1) / gridDim.x;
     const int p_beg = blockIdx.x * per, p_end = (p_beg + per < HW) ? p_beg + per : HW;
     if (pl < ppi) {
-        float mean[8], rs[8], gm[8], a_gx[8], a_g[8];
+        // y == nullptr (round 5): the ReLU mask is re-derived from x with the forward's own arithmetic (gn_apply_kernel: o = x * a + b) instead of
+        // reading the output tensor a second and third time -- two of the seven passes over the activation that the two backward kernels made
+        const bool remask = relu && y == nullptr;
+        float mean[8], rs[8], gm[8], a_gx[8], a_g[8], fa[8], fb[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = cc * 8 + j, g = c / Cg;
@@ -190,28 +215,53 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restr
             const float var = fmaxf(stats[((size_t)n * G + g) * 2 + 1] / cnt - mean[j] * mean[j], 0.f);
             rs[j] = rsqrtf(var + eps);
             gm[j] = gamma[c];
+            fa[j] = rs[j] * gm[j];
+            fb[j] = remask ? beta[c] - mean[j] * fa[j] : 0.f;
             a_gx[j] = 0.f; a_g[j] = 0.f;
         }
-        for (int p = p_beg + pl; p < p_end; p += ppi) {
+        auto one = [&](const uint4 rd, const uint4 rx, const size_t off) {
             float d[8], yy[8], xv[8];
-            const size_t off = ((size_t)n * HW + p) * C + cc * 8;
-            unpack8(*reinterpret_cast<const uint4*>(dy + off), d);
-            unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
-            if (relu) unpack8(*reinterpret_cast<const uint4*>(y + off), yy);
+            unpack8(rd, d);
+            unpack8(rx, xv);
+            if (remask) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) yy[j] = xv[j] * fa[j] + fb[j];
+            } else if (relu) unpack8(*reinterpret_cast<const uint4*>(y + off), yy);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float gj = (relu && !(yy[j] > 0.f)) ? 0.f : d[j];
                 a_gx[j] += gj * (xv[j] - mean[j]) * rs[j];
                 a_g[j] += gj;
             }
+        };
+        int p = p_beg + pl;
+        for (; p + ppi < p_end; p += 2 * ppi) {          // two pixels per trip: four loads in flight per thread
+            const size_t o0 = ((size_t)n * HW + p) * C + cc * 8, o1 = o0 + (size_t)ppi * C;
+            const uint4 d0 = *reinterpret_cast<const uint4*>(dy + o0), x0 = *reinterpret_cast<const uint4*>(x + o0);
+            const uint4 d1 = *reinterpret_cast<const uint4*>(dy + o1), x1 = *reinterpret_cast<const uint4*>(x + o1);
+            one(d0, x0, o0);
+            one(d1, x1, o1);
         }
+        for (; p < p_end; p += ppi) {
+            const size_t o0 = ((size_t)n * HW + p) * C + cc * 8;
+            one(*reinterpret_cast<const uint4*>(dy + o0), *reinterpret_cast<const uint4*>(x + o0), o0);
+        }
+        const bool pow2 = (c8 & (c8 - 1)) == 0 && c8 < 64;      // see gn_stats_kernel
+        if (pow2) {
+            for (int m = c8; m < 64; m <<= 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = cc * 8 + j, g = c / Cg;
-            atomicAdd(&cg[c], a_gx[j]);
-            atomicAdd(&cb[c], a_g[j]);
-            atomicAdd(&ga[g], a_g[j] * gm[j]);
-            atomicAdd(&ga[16 + g], a_gx[j] * gm[j]);
+                for (int j = 0; j < 8; ++j) { a_gx[j] += __shfl_xor(a_gx[j], m); a_g[j] += __shfl_xor(a_g[j], m); }
+            }
+        }
+        if (!pow2 || (int)(threadIdx.x & 63) < c8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = cc * 8 + j, g = c / Cg;
+                atomicAdd(&cg[c], a_gx[j]);
+                atomicAdd(&cb[c], a_g[j]);
+                atomicAdd(&ga[g], a_g[j] * gm[j]);
+                atomicAdd(&ga[16 + g], a_gx[j] * gm[j]);
+            }
         }
     }
     __syncthreads();
@@ -222,39 +272,42 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restr
         atomicAdd(bstats + ((size_t)n * G + threadIdx.x) * 2 + 1, ga[16 + threadIdx.x]);
     }
 }
-// backward pass 2: dx = rstd * (g*gamma - mean_g(g*gamma) - xhat * mean_g(g*gamma*xhat))
+// backward pass 2: dx = rstd * (g*gamma - mean_g(g*gamma) - xhat * mean_g(g*gamma*xhat)); thread = one channel chunk, as in gn_apply_kernel
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
                                                             const float* __restrict__ stats, const float* __restrict__ bstats,
-                                                            const float* __restrict__ gamma, int HW, int C, int G, float eps, int relu,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C, int G, float eps, int relu,
                                                             bf16_t* __restrict__ dx) {
     const int n = blockIdx.y;
     const int Cg = C / G, c8 = C >> 3;
     const float cnt = (float)HW * (float)Cg;
-    const long long total = (long long)HW * c8;
-    const long long stride = (long long)gridDim.x * 256;
-    const bool fixed = (stride % c8) == 0;          // see gn_apply_kernel: per-thread channel coefficients
-    float mu[8], rsd[8], gm[8], m1[8], m2[8];
-    auto coeffs = [&](int cc) {
+    const int ppi = 256 / c8;
+    const int cc = threadIdx.x % c8, pl = threadIdx.x / c8;
+    if (pl >= ppi) return;
+    const int per = (HW + gridDim.x - 1) / gridDim.x;
+    const int p_beg = blockIdx.x * per, p_end = (p_beg + per < HW) ? p_beg + per : HW;
+    const bool remask = relu && y == nullptr;       // see gn_bwd_stats_kernel
+    float mu[8], rsd[8], gm[8], m1[8], m2[8], fa[8], fb[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = cc * 8 + j, g = c / Cg;
-            mu[j] = stats[((size_t)n * G + g) * 2] / cnt;
-            const float var = fmaxf(stats[((size_t)n * G + g) * 2 + 1] / cnt - mu[j] * mu[j], 0.f);
-            rsd[j] = rsqrtf(var + eps);
-            gm[j] = gamma[c];
-            m1[j] = bstats[((size_t)n * G + g) * 2] / cnt;
-            m2[j] = bstats[((size_t)n * G + g) * 2 + 1] / cnt;
-        }
-    };
-    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (fixed) coeffs((int)(i0 % c8));
-    for (long long i = i0; i < total; i += stride) {
-        if (!fixed) coeffs((int)(i % c8));
+    for (int j = 0; j < 8; ++j) {
+        const int c = cc * 8 + j, g = c / Cg;
+        mu[j] = stats[((size_t)n * G + g) * 2] / cnt;
+        const float var = fmaxf(stats[((size_t)n * G + g) * 2 + 1] / cnt - mu[j] * mu[j], 0.f);
+        rsd[j] = rsqrtf(var + eps);
+        gm[j] = gamma[c];
+        fa[j] = rsd[j] * gm[j];
+        fb[j] = remask ? beta[c] - mu[j] * fa[j] : 0.f;
+        m1[j] = bstats[((size_t)n * G + g) * 2] / cnt;
+        m2[j] = bstats[((size_t)n * G + g) * 2 + 1] / cnt;
+    }
+    for (int p = p_beg + pl; p < p_end; p += ppi) {
         float d[8], yy[8], xv[8];
-        const size_t off = ((size_t)n * HW * C) + (size_t)i * 8;
+        const size_t off = ((size_t)n * HW + p) * C + cc * 8;
         unpack8(*reinterpret_cast<const uint4*>(dy + off), d);
         unpack8(*reinterpret_cast<const uint4*>(x + off), xv);
-        if (relu) unpack8(*reinterpret_cast<const uint4*>(y + off), yy);
+        if (remask) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) yy[j] = xv[j] * fa[j] + fb[j];
+        } else if (relu) unpack8(*reinterpret_cast<const uint4*>(y + off), yy);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xh = (xv[j] - mu[j]) * rsd[j];
@@ -264,7 +317,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restr
         *reinterpret_cast<uint4*>(dx + off) = pack8(d);
     }
 }
-
 // ------------------------------------------------------------------------------- nearest 2x upsample + shared FPN term
 // out[bq, Y, X, :] = fpn[bq / Q, Y, X, :] + in[bq, Y/2, X/2, :]   (in is [BQ, H, W, C], out [BQ, 2H, 2W, C])
 __global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ fpn, int BQ, int Q, int H,
@@ -438,6 +490,18 @@ static inline int grid_cap(long long n, int cap = 4096) {
     return (int)(g > cap ? cap : g);
 }
 
+// pixel slabs per sample for the GroupNorm apply kernels: the reducing kernels' split, widened when few samples would leave CUs idle
+static inline int gn_apply_slabs(int gx, int N, int HW, int C) {
+    const int ppi = 256 / (C / 8);
+    if ((long long)N * gx < 1024) {
+        int want = (1024 + N - 1) / N, most = HW / (ppi * 4);
+        if (most < 1) most = 1;
+        if (want > most) want = most;
+        if (want > gx) gx = want;
+    }
+    return gx;
+}
+
 }  // namespace toist
 
 using namespace toist;
@@ -468,13 +532,14 @@ extern "C" int toist_groupnorm_fwd(const void* x, const float* gamma, const floa
     if (gx > 32) gx = 32;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)x, HW, C, G, stats);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_cap(total, 64), N), dim3(256), 0, st, (const bf16_t*)x, stats, gamma, beta, HW, C, G, eps, relu,
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_apply_slabs(gx, N, HW, C), N), dim3(256), 0, st, (const bf16_t*)x, stats, gamma, beta, HW, C, G, eps, relu,
                        (bf16_t*)y);
     return check_launch("toist_groupnorm_fwd");
 }
-extern "C" int toist_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, int N, int HW, int C, int G,
-                                   float eps, int relu, void* dx, float* dgamma, float* dbeta, float* bstats, void* stream) {
+extern "C" int toist_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, const float* beta, int N, int HW,
+                                   int C, int G, float eps, int relu, void* dx, float* dgamma, float* dbeta, float* bstats, void* stream) {
     TOIST_REQUIRE(N > 0 && HW > 0 && C > 0 && (C % 8) == 0 && G > 0 && G <= 16 && (C % G) == 0 && C / 8 <= 256, "toist_groupnorm_bwd: bad shape");
+    TOIST_REQUIRE(!relu || y != nullptr || beta != nullptr, "toist_groupnorm_bwd: the ReLU mask needs y, or beta to re-derive it from x");
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(bstats, 0, sizeof(float) * 2 * (size_t)N * G, st);
     if (e != hipSuccess) { set_last_error("toist_groupnorm_bwd: memset: %s", hipGetErrorString(e)); return TOIST_EHIP; }
@@ -483,9 +548,9 @@ extern "C" int toist_groupnorm_bwd(const void* dy, const void* y, const void* x,
     if (gx > 32) gx = 32;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(gx, N), dim3(256), sizeof(float) * (2 * C + 32), st, (const bf16_t*)dy, (const bf16_t*)y,
-                       (const bf16_t*)x, stats, gamma, HW, C, G, eps, relu, bstats, dgamma, dbeta);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_cap(total, 64), N), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, stats,
-                       bstats, gamma, HW, C, G, eps, relu, (bf16_t*)dx);
+                       (const bf16_t*)x, stats, gamma, beta, HW, C, G, eps, relu, bstats, dgamma, dbeta);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gn_apply_slabs(gx, N, HW, C), N), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, stats,
+                       bstats, gamma, beta, HW, C, G, eps, relu, (bf16_t*)dx);
     return check_launch("toist_groupnorm_bwd");
 }
 

@@ -544,8 +544,9 @@ def groupnorm_fwd(x, gamma, beta, N, HW, C, G, eps, relu, y, stats):
                                               _p(stats, F32), _stream()), "toist_groupnorm_fwd")
 
 
-def groupnorm_bwd(dy, y, x, stats, gamma, N, HW, C, G, eps, relu, dx, dgamma, dbeta, bstats):
-    _lib.check(_lib.lib().toist_groupnorm_bwd(_p(dy, BF16), _p(y, BF16), _p(x, BF16), _p(stats, F32), _p(gamma, F32), N, HW, C, G, eps,
+def groupnorm_bwd(dy, y, x, stats, gamma, N, HW, C, G, eps, relu, dx, dgamma, dbeta, bstats, beta=None):
+    """y = None with beta given: the ReLU mask is re-derived from x (two passes over the activation fewer)"""
+    _lib.check(_lib.lib().toist_groupnorm_bwd(_p(dy, BF16), _p(y, BF16), _p(x, BF16), _p(stats, F32), _p(gamma, F32), _p(beta, F32), N, HW, C, G, eps,
                                               1 if relu else 0, _p(dx, BF16), _p(dgamma, F32), _p(dbeta, F32), _p(bstats, F32), _stream()),
                "toist_groupnorm_bwd")
 

@@ -93,7 +93,7 @@ def _conv_gn_relu(tape, x, W, b, G_w, G_b, shape, *, extra_res=None, res_bcast=N
             return
         dpre = torch.empty_like(g)
         bstats = torch.empty(N, 8, 2, dtype=torch.float32, device=g.device)
-        k.groupnorm_bwd(g, y, pre, stats, G_w.f32, N, H * Wd, Co, 8, 1e-5, True, dpre, G_w.g, G_b.g if G_w.g is not None else None, bstats)
+        k.groupnorm_bwd(g, None, pre, stats, G_w.f32, N, H * Wd, Co, 8, 1e-5, True, dpre, G_w.g, G_b.g if G_w.g is not None else None, bstats, beta=G_b.f32)
         pre_var.grad = dpre
         if W.g is not None:
             tmp = ops.conv2d_wgrad(dpre, x.data, wk.shape, pad=1)
