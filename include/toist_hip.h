@@ -301,6 +301,11 @@ TOIST_API int toist_l2norm_bwd(const float* x, const float* dy, int rows, int D,
  *      (alpha, gamma=2) + dice sums against gt[gt_row[t]] u8 [TH,TW] (mdetr.py:827-853, segmentation.py:276-319):
  *      sums[t] += {focal, p*t, p, t}; bwd scatters coef[0]*dfocal + coef[1]*ddice into dpred (f32 atomics).
  *      pred_row[t] < 0 = an unused slot of a fixed-capacity pair table: skipped by both kernels (sums stay 0).
+ *      mask_loss_bwd_compact writes pair t's gradient to row t of dpred_rows [T,h,w] instead of row pred_row[t] of a [B*Q,h,w] tensor:
+ *      the loss (mdetr.py:827-853 `src_masks = outputs["pred_masks"][src_idx]`) touches the matched maps only, every other map's
+ *      gradient is exactly zero, and the mask head's backward (per-map convolutions / GroupNorm(8, C) statistics, segmentation.py:203-241)
+ *      then runs on those T maps alone.
+ *  sum_segments: out[b,i] = sum over maps s in [seg[b], seg[b+1]) of in[s,i] -- sum_queries for maps packed image by image (seg on the device).
  */
 TOIST_API int toist_attnmap_softmax_fwd(const void* scores, const uint8_t* key_pad, int B, int Q, int H, int HW, int ld, void* out, void* stream);
 TOIST_API int toist_attnmap_softmax_bwd(const void* prob, const void* dprob, int BQ, int H, int HW, int ld, void* dscores, void* stream);
@@ -312,10 +317,13 @@ TOIST_API int toist_groupnorm_bwd(const void* dy, const void* y, const void* x, 
 TOIST_API int toist_upsample_add(const void* in, const void* fpn, int BQ, int Q, int H, int W, int C, void* out, void* stream);
 TOIST_API int toist_upsample_add_bwd(const void* dout, int BQ, int H, int W, int C, void* din, void* stream);
 TOIST_API int toist_sum_queries(const void* in, int B, int Q, int64_t per, void* out, void* stream);
+TOIST_API int toist_sum_segments(const void* in, const int32_t* seg, int B, int rows, int64_t per, void* out, void* stream);
 TOIST_API int toist_mask_loss_fwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
                         int TH, int TW, float alpha, float* sums, void* stream);
 TOIST_API int toist_mask_loss_bwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
                         int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred, void* stream);
+TOIST_API int toist_mask_loss_bwd_compact(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
+                        int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred_rows, void* stream);
 
 /* ---- optimizer tail: clip_grad_norm_ + AdamW + EMA + bf16 compute-copy refresh in one multi-tensor pass ------------
  * Replaces engine.py:87-101 of the reference (torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm);

@@ -132,8 +132,10 @@ _SIGNATURES = {
     "toist_upsample_add": ([c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p], ctypes.c_int),
     "toist_upsample_add_bwd": ([c_void_p] + [c_int32] * 4 + [c_void_p, c_void_p], ctypes.c_int),
     "toist_sum_queries": ([c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p], ctypes.c_int),
+    "toist_sum_segments": ([c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p], ctypes.c_int),
     "toist_mask_loss_fwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p], ctypes.c_int),
     "toist_mask_loss_bwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_loss_bwd_compact": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_dropout_bf16": ([c_void_p, c_int64, c_float, c_uint64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_attn2_splits": ([c_int32], ctypes.c_int),
     "toist_attn2_fwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 5 + [c_float, c_float, c_uint64, c_void_p, c_void_p,

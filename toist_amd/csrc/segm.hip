@@ -376,6 +376,27 @@ __global__ __launch_bounds__(256) void sum_queries_kernel(const bf16_t* __restri
     }
 }
 
+// out[b, i] = sum over the maps s in [seg[b], seg[b+1]) of in[s, i]: the per-image reduction when only a subset of the maps (the matched
+// queries, packed image by image) carries a gradient.  seg is read on the device (the hipGraph replay serves any batch).
+__global__ __launch_bounds__(256) void sum_segments_kernel(const bf16_t* __restrict__ in, const int* __restrict__ seg, int B, int rows, long long per8,
+                                                            bf16_t* __restrict__ out) {
+    const long long total = (long long)B * per8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / per8, r = i - b * per8;
+        int s0 = seg[b], s1 = seg[b + 1];
+        if (s0 < 0) s0 = 0;
+        if (s1 > rows) s1 = rows;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = s0; s < s1; ++s) {
+            float v[8];
+            unpack8(reinterpret_cast<const uint4*>(in)[(long long)s * per8 + r], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += v[j];
+        }
+        reinterpret_cast<uint4*>(out)[i] = pack8(a);
+    }
+}
+
 // ------------------------------------------------------------------------------- mask losses
 // For matched pair t: prediction map pred[pred_row[t]] [h,w] f32 is bilinearly upsampled (align_corners=False) to
 // [TH,TW] and compared with gt[gt_row[t]] (u8 [TH,TW], zero padded like NestedTensor.from_tensor_list).  Accumulates per pair
@@ -425,12 +446,12 @@ constexpr int MLB_TILE = 32, MLB_SRC = 36;
 __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restrict__ pred, const int* __restrict__ pred_row,
                                                              const unsigned char* __restrict__ gt, const int* __restrict__ gt_row,
                                                              int h, int w, int TH, int TW, float alpha, const float* __restrict__ sums,
-                                                             const float* __restrict__ coef, float* __restrict__ dpred) {
+                                                             const float* __restrict__ coef, float* __restrict__ dpred, int compact) {
     __shared__ float acc[MLB_SRC * MLB_SRC];
     const int t = blockIdx.y;
     if (pred_row[t] < 0) return;          // unused slot
     const float* pm = pred + (size_t)pred_row[t] * h * w;
-    float* dp = dpred + (size_t)pred_row[t] * h * w;
+    float* dp = dpred + (size_t)(compact ? t : pred_row[t]) * h * w;   // compact: the gradient of pair t goes to row t of a [T,h,w] buffer
     const unsigned char* gm = gt + (size_t)gt_row[t] * TH * TW;
     const float sf = coef[0], sd = coef[1];
     const float num = 2.f * sums[t * 4 + 1] + 1.f, den = sums[t * 4 + 2] + sums[t * 4 + 3] + 1.f;
@@ -572,6 +593,12 @@ extern "C" int toist_sum_queries(const void* in, int B, int Q, int64_t per, void
                        (long long)(per / 8), (bf16_t*)out);
     return check_launch("toist_sum_queries");
 }
+extern "C" int toist_sum_segments(const void* in, const int32_t* seg, int B, int rows, int64_t per, void* out, void* stream) {
+    TOIST_REQUIRE(in && seg && out && B > 0 && rows > 0 && per > 0 && (per % 8) == 0, "toist_sum_segments: bad shape");
+    hipLaunchKernelGGL(sum_segments_kernel, dim3(grid_cap((long long)B * (per / 8), 8192)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, seg, B, rows,
+                       (long long)(per / 8), (bf16_t*)out);
+    return check_launch("toist_sum_segments");
+}
 
 extern "C" int toist_mask_loss_fwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
                                    int TH, int TW, float alpha, float* sums, void* stream) {
@@ -584,6 +611,13 @@ extern "C" int toist_mask_loss_bwd(const float* pred, const int32_t* pred_row, c
                                    int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred, void* stream) {
     TOIST_REQUIRE(T > 0 && h > 0 && w > 0 && TH > 0 && TW > 0, "toist_mask_loss_bwd: bad shape");
     hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(((TH + MLB_TILE - 1) / MLB_TILE) * ((TW + MLB_TILE - 1) / MLB_TILE), T), dim3(256), 0, (hipStream_t)stream, pred, pred_row, gt, gt_row, h, w,
-                       TH, TW, alpha, sums, coef, dpred);
+                       TH, TW, alpha, sums, coef, dpred, 0);
     return check_launch("toist_mask_loss_bwd");
+}
+extern "C" int toist_mask_loss_bwd_compact(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
+                                           int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred_rows, void* stream) {
+    TOIST_REQUIRE(T > 0 && h > 0 && w > 0 && TH > 0 && TW > 0, "toist_mask_loss_bwd_compact: bad shape");
+    hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(((TH + MLB_TILE - 1) / MLB_TILE) * ((TW + MLB_TILE - 1) / MLB_TILE), T), dim3(256), 0, (hipStream_t)stream, pred, pred_row, gt, gt_row, h, w,
+                       TH, TW, alpha, sums, coef, dpred_rows, 1);
+    return check_launch("toist_mask_loss_bwd_compact");
 }

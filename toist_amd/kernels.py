@@ -18,7 +18,7 @@ __all__ = [
     "ACT_SIGMOID", "ACT_MASK_POS", "ACT_GELU_BWD", "ACT_SIGMOID_BWD", "ConvGeom", "operand", "gemm", "matcher",
     "layernorm_fwd", "layernorm_bwd", "softmax_fwd", "softmax_bwd", "colsum", "add", "dropout", "pack_image", "maxpool3x3s2", "stem_fwd",
     "unpack_nhwc", "sine_position", "embed_fwd", "embed_bwd", "criterion_fwd", "criterion_bwd", "attnmap_softmax_fwd", "attnmap_softmax_bwd",
-    "groupnorm_fwd", "groupnorm_bwd", "upsample_add", "upsample_add_bwd", "sum_queries", "mask_loss_fwd", "mask_loss_bwd",
+    "groupnorm_fwd", "groupnorm_bwd", "upsample_add", "upsample_add_bwd", "sum_queries", "sum_segments", "mask_loss_fwd", "mask_loss_bwd",
 ]
 
 
@@ -568,7 +568,16 @@ def mask_loss_fwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, alpha, sums):
                                               TW, alpha, _p(sums, F32), _stream()), "toist_mask_loss_fwd")
 
 
-def mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, alpha, sums, coef, dpred):
+def sum_segments(inp, seg, B, rows, per, out):
+    """out[b] = sum of the maps inp[seg[b]:seg[b+1]] (seg int32 [B+1] on the device)."""
+    _lib.check(_lib.lib().toist_sum_segments(_p(inp, BF16), _p(seg, torch.int32), B, rows, per, _p(out, BF16), _stream()), "toist_sum_segments")
+
+
+def mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, alpha, sums, coef, dpred, compact=False):
+    if compact:     # dpred is [T,h,w]: pair t's gradient in row t
+        _lib.check(_lib.lib().toist_mask_loss_bwd_compact(_p(pred, F32), _p(pred_row, torch.int32), _p(gt, torch.uint8), _p(gt_row, torch.int32), T, h, w,
+                                                          TH, TW, alpha, _p(sums, F32), _p(coef, F32), _p(dpred, F32), _stream()), "toist_mask_loss_bwd_compact")
+        return
     _lib.check(_lib.lib().toist_mask_loss_bwd(_p(pred, F32), _p(pred_row, torch.int32), _p(gt, torch.uint8), _p(gt_row, torch.int32), T, h, w, TH,
                                               TW, alpha, _p(sums, F32), _p(coef, F32), _p(dpred, F32), _stream()), "toist_mask_loss_bwd")
 

@@ -63,6 +63,25 @@ class MaskHeadSmallConv(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
 
+# The mask losses (mdetr.py:827-853) read `outputs["pred_masks"][src_idx]`: only the matched queries' maps carry a gradient, and every
+# operator of the mask head acts map by map (per-map convolutions, GroupNorm(8, C) statistics per sample, per-map upsampling; the FPN /
+# image terms are broadcast over the queries).  The gradient of every unmatched map is therefore exactly zero from out_lay back to lay1,
+# and the backward program runs on the matched maps alone (T of B*Q = 800).  The hand-off below carries (gradient rows, row indices,
+# per-image slot ranges) from _MaskLossFn.backward to the mask program's tape; any other consumer of pred_masks keeps the dense path.
+MATCHED_ONLY_BACKWARD = True
+
+
+class _MatchedRows:
+    __slots__ = ("grad", "rows", "seg", "dense_ptr")
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self.grad = self.rows = self.seg = None
+        self.dense_ptr = 0
+
+
 def _krsc_bf16(w):
     """[O,I,R,S] fp32 -> contiguous [O,R,S,I] bf16 (the GEMM B operand of an NHWC convolution)."""
     return w.detach().permute(0, 2, 3, 1).contiguous().to(BF16)
@@ -74,7 +93,7 @@ def _add_conv_grad(param_grad, tmp_krsc, c_lo=0, c_hi=None):
     param_grad[:, c_lo:c_hi].add_(tmp_krsc.permute(0, 3, 1, 2))
 
 
-def _conv_gn_relu(tape, x, W, b, G_w, G_b, shape, *, extra_res=None, res_bcast=None, w_slice=None):
+def _conv_gn_relu(tape, x, W, b, G_w, G_b, shape, *, extra_res=None, res_bcast=None, w_slice=None, pick=None):
     """y = relu(GN8(conv3x3(x) + bias [+ broadcast residual])).  x: Var NHWC; returns Var NHWC.
     W: ParamView of the [O,I,3,3] weight; w_slice = (lo, hi) restricts the input channels used."""
     N, H, Wd, C = shape
@@ -92,11 +111,13 @@ def _conv_gn_relu(tape, x, W, b, G_w, G_b, shape, *, extra_res=None, res_bcast=N
         if g is None:
             return
         dpre = torch.empty_like(g)
-        bstats = torch.empty(N, 8, 2, dtype=torch.float32, device=g.device)
-        k.groupnorm_bwd(g, None, pre, stats, G_w.f32, N, H * Wd, Co, 8, 1e-5, True, dpre, G_w.g, G_b.g if G_w.g is not None else None, bstats, beta=G_b.f32)
+        n = g.shape[0]                       # N, or the number of matched maps (pick gathers their rows of the saved tensors)
+        pre_s, stats_s, x_s = (pre, stats, x.data) if pick is None else (pick(pre), pick(stats), pick(x.data))
+        bstats = torch.empty(n, 8, 2, dtype=torch.float32, device=g.device)
+        k.groupnorm_bwd(g, None, pre_s, stats_s, G_w.f32, n, H * Wd, Co, 8, 1e-5, True, dpre, G_w.g, G_b.g if G_w.g is not None else None, bstats, beta=G_b.f32)
         pre_var.grad = dpre
         if W.g is not None:
-            tmp = ops.conv2d_wgrad(dpre, x.data, wk.shape, pad=1)
+            tmp = ops.conv2d_wgrad(dpre, x_s, wk.shape, pad=1)
             _add_conv_grad(W.g, tmp, *(w_slice or (0, None)))
             if extra_res is None and b.g is not None:
                 ops.bias_grad(dpre.view(-1, Co), out=b.g)
@@ -136,6 +157,20 @@ class DETRsegm(nn.Module):
         key_pad = feat_mask.flatten(1).to(torch.uint8).contiguous()
         dev = hs_last.device
 
+        BQ = B * Q
+        sel = {"rows": None, "scatter": None, "seg": None}     # set by out_bwd when only the matched maps carry a gradient
+
+        def pick(t):
+            """Rows of a saved [B*Q, ...] tensor that the backward needs (all of them on the dense path)."""
+            return t if sel["rows"] is None else t.index_select(0, sel["rows"])
+
+        def image_sum(g, per, out):
+            """out[b] = sum of the maps of image b: all Q of them, or the matched ones (packed image by image)."""
+            if sel["rows"] is None:
+                k.sum_queries(g, B, Q, per, out)
+            else:
+                k.sum_segments(g, sel["seg"], B, g.shape[0], per, out)
+
         def prog(tape, ps, hs, mem, src, f4, f3, f2):
             A = lambda n: ps["bbox_attention." + n]
             M = lambda n: ps["mask_head." + n]
@@ -154,6 +189,10 @@ class DETRsegm(nn.Module):
                 g = pv.take_grad()
                 if g is None:
                     return
+                if sel["rows"] is not None:          # matched maps only: back to one row per (image, query); unused slots land in row B*Q
+                    gd = torch.zeros(BQ + 1, h, w, H, dtype=BF16, device=dev)
+                    gd.index_copy_(0, sel["scatter"], g)
+                    g = gd[:BQ]
                 ds = torch.empty(B, Q, H, ld, dtype=BF16, device=dev)
                 k.attnmap_softmax_bwd(prob, g, B * Q, H, HW, ld, ds)
                 dq = torch.empty(B * Q, d, dtype=BF16, device=dev)
@@ -175,7 +214,7 @@ class DETRsegm(nn.Module):
             w1_img = W1.w[..., :d].contiguous()
             y_img = ops.conv2d(src4.data, w1_img, pad=1, shift=b1.f32)            # [B,h,w,264]
             a1, pre1 = _conv_gn_relu(tape, pv, W1, b1, M("gn1.weight"), M("gn1.bias"), (B * Q, h, w, H), extra_res=y_img.view(B * HW, -1),
-                                     res_bcast=(Q * HW, HW), w_slice=(d, d + H))
+                                     res_bcast=(Q * HW, HW), w_slice=(d, d + H), pick=pick)
 
             C1 = w1_img.shape[0]
 
@@ -184,7 +223,7 @@ class DETRsegm(nn.Module):
                 if g is None:
                     return
                 gsum = torch.empty(B, h, w, C1, dtype=BF16, device=dev)
-                k.sum_queries(g, B, Q, HW * C1, gsum)
+                image_sum(g, HW * C1, gsum)
                 if W1.g is not None:
                     tmp = ops.conv2d_wgrad(gsum, src4.data, w1_img.shape, pad=1)
                     _add_conv_grad(W1.g, tmp, 0, d)
@@ -196,7 +235,7 @@ class DETRsegm(nn.Module):
             # the block's backward (recorded inside _conv_gn_relu) must run BEFORE img_bwd: insert img_bwd just before it
             tape.steps.insert(len(tape.steps) - 1, img_bwd)
 
-            a2, _ = _conv_gn_relu(tape, a1, M("lay2.weight"), M("lay2.bias"), M("gn2.weight"), M("gn2.bias"), (B * Q, h, w, C1))
+            a2, _ = _conv_gn_relu(tape, a1, M("lay2.weight"), M("lay2.bias"), M("gn2.weight"), M("gn2.bias"), (B * Q, h, w, C1), pick=pick)
 
             def fpn_stage(x, feat, i, H_, W_):
                 """x [BQ,H_,W_,C] -> relu(GN(lay(adapter(feat) + up2(x))))"""
@@ -213,13 +252,14 @@ class DETRsegm(nn.Module):
                     g = uv.take_grad()
                     if g is None:
                         return
+                    n = g.shape[0]
                     if x.needs_grad:
-                        gx = torch.empty(B * Q, H_, W_, Cx, dtype=BF16, device=dev)
-                        k.upsample_add_bwd(g, B * Q, H_, W_, Cx, gx)
+                        gx = torch.empty(n, H_, W_, Cx, dtype=BF16, device=dev)
+                        k.upsample_add_bwd(g, n, H_, W_, Cx, gx)
                         engine.accumulate(x, gx)
                     if Wa.g is not None or feat.needs_grad:
                         gf = torch.empty(B * 4 * H_ * W_, Cx, dtype=BF16, device=dev)
-                        k.sum_queries(g, B, Q, 4 * H_ * W_ * Cx, gf)
+                        image_sum(g, 4 * H_ * W_ * Cx, gf)
                         if Wa.g is not None:
                             tmp = torch.zeros(Cx, Cin_f, dtype=torch.float32, device=dev)
                             ops.linear_wgrad(gf, feat.data.view(-1, Cin_f), out=tmp, bias_out=ba.g)
@@ -230,7 +270,7 @@ class DETRsegm(nn.Module):
 
                 tape.record(up_bwd)
                 return _conv_gn_relu(tape, uv, M(f"lay{i + 2}.weight"), M(f"lay{i + 2}.bias"), M(f"gn{i + 2}.weight"), M(f"gn{i + 2}.bias"),
-                                     (B * Q, 2 * H_, 2 * W_, Cx))[0]
+                                     (B * Q, 2 * H_, 2 * W_, Cx), pick=pick)[0]
 
             a3 = fpn_stage(a2, f4, 1, h, w)
             a4 = fpn_stage(a3, f3, 2, 2 * h, 2 * w)
@@ -250,10 +290,24 @@ class DETRsegm(nn.Module):
                 g = mv.take_grad()
                 if g is None:
                     return
-                g8 = torch.zeros(B * Q, 8 * h, 8 * w, 8, dtype=BF16, device=dev)
-                g8[..., 0] = g.view(B * Q, 8 * h, 8 * w).to(BF16)
+                g = g.view(BQ, 8 * h, 8 * w)
+                sel["rows"] = sel["scatter"] = sel["seg"] = None
+                if sink.grad is not None:
+                    rows = sink.rows
+                    if g.data_ptr() == sink.dense_ptr:
+                        # nothing but the mask losses looked at pred_masks: the gradient is sink.grad in rows `rows`, zero elsewhere
+                        sel["rows"] = rows.clamp(min=0).to(torch.int64)
+                        sel["scatter"] = torch.where(rows < 0, torch.full_like(rows, BQ), rows).to(torch.int64)
+                        sel["seg"] = sink.seg
+                        g = sink.grad
+                    else:                        # another consumer added its gradient: dense backward of the sum (unused slots hold zeros)
+                        g.index_add_(0, rows.clamp(min=0).to(torch.int64), sink.grad)
+                    sink.clear()
+                n = g.shape[0]
+                g8 = torch.zeros(n, 8 * h, 8 * w, 8, dtype=BF16, device=dev)
+                g8[..., 0] = g.to(BF16)
                 if Wo.g is not None:
-                    tmp = ops.conv2d_wgrad(g8, a5.data, wo8.shape, pad=1)
+                    tmp = ops.conv2d_wgrad(g8, pick(a5.data), wo8.shape, pad=1)
                     _add_conv_grad(Wo.g, tmp[:1])
                     bo.g.add_(g.sum().reshape(1))
                 a5.grad = ops.conv2d_dgrad(g8, wo8, (8 * h, 8 * w), pad=1, res=a5.grad)
@@ -261,8 +315,11 @@ class DETRsegm(nn.Module):
             tape.record(out_bwd)
             return [mv], None
 
+        sink = _MatchedRows()
         (masks,) = functions.run_program(prog, named, [hs_last, memory, src_proj, c4, c3, c2], cache=self._cache, training=self.training,
                                          transforms=transforms)
+        if MATCHED_ONLY_BACKWARD and masks.requires_grad:
+            masks.toist_matched_rows = sink        # read by mask_losses / mask_losses_static
         return masks
 
     # ---- reference-compatible forward ----------------------------------------------------------------------
@@ -299,8 +356,9 @@ class _MaskLossFn(torch.autograd.Function):
     """(loss_mask, loss_dice) of SetCriterion.loss_masks for the matched (prediction, target) pairs."""
 
     @staticmethod
-    def forward(ctx, pred, pred_row, gt, gt_row, num_boxes, TH, TW):
+    def forward(ctx, pred, pred_row, gt, gt_row, num_boxes, TH, TW, sink=None, seg=None):
         T = pred_row.numel()
+        ctx.sink, ctx.seg = sink, seg
         h, w = pred.shape[-2:]
         sums = torch.zeros(T, 4, dtype=torch.float32, device=pred.device)
         k.mask_loss_fwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, 0.25, sums)
@@ -316,11 +374,20 @@ class _MaskLossFn(torch.autograd.Function):
         T, h, w, TH, TW = ctx.dims
         coef = torch.stack([g[0] / (float(TH * TW) * num_boxes), g[1] / num_boxes]).float().contiguous()
         dpred = torch.zeros_like(pred)
-        k.mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, 0.25, sums, coef, dpred)
-        return dpred, None, None, None, None, None, None
+        sink = ctx.sink
+        if sink is not None and sink.grad is None:
+            # matched maps only: pair t's gradient goes to row t of a [T,h,w] buffer that the mask head's backward picks up together with the
+            # row indices; autograd carries the all-zero dense tensor, whose address tells the mask program that nobody added to it
+            rows_grad = torch.zeros(T, h, w, dtype=torch.float32, device=pred.device)
+            k.mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, 0.25, sums, coef, rows_grad, compact=True)
+            sink.grad, sink.rows, sink.seg, sink.dense_ptr = rows_grad, pred_row, ctx.seg, dpred.data_ptr()
+        else:
+            k.mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, 0.25, sums, coef, dpred)
+        return dpred, None, None, None, None, None, None, None, None
 
 
 _OFFSETS = {}
+_SEG = {}
 
 
 def _match_offsets(counts, sizes, dev):
@@ -363,7 +430,10 @@ def mask_losses_static(outputs, st, match, layer, L):
     img = torch.bucketize(j, mo[1:], right=True).clamp(max=B - 1)        # pair j belongs to the image whose run [match_off[i], match_off[i+1]) holds it
     pred_row = torch.where(live, img * Q + src, torch.full_like(src, -1)).to(torch.int32)
     gt_row = torch.where(live, st.tgt_off.to(torch.int64)[img] + tgt, torch.zeros_like(tgt)).to(torch.int32)
-    vals = _MaskLossFn.apply(pred.view(B * Q, pred.shape[-2], pred.shape[-1]), pred_row.contiguous(), st.masks, gt_row.contiguous(), st.num_boxes.reshape(()).float(), TH, TW)
+    sink = getattr(outputs["pred_masks"], "toist_matched_rows", None)
+    seg = mo[:B + 1].to(torch.int32).contiguous() if sink is not None else None      # slots [match_off[i], match_off[i+1]) belong to image i
+    vals = _MaskLossFn.apply(pred.view(B * Q, pred.shape[-2], pred.shape[-1]), pred_row.contiguous(), st.masks, gt_row.contiguous(), st.num_boxes.reshape(()).float(), TH, TW,
+                             sink, seg)
     return {"loss_mask": vals[0], "loss_dice": vals[1]}
 
 
@@ -388,5 +458,14 @@ def mask_losses(outputs, targets, match, layer, num_boxes):
     pred_row = (b_idx * Q + match.src[layer]).to(torch.int32)
     gt_row = (t_base + match.tgt[layer]).to(torch.int32)
     nb = num_boxes.reshape(()).float() if torch.is_tensor(num_boxes) else torch.tensor(float(num_boxes), device=dev)
-    vals = _MaskLossFn.apply(pred.view(B * Q, pred.shape[-2], pred.shape[-1]), pred_row.contiguous(), gt, gt_row.contiguous(), nb, TH, TW)
+    sink = getattr(outputs["pred_masks"], "toist_matched_rows", None)
+    seg = None
+    if sink is not None:
+        counts = tuple(match.counts)
+        seg = _SEG.get((counts, str(dev)))
+        if seg is None:
+            if len(_SEG) > 64:
+                _SEG.clear()
+            seg = _SEG[(counts, str(dev))] = torch.tensor([sum(counts[:i]) for i in range(len(counts) + 1)], dtype=torch.int32, device=dev)
+    vals = _MaskLossFn.apply(pred.view(B * Q, pred.shape[-2], pred.shape[-1]), pred_row.contiguous(), gt, gt_row.contiguous(), nb, TH, TW, sink, seg)
     return {"loss_mask": vals[0], "loss_dice": vals[1]}
