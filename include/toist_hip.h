@@ -305,18 +305,31 @@ TOIST_API int toist_l2norm_bwd(const float* x, const float* dy, int rows, int D,
  *      the loss (mdetr.py:827-853 `src_masks = outputs["pred_masks"][src_idx]`) touches the matched maps only, every other map's
  *      gradient is exactly zero, and the mask head's backward (per-map convolutions / GroupNorm(8, C) statistics, segmentation.py:203-241)
  *      then runs on those T maps alone.
+ *  upsample_add_rows: upsample_add on a gathered subset of the maps: map i is map rows[i] of the batch (its FPN term: image rows[i] / Q).
+ *  groupnorm_fwd with y == NULL computes the statistics only; groupnorm_apply normalises with statistics computed earlier.
+ *  mask_stage_fwd: one launch per stage of MaskHeadSmallConv's tail (segmentation.py:223-240): the 3x3 convolution `lay` / `out_lay` whose
+ *      INPUT is built on the way in from the previous convolution's raw output src [N,SH,SW,c_in]: gn_in = GroupNorm(8, c_in) + ReLU from
+ *      src_stats [N,8,2] ({sum, sum of squares}) / gamma / beta; up = nearest 2x (SH = H/2) + the FPN term fpn [N/Q,H,W,c_in] of the map's image.
+ *      w [w_rows,3,3,c_in] bf16, bias f32.  c_out > 1: out [N,H,W,c_out] bf16 = raw convolution output, out_stats [N,8,2] its GroupNorm(8, c_out)
+ *      sums (zeroed here, f32 atomics); c_out == 1 (out_lay): out is f32 [N,H,W].  Shapes: (32,16,gn_in,up), (64,32,up), (16,1,gn_in).
  *  sum_segments: out[b,i] = sum over maps s in [seg[b], seg[b+1]) of in[s,i] -- sum_queries for maps packed image by image (seg on the device).
  */
 TOIST_API int toist_attnmap_softmax_fwd(const void* scores, const uint8_t* key_pad, int B, int Q, int H, int HW, int ld, void* out, void* stream);
 TOIST_API int toist_attnmap_softmax_bwd(const void* prob, const void* dprob, int BQ, int H, int HW, int ld, void* dscores, void* stream);
 TOIST_API int toist_groupnorm_fwd(const void* x, const float* gamma, const float* beta, int N, int HW, int C, int G, float eps, int relu,
                         void* y, float* stats, void* stream);
+TOIST_API int toist_groupnorm_apply(const void* x, const float* stats, const float* gamma, const float* beta, int N, int HW, int C, int G, float eps, int relu,
+                        void* y, void* stream);
 /* y may be NULL when beta is given: the ReLU mask (y > 0) is then re-derived from x, stats, gamma and beta with the forward's arithmetic */
 TOIST_API int toist_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, const float* beta, int N, int HW,
                         int C, int G, float eps, int relu, void* dx, float* dgamma, float* dbeta, float* bstats, void* stream);
 TOIST_API int toist_upsample_add(const void* in, const void* fpn, int BQ, int Q, int H, int W, int C, void* out, void* stream);
+TOIST_API int toist_upsample_add_rows(const void* in, const void* fpn, const int64_t* rows, int n, int Q, int H, int W, int C, void* out, void* stream);
 TOIST_API int toist_upsample_add_bwd(const void* dout, int BQ, int H, int W, int C, void* din, void* stream);
 TOIST_API int toist_sum_queries(const void* in, int B, int Q, int64_t per, void* out, void* stream);
+TOIST_API int toist_mask_stage_fwd(const void* src, const float* src_stats, const float* gamma, const float* beta, const void* fpn, const void* w,
+                        const float* bias, void* out, float* out_stats, int N, int Q, int H, int W, int c_in, int c_out, int w_rows, int gn_in, int up,
+                        float eps, void* stream);
 TOIST_API int toist_sum_segments(const void* in, const int32_t* seg, int B, int rows, int64_t per, void* out, void* stream);
 TOIST_API int toist_mask_loss_fwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
                         int TH, int TW, float alpha, float* sums, void* stream);

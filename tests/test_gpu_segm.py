@@ -181,8 +181,59 @@ def test_matched_only_backward_equals_dense(dev, extra_consumer):
     top = max(float(v.norm()) for v in pd.values())
     for n in pd:
         err = float((pd[n] - ps[n]).norm())
-        assert err <= 2e-3 * float(pd[n].norm()) + 1e-6 * top, (n, err, float(pd[n].norm()))
+        assert err <= 1e-2 * float(pd[n].norm()) + 1e-5 * top, (n, err, float(pd[n].norm()))
     # the loss gradient is summed with f32 atomics (run-to-run order), so bf16 roundings downstream may flip: direction and size, not bits
     for n, a, b in zip(["hs", "memory", "src_proj", "c4", "c3", "c2"], idn, isp):
         ratio = float(b.norm() / a.norm())
         assert cos(a, b) > 0.9995 and 0.99 < ratio < 1.01, (n, cos(a, b), ratio)
+
+
+def test_fused_tail_equals_per_op_launches(dev):
+    """lay4 / lay5 / out_lay as one launch each (csrc/maskstage.hip: GroupNorm + ReLU and the 2x upsample + FPN term applied on the way into the
+    3x3, statistics in the epilogue) against the per-op launches: same roundings, so logits agree to the bf16 rounding the per-op path puts
+    on out_lay's output, and every gradient agrees in direction and size.  Odd tile counts (40 x 48 and 20 x 24 outputs: partial 16 x 16 tiles)."""
+    from toist_amd import segmentation
+    from toist_amd.segmentation import DETRsegm
+    B, Q, d, H, h, w = 2, 5, 256, 8, 5, 6
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.transformer = type("T", (), {"d_model": d, "nhead": H})()
+    torch.manual_seed(0)
+    seg = DETRsegm(Stub(), "smallconv", freeze_detr=False)
+    g = torch.Generator().manual_seed(11)
+    for n, p in seg.named_parameters():
+        if n.endswith("bias") or "gn" in n:
+            p.data.add_(torch.randn(p.shape, generator=g) * 0.05)
+    seg.to(dev)
+    base = [torch.randn(B * Q, d, generator=g), torch.randn(B * h * w, d, generator=g), torch.randn(B * h * w, d, generator=g),
+            torch.randn(B, 2 * h, 2 * w, 1024, generator=g).clamp(min=0), torch.randn(B, 4 * h, 4 * w, 512, generator=g).clamp(min=0),
+            torch.randn(B, 8 * h, 8 * w, 256, generator=g).clamp(min=0)]
+    fmask = torch.zeros(B, h, w, dtype=torch.bool, device=dev)
+    gout = (torch.randn(B, Q, 8 * h, 8 * w, generator=g) * 0.1).to(dev)
+
+    def run(flag):
+        segmentation.FUSED_TAIL = flag
+        try:
+            seg.zero_grad(set_to_none=True)
+            ins = [t.to(BF).to(dev).requires_grad_(True) for t in base]
+            masks = seg._masks(*ins, fmask, B, Q, h, w)
+            masks.backward(gout)
+            torch.cuda.synchronize()
+            return masks.detach().float(), {n: p.grad.detach().float().clone() for n, p in seg.named_parameters()}, [t.grad.detach().float().clone() for t in ins]
+        finally:
+            segmentation.FUSED_TAIL = True
+    m0, p0, i0 = run(False)
+    m1, p1, i1 = run(True)
+    assert float((m0 - m1).abs().max()) <= 2 ** -7 * float(m0.abs().max()), float((m0 - m1).abs().max())
+    assert rel(m1, m0) < 4e-3, rel(m1, m0)
+    top = max(float(v.norm()) for v in p0.values())
+    for n in p0:
+        if float(p0[n].norm()) < 1e-5 * top:
+            continue
+        ratio = float(p1[n].norm() / p0[n].norm())
+        assert cos(p0[n], p1[n]) > 0.999 and 0.98 < ratio < 1.02, (n, cos(p0[n], p1[n]), ratio)
+    for n, a, b in zip(["hs", "memory", "src_proj", "c4", "c3", "c2"], i0, i1):
+        ratio = float(b.norm() / a.norm())
+        assert cos(a, b) > 0.999 and 0.98 < ratio < 1.02, (n, cos(a, b), ratio)

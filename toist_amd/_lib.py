@@ -127,11 +127,14 @@ _SIGNATURES = {
     "toist_l2norm_bwd": ([c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_attnmap_softmax_fwd": ([c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p], ctypes.c_int),
     "toist_attnmap_softmax_bwd": ([c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p, c_void_p], ctypes.c_int),
+    "toist_groupnorm_apply": ([c_void_p] * 4 + [c_int32] * 4 + [c_float, c_int32, c_void_p, c_void_p], ctypes.c_int),
     "toist_groupnorm_fwd": ([c_void_p] * 3 + [c_int32] * 4 + [c_float, c_int32, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_groupnorm_bwd": ([c_void_p] * 6 + [c_int32] * 4 + [c_float, c_int32] + [c_void_p] * 5, ctypes.c_int),
     "toist_upsample_add": ([c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p], ctypes.c_int),
     "toist_upsample_add_bwd": ([c_void_p] + [c_int32] * 4 + [c_void_p, c_void_p], ctypes.c_int),
     "toist_sum_queries": ([c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p], ctypes.c_int),
+    "toist_upsample_add_rows": ([c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_stage_fwd": ([c_void_p] * 9 + [c_int32] * 9 + [c_float, c_void_p], ctypes.c_int),
     "toist_sum_segments": ([c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p], ctypes.c_int),
     "toist_mask_loss_fwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p], ctypes.c_int),
     "toist_mask_loss_bwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),

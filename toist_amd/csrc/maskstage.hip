@@ -1,0 +1,254 @@
+// One pass per stage of the mask head's FPN tail (/root/reference/models/segmentation.py:203-241, MaskHeadSmallConv.forward):
+//     x = adapter(fpn) + interpolate(x, nearest 2x);  x = relu(gn(lay(x)))            (lay3..lay5)      and      x = out_lay(x)
+// Per-op launches write and re-read every intermediate of the 800 maps: the upsampled sum (1.3 GB at 160 x 160), the convolution output, a
+// statistics pass, the normalised activation (0.66 GB), an 8-channel padded out_lay output.  Here a workgroup owns a 16 x 16 output tile
+// of one map and builds the convolution's INPUT tile (18 x 18 with the halo) in LDS from what the previous stage left in HBM:
+//   GNIN : the source is the previous convolution's raw output; GroupNorm(8, CIN) + ReLU are applied on the way in, from that stage's
+//          {sum, sum of squares} per (map, group) -- the normalised activation is never written;
+//   UP   : source pixel (y/2, x/2) + the shared FPN term of the map's image (fpn[n / Q]) -- the upsampled sum is never written;
+// then runs the 3x3 as nine taps of MFMAs straight out of that tile (weights in registers, D^T = W.X^T: a lane ends up with 4 consecutive
+// output channels of one pixel), writes the raw convolution output once and folds its GroupNorm statistics in the epilogue (OUT1: the
+// single out_lay channel goes out as f32 [N,H,W], no statistics).  Every rounding of the per-op path is kept (bf16 after GroupNorm + ReLU,
+// bf16 after the FPN add, bf16 convolution output, statistics of the rounded output), so the two paths differ only in summation order.
+// HBM traffic per stage: one read of the (4x smaller) source + one write of the output.
+#include "common.h"
+
+namespace toist {
+
+typedef __attribute__((ext_vector_type(4))) short ms_bf16x4_t;
+
+__device__ __forceinline__ void ms_unpack8(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 ms_pack8(const float* f) {
+    return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+template <int KM>
+struct MsFrag {
+    typedef typename std::conditional<KM == 32, bf16x8_t, ms_bf16x4_t>::type type;
+};
+template <int KM>
+__device__ __forceinline__ f32x4_t ms_mfma(typename MsFrag<KM>::type b, typename MsFrag<KM>::type a, f32x4_t c) {
+    if constexpr (KM == 32) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(b, a, c, 0, 0, 0);
+}
+
+// LDS tile: pixel-major, CIN channels per pixel as CH = CIN / 8 chunks of 16 bytes.  A 16-lane group of a fragment read takes the same chunk of
+// 16 consecutive pixels (stride CIN * 2 bytes): the chunk position is XOR-ed with the pixel index so those 16 reads cover 16 different
+// 16-byte bank groups (CH = 2 needs nothing: 32-byte pixels, 8-byte reads of a 32-lane half are contiguous).
+template <int CH>
+__device__ __forceinline__ int ms_swz(int hp) {
+    if constexpr (CH >= 4) return (hp / (16 / CH)) & (CH - 1);
+    else return 0;
+}
+
+template <int CIN, int COUT, bool GNIN, bool UP, bool OUT1>
+__global__ __launch_bounds__(256) void mask_stage_kernel(const bf16_t* __restrict__ src, const float* __restrict__ src_stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const bf16_t* __restrict__ fpn, const bf16_t* __restrict__ w,
+                                                          const float* __restrict__ bias, bf16_t* __restrict__ out, float* __restrict__ out_stats,
+                                                          float* __restrict__ out1, int Q, int H, int W, int w_rows, float eps) {
+    constexpr int CH = CIN / 8;
+    constexpr int TS = 16, HS = TS + 2;
+    constexpr int KM = (CIN >= 32) ? 32 : 16;
+    constexpr int KS = CIN / KM;
+    constexpr int KL = KM / 4;
+    constexpr int NB = (COUT + 15) / 16;
+    constexpr int CG = OUT1 ? 1 : COUT / 8;          // channels per output GroupNorm group
+    static_assert(OUT1 || CG == 2 || CG == 4 || CG == 8, "output groups of 2, 4 or 8 channels");
+    typedef typename MsFrag<KM>::type frag_t;
+    __shared__ __attribute__((aligned(16))) bf16_t tile[HS * HS * CIN];
+    __shared__ float sacc[2][8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+    const int tiles_y = (H + TS - 1) / TS, tiles_x = (W + TS - 1) / TS;
+    const int n = blockIdx.x / tiles_y, ty = blockIdx.x - n * tiles_y;
+    const int y0 = ty * TS;
+    const int SH = UP ? (H >> 1) : H, SW = UP ? (W >> 1) : W;
+    const int cc = tid % CH;                          // this thread's channel chunk in the fill phase (256 % CH == 0)
+
+    // ---- weights -> registers: row (nb*16 + c16) of w[row][tap][CIN], channels ks*KM + g*KL .. +KL-1 ----
+    frag_t bw[9][NB][KS];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int row = nb * 16 + c16;
+                union { uint4 q; uint2 d; frag_t v; } f;
+                f.q = make_uint4(0, 0, 0, 0);
+                if (row < w_rows) {
+                    const bf16_t* p = w + ((size_t)row * 9 + t) * CIN + ks * KM + g * KL;
+                    if constexpr (KL == 8) f.q = *reinterpret_cast<const uint4*>(p);
+                    else f.d = *reinterpret_cast<const uint2*>(p);
+                }
+                bw[t][nb][ks] = f.v;
+            }
+    float bs[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = nb * 16 + g * 4 + j;
+            bs[nb][j] = (bias != nullptr && c < (OUT1 ? 1 : COUT)) ? bias[c] : 0.f;
+        }
+    // ---- GroupNorm + ReLU coefficients of this thread's 8 source channels: y = max(x * ca + cb, 0) (the arithmetic of gn_apply_kernel) ----
+    float ca[8], cb[8];
+    if constexpr (GNIN) {
+        constexpr int SCG = CIN / 8;
+        const float cnt = (float)SH * (float)SW * (float)SCG;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cc * 8 + j, gi = c / SCG;
+            const float mean = src_stats[((size_t)n * 8 + gi) * 2] / cnt;
+            const float var = fmaxf(src_stats[((size_t)n * 8 + gi) * 2 + 1] / cnt - mean * mean, 0.f);
+            ca[j] = rsqrtf(var + eps) * gamma[c];
+            cb[j] = beta[c] - mean * ca[j];
+        }
+    }
+    if (tid < 16) sacc[tid >> 3][tid & 7] = 0.f;
+    float ssum[NB][2], ssq[NB][2];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { ssum[nb][0] = ssum[nb][1] = 0.f; ssq[nb][0] = ssq[nb][1] = 0.f; }
+
+    const bf16_t* src_n = src + (size_t)n * SH * SW * CIN;
+    const bf16_t* fpn_b = UP ? fpn + (size_t)(n / Q) * H * W * CIN : nullptr;
+
+    for (int tx = 0; tx < tiles_x; ++tx) {
+        const int x0 = tx * TS;
+        __syncthreads();                                  // the previous tile's fragment reads are done
+        // ---- input tile (with halo) -> LDS ----
+        for (int task = tid; task < HS * HS * CH; task += 256) {
+            const int hp = task / CH;
+            const int hy = hp / HS, hx = hp - hy * HS;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            uint4 val = make_uint4(0, 0, 0, 0);           // zero padding of the convolution
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+                const int sy = UP ? (y >> 1) : y, sx = UP ? (x >> 1) : x;
+                val = *reinterpret_cast<const uint4*>(src_n + ((size_t)sy * SW + sx) * CIN + cc * 8);
+                if constexpr (GNIN || UP) {
+                    float v[8];
+                    ms_unpack8(val, v);
+                    if constexpr (GNIN) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * ca[j] + cb[j], 0.f);
+                        if constexpr (UP) { const uint4 r = ms_pack8(v); ms_unpack8(r, v); }   // the normalised activation is a bf16 tensor
+                    }
+                    if constexpr (UP) {
+                        float f[8];
+                        ms_unpack8(*reinterpret_cast<const uint4*>(fpn_b + ((size_t)y * W + x) * CIN + cc * 8), f);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += f[j];
+                    }
+                    val = ms_pack8(v);
+                }
+            }
+            *reinterpret_cast<uint4*>(tile + ((size_t)hp * CH + (cc ^ ms_swz<CH>(hp))) * 8) = val;
+        }
+        __syncthreads();
+        // ---- 3x3 convolution: a wave owns 4 rows of the tile, 16 pixels (one row) per MFMA column block ----
+#pragma unroll 1
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wave * 4 + rr;
+            f32x4_t acc[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int hp = (r + t / 3) * HS + c16 + (t % 3);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    frag_t a;
+                    if constexpr (KL == 8) a = *reinterpret_cast<const frag_t*>(tile + ((size_t)hp * CH + ((ks * 4 + g) ^ ms_swz<CH>(hp))) * 8);
+                    else a = *reinterpret_cast<const frag_t*>(tile + (size_t)hp * CIN + ks * KM + g * KL);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[nb] = ms_mfma<KM>(bw[t][nb][ks], a, acc[nb]);
+                }
+            }
+            const int y = y0 + r, x = x0 + c16;
+            const bool live = y < H && x < W;
+            if constexpr (OUT1) {
+                if (live && g == 0) out1[((size_t)n * H + y) * W + x] = acc[0][0] + bs[0][0];
+            } else if (live) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int c0 = nb * 16 + g * 4;
+                    if (c0 < COUT) {
+                        const unsigned lo = pack2bf(acc[nb][0] + bs[nb][0], acc[nb][1] + bs[nb][1]);
+                        const unsigned hi = pack2bf(acc[nb][2] + bs[nb][2], acc[nb][3] + bs[nb][3]);
+                        *reinterpret_cast<uint2*>(out + (((size_t)n * H + y) * W + x) * COUT + c0) = make_uint2(lo, hi);
+                        const float v0 = __uint_as_float(lo << 16), v1 = __uint_as_float(lo & 0xffff0000u);
+                        const float v2 = __uint_as_float(hi << 16), v3 = __uint_as_float(hi & 0xffff0000u);
+                        if constexpr (CG == 2) {
+                            ssum[nb][0] += v0 + v1; ssq[nb][0] += v0 * v0 + v1 * v1;
+                            ssum[nb][1] += v2 + v3; ssq[nb][1] += v2 * v2 + v3 * v3;
+                        } else {
+                            ssum[nb][0] += (v0 + v1) + (v2 + v3); ssq[nb][0] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (!OUT1) {
+        // ---- statistics of this strip: fold the 16 pixel lanes of a channel quad, then the waves through LDS, then one atomic per (group, moment) ----
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int h = 0; h < (CG == 2 ? 2 : 1); ++h) {
+                float s = ssum[nb][h], q = ssq[nb][h];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { s += __shfl_xor(s, m); q += __shfl_xor(q, m); }
+                const int c0 = nb * 16 + g * 4 + 2 * h;
+                if (c16 == 0 && c0 < COUT) {
+                    atomicAdd(&sacc[0][c0 / CG], s);
+                    atomicAdd(&sacc[1][c0 / CG], q);
+                }
+            }
+        __syncthreads();
+        if (tid < 16) atomicAdd(out_stats + ((size_t)n * 8 + (tid & 7)) * 2 + (tid >> 3), sacc[tid >> 3][tid & 7]);
+    }
+}
+
+template <int CIN, int COUT, bool GNIN, bool UP, bool OUT1>
+static void launch_stage(const void* src, const float* src_stats, const float* gamma, const float* beta, const void* fpn, const void* w, const float* bias,
+                         void* out, float* out_stats, int N, int Q, int H, int W, int w_rows, float eps, hipStream_t st) {
+    const int tiles_y = (H + 15) / 16;
+    hipLaunchKernelGGL((mask_stage_kernel<CIN, COUT, GNIN, UP, OUT1>), dim3((unsigned)(N * tiles_y)), dim3(256), 0, st, (const bf16_t*)src, src_stats, gamma, beta,
+                       (const bf16_t*)fpn, (const bf16_t*)w, bias, OUT1 ? nullptr : (bf16_t*)out, out_stats, OUT1 ? (float*)out : nullptr, Q, H, W, w_rows, eps);
+}
+
+}  // namespace toist
+
+using namespace toist;
+
+// See include/toist_hip.h.  Supported shapes: (c_in, c_out) = (32, 16) with gn_in and up (lay5), (64, 32) with up (lay4), (16, 1) with gn_in, no up (out_lay).
+extern "C" int toist_mask_stage_fwd(const void* src, const float* src_stats, const float* gamma, const float* beta, const void* fpn, const void* w,
+                                    const float* bias, void* out, float* out_stats, int N, int Q, int H, int W, int c_in, int c_out, int w_rows, int gn_in,
+                                    int up, float eps, void* stream) {
+    TOIST_REQUIRE(src && w && out && N > 0 && Q > 0 && H > 0 && W > 0 && w_rows > 0, "toist_mask_stage_fwd: bad args");
+    TOIST_REQUIRE(!gn_in || (src_stats && gamma && beta), "toist_mask_stage_fwd: gn_in needs src_stats, gamma and beta");
+    TOIST_REQUIRE(!up || (fpn && (H % 2) == 0 && (W % 2) == 0), "toist_mask_stage_fwd: up needs the FPN term and even output sizes");
+    TOIST_REQUIRE(c_out == 1 || out_stats, "toist_mask_stage_fwd: out_stats missing");
+    TOIST_REQUIRE((long long)N * ((H + 15) / 16) < (1ll << 31), "toist_mask_stage_fwd: too many strips");
+    hipStream_t st = (hipStream_t)stream;
+    if (c_out != 1) {
+        hipError_t e = hipMemsetAsync(out_stats, 0, sizeof(float) * 16 * (size_t)N, st);
+        if (e != hipSuccess) { set_last_error("toist_mask_stage_fwd: memset: %s", hipGetErrorString(e)); return TOIST_EHIP; }
+    }
+    if (c_in == 32 && c_out == 16 && gn_in && up && w_rows == 16)
+        launch_stage<32, 16, true, true, false>(src, src_stats, gamma, beta, fpn, w, bias, out, out_stats, N, Q, H, W, w_rows, eps, st);
+    else if (c_in == 64 && c_out == 32 && !gn_in && up && w_rows == 32)
+        launch_stage<64, 32, false, true, false>(src, src_stats, gamma, beta, fpn, w, bias, out, out_stats, N, Q, H, W, w_rows, eps, st);
+    else if (c_in == 16 && c_out == 1 && gn_in && !up && w_rows <= 16)
+        launch_stage<16, 16, true, false, true>(src, src_stats, gamma, beta, fpn, w, bias, out, out_stats, N, Q, H, W, w_rows, eps, st);
+    else {
+        set_last_error("toist_mask_stage_fwd: unsupported stage (c_in %d, c_out %d, w_rows %d, gn_in %d, up %d)", c_in, c_out, w_rows, gn_in, up);
+        return TOIST_EINVAL;
+    }
+    return check_launch("toist_mask_stage_fwd");
+}

@@ -319,8 +319,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restr
 }
 // ------------------------------------------------------------------------------- nearest 2x upsample + shared FPN term
 // out[bq, Y, X, :] = fpn[bq / Q, Y, X, :] + in[bq, Y/2, X/2, :]   (in is [BQ, H, W, C], out [BQ, 2H, 2W, C])
-__global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ fpn, int BQ, int Q, int H,
-                                                            int W, int C, bf16_t* __restrict__ out) {
+// rows != nullptr: map i of `in` / `out` is map rows[i] of the batch (a gathered subset), its image rows[i] / Q
+__global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ fpn, const long long* __restrict__ rows,
+                                                            int BQ, int Q, int H, int W, int C, bf16_t* __restrict__ out) {
     const int c8 = C >> 3, OH = 2 * H, OW = 2 * W;
     const long long total = (long long)BQ * OH * OW * c8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restr
         const int bq = (int)(p / OH);
         float a[8], f[8];
         unpack8(*reinterpret_cast<const uint4*>(in + ((((size_t)bq * H + (Y >> 1)) * W + (X >> 1)) * C) + cc * 8), a);
-        unpack8(*reinterpret_cast<const uint4*>(fpn + ((((size_t)(bq / Q) * OH + Y) * OW + X) * C) + cc * 8), f);
+        const int img = (int)((rows != nullptr ? rows[bq] : (long long)bq) / Q);
+        unpack8(*reinterpret_cast<const uint4*>(fpn + ((((size_t)img * OH + Y) * OW + X) * C) + cc * 8), f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] += f[j];
         *reinterpret_cast<uint4*>(out + (size_t)i * 8) = pack8(a);
@@ -553,9 +555,24 @@ extern "C" int toist_groupnorm_fwd(const void* x, const float* gamma, const floa
     if (gx > 32) gx = 32;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)x, HW, C, G, stats);
+    if (y == nullptr) return check_launch("toist_groupnorm_fwd");      // statistics only: the consumer normalises on the way in (toist_mask_stage_fwd)
     hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_apply_slabs(gx, N, HW, C), N), dim3(256), 0, st, (const bf16_t*)x, stats, gamma, beta, HW, C, G, eps, relu,
                        (bf16_t*)y);
     return check_launch("toist_groupnorm_fwd");
+}
+// y = [relu](GroupNorm(x)) from statistics computed earlier (toist_groupnorm_fwd / toist_mask_stage_fwd): the backward of the fused mask stages
+// re-creates the normalised activation of the maps it needs instead of keeping it for all of them
+extern "C" int toist_groupnorm_apply(const void* x, const float* stats, const float* gamma, const float* beta, int N, int HW, int C, int G, float eps, int relu,
+                                     void* y, void* stream) {
+    TOIST_REQUIRE(x && stats && gamma && beta && y && N > 0 && HW > 0 && C > 0 && (C % 8) == 0 && C / 8 <= 256 && G > 0 && G <= 16 && (C % G) == 0,
+                  "toist_groupnorm_apply: bad shape (C%%8==0, C<=2048, G<=16)");
+    const long long total = (long long)HW * (C / 8);
+    int gx = (int)((total + 8191) / 8192);
+    if (gx > 32) gx = 32;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_apply_slabs(gx, N, HW, C), N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, stats, gamma, beta, HW, C, G,
+                       eps, relu, (bf16_t*)y);
+    return check_launch("toist_groupnorm_apply");
 }
 extern "C" int toist_groupnorm_bwd(const void* dy, const void* y, const void* x, const float* stats, const float* gamma, const float* beta, int N, int HW,
                                    int C, int G, float eps, int relu, void* dx, float* dgamma, float* dbeta, float* bstats, void* stream) {
@@ -578,8 +595,14 @@ extern "C" int toist_groupnorm_bwd(const void* dy, const void* y, const void* x,
 extern "C" int toist_upsample_add(const void* in, const void* fpn, int BQ, int Q, int H, int W, int C, void* out, void* stream) {
     TOIST_REQUIRE(BQ > 0 && Q > 0 && (BQ % Q) == 0 && H > 0 && W > 0 && (C % 8) == 0, "toist_upsample_add: bad shape");
     hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_cap((long long)BQ * 4 * H * W * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)in, (const bf16_t*)fpn, BQ, Q, H, W, C, (bf16_t*)out);
+                       (const bf16_t*)in, (const bf16_t*)fpn, (const long long*)nullptr, BQ, Q, H, W, C, (bf16_t*)out);
     return check_launch("toist_upsample_add");
+}
+extern "C" int toist_upsample_add_rows(const void* in, const void* fpn, const int64_t* rows, int n, int Q, int H, int W, int C, void* out, void* stream) {
+    TOIST_REQUIRE(in && fpn && rows && out && n > 0 && Q > 0 && H > 0 && W > 0 && (C % 8) == 0, "toist_upsample_add_rows: bad shape");
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_cap((long long)n * 4 * H * W * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, (const bf16_t*)fpn, (const long long*)rows, n, Q, H, W, C, (bf16_t*)out);
+    return check_launch("toist_upsample_add_rows");
 }
 extern "C" int toist_upsample_add_bwd(const void* dout, int BQ, int H, int W, int C, void* din, void* stream) {
     TOIST_REQUIRE(BQ > 0 && H > 0 && W > 0 && (C % 8) == 0, "toist_upsample_add_bwd: bad shape");

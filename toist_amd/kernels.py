@@ -18,7 +18,7 @@ __all__ = [
     "ACT_SIGMOID", "ACT_MASK_POS", "ACT_GELU_BWD", "ACT_SIGMOID_BWD", "ConvGeom", "operand", "gemm", "matcher",
     "layernorm_fwd", "layernorm_bwd", "softmax_fwd", "softmax_bwd", "colsum", "add", "dropout", "pack_image", "maxpool3x3s2", "stem_fwd",
     "unpack_nhwc", "sine_position", "embed_fwd", "embed_bwd", "criterion_fwd", "criterion_bwd", "attnmap_softmax_fwd", "attnmap_softmax_bwd",
-    "groupnorm_fwd", "groupnorm_bwd", "upsample_add", "upsample_add_bwd", "sum_queries", "sum_segments", "mask_loss_fwd", "mask_loss_bwd",
+    "groupnorm_fwd", "groupnorm_apply", "groupnorm_bwd", "upsample_add", "upsample_add_bwd", "sum_queries", "sum_segments", "upsample_add_rows", "mask_stage_fwd", "mask_loss_fwd", "mask_loss_bwd",
 ]
 
 
@@ -544,6 +544,11 @@ def groupnorm_fwd(x, gamma, beta, N, HW, C, G, eps, relu, y, stats):
                                               _p(stats, F32), _stream()), "toist_groupnorm_fwd")
 
 
+def groupnorm_apply(x, stats, gamma, beta, N, HW, C, G, eps, relu, y):
+    _lib.check(_lib.lib().toist_groupnorm_apply(_p(x, BF16), _p(stats, F32), _p(gamma, F32), _p(beta, F32), N, HW, C, G, eps, 1 if relu else 0, _p(y, BF16),
+                                                _stream()), "toist_groupnorm_apply")
+
+
 def groupnorm_bwd(dy, y, x, stats, gamma, N, HW, C, G, eps, relu, dx, dgamma, dbeta, bstats, beta=None):
     """y = None with beta given: the ReLU mask is re-derived from x (two passes over the activation fewer)"""
     _lib.check(_lib.lib().toist_groupnorm_bwd(_p(dy, BF16), _p(y, BF16), _p(x, BF16), _p(stats, F32), _p(gamma, F32), _p(beta, F32), N, HW, C, G, eps,
@@ -553,6 +558,20 @@ def groupnorm_bwd(dy, y, x, stats, gamma, N, HW, C, G, eps, relu, dx, dgamma, db
 
 def upsample_add(inp, fpn, BQ, Q, H, W, C, out):
     _lib.check(_lib.lib().toist_upsample_add(_p(inp, BF16), _p(fpn, BF16), BQ, Q, H, W, C, _p(out, BF16), _stream()), "toist_upsample_add")
+
+
+def upsample_add_rows(inp, fpn, rows, n, Q, H, W, C, out):
+    """upsample_add on gathered maps: map i of inp / out is map rows[i] (int64, device) of the batch."""
+    _lib.check(_lib.lib().toist_upsample_add_rows(_p(inp, BF16), _p(fpn, BF16), _p(rows, torch.int64), n, Q, H, W, C, _p(out, BF16), _stream()),
+               "toist_upsample_add_rows")
+
+
+def mask_stage_fwd(src, src_stats, gamma, beta, fpn, w, bias, out, out_stats, N, Q, H, W, c_in, c_out, w_rows, gn_in, up, eps=1e-5):
+    """One fused stage of the mask head's tail (csrc/maskstage.hip): [GroupNorm + ReLU of the source] -> [2x upsample + FPN term] -> 3x3 conv
+    -> raw output + its GroupNorm sums (c_out > 1: out bf16 [N,H,W,c_out]) or the f32 mask logits (c_out == 1: out f32 [N,H,W])."""
+    _lib.check(_lib.lib().toist_mask_stage_fwd(_p(src, BF16), _p(src_stats, F32), _p(gamma, F32), _p(beta, F32), _p(fpn, BF16), _p(w, BF16), _p(bias, F32),
+                                               _p(out, F32 if c_out == 1 else BF16), _p(out_stats, F32), N, Q, H, W, c_in, c_out, w_rows,
+                                               1 if gn_in else 0, 1 if up else 0, eps, _stream()), "toist_mask_stage_fwd")
 
 
 def upsample_add_bwd(dout, BQ, H, W, C, din):

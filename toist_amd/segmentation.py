@@ -69,6 +69,8 @@ class MaskHeadSmallConv(nn.Module):
 # and the backward program runs on the matched maps alone (T of B*Q = 800).  The hand-off below carries (gradient rows, row indices,
 # per-image slot ranges) from _MaskLossFn.backward to the mask program's tape; any other consumer of pred_masks keeps the dense path.
 MATCHED_ONLY_BACKWARD = True
+# lay4 / lay5 / out_lay as one launch each (csrc/maskstage.hip) when the head has the reference's widths (64 -> 32 -> 16 -> 1); False = per-op launches
+FUSED_TAIL = True
 
 
 class _MatchedRows:
@@ -237,59 +239,52 @@ class DETRsegm(nn.Module):
 
             a2, _ = _conv_gn_relu(tape, a1, M("lay2.weight"), M("lay2.bias"), M("gn2.weight"), M("gn2.bias"), (B * Q, h, w, C1), pick=pick)
 
+            def adapter(feat, i):
+                """The FPN term of stage i (adapter{i}, a 1x1 convolution of the backbone feature): [B*2H*2W, Cx] bf16."""
+                Wa, ba = M(f"adapter{i}.weight"), M(f"adapter{i}.bias")
+                Cx, Cin_f = Wa.w.shape[0], feat.data.shape[-1]
+                wa = Wa.w.view(Cx, Cin_f)
+                return ops.linear(feat.data.view(-1, Cin_f), wa, ba.f32), wa
+
+            def up_grads(g, x, feat, i, wa, H_, W_):
+                """Backward of `adapter{i}(feat) + upsample2(x)` for the gradient g [n,2H_,2W_,Cx] of the sum."""
+                Wa, ba = M(f"adapter{i}.weight"), M(f"adapter{i}.bias")
+                Cx, Cin_f = wa.shape
+                n = g.shape[0]
+                if x.needs_grad:
+                    gx = torch.empty(n, H_, W_, Cx, dtype=BF16, device=dev)
+                    k.upsample_add_bwd(g, n, H_, W_, Cx, gx)
+                    engine.accumulate(x, gx)
+                if Wa.g is not None or feat.needs_grad:
+                    gf = torch.empty(B * 4 * H_ * W_, Cx, dtype=BF16, device=dev)
+                    image_sum(g, 4 * H_ * W_ * Cx, gf)
+                    if Wa.g is not None:
+                        tmp = torch.zeros(Cx, Cin_f, dtype=torch.float32, device=dev)
+                        ops.linear_wgrad(gf, feat.data.view(-1, Cin_f), out=tmp, bias_out=ba.g)
+                        Wa.g.add_(tmp.view(Cx, Cin_f, 1, 1))
+                    if feat.needs_grad:
+                        gfeat = ops.linear_dgrad(gf, wa)
+                        engine.accumulate(feat, gfeat.view(feat.data.shape))
+
             def fpn_stage(x, feat, i, H_, W_):
                 """x [BQ,H_,W_,C] -> relu(GN(lay(adapter(feat) + up2(x))))"""
-                Wa, ba = M(f"adapter{i}.weight"), M(f"adapter{i}.bias")
-                Cin_f = feat.data.shape[-1]
                 Cx = x.data.shape[-1]
-                wa = Wa.w.view(Cx, Cin_f)
-                f = ops.linear(feat.data.view(-1, Cin_f), wa, ba.f32)               # [B*2H*2W, Cx]
+                f, wa = adapter(feat, i)                                             # [B*2H*2W, Cx]
                 up = torch.empty(B * Q, 2 * H_, 2 * W_, Cx, dtype=BF16, device=dev)
                 k.upsample_add(x.data, f, B * Q, Q, H_, W_, Cx, up)
                 uv = engine.Var(up)
 
                 def up_bwd():
                     g = uv.take_grad()
-                    if g is None:
-                        return
-                    n = g.shape[0]
-                    if x.needs_grad:
-                        gx = torch.empty(n, H_, W_, Cx, dtype=BF16, device=dev)
-                        k.upsample_add_bwd(g, n, H_, W_, Cx, gx)
-                        engine.accumulate(x, gx)
-                    if Wa.g is not None or feat.needs_grad:
-                        gf = torch.empty(B * 4 * H_ * W_, Cx, dtype=BF16, device=dev)
-                        image_sum(g, 4 * H_ * W_ * Cx, gf)
-                        if Wa.g is not None:
-                            tmp = torch.zeros(Cx, Cin_f, dtype=torch.float32, device=dev)
-                            ops.linear_wgrad(gf, feat.data.view(-1, Cin_f), out=tmp, bias_out=ba.g)
-                            Wa.g.add_(tmp.view(Cx, Cin_f, 1, 1))
-                        if feat.needs_grad:
-                            gfeat = ops.linear_dgrad(gf, wa)
-                            engine.accumulate(feat, gfeat.view(feat.data.shape))
+                    if g is not None:
+                        up_grads(g, x, feat, i, wa, H_, W_)
 
                 tape.record(up_bwd)
                 return _conv_gn_relu(tape, uv, M(f"lay{i + 2}.weight"), M(f"lay{i + 2}.bias"), M(f"gn{i + 2}.weight"), M(f"gn{i + 2}.bias"),
                                      (B * Q, 2 * H_, 2 * W_, Cx), pick=pick)[0]
 
-            a3 = fpn_stage(a2, f4, 1, h, w)
-            a4 = fpn_stage(a3, f3, 2, 2 * h, 2 * w)
-            a5 = fpn_stage(a4, f2, 3, 4 * h, 4 * w)
-            # -- out_lay: Cout = 1 padded to 8 output channels (16-byte rows for the backward GEMM operands)
-            Wo, bo = M("out_lay.weight"), M("out_lay.bias")
-            C5 = a5.data.shape[-1]
-            wo8 = torch.zeros(8, 3, 3, C5, dtype=BF16, device=dev)
-            wo8[:1] = Wo.w
-            bo8 = torch.zeros(8, dtype=torch.float32, device=dev)
-            bo8[:1] = bo.f32
-            o8 = ops.conv2d(a5.data, wo8, pad=1, shift=bo8)                         # [BQ,8h,8w,8] bf16
-            masks = o8[..., 0].float().view(B, Q, 8 * h, 8 * w).contiguous()
-            mv = engine.Var(masks)
-
-            def out_bwd():
-                g = mv.take_grad()
-                if g is None:
-                    return
+            def matched_rows_of(g):
+                """g = gradient of the mask logits [BQ,8h,8w] as autograd delivered it -> the rows the backward has to run on (sets `sel`)."""
                 g = g.view(BQ, 8 * h, 8 * w)
                 sel["rows"] = sel["scatter"] = sel["seg"] = None
                 if sink.grad is not None:
@@ -303,13 +298,118 @@ class DETRsegm(nn.Module):
                     else:                        # another consumer added its gradient: dense backward of the sum (unused slots hold zeros)
                         g.index_add_(0, rows.clamp(min=0).to(torch.int64), sink.grad)
                     sink.clear()
+                return g
+
+            def out_lay_grads(g, a5_rows, Wo, bo, wo8):
+                """Backward of out_lay (one output channel, padded to 8 for the GEMM operands) for the logit gradient g [n,8h,8w] f32."""
                 n = g.shape[0]
                 g8 = torch.zeros(n, 8 * h, 8 * w, 8, dtype=BF16, device=dev)
                 g8[..., 0] = g.to(BF16)
                 if Wo.g is not None:
-                    tmp = ops.conv2d_wgrad(g8, pick(a5.data), wo8.shape, pad=1)
+                    tmp = ops.conv2d_wgrad(g8, a5_rows, wo8.shape, pad=1)
                     _add_conv_grad(Wo.g, tmp[:1])
                     bo.g.add_(g.sum().reshape(1))
+                return g8
+
+            a3 = fpn_stage(a2, f4, 1, h, w)
+            Wo, bo = M("out_lay.weight"), M("out_lay.bias")
+            W4, W5 = M("lay4.weight"), M("lay5.weight")
+            C3, C4, C5 = a3.data.shape[-1], W4.w.shape[0], W5.w.shape[0]
+            wo8 = torch.zeros(8, 3, 3, C5, dtype=BF16, device=dev)   # out_lay: Cout = 1 padded to 8 output channels (16-byte rows for the backward GEMM operands)
+            wo8[:1] = Wo.w
+            if FUSED_TAIL and (C3, C4, C5) == (64, 32, 16) and W4.w.shape[-1] == 64 and W5.w.shape[-1] == 32 and Wo.w.shape[0] == 1:
+                # ---- lay4 / lay5 / out_lay as one launch each (csrc/maskstage.hip): the upsampled sums, the normalised activations and the padded
+                # out_lay output are never written; the backward re-creates them for the maps it runs on (the matched ones)
+                b4, b5 = M("lay4.bias"), M("lay5.bias")
+                g4w, g4b, g5w, g5b = M("gn4.weight"), M("gn4.bias"), M("gn5.weight"), M("gn5.bias")
+                H4, W4_, H5, W5_ = 4 * h, 4 * w, 8 * h, 8 * w
+                fa, wa2 = adapter(f3, 2)
+                pre4 = torch.empty(BQ, H4, W4_, C4, dtype=BF16, device=dev)
+                st4 = torch.empty(BQ, 8, 2, dtype=torch.float32, device=dev)
+                k.mask_stage_fwd(a3.data, None, None, None, fa, W4.w, b4.f32, pre4, st4, BQ, Q, H4, W4_, C3, C4, C4, False, True)
+                fb, wa3 = adapter(f2, 3)
+                pre5 = torch.empty(BQ, H5, W5_, C5, dtype=BF16, device=dev)
+                st5 = torch.empty(BQ, 8, 2, dtype=torch.float32, device=dev)
+                k.mask_stage_fwd(pre4, st4, g4w.f32, g4b.f32, fb, W5.w, b5.f32, pre5, st5, BQ, Q, H5, W5_, C4, C5, C5, True, True)
+                masks = torch.empty(B, Q, H5, W5_, dtype=torch.float32, device=dev)
+                k.mask_stage_fwd(pre5, st5, g5w.f32, g5b.f32, None, Wo.w, bo.f32, masks, None, BQ, Q, H5, W5_, C5, 1, 1, True, False)
+                mv = engine.Var(masks)
+
+                def norm_rows(pre, st, gw, gb, HW_, C):
+                    """relu(GroupNorm(pre)) of the rows the backward runs on, from the forward's statistics."""
+                    x_s, st_s = pick(pre), pick(st)
+                    y = torch.empty_like(x_s)
+                    k.groupnorm_apply(x_s, st_s, gw.f32, gb.f32, x_s.shape[0], HW_, C, 8, 1e-5, True, y)
+                    return x_s, st_s, y
+
+                def up_rows(x_rows, f, H_, W_, C):
+                    n = x_rows.shape[0]
+                    up = torch.empty(n, 2 * H_, 2 * W_, C, dtype=BF16, device=dev)
+                    if sel["rows"] is None:
+                        k.upsample_add(x_rows, f, n, Q, H_, W_, C, up)
+                    else:
+                        k.upsample_add_rows(x_rows, f, sel["rows"], n, Q, H_, W_, C, up)
+                    return up
+
+                def conv_grads(dpre, x_in, Wp, bp, hw):
+                    Co = dpre.shape[-1]
+                    if Wp.g is not None:
+                        tmp = ops.conv2d_wgrad(dpre, x_in, Wp.w.shape, pad=1)
+                        _add_conv_grad(Wp.g, tmp)
+                        if bp.g is not None:
+                            ops.bias_grad(dpre.view(-1, Co), out=bp.g)
+                    return ops.conv2d_dgrad(dpre, Wp.w, hw, pad=1)
+
+                def gn_grads(g, x_s, st_s, gw, gb, HW_, C):
+                    n = g.shape[0]
+                    dpre = torch.empty_like(g)
+                    bstats = torch.empty(n, 8, 2, dtype=torch.float32, device=dev)
+                    k.groupnorm_bwd(g, None, x_s, st_s, gw.f32, n, HW_, C, 8, 1e-5, True, dpre, gw.g, gb.g if gw.g is not None else None, bstats, beta=gb.f32)
+                    return dpre
+
+                a4v = engine.Var(pre4)     # gradient slots of the (never materialised) normalised activations
+                def tail_bwd():
+                    g = mv.take_grad()
+                    if g is None:
+                        return
+                    g = matched_rows_of(g)
+                    # out_lay
+                    x5, s5, a5r = norm_rows(pre5, st5, g5w, g5b, H5 * W5_, C5)
+                    g8 = out_lay_grads(g, a5r, Wo, bo, wo8)
+                    da5 = ops.conv2d_dgrad(g8, wo8, (H5, W5_), pad=1)
+                    del a5r, g8
+                    # gn5 + lay5 on (adapter3(f2) + up2(relu(gn4(pre4))))
+                    dpre5 = gn_grads(da5, x5, s5, g5w, g5b, H5 * W5_, C5)
+                    x4, s4, a4r = norm_rows(pre4, st4, g4w, g4b, H4 * W4_, C4)
+                    up5 = up_rows(a4r, fb, H4, W4_, C4)
+                    dup5 = conv_grads(dpre5, up5, W5, b5, (H5, W5_))
+                    del up5, a4r, dpre5, da5
+                    up_grads(dup5, a4v, f2, 3, wa3, H4, W4_)
+                    del dup5
+                    # gn4 + lay4 on (adapter2(f3) + up2(a3))
+                    dpre4 = gn_grads(a4v.take_grad(), x4, s4, g4w, g4b, H4 * W4_, C4)
+                    up4 = up_rows(pick(a3.data), fa, 2 * h, 2 * w, C3)
+                    dup4 = conv_grads(dpre4, up4, W4, b4, (H4, W4_))
+                    del up4, dpre4
+                    up_grads(dup4, a3, f3, 2, wa2, 2 * h, 2 * w)
+
+                tape.record(tail_bwd)
+                return [mv], None
+
+            a4 = fpn_stage(a3, f3, 2, 2 * h, 2 * w)
+            a5 = fpn_stage(a4, f2, 3, 4 * h, 4 * w)
+            bo8 = torch.zeros(8, dtype=torch.float32, device=dev)
+            bo8[:1] = bo.f32
+            o8 = ops.conv2d(a5.data, wo8, pad=1, shift=bo8)                         # [BQ,8h,8w,8] bf16
+            masks = o8[..., 0].float().view(B, Q, 8 * h, 8 * w).contiguous()
+            mv = engine.Var(masks)
+
+            def out_bwd():
+                g = mv.take_grad()
+                if g is None:
+                    return
+                g = matched_rows_of(g)
+                g8 = out_lay_grads(g, pick(a5.data), Wo, bo, wo8)
                 a5.grad = ops.conv2d_dgrad(g8, wo8, (8 * h, 8 * w), pad=1, res=a5.grad)
 
             tape.record(out_bwd)
