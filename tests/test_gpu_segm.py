@@ -181,7 +181,7 @@ def test_matched_only_backward_equals_dense(dev, extra_consumer):
     top = max(float(v.norm()) for v in pd.values())
     for n in pd:
         err = float((pd[n] - ps[n]).norm())
-        assert err <= 1e-2 * float(pd[n].norm()) + 1e-5 * top, (n, err, float(pd[n].norm()))
+        assert err <= 2e-2 * float(pd[n].norm()) + 2e-5 * top, (n, err, float(pd[n].norm()))
     # the loss gradient is summed with f32 atomics (run-to-run order), so bf16 roundings downstream may flip: direction and size, not bits
     for n, a, b in zip(["hs", "memory", "src_proj", "c4", "c3", "c2"], idn, isp):
         ratio = float(b.norm() / a.norm())

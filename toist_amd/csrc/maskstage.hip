@@ -17,16 +17,6 @@ namespace toist {
 
 typedef __attribute__((ext_vector_type(4))) short ms_bf16x4_t;
 
-__device__ __forceinline__ void ms_unpack8(const uint4& u, float* f) {
-    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
-}
-__device__ __forceinline__ uint4 ms_pack8(const float* f) {
-    return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
-}
-
 template <int KM>
 struct MsFrag {
     typedef typename std::conditional<KM == 32, bf16x8_t, ms_bf16x4_t>::type type;
@@ -37,30 +27,38 @@ __device__ __forceinline__ f32x4_t ms_mfma(typename MsFrag<KM>::type b, typename
     else return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(b, a, c, 0, 0, 0);
 }
 
-// LDS tile: pixel-major, CIN channels per pixel as CH = CIN / 8 chunks of 16 bytes.  A 16-lane group of a fragment read takes the same chunk of
-// 16 consecutive pixels (stride CIN * 2 bytes): the chunk position is XOR-ed with the pixel index so those 16 reads cover 16 different
-// 16-byte bank groups (CH = 2 needs nothing: 32-byte pixels, 8-byte reads of a 32-lane half are contiguous).
-template <int CH>
-__device__ __forceinline__ int ms_swz(int hp) {
-    if constexpr (CH >= 4) return (hp / (16 / CH)) & (CH - 1);
-    else return 0;
+// LDS tile: pixel-major, CIN channels per pixel (16-byte chunks) + one chunk of padding when a pixel is 64 bytes or more: a 16-lane group of a
+// fragment read takes the same chunk of 16 consecutive pixels, and with the pixel stride at 80 / 144 bytes those 16 reads start in 16 different
+// 4-bank groups (32-byte pixels with 8-byte reads are contiguous as they are).  No swizzle: every tap is a compile-time offset from one per-lane base.
+typedef __attribute__((ext_vector_type(2))) float ms_f2;
+
+__device__ __forceinline__ void ms_unpack8v(const uint4& u, ms_f2* f) {
+    f[0] = ms_f2{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u)};
+    f[1] = ms_f2{__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    f[2] = ms_f2{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u)};
+    f[3] = ms_f2{__uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+}
+__device__ __forceinline__ uint4 ms_pack8v(const ms_f2* f) {
+    return make_uint4(pack2bf(f[0].x, f[0].y), pack2bf(f[1].x, f[1].y), pack2bf(f[2].x, f[2].y), pack2bf(f[3].x, f[3].y));
 }
 
 template <int CIN, int COUT, bool GNIN, bool UP, bool OUT1>
-__global__ __launch_bounds__(256) void mask_stage_kernel(const bf16_t* __restrict__ src, const float* __restrict__ src_stats, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mask_stage_kernel(const bf16_t* __restrict__ src, const float* __restrict__ src_stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const bf16_t* __restrict__ fpn, const bf16_t* __restrict__ w,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ out, float* __restrict__ out_stats,
                                                           float* __restrict__ out1, int Q, int H, int W, int w_rows, float eps) {
     constexpr int CH = CIN / 8;
     constexpr int TS = 16, HS = TS + 2;
+    constexpr int PX = (CH >= 4) ? CIN + 8 : CIN;       // elements per pixel of the LDS tile (one chunk of padding)
     constexpr int KM = (CIN >= 32) ? 32 : 16;
     constexpr int KS = CIN / KM;
     constexpr int KL = KM / 4;
     constexpr int NB = (COUT + 15) / 16;
     constexpr int CG = OUT1 ? 1 : COUT / 8;          // channels per output GroupNorm group
     static_assert(OUT1 || CG == 2 || CG == 4 || CG == 8, "output groups of 2, 4 or 8 channels");
+    static_assert(256 % CH == 0, "a thread keeps one channel chunk");
     typedef typename MsFrag<KM>::type frag_t;
-    __shared__ __attribute__((aligned(16))) bf16_t tile[HS * HS * CIN];
+    __shared__ __attribute__((aligned(16))) bf16_t tile[HS * HS * PX];
     __shared__ float sacc[2][8];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
@@ -68,7 +66,7 @@ __global__ __launch_bounds__(256) void mask_stage_kernel(const bf16_t* __restric
     const int n = blockIdx.x / tiles_y, ty = blockIdx.x - n * tiles_y;
     const int y0 = ty * TS;
     const int SH = UP ? (H >> 1) : H, SW = UP ? (W >> 1) : W;
-    const int cc = tid % CH;                          // this thread's channel chunk in the fill phase (256 % CH == 0)
+    const int cc = tid % CH;                          // this thread's channel chunk in the fill phase
 
     // ---- weights -> registers: row (nb*16 + c16) of w[row][tap][CIN], channels ks*KM + g*KL .. +KL-1 ----
     frag_t bw[9][NB][KS];
@@ -97,7 +95,7 @@ __global__ __launch_bounds__(256) void mask_stage_kernel(const bf16_t* __restric
             bs[nb][j] = (bias != nullptr && c < (OUT1 ? 1 : COUT)) ? bias[c] : 0.f;
         }
     // ---- GroupNorm + ReLU coefficients of this thread's 8 source channels: y = max(x * ca + cb, 0) (the arithmetic of gn_apply_kernel) ----
-    float ca[8], cb[8];
+    ms_f2 ca[4], cb[4];
     if constexpr (GNIN) {
         constexpr int SCG = CIN / 8;
         const float cnt = (float)SH * (float)SW * (float)SCG;
@@ -106,10 +104,19 @@ __global__ __launch_bounds__(256) void mask_stage_kernel(const bf16_t* __restric
             const int c = cc * 8 + j, gi = c / SCG;
             const float mean = src_stats[((size_t)n * 8 + gi) * 2] / cnt;
             const float var = fmaxf(src_stats[((size_t)n * 8 + gi) * 2 + 1] / cnt - mean * mean, 0.f);
-            ca[j] = rsqrtf(var + eps) * gamma[c];
-            cb[j] = beta[c] - mean * ca[j];
+            const float a = rsqrtf(var + eps) * gamma[c];
+            ca[j >> 1][j & 1] = a;
+            cb[j >> 1][j & 1] = beta[c] - mean * a;
         }
     }
+    auto normalise = [&](ms_f2* v) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = v[j] * ca[j] + cb[j];
+            v[j].x = fmaxf(v[j].x, 0.f);
+            v[j].y = fmaxf(v[j].y, 0.f);
+        }
+    };
     if (tid < 16) sacc[tid >> 3][tid & 7] = 0.f;
     float ssum[NB][2], ssq[NB][2];
 #pragma unroll
@@ -118,58 +125,147 @@ __global__ __launch_bounds__(256) void mask_stage_kernel(const bf16_t* __restric
     const bf16_t* src_n = src + (size_t)n * SH * SW * CIN;
     const bf16_t* fpn_b = UP ? fpn + (size_t)(n / Q) * H * W * CIN : nullptr;
 
+    // ---- fill-phase tasks of this thread, fixed for the whole strip (only the column origin moves) ----
+    //   UP : a task = one SOURCE pixel of the 10 x 10 window under the 18 x 18 halo tile x one channel chunk: normalised once, then written to the
+    //        (up to) four halo pixels it is upsampled to, each with its own FPN term;
+    //   else: a task = one halo pixel x one channel chunk.
+    constexpr int SP = UP ? 10 : HS;
+    constexpr int NTASK = SP * SP * CH;
+    constexpr int U = (NTASK + 255) / 256;
+    int t_i[U], t_j[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int q = tid + 256 * u, sp = q / CH;
+        t_i[u] = (q < NTASK) ? sp / SP : -100;           // -100: no task (every bound check below fails)
+        t_j[u] = sp - (sp / SP) * SP;
+    }
+    // per-lane base of the fragment reads: pixel (row wave*4, column c16) of the halo tile, channel block g
+    const bf16_t* frag_base = tile + (size_t)(wave * 4 * HS + c16) * PX + g * KL;
+
+    // The fill of a tile is split in two: `issue` puts the tile's global loads in flight (raw 16-byte chunks into registers), `commit` normalises /
+    // adds / rounds and writes the LDS tile.  PIPE (register budget permitting): the loads of tile k+1 are issued before tile k's MFMAs, so a
+    // workgroup's strip is not a chain of (load latency -> fill -> barrier -> MFMAs) any more -- measured per-tile time was the load latency.
+    constexpr bool PIPE = CIN <= 32;
+    constexpr int NF = UP ? 4 : 1;
+    uint4 r_src[U], r_f[U][NF];
+    auto issue = [&](const int x0, const int u) __attribute__((always_inline)) {
+        if constexpr (UP) {
+            const int sy0 = (y0 >> 1) - 1, sx0 = (x0 >> 1) - 1;
+            {
+                const int i = t_i[u], j = t_j[u];
+                const int sy = sy0 + i, sx = sx0 + j;
+                const bool ok = i >= 0 && (unsigned)sy < (unsigned)SH && (unsigned)sx < (unsigned)SW;
+                r_src[u] = make_uint4(0, 0, 0, 0);
+                if (ok) r_src[u] = *reinterpret_cast<const uint4*>(src_n + ((size_t)sy * SW + sx) * CIN + cc * 8);
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int hy = 2 * i - 1 + dy, hx = 2 * j - 1 + dx;
+                        r_f[u][dy * 2 + dx] = make_uint4(0, 0, 0, 0);
+                        if (ok && (unsigned)hy < (unsigned)HS && (unsigned)hx < (unsigned)HS)
+                            r_f[u][dy * 2 + dx] = *reinterpret_cast<const uint4*>(fpn_b + ((size_t)(2 * sy + dy) * W + (2 * sx + dx)) * CIN + cc * 8);
+                    }
+            }
+        } else {
+            {
+                const int y = y0 - 1 + t_i[u], x = x0 - 1 + t_j[u];
+                r_src[u] = make_uint4(0, 0, 0, 0);
+                if (t_i[u] >= 0 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                    r_src[u] = *reinterpret_cast<const uint4*>(src_n + ((size_t)y * SW + x) * CIN + cc * 8);
+            }
+        }
+    };
+    auto commit = [&](const int x0, const int u) __attribute__((always_inline)) {
+        if constexpr (UP) {
+            const int sy0 = (y0 >> 1) - 1, sx0 = (x0 >> 1) - 1;
+            {
+                const int i = t_i[u], j = t_j[u];
+                if (i < 0) return;
+                const bool ok = (unsigned)(sy0 + i) < (unsigned)SH && (unsigned)(sx0 + j) < (unsigned)SW;
+                ms_f2 a[4];
+                ms_unpack8v(r_src[u], a);
+                if constexpr (GNIN) {
+                    normalise(a);
+                    const uint4 r = ms_pack8v(a);      // the normalised activation is a bf16 tensor in the per-op path
+                    ms_unpack8v(r, a);
+                }
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int hy = 2 * i - 1 + dy, hx = 2 * j - 1 + dx;
+                        if ((unsigned)hy < (unsigned)HS && (unsigned)hx < (unsigned)HS) {
+                            ms_f2 f[4];
+                            ms_unpack8v(r_f[u][dy * 2 + dx], f);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) f[e] += a[e];
+                            const uint4 val = ms_pack8v(f);
+                            // outside the image: the convolution's zero padding
+                            *reinterpret_cast<uint4*>(tile + (size_t)(hy * HS + hx) * PX + cc * 8) = ok ? val : make_uint4(0, 0, 0, 0);
+                        }
+                    }
+            }
+        } else {
+            {
+                const int hy = t_i[u], hx = t_j[u];
+                if (hy < 0) return;
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                uint4 val = make_uint4(0, 0, 0, 0);
+                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+                    val = r_src[u];
+                    if constexpr (GNIN) {
+                        ms_f2 v[4];
+                        ms_unpack8v(val, v);
+                        normalise(v);
+                        val = ms_pack8v(v);
+                    }
+                }
+                *reinterpret_cast<uint4*>(tile + (size_t)(hy * HS + hx) * PX + cc * 8) = val;
+            }
+        }
+    };
+
+    if constexpr (PIPE) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) issue(0, u);
+    }
     for (int tx = 0; tx < tiles_x; ++tx) {
         const int x0 = tx * TS;
         __syncthreads();                                  // the previous tile's fragment reads are done
-        // ---- input tile (with halo) -> LDS ----
-        for (int task = tid; task < HS * HS * CH; task += 256) {
-            const int hp = task / CH;
-            const int hy = hp / HS, hx = hp - hy * HS;
-            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            uint4 val = make_uint4(0, 0, 0, 0);           // zero padding of the convolution
-            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
-                const int sy = UP ? (y >> 1) : y, sx = UP ? (x >> 1) : x;
-                val = *reinterpret_cast<const uint4*>(src_n + ((size_t)sy * SW + sx) * CIN + cc * 8);
-                if constexpr (GNIN || UP) {
-                    float v[8];
-                    ms_unpack8(val, v);
-                    if constexpr (GNIN) {
+        if constexpr (PIPE) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * ca[j] + cb[j], 0.f);
-                        if constexpr (UP) { const uint4 r = ms_pack8(v); ms_unpack8(r, v); }   // the normalised activation is a bf16 tensor
-                    }
-                    if constexpr (UP) {
-                        float f[8];
-                        ms_unpack8(*reinterpret_cast<const uint4*>(fpn_b + ((size_t)y * W + x) * CIN + cc * 8), f);
+            for (int u = 0; u < U; ++u) commit(x0, u);
+        } else {                                          // two tasks (ten loads) in flight at a time
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += f[j];
-                    }
-                    val = ms_pack8(v);
-                }
+            for (int u = 0; u < U; u += 2) {
+                issue(x0, u);
+                if (u + 1 < U) issue(x0, u + 1);
+                commit(x0, u);
+                if (u + 1 < U) commit(x0, u + 1);
             }
-            *reinterpret_cast<uint4*>(tile + ((size_t)hp * CH + (cc ^ ms_swz<CH>(hp))) * 8) = val;
         }
         __syncthreads();
+        if constexpr (PIPE) {
+            if (tx + 1 < tiles_x) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) issue(x0 + TS, u);
+            }
+        }
         // ---- 3x3 convolution: a wave owns 4 rows of the tile, 16 pixels (one row) per MFMA column block ----
-#pragma unroll 1
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = wave * 4 + rr;
+        auto conv_row = [&](const int rr) __attribute__((always_inline)) {
             f32x4_t acc[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int hp = (r + t / 3) * HS + c16 + (t % 3);
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    frag_t a;
-                    if constexpr (KL == 8) a = *reinterpret_cast<const frag_t*>(tile + ((size_t)hp * CH + ((ks * 4 + g) ^ ms_swz<CH>(hp))) * 8);
-                    else a = *reinterpret_cast<const frag_t*>(tile + (size_t)hp * CIN + ks * KM + g * KL);
+                    const frag_t a = *reinterpret_cast<const frag_t*>(frag_base + ((rr + t / 3) * HS + (t % 3)) * PX + ks * KM);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) acc[nb] = ms_mfma<KM>(bw[t][nb][ks], a, acc[nb]);
                 }
-            }
-            const int y = y0 + r, x = x0 + c16;
+            const int y = y0 + wave * 4 + rr, x = x0 + c16;
             const bool live = y < H && x < W;
             if constexpr (OUT1) {
                 if (live && g == 0) out1[((size_t)n * H + y) * W + x] = acc[0][0] + bs[0][0];
@@ -192,6 +288,13 @@ __global__ __launch_bounds__(256) void mask_stage_kernel(const bf16_t* __restric
                     }
                 }
             }
+        };
+        if constexpr (CIN >= 64) {      // 36 weight fragments live: the four rows share one copy of the tap loop (297 -> fewer VGPRs, two workgroups per CU)
+#pragma unroll 1
+            for (int rr = 0; rr < 4; ++rr) conv_row(rr);
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) conv_row(rr);
         }
     }
     if constexpr (!OUT1) {
