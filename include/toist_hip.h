@@ -309,9 +309,11 @@ TOIST_API int toist_l2norm_bwd(const float* x, const float* dy, int rows, int D,
  *  groupnorm_fwd with y == NULL computes the statistics only; groupnorm_apply normalises with statistics computed earlier.
  *  mask_stage_fwd: one launch per stage of MaskHeadSmallConv's tail (segmentation.py:223-240): the 3x3 convolution `lay` / `out_lay` whose
  *      INPUT is built on the way in from the previous convolution's raw output src [N,SH,SW,c_in]: gn_in = GroupNorm(8, c_in) + ReLU from
- *      src_stats [N,8,2] ({sum, sum of squares}) / gamma / beta; up = nearest 2x (SH = H/2) + the FPN term fpn [N/Q,H,W,c_in] of the map's image.
- *      w [w_rows,3,3,c_in] bf16, bias f32.  c_out > 1: out [N,H,W,c_out] bf16 = raw convolution output, out_stats [N,8,2] its GroupNorm(8, c_out)
- *      sums (zeroed here, f32 atomics); c_out == 1 (out_lay): out is f32 [N,H,W].  Shapes: (32,16,gn_in,up), (64,32,up), (16,1,gn_in).
+ *      src_stats [N,8,2] ({sum, sum of squares}) / gamma / beta; up = nearest 2x (SH = H/2), with the FPN term of `adapter(fpn) + up2(x)`
+ *      taken out of the convolution by linearity: fpn_conv [N/Q,H,W,c_out] bf16 = lay(adapter(fpn)) of the map's image (bias included, the
+ *      caller's one small convolution per image) is added in the epilogue.  w [w_rows,3,3,c_in] bf16, bias f32 or NULL.  c_out > 1: out
+ *      [N,H,W,c_out] bf16 = raw convolution output, out_stats [N,8,2] its GroupNorm(8, c_out) sums (zeroed here, f32 atomics); c_out == 1
+ *      (out_lay): out is f32 [N,H,W].  Shapes: (32,16,gn_in,up), (64,32,up), (16,1,gn_in).
  *  sum_segments: out[b,i] = sum over maps s in [seg[b], seg[b+1]) of in[s,i] -- sum_queries for maps packed image by image (seg on the device).
  */
 TOIST_API int toist_attnmap_softmax_fwd(const void* scores, const uint8_t* key_pad, int B, int Q, int H, int HW, int ld, void* out, void* stream);
@@ -327,7 +329,7 @@ TOIST_API int toist_upsample_add(const void* in, const void* fpn, int BQ, int Q,
 TOIST_API int toist_upsample_add_rows(const void* in, const void* fpn, const int64_t* rows, int n, int Q, int H, int W, int C, void* out, void* stream);
 TOIST_API int toist_upsample_add_bwd(const void* dout, int BQ, int H, int W, int C, void* din, void* stream);
 TOIST_API int toist_sum_queries(const void* in, int B, int Q, int64_t per, void* out, void* stream);
-TOIST_API int toist_mask_stage_fwd(const void* src, const float* src_stats, const float* gamma, const float* beta, const void* fpn, const void* w,
+TOIST_API int toist_mask_stage_fwd(const void* src, const float* src_stats, const float* gamma, const float* beta, const void* fpn_conv, const void* w,
                         const float* bias, void* out, float* out_stats, int N, int Q, int H, int W, int c_in, int c_out, int w_rows, int gn_in, int up,
                         float eps, void* stream);
 TOIST_API int toist_sum_segments(const void* in, const int32_t* seg, int B, int rows, int64_t per, void* out, void* stream);

@@ -566,10 +566,11 @@ def upsample_add_rows(inp, fpn, rows, n, Q, H, W, C, out):
                "toist_upsample_add_rows")
 
 
-def mask_stage_fwd(src, src_stats, gamma, beta, fpn, w, bias, out, out_stats, N, Q, H, W, c_in, c_out, w_rows, gn_in, up, eps=1e-5):
-    """One fused stage of the mask head's tail (csrc/maskstage.hip): [GroupNorm + ReLU of the source] -> [2x upsample + FPN term] -> 3x3 conv
-    -> raw output + its GroupNorm sums (c_out > 1: out bf16 [N,H,W,c_out]) or the f32 mask logits (c_out == 1: out f32 [N,H,W])."""
-    _lib.check(_lib.lib().toist_mask_stage_fwd(_p(src, BF16), _p(src_stats, F32), _p(gamma, F32), _p(beta, F32), _p(fpn, BF16), _p(w, BF16), _p(bias, F32),
+def mask_stage_fwd(src, src_stats, gamma, beta, fpn_conv, w, bias, out, out_stats, N, Q, H, W, c_in, c_out, w_rows, gn_in, up, eps=1e-5):
+    """One fused stage of the mask head's tail (csrc/maskstage.hip): [GroupNorm + ReLU of the source] -> [2x upsample] -> 3x3 conv [+ fpn_conv, the
+    image's lay(adapter(fpn)) [N/Q,H,W,c_out]] -> raw output + its GroupNorm sums (c_out > 1: out bf16 [N,H,W,c_out]) or the f32 mask logits
+    (c_out == 1: out f32 [N,H,W])."""
+    _lib.check(_lib.lib().toist_mask_stage_fwd(_p(src, BF16), _p(src_stats, F32), _p(gamma, F32), _p(beta, F32), _p(fpn_conv, BF16), _p(w, BF16), _p(bias, F32),
                                                _p(out, F32 if c_out == 1 else BF16), _p(out_stats, F32), N, Q, H, W, c_in, c_out, w_rows,
                                                1 if gn_in else 0, 1 if up else 0, eps, _stream()), "toist_mask_stage_fwd")
 

@@ -326,11 +326,14 @@ class DETRsegm(nn.Module):
                 fa, wa2 = adapter(f3, 2)
                 pre4 = torch.empty(BQ, H4, W4_, C4, dtype=BF16, device=dev)
                 st4 = torch.empty(BQ, 8, 2, dtype=torch.float32, device=dev)
-                k.mask_stage_fwd(a3.data, None, None, None, fa, W4.w, b4.f32, pre4, st4, BQ, Q, H4, W4_, C3, C4, C4, False, True)
+                # the convolution is linear: lay(adapter(fpn) + up2(x)) = lay(adapter(fpn)) [one small convolution per IMAGE, bias included] + lay_nobias(up2(x))
+                fa_conv = ops.conv2d(fa.view(B, H4, W4_, C3), W4.w, pad=1, shift=b4.f32)
+                k.mask_stage_fwd(a3.data, None, None, None, fa_conv, W4.w, None, pre4, st4, BQ, Q, H4, W4_, C3, C4, C4, False, True)
                 fb, wa3 = adapter(f2, 3)
                 pre5 = torch.empty(BQ, H5, W5_, C5, dtype=BF16, device=dev)
                 st5 = torch.empty(BQ, 8, 2, dtype=torch.float32, device=dev)
-                k.mask_stage_fwd(pre4, st4, g4w.f32, g4b.f32, fb, W5.w, b5.f32, pre5, st5, BQ, Q, H5, W5_, C4, C5, C5, True, True)
+                fb_conv = ops.conv2d(fb.view(B, H5, W5_, C4), W5.w, pad=1, shift=b5.f32)
+                k.mask_stage_fwd(pre4, st4, g4w.f32, g4b.f32, fb_conv, W5.w, None, pre5, st5, BQ, Q, H5, W5_, C4, C5, C5, True, True)
                 masks = torch.empty(B, Q, H5, W5_, dtype=torch.float32, device=dev)
                 k.mask_stage_fwd(pre5, st5, g5w.f32, g5b.f32, None, Wo.w, bo.f32, masks, None, BQ, Q, H5, W5_, C5, 1, 1, True, False)
                 mv = engine.Var(masks)

@@ -34,22 +34,22 @@ def timed(fn):
 rows = []
 # lay4: a3 [N,40,40,64] (normalised) + fpn [B,80,80,64] -> pre4 [N,80,80,32]
 a3 = rnd(N, 40, 40, 64).clamp(min=0).to(BF).to(dev)
-f3 = rnd(B, 80, 80, 64).to(BF).to(dev)
+f3 = rnd(B, 80, 80, 32).to(BF).to(dev)      # lay4(adapter2(fpn)) of the image, bias included
 w4 = (rnd(32, 3, 3, 64) * 0.05).to(BF).to(dev)
 b4 = rnd(32).to(dev)
 pre4 = torch.empty(N, 80, 80, 32, dtype=BF, device=dev)
 st4 = torch.empty(N, 8, 2, dtype=torch.float32, device=dev)
-us = timed(lambda: k.mask_stage_fwd(a3, None, None, None, f3, w4, b4, pre4, st4, N, Q, 80, 80, 64, 32, 32, False, True))
-rows.append(("lay4  64->32 @ 80x80   (up + FPN)", us, a3.numel() * 2 + f3.numel() * 2 + pre4.numel() * 2, 2 * N * 6400 * 64 * 32 * 9))
+us = timed(lambda: k.mask_stage_fwd(a3, None, None, None, f3, w4, None, pre4, st4, N, Q, 80, 80, 64, 32, 32, False, True))
+rows.append(("lay4  64->32 @ 80x80   (up, + FPN conv)", us, a3.numel() * 2 + f3.numel() * 2 + pre4.numel() * 2, 2 * N * 6400 * 64 * 32 * 9))
 # lay5: pre4 (+ GN) + fpn [B,160,160,32] -> pre5 [N,160,160,16]
-f2 = rnd(B, 160, 160, 32).to(BF).to(dev)
+f2 = rnd(B, 160, 160, 16).to(BF).to(dev)
 w5 = (rnd(16, 3, 3, 32) * 0.05).to(BF).to(dev)
 b5 = rnd(16).to(dev)
 g4w, g4b = (1 + 0.1 * rnd(32)).to(dev), (0.1 * rnd(32)).to(dev)
 pre5 = torch.empty(N, 160, 160, 16, dtype=BF, device=dev)
 st5 = torch.empty(N, 8, 2, dtype=torch.float32, device=dev)
-us = timed(lambda: k.mask_stage_fwd(pre4, st4, g4w, g4b, f2, w5, b5, pre5, st5, N, Q, 160, 160, 32, 16, 16, True, True))
-rows.append(("lay5  32->16 @ 160x160 (GN + up + FPN)", us, pre4.numel() * 2 + f2.numel() * 2 + pre5.numel() * 2, 2 * N * 25600 * 32 * 16 * 9))
+us = timed(lambda: k.mask_stage_fwd(pre4, st4, g4w, g4b, f2, w5, None, pre5, st5, N, Q, 160, 160, 32, 16, 16, True, True))
+rows.append(("lay5  32->16 @ 160x160 (GN + up, + FPN conv)", us, pre4.numel() * 2 + f2.numel() * 2 + pre5.numel() * 2, 2 * N * 25600 * 32 * 16 * 9))
 # out_lay: pre5 (+ GN) -> logits f32 [N,160,160]
 wo = (rnd(1, 3, 3, 16) * 0.05).to(BF).to(dev)
 bo = rnd(1).to(dev)
