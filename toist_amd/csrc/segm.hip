@@ -441,10 +441,10 @@ __global__ __launch_bounds__(256) void mask_loss_fwd_kernel(const float* __restr
 }
 // d(loss_mask*g_f + loss_dice*g_d)/d pred, scattered back through the bilinear weights (f32 atomics into dpred,
 // which the caller zeroes).  scale_f = g_f / (TH*TW*num_boxes), scale_d = g_d / num_boxes are read from `coef`.
-// Tiled form: a workgroup owns a 32 x 32 block of target pixels of one pair, whose bilinear footprint in the prediction is
+// Tiled form: a workgroup owns an MLB_TILE x MLB_TILE block of target pixels of one pair, whose bilinear footprint in the prediction is
 // at most MLB_SRC x MLB_SRC source pixels; contributions are summed in LDS and only the footprint goes out as global
 // atomics (the plain form issued four global atomics per target pixel: 65 M per step).
-constexpr int MLB_TILE = 32, MLB_SRC = 36;
+constexpr int MLB_TILE = 64, MLB_SRC = 36;   // 64 x 64 target pixels per workgroup (16 per thread: the LDS window's zeroing and write-back were most of a 32 x 32 tile's time); the window fits up-sampling ratios >= 1.9, others take the global-atomic path
 __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restrict__ pred, const int* __restrict__ pred_row,
                                                              const unsigned char* __restrict__ gt, const int* __restrict__ gt_row,
                                                              int h, int w, int TH, int TW, float alpha, const float* __restrict__ sums,
