@@ -444,12 +444,14 @@ __global__ __launch_bounds__(256) void mask_loss_fwd_kernel(const float* __restr
 // Tiled form: a workgroup owns an MLB_TILE x MLB_TILE block of target pixels of one pair, whose bilinear footprint in the prediction is
 // at most MLB_SRC x MLB_SRC source pixels; contributions are summed in LDS and only the footprint goes out as global
 // atomics (the plain form issued four global atomics per target pixel: 65 M per step).
-constexpr int MLB_TILE = 64, MLB_SRC = 36;   // 64 x 64 target pixels per workgroup (16 per thread: the LDS window's zeroing and write-back were most of a 32 x 32 tile's time); the window fits up-sampling ratios >= 1.9, others take the global-atomic path
+constexpr int MLB_TILE = 64, MLB_SRC = 36, MLB_CAND = 16;   // 64 x 64 target pixels per workgroup (16 per thread: the LDS window's zeroing and write-back were most of a 32 x 32 tile's time); the window fits up-sampling ratios >= 1.9, others take the global-atomic path
 __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restrict__ pred, const int* __restrict__ pred_row,
                                                              const unsigned char* __restrict__ gt, const int* __restrict__ gt_row,
                                                              int h, int w, int TH, int TW, float alpha, const float* __restrict__ sums,
                                                              const float* __restrict__ coef, float* __restrict__ dpred, int compact) {
     __shared__ float acc[MLB_SRC * MLB_SRC];
+    __shared__ float win[MLB_SRC * MLB_SRC];
+    __shared__ float gvs[MLB_TILE * MLB_TILE];
     const int t = blockIdx.y;
     if (pred_row[t] < 0) return;          // unused slot
     const float* pm = pred + (size_t)pred_row[t] * h * w;
@@ -464,16 +466,37 @@ __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restr
     int sy0, sx0, dummy; float wdummy;
     bilinear_src(Y0, h, TH, sy0, dummy, wdummy);
     bilinear_src(X0, w, TW, sx0, dummy, wdummy);
-    for (int i = threadIdx.x; i < MLB_SRC * MLB_SRC; i += 256) acc[i] = 0.f;
+    // Up-sampling ratios in [1.9, 5.5] (the reference predicts masks at 1/4 of the padded image): the tile's footprint fits the LDS window and a
+    // source pixel is touched by at most MLB_CAND target rows / columns -> GATHER: per-target-pixel gradients go to LDS with plain stores and
+    // every source pixel of the window sums its own contributions (the scatter form below spent 420 of its 520 us in same-address LDS float
+    // atomics: measured 110 us with the atomics replaced by stores).  Other ratios keep the scatter form.
+    const float sc_y = (float)TH / (float)h, sc_x = (float)TW / (float)w;
+    const bool gather = sc_y >= 1.9f && sc_y <= 5.5f && sc_x >= 1.9f && sc_x <= 5.5f;     // 2 * 5.5 + 5 = MLB_CAND candidate columns
+    // the prediction window under this tile goes to LDS once
+    for (int i = threadIdx.x; i < MLB_SRC * MLB_SRC; i += 256) {
+        acc[i] = 0.f;
+        const int y = sy0 + i / MLB_SRC, x = sx0 + i % MLB_SRC;
+        win[i] = (y < h && x < w) ? pm[y * w + x] : 0.f;
+    }
     __syncthreads();
-    bool spill = false;   // a footprint larger than the LDS window (down-sampling ratios): those pixels use global atomics
     for (int i = threadIdx.x; i < MLB_TILE * MLB_TILE; i += 256) {
         const int Y = Y0 + i / MLB_TILE, X = X0 + i % MLB_TILE;
-        if (Y >= TH || X >= TW) continue;
+        if (Y >= TH || X >= TW) {
+            gvs[i] = 0.f;
+            continue;
+        }
         int y0, y1, x0, x1; float wy, wx;
         bilinear_src(Y, h, TH, y0, y1, wy);
         bilinear_src(X, w, TW, x0, x1, wx);
-        const float v = (1.f - wy) * ((1.f - wx) * pm[y0 * w + x0] + wx * pm[y0 * w + x1]) + wy * ((1.f - wx) * pm[y1 * w + x0] + wx * pm[y1 * w + x1]);
+        const int ly0 = y0 - sy0, ly1 = y1 - sy0, lx0 = x0 - sx0, lx1 = x1 - sx0;
+        const bool inside = ly1 < MLB_SRC && lx1 < MLB_SRC;      // always true in gather mode
+        float p00, p01, p10, p11;
+        if (inside) {
+            p00 = win[ly0 * MLB_SRC + lx0]; p01 = win[ly0 * MLB_SRC + lx1]; p10 = win[ly1 * MLB_SRC + lx0]; p11 = win[ly1 * MLB_SRC + lx1];
+        } else {
+            p00 = pm[y0 * w + x0]; p01 = pm[y0 * w + x1]; p10 = pm[y1 * w + x0]; p11 = pm[y1 * w + x1];
+        }
+        const float v = (1.f - wy) * ((1.f - wx) * p00 + wx * p01) + wy * ((1.f - wx) * p10 + wx * p11);
         const float tg = gm[(size_t)Y * TW + X] ? 1.f : 0.f;
         const float p = 1.f / (1.f + __expf(-v));
         const float ce = fmaxf(v, 0.f) - v * tg + log1pf(__expf(-fabsf(v)));
@@ -484,26 +507,60 @@ __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restr
         // dice: loss = 1 - num/den ; d/dp = -(2 t den - num) / den^2
         const float ddice = -(2.f * tg * den - num) / (den * den) * p * (1.f - p);
         const float gv = sf * dfocal + sd * ddice;
-        const int ly0 = y0 - sy0, ly1 = y1 - sy0, lx0 = x0 - sx0, lx1 = x1 - sx0;
-        if (ly1 < MLB_SRC && lx1 < MLB_SRC) {
+        if (gather) {
+            gvs[i] = gv;
+        } else if (inside) {
             atomicAdd(&acc[ly0 * MLB_SRC + lx0], gv * (1.f - wy) * (1.f - wx));
             atomicAdd(&acc[ly0 * MLB_SRC + lx1], gv * (1.f - wy) * wx);
             atomicAdd(&acc[ly1 * MLB_SRC + lx0], gv * wy * (1.f - wx));
             atomicAdd(&acc[ly1 * MLB_SRC + lx1], gv * wy * wx);
-        } else {
-            spill = true;
+        } else {      // a footprint larger than the LDS window (down-sampling ratios): global atomics
             atomicAdd(dp + y0 * w + x0, gv * (1.f - wy) * (1.f - wx));
             atomicAdd(dp + y0 * w + x1, gv * (1.f - wy) * wx);
             atomicAdd(dp + y1 * w + x0, gv * wy * (1.f - wx));
             atomicAdd(dp + y1 * w + x1, gv * wy * wx);
         }
     }
-    (void)spill;
     __syncthreads();
-    for (int i = threadIdx.x; i < MLB_SRC * MLB_SRC; i += 256) {
-        const float a = acc[i];
-        const int y = sy0 + i / MLB_SRC, x = sx0 + i % MLB_SRC;
-        if (a != 0.f && y < h && x < w) atomicAdd(dp + y * w + x, a);
+    if (!gather) {
+        for (int i = threadIdx.x; i < MLB_SRC * MLB_SRC; i += 256) {
+            const float a = acc[i];
+            const int y = sy0 + i / MLB_SRC, x = sx0 + i % MLB_SRC;
+            if (a != 0.f && y < h && x < w) atomicAdd(dp + y * w + x, a);
+        }
+        return;
+    }
+    // gather: source pixel (gy, gx) of the window receives sum over the tile's target pixels of gv * Wy(Y -> gy) * Wx(X -> gx), where a target row
+    // Y gives weight (1 - wy) to its upper source row y0 and wy to y1 (both to the same row at the image border) -- the scatter form's weights
+    const int Yend = min(Y0 + MLB_TILE, TH) - 1, Xend = min(X0 + MLB_TILE, TW) - 1;
+    for (int s = threadIdx.x; s < MLB_SRC * MLB_SRC; s += 256) {
+        const int gy = sy0 + s / MLB_SRC, gx = sx0 + s % MLB_SRC;
+        if (gy >= h || gx >= w) continue;
+        // targets whose bilinear support can contain this source pixel: (o + 0.5) / sc - 0.5 in [g - 1, g + 1), widened by one each side
+        const int Ylo = max(Y0, (int)floorf(((float)gy - 0.5f) * sc_y - 0.5f) - 1), Yhi = min(Yend, (int)ceilf(((float)gy + 1.5f) * sc_y - 0.5f) + 1);
+        const int Xlo = max(X0, (int)floorf(((float)gx - 0.5f) * sc_x - 0.5f) - 1), Xhi = min(Xend, (int)ceilf(((float)gx + 1.5f) * sc_x - 0.5f) + 1);
+        if (Ylo > Yhi || Xlo > Xhi) continue;
+        float wxv[MLB_CAND];
+#pragma unroll
+        for (int j = 0; j < MLB_CAND; ++j) {
+            int x0, x1; float wx;
+            bilinear_src(Xlo + j, w, TW, x0, x1, wx);
+            wxv[j] = (Xlo + j <= Xhi) ? ((x0 == gx ? 1.f - wx : 0.f) + (x1 == gx ? wx : 0.f)) : 0.f;
+        }
+        float total = 0.f;
+        for (int Y = Ylo; Y <= Yhi; ++Y) {
+            int y0, y1; float wy;
+            bilinear_src(Y, h, TH, y0, y1, wy);
+            const float wyk = (y0 == gy ? 1.f - wy : 0.f) + (y1 == gy ? wy : 0.f);
+            if (wyk == 0.f) continue;
+            const float* row = gvs + (Y - Y0) * MLB_TILE + (Xlo - X0);
+            float rs = 0.f;
+#pragma unroll
+            for (int j = 0; j < MLB_CAND; ++j)
+                if (Xlo + j <= Xhi) rs += wxv[j] * row[j];
+            total += wyk * rs;
+        }
+        if (total != 0.f) atomicAdd(dp + gy * w + gx, total);
     }
 }
 
