@@ -228,3 +228,17 @@ def test_memory_cache_materialises_lazy_entries_on_read():
     mc2 = MemoryCache({}, lazy={"a": thunk("a", 5)})
     assert dict(mc2.items()) == {"a": 5} and calls[-1] == "a" and list(mc2) == ["a"]
     assert mc2.get("missing", 7) == 7 and mc2.pop("a") == 5 and "a" not in mc2
+
+
+def test_distill_tables_follow_in_place_refills():
+    """distill._cached_table keys a batch's caption-driven tables on the identity AND the in-place version of its token tensor: a loop that refills a
+    static input_ids buffer in place (a captured step's feed) must not be served the previous batch's tables."""
+    import torch
+    from toist_amd import distill
+    ids = torch.zeros(2, 4, dtype=torch.long)
+    calls = []
+    make = lambda: calls.append(1) or len(calls)
+    assert distill._cached_table("t_test", (ids,), (), make) == 1
+    assert distill._cached_table("t_test", (ids,), (), make) == 1          # same contents: cached
+    ids.copy_(torch.ones(2, 4, dtype=torch.long))                          # refilled in place
+    assert distill._cached_table("t_test", (ids,), (), make) == 2

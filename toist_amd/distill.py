@@ -71,7 +71,9 @@ def _tok_ref(tokenized):
 
 
 def _cached_table(kind, refs, extra, make):
-    key = (kind, tuple(id(r) for r in refs), extra)
+    # identity + in-place version of tensor refs: a caller that refills a static input_ids buffer in place (a captured step's feed) bumps
+    # Tensor._version, so a table built for the previous contents is not served again
+    key = (kind, tuple((id(r), r._version) if torch.is_tensor(r) else id(r) for r in refs), extra)
     ent = _TABLES.get(key)
     if ent is not None:
         _TABLES.move_to_end(key)
