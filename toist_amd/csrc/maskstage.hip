@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mask_stage_kernel(co
     static_assert(OUT1 || CG == 2 || CG == 4 || CG == 8, "output groups of 2, 4 or 8 channels");
     static_assert(256 % CH == 0, "a thread keeps one channel chunk");
     typedef typename MsFrag<KM>::type frag_t;
-    __shared__ __attribute__((aligned(16))) bf16_t tile[SP * SP * PX];
+    __shared__ __attribute__((aligned(16))) bf16_t tile[2][SP * SP * PX];     // two buffers: tile k+1 is written while slower waves still read tile k -> ONE barrier per tile
     __shared__ float sacc[2][8];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mask_stage_kernel(co
     // per-lane bases of the fragment reads (channel block g).  Halo tile: pixel (row wave*4, column c16).  Source tile: output column c16 reads
     // source column (c16 + dx + 1) >> 1 = jA, jB + 1, jA + 1 for dx = 0, 1, 2 with jA = (c16 + 1) >> 1, jB = c16 >> 1; output row wave*4 + rr reads
     // source row wave*2 + ((rr + dy + 1) >> 1).
-    const bf16_t* base_a = UP ? tile + (size_t)(wave * 2 * SP + ((c16 + 1) >> 1)) * PX + g * KL : tile + (size_t)(wave * 4 * HS + c16) * PX + g * KL;
-    const bf16_t* base_b = UP ? tile + (size_t)(wave * 2 * SP + (c16 >> 1)) * PX + g * KL : base_a;
+    const bf16_t* base_a0 = UP ? tile[0] + (size_t)(wave * 2 * SP + ((c16 + 1) >> 1)) * PX + g * KL : tile[0] + (size_t)(wave * 4 * HS + c16) * PX + g * KL;
+    const bf16_t* base_b0 = UP ? tile[0] + (size_t)(wave * 2 * SP + (c16 >> 1)) * PX + g * KL : base_a0;
 
     // The fill of a tile is split in two: `issue` puts the tile's global loads in flight (raw 16-byte chunks into registers), `commit` normalises
     // and writes the LDS tile.  The loads of tile k+1 are issued before tile k's MFMAs, so a workgroup's strip is not a chain of
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mask_stage_kernel(co
         if (t_i[u] >= 0 && (unsigned)sy < (unsigned)SH && (unsigned)sx < (unsigned)SW)
             r_src[u] = *reinterpret_cast<const uint4*>(src_n + ((size_t)sy * SW + sx) * CIN + cc * 8);
     };
-    auto commit = [&](const int x0, const int u) __attribute__((always_inline)) {
+    auto commit = [&](const int x0, const int u, bf16_t* buf) __attribute__((always_inline)) {
         if (t_i[u] < 0) return;
         const int sy = ty0 + t_i[u], sx = (UP ? (x0 >> 1) - 1 : x0 - 1) + t_j[u];
         uint4 val = r_src[u];
@@ -162,17 +162,19 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mask_stage_kernel(co
             val = ms_pack8v(v);                        // the normalised activation is a bf16 tensor in the per-op path
             if (!((unsigned)sy < (unsigned)SH && (unsigned)sx < (unsigned)SW)) val = make_uint4(0, 0, 0, 0);   // outside the image: the convolution's zero padding
         }
-        *reinterpret_cast<uint4*>(tile + (size_t)(t_i[u] * SP + t_j[u]) * PX + cc * 8) = val;
+        *reinterpret_cast<uint4*>(buf + (size_t)(t_i[u] * SP + t_j[u]) * PX + cc * 8) = val;
     };
 
 #pragma unroll
     for (int u = 0; u < U; ++u) issue(0, u);
     for (int tx = 0; tx < tiles_x; ++tx) {
         const int x0 = tx * TS;
-        __syncthreads();                                  // the previous tile's fragment reads are done
+        const int bsel = (tx & 1) * (SP * SP * PX);
+        const bf16_t* base_a = base_a0 + bsel;
+        const bf16_t* base_b = base_b0 + bsel;
 #pragma unroll
-        for (int u = 0; u < U; ++u) commit(x0, u);
-        __syncthreads();
+        for (int u = 0; u < U; ++u) commit(x0, u, tile[0] + bsel);
+        __syncthreads();                                  // tile k is complete; every wave has finished tile k-1, whose buffer tile k+1 will overwrite
         if (tx + 1 < tiles_x) {
 #pragma unroll
             for (int u = 0; u < U; ++u) issue(x0 + TS, u);
@@ -182,6 +184,18 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mask_stage_kernel(co
             f32x4_t acc[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const int y = y0 + wave * 4 + rr, x = x0 + c16;
+            const bool live = y < H && x < W;
+            // the image's share of this row (lay(adapter(fpn)), L2-resident) is requested BEFORE the taps: its latency used to sit between the last MFMA
+            // and the store of every row (waves waited 55-65 % of their life)
+            uint2 fr[NB];
+            if constexpr (UP) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    fr[nb] = make_uint2(0, 0);
+                    if (live && nb * 16 + g * 4 < COUT) fr[nb] = *reinterpret_cast<const uint2*>(res_b + ((size_t)y * W + x) * COUT + nb * 16 + g * 4);
+                }
+            }
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -193,8 +207,6 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mask_stage_kernel(co
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) acc[nb] = ms_mfma<KM>(bw[t][nb][ks], a, acc[nb]);
                 }
-            const int y = y0 + wave * 4 + rr, x = x0 + c16;
-            const bool live = y < H && x < W;
             if constexpr (OUT1) {
                 if (live && g == 0) out1[((size_t)n * H + y) * W + x] = acc[0][0] + bs[0][0];
             } else if (live) {
@@ -204,9 +216,8 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mask_stage_kernel(co
                     if (c0 < COUT) {
                         float r0 = acc[nb][0] + bs[nb][0], r1 = acc[nb][1] + bs[nb][1], r2 = acc[nb][2] + bs[nb][2], r3 = acc[nb][3] + bs[nb][3];
                         if constexpr (UP) {           // the image's share: lay(adapter(fpn)) at this pixel
-                            const uint2 fr = *reinterpret_cast<const uint2*>(res_b + ((size_t)y * W + x) * COUT + c0);
-                            r0 += __uint_as_float(fr.x << 16); r1 += __uint_as_float(fr.x & 0xffff0000u);
-                            r2 += __uint_as_float(fr.y << 16); r3 += __uint_as_float(fr.y & 0xffff0000u);
+                            r0 += __uint_as_float(fr[nb].x << 16); r1 += __uint_as_float(fr[nb].x & 0xffff0000u);
+                            r2 += __uint_as_float(fr[nb].y << 16); r3 += __uint_as_float(fr[nb].y & 0xffff0000u);
                         }
                         const unsigned lo = pack2bf(r0, r1), hi = pack2bf(r2, r3);
                         *reinterpret_cast<uint2*>(out + (((size_t)n * H + y) * W + x) * COUT + c0) = make_uint2(lo, hi);
