@@ -23,3 +23,7 @@ grep -E "decoder forward|backward launch|one-launch" $O/xdec_bench.txt
 ( timeout 120 build/xcd_barrier_probe ) > $O/xcd_barrier.txt 2>&1
 ( timeout 600 python bench.py --no-secondary --no-cpu-baseline --no-roofline --glue-report ) 2>&1 | grep -v amdgpu.ids | tail -80 > $O/glue.txt
 head -1 $O/glue.txt
+# configs[2]: kernel timeline of the replayed step, the fused mask stages against their HBM bytes
+( bash tools/r5/masks_prof.sh $TAG/masks ) > $O/masks_prof.txt 2>&1
+( timeout 300 python tools/r5/maskstage_bench.py ) 2>&1 | grep -v amdgpu.ids > $O/maskstage_bench.txt
+cat $O/maskstage_bench.txt
