@@ -321,3 +321,76 @@ def test_segment_sum_and_row_variants(dev):
     assert torch.equal(y0, y1)
     ref = F.relu(F.group_norm(x.float().permute(0, 3, 1, 2), 8, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
     assert rel(y1, ref) < 1e-2
+
+
+@pytest.mark.parametrize("sizes", [[2, 0, 3], [0, 0, 0]])
+def test_static_pair_table_matches_the_eager_pairs(dev, sizes):
+    """mask_losses_static (fixed-capacity pair table, live slots computed on the device: the hipGraph replay's path) against mask_losses on the same
+    assignment: same losses, same gradients through the matched-rows backward -- including a batch WITHOUT any target (every slot unused: zero losses,
+    zero gradients, nothing non-finite)."""
+    from types import SimpleNamespace
+    from toist_amd.matcher import MatchResult
+    from toist_amd.segmentation import DETRsegm, mask_losses, mask_losses_static
+    B, Q, d, H, h, w = 3, 7, 256, 8, 5, 6
+    TH, TW = 160, 192
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.transformer = type("T", (), {"d_model": d, "nhead": H})()
+    torch.manual_seed(0)
+    seg = DETRsegm(Stub(), "smallconv", freeze_detr=False).to(dev)
+    g = torch.Generator().manual_seed(9)
+    base = [torch.randn(B * Q, d, generator=g), torch.randn(B * h * w, d, generator=g), torch.randn(B * h * w, d, generator=g),
+            torch.randn(B, 2 * h, 2 * w, 1024, generator=g).clamp(min=0), torch.randn(B, 4 * h, 4 * w, 512, generator=g).clamp(min=0),
+            torch.randn(B, 8 * h, 8 * w, 256, generator=g).clamp(min=0)]
+    fmask = torch.zeros(B, h, w, dtype=torch.bool, device=dev)
+    M = sum(sizes)
+    cap_per = 4
+    gt_list = [(torch.rand(t, TH, TW, generator=g) > 0.6) for t in sizes]
+    src_all = [torch.tensor([5, 1]), torch.tensor([], dtype=torch.long), torch.tensor([0, 2, 6])]
+    tgt_all = [torch.tensor([1, 0]), torch.tensor([], dtype=torch.long), torch.tensor([2, 0, 1])]
+    src = torch.cat([s[:t] for s, t in zip(src_all, sizes)])[None].to(dev)
+    tgt = torch.cat([s[:t] for s, t in zip(tgt_all, sizes)])[None].to(dev)
+    match = MatchResult(src, tgt, torch.zeros(B, dtype=torch.int32), sizes, Q)
+    # the static image of the same batch: masks packed at stride cap_per per image, offsets on the device
+    st_masks = torch.zeros(B * cap_per, TH, TW, dtype=torch.uint8, device=dev)
+    for i, m in enumerate(gt_list):
+        st_masks[i * cap_per:i * cap_per + m.shape[0]] = m.to(torch.uint8).to(dev)
+    off = [0]
+    for t in sizes:
+        off.append(off[-1] + t)
+    st = SimpleNamespace(cap=B * cap_per, masks=st_masks, mask_hw=(TH, TW), match_off=torch.tensor(off, dtype=torch.int32, device=dev),
+                         tgt_off=torch.tensor([i * cap_per for i in range(B)], dtype=torch.int32, device=dev), num_boxes=torch.tensor([5.0], device=dev))
+    pad = torch.zeros(1, st.cap - M, dtype=torch.long, device=dev)
+    match_st = SimpleNamespace(src=torch.cat([src, pad], 1), tgt=torch.cat([tgt, pad], 1))
+
+    def run(static):
+        seg.zero_grad(set_to_none=True)
+        ins = [t.to(BF).to(dev).requires_grad_(True) for t in base]
+        masks = seg._masks(*ins, fmask, B, Q, h, w)
+        if static:
+            out = mask_losses_static({"pred_masks": masks}, st, match_st, 0, 1)
+        else:
+            targets = [{"masks": m.to(dev), "boxes": torch.zeros(m.shape[0], 4, device=dev)} for m in gt_list]
+            out = mask_losses({"pred_masks": masks}, targets, match, 0, torch.tensor(5.0, device=dev))
+        (out["loss_mask"] * 1.5 + out["loss_dice"] * 0.7).backward()
+        torch.cuda.synchronize()
+        return {k_: float(v) for k_, v in out.items()}, {n: p.grad.detach().float().clone() for n, p in seg.named_parameters()}, [t.grad.detach().float().clone() for t in ins]
+    ls, ps, gs = run(True)
+    for v in list(ps.values()) + gs:
+        assert torch.isfinite(v).all()
+    if M == 0:
+        assert ls["loss_mask"] == 0.0 and ls["loss_dice"] == 0.0
+        assert all(float(v.abs().max()) == 0.0 for v in ps.values()) and all(float(v.abs().max()) == 0.0 for v in gs)
+        return
+    le, pe, ge = run(False)
+    for k_ in ("loss_mask", "loss_dice"):
+        assert abs(ls[k_] - le[k_]) <= 1e-4 * abs(le[k_]) + 1e-6, (k_, ls[k_], le[k_])
+    top = max(float(v.norm()) for v in pe.values())
+    for n in pe:
+        err = float((pe[n] - ps[n]).norm())
+        assert err <= 2e-2 * float(pe[n].norm()) + 2e-5 * top, (n, err, float(pe[n].norm()))
+    for n, a, b in zip(["hs", "memory", "src_proj", "c4", "c3", "c2"], ge, gs):
+        ratio = float(b.norm() / a.norm())
+        assert cos(a, b) > 0.9995 and 0.99 < ratio < 1.01, (n, cos(a, b), ratio)
