@@ -332,7 +332,7 @@ class DETRsegm(nn.Module):
                 fb, wa3 = adapter(f2, 3)
                 pre5 = torch.empty(BQ, H5, W5_, C5, dtype=BF16, device=dev)
                 st5 = torch.empty(BQ, 8, 2, dtype=torch.float32, device=dev)
-                fb_conv = ops.conv2d(fb.view(B, H5, W5_, C4), W5.w, pad=1, shift=b5.f32)
+                fb_conv = ops.conv2d(fb.view(B, H5, W5_, C4), W5.w, pad=1, shift=b5.f32, tile=64)   # 8 images: the tiled implicit GEMM (the direct few-channel kernel is sized for 800 maps: 71 us here)
                 k.mask_stage_fwd(pre4, st4, g4w.f32, g4b.f32, fb_conv, W5.w, None, pre5, st5, BQ, Q, H5, W5_, C4, C5, C5, True, True)
                 masks = torch.empty(B, Q, H5, W5_, dtype=torch.float32, device=dev)
                 k.mask_stage_fwd(pre5, st5, g5w.f32, g5b.f32, None, Wo.w, bo.f32, masks, None, BQ, Q, H5, W5_, C5, 1, 1, True, False)
