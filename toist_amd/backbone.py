@@ -216,9 +216,7 @@ class BackboneBase(nn.Module):
                     nxt.needs_grad = train
                     cur = nxt
                 if li in levels:
-                    outs.append(cur)
-            for o in outs:
-                o.needs_grad = True
+                    outs.append(cur)      # needs_grad = this stage trains: a consumer (the mask head's adapter on the frozen layer1 output) does not compute a gradient nobody takes
             return outs, None
 
         return prog
@@ -231,7 +229,7 @@ class BackboneBase(nn.Module):
             outs, extra = prog(tape, ps, img)
             finals = []
             for oi, o in enumerate(outs):
-                f = engine.Var(o.data)
+                f = engine.Var(o.data, needs_grad=o.needs_grad)
 
                 def bwd(o=o, f=f, oi=oi):
                     g = f.take_grad()
