@@ -109,6 +109,42 @@ def test_torch_optimizer_step_invalidates_compute_copies(dev):
     assert not torch.equal(w0, w1) and torch.equal(w1, p.detach().to(torch.bfloat16))
 
 
+def test_two_tails_keep_each_others_compute_copies_valid(dev):
+    """Two models, two fused tails (the distillation step: teacher + student): a tail's step bumps the GLOBAL weight epoch, which used to make the
+    other model's compute copies look stale -- its next forward re-made ~260 copies one torch launch at a time.  Each tail now carries the other
+    tails' valid copies over its own bump; a torch optimizer's step still invalidates everything."""
+    from toist_amd import engine
+    from toist_amd.optim import FusedClipAdamWEMA
+    pa = torch.nn.Parameter(torch.randn(64, 32, device=dev))
+    pb = torch.nn.Parameter(torch.randn(48, 16, device=dev))
+    ca, cb = {}, {}
+    made = []
+
+    def make(m):
+        made.append(tuple(m.shape))
+        return engine._cast_bf16(m)
+    make.elementwise = True
+    engine.compute_copy(pa, make, ca, "w")
+    engine.compute_copy(pb, make, cb, "w")
+    oa = FusedClipAdamWEMA([{"params": [pa]}], lr=0.1, max_norm=0.0)
+    ob = FusedClipAdamWEMA([{"params": [pb]}], lr=0.1, max_norm=0.0)
+    for _ in range(2):
+        pa.grad, pb.grad = torch.ones_like(pa), torch.ones_like(pb)
+        oa.step()
+        ob.step()
+        n = len(made)
+        wa = engine.compute_copy(pa, make, ca, "w")
+        wb = engine.compute_copy(pb, make, cb, "w")
+        assert len(made) == n, made[n:]                    # neither copy was re-made: the tails rewrote them and kept each other's valid
+        assert torch.equal(wa, pa.detach().to(torch.bfloat16)) and torch.equal(wb, pb.detach().to(torch.bfloat16))
+    pa.grad = torch.ones_like(pa)
+    torch.optim.SGD([pa], lr=0.1).step()                   # a torch optimizer: unknown which masters moved -> every copy is stale
+    n = len(made)
+    engine.compute_copy(pa, make, ca, "w")
+    engine.compute_copy(pb, make, cb, "w")
+    assert len(made) == n + 2
+
+
 def test_deferred_ema_is_the_same_average(dev):
     """defer_ema=True: the moving average leaves step() and runs as ema_update() (beside the next forward pass in bench.py); parameters,
     moments and -- once the last update is flushed -- the average equal those of the in-step variant bit for bit."""

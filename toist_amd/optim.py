@@ -38,6 +38,17 @@ def _dense(t):
     return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
 
 
+import weakref as _weakref
+
+# Live tails of this process.  A step bumps the GLOBAL weight epoch (engine.WEIGHT_EPOCH: the masters changed behind torch's version counters),
+# which also makes the compute copies of every OTHER model look stale -- with two models and two tails (the distillation step: teacher +
+# student) each step() invalidated the other model's ~260 copies, and the next forward re-made them one torch launch at a time (524 of the
+# 883 torch operators of an eager configs[4] step).  A tail therefore carries the copies of the other tails over its own bump when they were
+# valid before it and none of their masters is a parameter of this tail.
+_LIVE_TAILS = _weakref.WeakSet()
+CARRY_OTHER_TAILS = True      # False: A/B switch (every step() invalidates the other tails' copies, as before)
+
+
 class FusedClipAdamWEMA:
     """clip_grad_norm_ + AdamW + EMA (+ bf16 compute-copy refresh) in one multi-tensor pass.
 
@@ -95,6 +106,8 @@ class FusedClipAdamWEMA:
         self._group_of = [gi for gi, g in enumerate(self.param_groups) for _ in g["params"]]
         self._late = [bool(g.get("late", False)) for g in self.param_groups for _ in g["params"]]
         self._early = [bool(g.get("early_norm", False)) and not bool(g.get("late", False)) for g in self.param_groups for _ in g["params"]]
+        self._param_ids = frozenset(id(p) for p in params)
+        _LIVE_TAILS.add(self)
         self._early_ids = frozenset(id(p) for p, e in zip(params, self._early) if e)
         self._early_idx = [i for i, e in enumerate(self._early) if e]
         self._early_done = False
@@ -286,12 +299,8 @@ class FusedClipAdamWEMA:
             k.opt_adamw_ema(self._table, self._grads_dev, self._chunks, self._n_now, self._groups_dev, self.state, self.betas[0],
                             self.betas[1], self.eps, self.ema_decay)
         self._ema_pending = self.defer_ema
-        # the masters changed behind torch's version counters: every compute copy is stale except the ones just rewritten
-        engine.bump_weight_epoch()
-        late_ids = {id(p_) for _, p_ in self._late_copies} if self._n_late else ()
-        for ent, p in self._copies:
-            if p.grad is not None and id(p) not in late_ids:
-                ent.epoch = engine.WEIGHT_EPOCH
+        # the masters changed behind torch's version counters: every compute copy of THESE parameters is stale except the ones just rewritten
+        self._bump_epoch()
         if self._n_late:
             self._late_pending = True
             self._late_grads = [p.grad for p, l in zip(self.params, self._late) if l]     # the pointers in the device table must stay valid
@@ -300,11 +309,21 @@ class FusedClipAdamWEMA:
         """Host-side bookkeeping of ONE replay of a hipGraph that holds this optimizer's step(): the replay rewrote the masters and the bf16 compute
         copies in the tail's table, but no Python ran -- every OTHER cached copy of a parameter (another program cache of the same module, an
         evaluation-time transform) must be seen as stale, exactly as after an eager step()."""
+        self._bump_epoch()
+
+    def _bump_epoch(self):
+        old = engine.WEIGHT_EPOCH
         engine.bump_weight_epoch()
         late_ids = {id(p_) for _, p_ in self._late_copies} if self._n_late else ()
         for ent, p in self._copies:
             if p.grad is not None and id(p) not in late_ids:
                 ent.epoch = engine.WEIGHT_EPOCH
+        for other in list(_LIVE_TAILS) if CARRY_OTHER_TAILS else ():          # the other tails' copies: their masters did not move in this step
+            if other is self:
+                continue
+            for ent, p in getattr(other, "_copies", ()):
+                if ent.epoch == old and id(p) not in self._param_ids:
+                    ent.epoch = engine.WEIGHT_EPOCH
 
     @torch.no_grad()
     def _maybe_norm_early(self, prog_params):
