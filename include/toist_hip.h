@@ -334,11 +334,14 @@ TOIST_API int toist_mask_stage_fwd(const void* src, const float* src_stats, cons
                         float eps, void* stream);
 TOIST_API int toist_sum_segments(const void* in, const int32_t* seg, int B, int rows, int64_t per, void* out, void* stream);
 TOIST_API int toist_mask_loss_fwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
-                        int TH, int TW, float alpha, float* sums, void* stream);
+                        int TH, int TW, float alpha, float* sums, const int32_t* valid_hw, void* stream);
 TOIST_API int toist_mask_loss_bwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
-                        int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred, void* stream);
+                        int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred, const int32_t* valid_hw, void* stream);
 TOIST_API int toist_mask_loss_bwd_compact(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
-                        int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred_rows, void* stream);
+                        int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred_rows, const int32_t* valid_hw, void* stream);
+/* valid_hw (all three; NULL = the whole [TH, TW]): device int32 [2] = the batch's own padded mask size inside a larger bucket (a captured graph's
+ * static shape): target pixels at y >= valid_hw[0] or x >= valid_hw[1] take no part (the reference resizes to the batch's largest image,
+ * mdetr.py:843, and the caller divides loss_mask by valid_hw[0] * valid_hw[1]); the pixel grid stays the bucket's (scale h / TH). */
 
 /* ---- optimizer tail: clip_grad_norm_ + AdamW + EMA + bf16 compute-copy refresh in one multi-tensor pass ------------
  * Replaces engine.py:87-101 of the reference (torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm);
@@ -463,7 +466,8 @@ TOIST_API int toist_rowgemm(const toist_rowgemm_desc* d, void* stream);
  * the backward pass is unchanged.  Limits: Q <= 128, S <= 512, L <= 8, the device must expose 8 XCDs x 32 CUs.
  * ctl: 1024 uint32 of caller scratch, zeroed once by the caller; the launch function re-zeroes words 0 .. 1022 (a memset node under
  * capture).  ctl[1023] is sticky: != 0 = a bounded spin expired in some launch (a group was not co-resident) and that launch's
- * results are invalid. */
+ * results are invalid.  Such a launch also overwrites every layer output (y4) of the affected images with NaN (the backward launch: their
+ * `sink` rows), so the failure reaches the losses / the gradient norm even if nobody reads the status word. */
 enum { TOIST_XDEC_MAX_LAYERS = 8, TOIST_XDEC_CTL_WORDS = 1024 };
 
 typedef struct toist_xdec_layer {
@@ -484,7 +488,10 @@ typedef struct toist_xdec_desc {
     const void* x0;            /* bf16 [B*Q, 256]: tgt entering layer 0 (zeros in the reference) */
     const void* qpos;          /* bf16 [B*Q, 256]: query_pos broadcast over the batch */
     const void* kv;            /* bf16 [B*S, ldkv]: memory K (with pos) / V projections of layer l at columns l*512 / l*512 + 256 */
-    int32_t ldkv, reserved;
+    int32_t ldkv;
+    int32_t ff;                /* dim_feedforward of linear1 / linear2: the launch is compiled for 2048, anything else is refused (TOIST_EINVAL) */
+    int32_t test_absent;       /* 0.  Failure-path tests only: that many workgroups per XCD leave at once, as if they were not co-resident */
+    int32_t reserved;
     const uint8_t* key_pad;    /* [B, S] 1 = padding, or NULL */
     float drop_p, eps;
     const uint64_t* seed_dev;  /* optional device word added to every seed (graph replay) */
@@ -536,7 +543,10 @@ typedef struct toist_xdec_bwd_layer {
 typedef struct toist_xdec_bwd_desc {
     int32_t B, Q, S, L;
     const void* kv;            /* as toist_xdec_desc */
-    int32_t ldkv, ldsink, lddkv, reserved;
+    int32_t ldkv, ldsink, lddkv;
+    int32_t ff;                /* as toist_xdec_desc: must be 2048 */
+    int32_t test_absent;       /* as toist_xdec_desc: 0 outside failure-path tests */
+    int32_t reserved;
     const uint8_t* key_pad;
     float drop_p, reserved2;
     const uint64_t* seed_dev;

@@ -242,3 +242,87 @@ def test_distill_tables_follow_in_place_refills():
     assert distill._cached_table("t_test", (ids,), (), make) == 1          # same contents: cached
     ids.copy_(torch.ones(2, 4, dtype=torch.long))                          # refilled in place
     assert distill._cached_table("t_test", (ids,), (), make) == 2
+
+
+@pytest.mark.parametrize("order", ["alone", "extra_before", "extra_after"])
+def test_matched_rows_sentinel_survives_autograd_accumulation(order):
+    """The hand-off of toist_amd/segmentation.py (`_MaskLossFn.backward` -> `matched_rows_of`), driven on the CPU with the same objects: the
+    producer returns the zero sentinel (one element, expanded, kept alive by the sink); the consumer must see THAT tensor iff nothing else
+    consumed pred_masks, and a correct dense sum otherwise -- in particular when the other consumer was created first, the order in which
+    autograd's input buffer accumulates onto the first-arrived gradient (in place, if it owns it alone: VERDICT r5 weak #1)."""
+    from toist_amd import segmentation as sg
+    sink = sg._MatchedRows()
+    seen = {}
+
+    class Producer(torch.autograd.Function):          # stands for the mask program: receives the gradient of pred_masks
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            zero = sink.sentinel
+            seen["is_sentinel"] = bool(zero is not None and g.data_ptr() == zero.data_ptr() and not any(g.stride()) and zero._version == sink.version)
+            seen["g"] = g.clone()
+            return g.contiguous()
+
+    class Loss(torch.autograd.Function):              # stands for _MaskLossFn
+        @staticmethod
+        def forward(ctx, pred):
+            ctx.shape = pred.shape
+            return pred.sum() * 0.0
+
+        @staticmethod
+        def backward(ctx, g):
+            zero = sg._zero_sentinel(torch.device("cpu"))
+            sink.grad, sink.sentinel, sink.version = torch.ones(1), zero, zero._version
+            return zero.expand(ctx.shape)
+
+    x = torch.randn(3, 4, 5, requires_grad=True)
+    masks = Producer.apply(x)
+    extra = (masks * masks).mean() if order == "extra_before" else None
+    loss = Loss.apply(masks.view(12, 5))
+    if order == "extra_after":
+        extra = (masks * masks).mean()
+    (loss if extra is None else loss + extra).backward()
+    assert seen["is_sentinel"] == (order == "alone")
+    want = torch.zeros_like(x) if order == "alone" else 2 * x.detach() / x.numel()
+    assert torch.allclose(seen["g"], want, atol=1e-7)
+    assert float(sg._zero_sentinel(torch.device("cpu"))) == 0.0 and sg._zero_sentinel(torch.device("cpu"))._version == sink.version
+
+
+def test_box_ops_against_the_reference_fixture():
+    """toist_amd/box_ops.py (API-edge helpers, rewritten in round 6 as one broadcast over the four corners) against values the REAL reference's
+    util/box_ops.py produced (tests/golden/box_ops.npz, make_golden.py)."""
+    import numpy as np
+    from toist_amd import box_ops
+    d = np.load(os.path.join(ROOT, "tests", "golden", "box_ops.npz"))
+    a, b = torch.from_numpy(d["a"]), torch.from_numpy(d["b"])
+    axy, bxy = box_ops.box_cxcywh_to_xyxy(a), box_ops.box_cxcywh_to_xyxy(b)
+    assert np.allclose(axy.numpy(), d["axy"], atol=1e-7)
+    assert np.allclose(box_ops.box_xyxy_to_cxcywh(axy).numpy(), d["back"], atol=1e-6)
+    iou, union = box_ops.box_iou(axy, bxy)
+    assert np.allclose(iou.numpy(), d["iou"], atol=1e-6) and np.allclose(union.numpy(), d["union"], atol=1e-6)
+    assert np.allclose(box_ops.generalized_box_iou(axy, bxy).numpy(), d["giou"], atol=1e-6)
+    bad = axy.clone()
+    bad[0, 2] = bad[0, 0] - 1.0
+    with pytest.raises(AssertionError):
+        box_ops.generalized_box_iou(bad, bxy)
+
+
+def test_postprocess_forwards_pred_isfinal():
+    """PostProcess keeps the reference's `pred_isfinal` -> `scores_refexp` branch (/root/reference/models/postprocessors.py:49-54), and
+    its scores / boxes equal the reference fixture's (postprocess.npz) when the key is absent."""
+    import numpy as np
+    from toist_amd.postprocessors import PostProcess
+    d = np.load(os.path.join(ROOT, "tests", "golden", "postprocess.npz"))
+    out = {"pred_logits": torch.from_numpy(d["logits"]), "pred_boxes": torch.from_numpy(d["boxes"])}
+    sizes = torch.from_numpy(d["sizes"])
+    res = PostProcess()(out, sizes)
+    for i, r in enumerate(res):
+        assert set(r) == {"scores", "labels", "boxes"}
+        assert np.allclose(r["scores"].numpy(), d["scores"][i], atol=1e-6) and np.allclose(r["boxes"].numpy(), d["out_boxes"][i], atol=1e-4)
+    fin = torch.linspace(-3, 3, d["logits"].shape[0] * d["logits"].shape[1]).view(d["logits"].shape[0], -1, 1)
+    res2 = PostProcess()(dict(out, pred_isfinal=fin), sizes)
+    for i, r in enumerate(res2):
+        assert torch.allclose(r["scores_refexp"], res[i]["scores"] * torch.sigmoid(fin[i, :, 0]), atol=1e-7)

@@ -133,11 +133,13 @@ def test_groupnorm_backward_rederives_the_relu_mask(dev, N, HW, C):
     assert (outs[1][1] - gr.grad).norm() / gr.grad.norm() < 1e-2 and (outs[1][2] - br.grad).norm() / br.grad.norm() < 1e-2
 
 
-@pytest.mark.parametrize("extra_consumer", [False, True])
+@pytest.mark.parametrize("extra_consumer", [False, "after", "before"])
 def test_matched_only_backward_equals_dense(dev, extra_consumer):
     """The mask losses read pred_masks[src_idx] only (/root/reference/models/mdetr.py:827-853), so the mask head's backward runs on the
     matched maps alone; every parameter / input gradient must equal the dense backward's (which multiplies the zeros through).  With a
-    second consumer of pred_masks the program has to notice and fall back to the dense path."""
+    second consumer of pred_masks the program has to notice and fall back to the dense path -- WHICHEVER consumer was created first
+    ("before": the extra consumer's gradient reaches autograd's input buffer after the mask losses' and is accumulated onto it; round 5's
+    address-compared dense sentinel was added into in place there and the extra gradient was silently dropped)."""
     from toist_amd import segmentation
     from toist_amd.matcher import MatchResult
     from toist_amd.segmentation import DETRsegm, mask_losses
@@ -160,22 +162,37 @@ def test_matched_only_backward_equals_dense(dev, extra_consumer):
     tgt = torch.tensor([[1, 0, 2, 0, 1]], device=dev)
     match = MatchResult(src, tgt, torch.zeros(B, dtype=torch.int32), sizes, Q)
 
+    ran = []
+    from toist_amd import kernels as _k
+    orig_rows = _k.upsample_add_rows
+
+    def spy(*a, **kw):
+        ran.append(1)
+        return orig_rows(*a, **kw)
+
     def run(flag):
         segmentation.MATCHED_ONLY_BACKWARD = flag
+        _k.upsample_add_rows = spy
         try:
             seg.zero_grad(set_to_none=True)
             ins = [t.to(BF).to(dev).requires_grad_(True) for t in base]
             masks = seg._masks(*ins, fmask, B, Q, h, w)
             assert hasattr(masks, "toist_matched_rows") == flag
+            extra = (masks * masks).mean() * 0.05 if extra_consumer == "before" else None
             out = mask_losses({"pred_masks": masks}, targets, match, 0, torch.tensor(5.0, device=dev))
             loss = out["loss_mask"] * 1.5 + out["loss_dice"] * 0.7
-            if extra_consumer:
-                loss = loss + (masks * masks).mean() * 0.05
+            if extra_consumer == "after":
+                extra = (masks * masks).mean() * 0.05
+            if extra is not None:
+                loss = loss + extra
+            ran.clear()
             loss.backward()
+            assert (len(ran) > 0) == (flag and not extra_consumer), (flag, extra_consumer, ran)   # the matched-rows path ran iff nobody else consumed pred_masks
             torch.cuda.synchronize()
             return {n: p.grad.detach().float().clone() for n, p in seg.named_parameters()}, [t.grad.detach().float().clone() for t in ins]
         finally:
             segmentation.MATCHED_ONLY_BACKWARD = True
+            _k.upsample_add_rows = orig_rows
     pd, idn = run(False)
     ps, isp = run(True)
     top = max(float(v.norm()) for v in pd.values())

@@ -71,7 +71,7 @@ class XdecLayer(Structure):
 class Xdec(Structure):
     """toist_xdec_desc (include/toist_hip.h): the XCD-resident decoder stack of csrc/xdec.hip"""
     _fields_ = [("B", c_int32), ("Q", c_int32), ("S", c_int32), ("L", c_int32), ("x0", c_void_p), ("qpos", c_void_p), ("kv", c_void_p), ("ldkv", c_int32),
-                ("reserved", c_int32), ("key_pad", c_void_p), ("drop_p", c_float), ("eps", c_float), ("seed_dev", c_void_p)] + \
+                ("ff", c_int32), ("test_absent", c_int32), ("reserved", c_int32), ("key_pad", c_void_p), ("drop_p", c_float), ("eps", c_float), ("seed_dev", c_void_p)] + \
                [(n, c_void_p) for n in ("qkv", "ctx_s", "lse_s", "z1", "y1", "y1e", "mean1", "rstd1", "qc", "ctx_c", "lse_c", "z3", "y3", "mean3", "rstd3", "h", "z4", "y4",
                                         "y4e", "mean4", "rstd4", "part", "ctl", "prof")] + \
                [("layer", XdecLayer * XDEC_MAX_LAYERS)]
@@ -85,7 +85,7 @@ class XdecBwdLayer(Structure):
 class XdecBwd(Structure):
     """toist_xdec_bwd_desc (include/toist_hip.h): backward of the XCD-resident decoder stack"""
     _fields_ = [("B", c_int32), ("Q", c_int32), ("S", c_int32), ("L", c_int32), ("kv", c_void_p), ("ldkv", c_int32), ("ldsink", c_int32), ("lddkv", c_int32),
-                ("reserved", c_int32), ("key_pad", c_void_p), ("drop_p", c_float), ("reserved2", c_float), ("seed_dev", c_void_p)] + \
+                ("ff", c_int32), ("test_absent", c_int32), ("reserved", c_int32), ("key_pad", c_void_p), ("drop_p", c_float), ("reserved2", c_float), ("seed_dev", c_void_p)] + \
                [(n, c_void_p) for n in ("qkv", "ctx_s", "lse_s", "z1", "mean1", "rstd1", "qc", "ctx_c", "lse_c", "z3", "mean3", "rstd3", "h", "z4", "mean4", "rstd4", "g_out",
                                         "gb4", "dh", "go3", "go1", "sink", "dkv", "ln_part", "dctx", "part", "dq_part", "ctl", "prof")] + \
                [("layer", XdecBwdLayer * XDEC_MAX_LAYERS)]
@@ -136,9 +136,9 @@ _SIGNATURES = {
     "toist_upsample_add_rows": ([c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p], ctypes.c_int),
     "toist_mask_stage_fwd": ([c_void_p] * 9 + [c_int32] * 9 + [c_float, c_void_p], ctypes.c_int),
     "toist_sum_segments": ([c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p], ctypes.c_int),
-    "toist_mask_loss_fwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p], ctypes.c_int),
-    "toist_mask_loss_bwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
-    "toist_mask_loss_bwd_compact": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_loss_fwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_loss_bwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
+    "toist_mask_loss_bwd_compact": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_dropout_bf16": ([c_void_p, c_int64, c_float, c_uint64, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_attn2_splits": ([c_int32], ctypes.c_int),
     "toist_attn2_fwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 5 + [c_float, c_float, c_uint64, c_void_p, c_void_p,

@@ -412,16 +412,21 @@ __device__ __forceinline__ void bilinear_src(int o, int in, int out, int& i0, in
 }
 __global__ __launch_bounds__(256) void mask_loss_fwd_kernel(const float* __restrict__ pred, const int* __restrict__ pred_row,
                                                              const unsigned char* __restrict__ gt, const int* __restrict__ gt_row,
-                                                             int h, int w, int TH, int TW, float alpha, float* __restrict__ sums) {
+                                                             int h, int w, int TH, int TW, float alpha, float* __restrict__ sums,
+                                                             const int* __restrict__ valid_hw) {
     __shared__ float red[4];
     const int t = blockIdx.y;
     if (pred_row[t] < 0) return;          // an unused slot of a fixed-capacity pair table (matcher.StaticTargets): its sums stay 0 -> both losses 0
+    // valid_hw (device, optional): the batch's own padded size inside a larger [TH, TW] bucket (harness.CapturedTrainStep) -- target pixels beyond it
+    // are not part of the reference's loss (mdetr.py:843 resizes to the batch's largest image); the pixel grid (scale h / TH) is the bucket's
+    const int VH = valid_hw ? min(valid_hw[0], TH) : TH, VW = valid_hw ? min(valid_hw[1], TW) : TW;
     const float* pm = pred + (size_t)pred_row[t] * h * w;
     const unsigned char* gm = gt + (size_t)gt_row[t] * TH * TW;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const int total = TH * TW;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int Y = i / TW, X = i - Y * TW;
+        if (Y >= VH || X >= VW) continue;
         int y0, y1, x0, x1; float wy, wx;
         bilinear_src(Y, h, TH, y0, y1, wy);
         bilinear_src(X, w, TW, x0, x1, wx);
@@ -448,7 +453,8 @@ constexpr int MLB_TILE = 64, MLB_SRC = 36, MLB_CAND = 16;   // 64 x 64 target pi
 __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restrict__ pred, const int* __restrict__ pred_row,
                                                              const unsigned char* __restrict__ gt, const int* __restrict__ gt_row,
                                                              int h, int w, int TH, int TW, float alpha, const float* __restrict__ sums,
-                                                             const float* __restrict__ coef, float* __restrict__ dpred, int compact) {
+                                                             const float* __restrict__ coef, float* __restrict__ dpred, int compact,
+                                                             const int* __restrict__ valid_hw) {
     __shared__ float acc[MLB_SRC * MLB_SRC];
     __shared__ float win[MLB_SRC * MLB_SRC];
     __shared__ float gvs[MLB_TILE * MLB_TILE];
@@ -462,6 +468,8 @@ __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restr
     const int tiles_x = (TW + MLB_TILE - 1) / MLB_TILE;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int Y0 = ty * MLB_TILE, X0 = tx * MLB_TILE;
+    const int VH = valid_hw ? min(valid_hw[0], TH) : TH, VW = valid_hw ? min(valid_hw[1], TW) : TW;      // as in the forward kernel
+    if (Y0 >= VH || X0 >= VW) return;
     // source origin of this tile (first source row / column any of its pixels touches)
     int sy0, sx0, dummy; float wdummy;
     bilinear_src(Y0, h, TH, sy0, dummy, wdummy);
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restr
     __syncthreads();
     for (int i = threadIdx.x; i < MLB_TILE * MLB_TILE; i += 256) {
         const int Y = Y0 + i / MLB_TILE, X = X0 + i % MLB_TILE;
-        if (Y >= TH || X >= TW) {
+        if (Y >= VH || X >= VW) {
             gvs[i] = 0.f;
             continue;
         }
@@ -681,23 +689,23 @@ extern "C" int toist_sum_segments(const void* in, const int32_t* seg, int B, int
 }
 
 extern "C" int toist_mask_loss_fwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
-                                   int TH, int TW, float alpha, float* sums, void* stream) {
+                                   int TH, int TW, float alpha, float* sums, const int32_t* valid_hw, void* stream) {
     TOIST_REQUIRE(T > 0 && h > 0 && w > 0 && TH > 0 && TW > 0, "toist_mask_loss_fwd: bad shape");
     hipLaunchKernelGGL(mask_loss_fwd_kernel, dim3(grid_cap((long long)TH * TW, 64), T), dim3(256), 0, (hipStream_t)stream, pred, pred_row, gt, gt_row, h, w,
-                       TH, TW, alpha, sums);
+                       TH, TW, alpha, sums, valid_hw);
     return check_launch("toist_mask_loss_fwd");
 }
 extern "C" int toist_mask_loss_bwd(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
-                                   int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred, void* stream) {
+                                   int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred, const int32_t* valid_hw, void* stream) {
     TOIST_REQUIRE(T > 0 && h > 0 && w > 0 && TH > 0 && TW > 0, "toist_mask_loss_bwd: bad shape");
     hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(((TH + MLB_TILE - 1) / MLB_TILE) * ((TW + MLB_TILE - 1) / MLB_TILE), T), dim3(256), 0, (hipStream_t)stream, pred, pred_row, gt, gt_row, h, w,
-                       TH, TW, alpha, sums, coef, dpred, 0);
+                       TH, TW, alpha, sums, coef, dpred, 0, valid_hw);
     return check_launch("toist_mask_loss_bwd");
 }
 extern "C" int toist_mask_loss_bwd_compact(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
-                                           int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred_rows, void* stream) {
+                                           int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred_rows, const int32_t* valid_hw, void* stream) {
     TOIST_REQUIRE(T > 0 && h > 0 && w > 0 && TH > 0 && TW > 0, "toist_mask_loss_bwd_compact: bad shape");
     hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(((TH + MLB_TILE - 1) / MLB_TILE) * ((TW + MLB_TILE - 1) / MLB_TILE), T), dim3(256), 0, (hipStream_t)stream, pred, pred_row, gt, gt_row, h, w,
-                       TH, TW, alpha, sums, coef, dpred_rows, 1);
+                       TH, TW, alpha, sums, coef, dpred_rows, 1, valid_hw);
     return check_launch("toist_mask_loss_bwd_compact");
 }

@@ -152,6 +152,18 @@ __device__ __forceinline__ void xcd_barrier(XSync& sy) {
     __syncthreads();
 }
 
+// rows [b * Q, (b + 1) * Q) of the images b = xcd, xcd + 8, ... in `copies` stacked [rows][ld] bf16 tensors, columns 0 .. cols - 1 (cols % 8 == 0) := NaN
+__device__ __forceinline__ void poison_rows(bf16_t* base, size_t ld, int cols, int copies, size_t copy_stride, int xcd, int B, int Q) {
+    const uint4 nan8 = make_uint4(0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u);
+    const int per_row = cols >> 3;
+    for (int b = xcd; b < B; b += 8)
+        for (int c = 0; c < copies; ++c)
+            for (int i = threadIdx.x; i < Q * per_row; i += XNT) {
+                const int r = i / per_row, pc = i - r * per_row;
+                *reinterpret_cast<uint4*>(base + c * copy_stride + ((size_t)b * Q + r) * ld + pc * 8) = nan8;
+            }
+}
+
 __device__ __forceinline__ void xstamp(uint64_t* prof, int wg, int L, int layer, int phase) {
     if (prof != nullptr && threadIdx.x == 0) prof[((size_t)wg * L + layer) * 16 + phase] = wall_clock64();
 }
@@ -420,7 +432,10 @@ __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) 
     __syncthreads();
     const int xcd = __builtin_amdgcn_readfirstlane((int)sInfo[0]);
     const int slot = __builtin_amdgcn_readfirstlane((int)sInfo[1]);
-    if (slot >= XWG) return;          // a 33rd workgroup on one XCD takes no part (256 workgroups: 32 per XCD in every launch measured)
+    if (slot >= XWG || slot < p.test_absent) {      // a 33rd workgroup on one XCD takes no part (256 workgroups: 32 per XCD in every launch measured) -- some other XCD then
+        if (tid0 == 0) __hip_atomic_store(p.ctl + (TOIST_XDEC_CTL_WORDS - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // has 31 and its spins expire: say so at once
+        return;                                       // (test_absent: the failure-path test makes `test_absent` workgroups per XCD leave like this)
+    }
     XSync sy{p.ctl + 256 + xcd * 32, p.ctl + (TOIST_XDEC_CTL_WORDS - 1), sInfo + 2, 0u};
 
     const int Q = p.Q, S = p.S, M = p.B * p.Q;
@@ -749,6 +764,11 @@ __global__ __launch_bounds__(XNT) void xdec_fwd_kernel(const toist_xdec_desc p) 
         }
     }
     if (touched == 0x9E3779B9u) __hip_atomic_store(p.ctl + 1000, touched, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // keeps the L2 touches alive
+    // A bounded spin expired in this workgroup (its group was not co-resident): once one member stops arriving every other member's next
+    // wait expires too, and nothing the group wrote can be trusted.  Make that unmissable without a host read: every layer output of the
+    // group's images becomes NaN, hence NaN logits / boxes / losses (the reference's finite-loss guard, engine.py:82-85, trips in the same step).
+    __syncthreads();
+    if (*sy.s_dead != 0u) poison_rows(reinterpret_cast<bf16_t*>(p.y4), (size_t)XD, XD, p.L, (size_t)M * XD, xcd, p.B, Q);
 }
 
 
@@ -887,7 +907,10 @@ __global__ __launch_bounds__(XNT) void xdec_bwd_kernel(const toist_xdec_bwd_desc
     __syncthreads();
     const int xcd = __builtin_amdgcn_readfirstlane((int)sInfo[0]);
     const int slot = __builtin_amdgcn_readfirstlane((int)sInfo[1]);
-    if (slot >= XWG) return;
+    if (slot >= XWG || slot < p.test_absent) {
+        if (tid0 == 0) __hip_atomic_store(p.ctl + (TOIST_XDEC_CTL_WORDS - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     XSync sy{p.ctl + 256 + xcd * 32, p.ctl + (TOIST_XDEC_CTL_WORDS - 1), sInfo + 2, 0u};
 
     const int Q = p.Q, S = p.S, M = p.B * p.Q;
@@ -1205,6 +1228,10 @@ __global__ __launch_bounds__(XNT) void xdec_bwd_kernel(const toist_xdec_bwd_desc
         }
         if (b + 8 < p.B) xcd_barrier(sy);
     }
+    // as in the forward launch: an expired spin turns the gradients every consumer reads (dq | dk | dv of the self-attention and dq of the cross-attention
+    // of every layer: the query_pos gradient and the in_proj weight gradients) into NaN, so the gradient norm and the next loss are NaN
+    __syncthreads();
+    if (*sy.s_dead != 0u) poison_rows(reinterpret_cast<bf16_t*>(p.sink), (size_t)p.ldsink, p.L * 4 * XD, 1, 0, xcd, p.B, Q);
 }
 
 }  // namespace toist
@@ -1228,6 +1255,8 @@ extern "C" int toist_xdec_fwd(const toist_xdec_desc* d, void* stream) {
     TOIST_REQUIRE(d != nullptr, "toist_xdec_fwd: null descriptor");
     TOIST_REQUIRE(toist_xdec_supported(d->B, d->Q, d->S, d->L), "toist_xdec_fwd: unsupported shape B=%d Q=%d S=%d L=%d (Q <= 128, S <= 512, L <= 8, 256 CUs)", d->B, d->Q,
                   d->S, d->L);
+    TOIST_REQUIRE(d->ff == XFF, "toist_xdec_fwd: dim_feedforward %d: the launch is compiled for linear1 [%d, 256] / linear2 [256, %d] (use the per-op path)", d->ff, XFF, XFF);
+    TOIST_REQUIRE(d->test_absent >= 0 && d->test_absent <= XWG, "toist_xdec_fwd: bad test_absent");
     TOIST_REQUIRE(d->x0 && d->qpos && d->kv && d->qkv && d->ctx_s && d->lse_s && d->z1 && d->y1 && d->y1e && d->mean1 && d->rstd1 && d->qc && d->ctx_c && d->lse_c &&
                       d->z3 && d->y3 && d->mean3 && d->rstd3 && d->h && d->z4 && d->y4 && d->y4e && d->mean4 && d->rstd4 && d->part && d->ctl,
                   "toist_xdec_fwd: every buffer of the descriptor is required");
@@ -1262,6 +1291,8 @@ extern "C" int toist_xdec_fwd(const toist_xdec_desc* d, void* stream) {
 extern "C" int toist_xdec_bwd(const toist_xdec_bwd_desc* d, void* stream) {
     TOIST_REQUIRE(d != nullptr, "toist_xdec_bwd: null descriptor");
     TOIST_REQUIRE(toist_xdec_supported(d->B, d->Q, d->S, d->L), "toist_xdec_bwd: unsupported shape B=%d Q=%d S=%d L=%d", d->B, d->Q, d->S, d->L);
+    TOIST_REQUIRE(d->ff == XFF, "toist_xdec_bwd: dim_feedforward %d: the launch is compiled for %d hidden units (use the per-op path)", d->ff, XFF);
+    TOIST_REQUIRE(d->test_absent >= 0 && d->test_absent <= XWG, "toist_xdec_bwd: bad test_absent");
     TOIST_REQUIRE(d->kv && d->qkv && d->ctx_s && d->lse_s && d->z1 && d->mean1 && d->rstd1 && d->qc && d->ctx_c && d->lse_c && d->z3 && d->mean3 && d->rstd3 && d->h && d->z4 &&
                       d->mean4 && d->rstd4 && d->g_out && d->gb4 && d->dh && d->go3 && d->go1 && d->sink && d->dkv && d->ln_part && d->dctx && d->part && d->dq_part && d->ctl,
                   "toist_xdec_bwd: every buffer of the descriptor is required");

@@ -22,12 +22,13 @@ BF16 = torch.bfloat16
 class Var:
     """An activation (bf16, [rows, features] or NHWC) and its gradient slot."""
 
-    __slots__ = ("data", "grad", "needs_grad", "drop", "gdrop", "plus")
+    __slots__ = ("data", "grad", "needs_grad", "drop", "gdrop", "plus", "raw_grad")
 
     def __init__(self, data, needs_grad=True):
         self.data = data
         self.grad = None
         self.needs_grad = needs_grad
+        self.raw_grad = False   # True: the program's backward wants the output gradient exactly as autograd delivered it (no dtype cast, no .contiguous())
         self.plus = None    # data + a constant embedding (pos / query_pos), when the producing layernorm emitted it in the same pass
         self.drop = None    # (p, seed) when data = residual + dropout(branch): the branch gradient is dropout(grad) with that mask
         self.gdrop = None   # that masked gradient, when the consumer's backward produced it in the same pass (layernorm)

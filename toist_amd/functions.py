@@ -84,6 +84,9 @@ class _TapeFn(torch.autograd.Function):
             kernels.stamp("bwd." + ctx.label + ".start")
         for v, g in zip(ctx.out_vars, grads):
             if g is not None and v.needs_grad:
+                if v.raw_grad:           # the program inspects it first (segmentation: an untouched zero sentinel = "only the mask losses read pred_masks")
+                    v.grad = g
+                    continue
                 if g.dtype != v.data.dtype:
                     g = g.to(v.data.dtype)
                 v.grad = g.contiguous()

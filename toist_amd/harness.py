@@ -192,6 +192,8 @@ def evaluate(model, criterion, cluster_criterion, postprocessors, weight_dict, b
         res = {int(t["image_id"]): r for t, r in zip(targets, results)}
         for evaluator in evaluator_list:
             evaluator.update(res)
+        from . import kernels
+        kernels.xdec_check()      # (the results above reached the host: no extra synchronisation) an XCD-resident launch whose groups were not co-resident
     stats = {name: v / max(n, 1) for name, v in sums.items()}
     for evaluator in evaluator_list:
         evaluator.synchronize_between_processes()
@@ -253,6 +255,7 @@ class CapturedTrainStep:
         engine.REUSE_GRAD_BUFFERS = True       # the loop owns the gradients: one flat buffer per program, shared by every bucket's graph and the eager steps
         self.captures = 0
         self.replays = 0
+        self._xdec_off = kernels.XDEC_FAILED
 
     # -- helpers ------------------------------------------------------------------------------------------------------------------
     def bucket_of(self, samples, tokenized):
@@ -324,6 +327,15 @@ class CapturedTrainStep:
             self._buckets[key] = ent
             while len(self._buckets) > self.max_graphs:
                 self._buckets.popitem(last=False)          # least recently used bucket: its graph and activation pool are released
+        from . import kernels as _k
+        if _k.XDEC_FAILED and not self._xdec_off:
+            # an XCD-resident decoder launch reported an expired spin (kernels.xdec_check, reached through harness.finite_or_exit on the NaN loss of
+            # that step): the captured graphs contain those launches -- drop them; the next step of every bucket runs eagerly on the per-op launches
+            # and is captured again
+            self._xdec_off = True
+            for e in self._buckets.values():
+                e["graph"] = e["loss"] = None
+            ent["graph"] = None
         self._buckets.move_to_end(key)
         self._fill(ent, samples, tokenized, targets, positive_map, packed)
         if ent["graph"] is not None:

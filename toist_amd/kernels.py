@@ -5,6 +5,7 @@ through ctypes on torch's current stream, and returns immediately (no host sync)
 memory and streams only.  There is no fallback: a CPU tensor or a missing library raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -583,9 +584,10 @@ def sum_queries(inp, B, Q, per, out):
     _lib.check(_lib.lib().toist_sum_queries(_p(inp, BF16), B, Q, per, _p(out, BF16), _stream()), "toist_sum_queries")
 
 
-def mask_loss_fwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, alpha, sums):
+def mask_loss_fwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, alpha, sums, valid_hw=None):
+    """valid_hw: optional device int32 [2], the batch's own padded mask size inside the [TH, TW] bucket (include/toist_hip.h)."""
     _lib.check(_lib.lib().toist_mask_loss_fwd(_p(pred, F32), _p(pred_row, torch.int32), _p(gt, torch.uint8), _p(gt_row, torch.int32), T, h, w, TH,
-                                              TW, alpha, _p(sums, F32), _stream()), "toist_mask_loss_fwd")
+                                              TW, alpha, _p(sums, F32), _p(valid_hw, torch.int32), _stream()), "toist_mask_loss_fwd")
 
 
 def sum_segments(inp, seg, B, rows, per, out):
@@ -593,13 +595,13 @@ def sum_segments(inp, seg, B, rows, per, out):
     _lib.check(_lib.lib().toist_sum_segments(_p(inp, BF16), _p(seg, torch.int32), B, rows, per, _p(out, BF16), _stream()), "toist_sum_segments")
 
 
-def mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, alpha, sums, coef, dpred, compact=False):
+def mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, alpha, sums, coef, dpred, compact=False, valid_hw=None):
     if compact:     # dpred is [T,h,w]: pair t's gradient in row t
         _lib.check(_lib.lib().toist_mask_loss_bwd_compact(_p(pred, F32), _p(pred_row, torch.int32), _p(gt, torch.uint8), _p(gt_row, torch.int32), T, h, w,
-                                                          TH, TW, alpha, _p(sums, F32), _p(coef, F32), _p(dpred, F32), _stream()), "toist_mask_loss_bwd_compact")
+                                                          TH, TW, alpha, _p(sums, F32), _p(coef, F32), _p(dpred, F32), _p(valid_hw, torch.int32), _stream()), "toist_mask_loss_bwd_compact")
         return
     _lib.check(_lib.lib().toist_mask_loss_bwd(_p(pred, F32), _p(pred_row, torch.int32), _p(gt, torch.uint8), _p(gt_row, torch.int32), T, h, w, TH,
-                                              TW, alpha, _p(sums, F32), _p(coef, F32), _p(dpred, F32), _stream()), "toist_mask_loss_bwd")
+                                              TW, alpha, _p(sums, F32), _p(coef, F32), _p(dpred, F32), _p(valid_hw, torch.int32), _stream()), "toist_mask_loss_bwd")
 
 
 # ---- optimizer tail (include/toist_hip.h: toist_opt_*) ---------------------------------------------------------
@@ -725,27 +727,46 @@ ROW_PLAIN, ROW_LN_FWD, ROW_LN_BWD = _lib.ROW_PLAIN, _lib.ROW_LN_FWD, _lib.ROW_LN
 
 # ---- XCD-resident decoder stack (csrc/xdec.hip) ------------------------------------------------------------------------------------------
 XDEC_PROF = None
-_XDEC_CTL = {}      # device -> int32[1024] control words (tickets, arrival counters, sticky status)
+XDEC_TEST_ABSENT = 0    # failure-path tests only (tests/test_gpu_xdec.py): that many workgroups per XCD leave the launch at once
+XDEC_LAUNCHES = 0       # forward launches issued (or captured) so far: Transformer.decode_tokens learns from it whether its program used one
+XDEC_FAILED = False     # process-wide: a launch reported an expired spin (xdec_check) -> the decoder runs on the per-op launches from then on
+_XDEC_CTL = {}          # device -> int32[1024] control words (tickets, arrival counters, sticky status)
 
 
-def _xdec_ctl(device):
+def _xdec_ctl(device, create=True):
     """One set of control words per device: the launches need the whole chip, so two of them never run at the same time on one device (the forward and
-    the backward launch of a step are ordered by the stream).  Allocated on first use -- normally an eager warm-up step; a first use inside a capture
-    takes the words from the graph's pool (the fill is then replayed: the sticky status word is cleared by every replay)."""
+    the backward launch of a step are ordered by the stream).  Allocated EAGERLY: words taken from a capturing graph's pool would be re-zeroed by every
+    replay, sticky status word included -- xdec_supported() therefore refuses the launches while a capture is running and no words exist yet
+    (a capture is always preceded by an eager warm-up step in toist_amd.harness / bench.py, which allocates them)."""
     ctl = _XDEC_CTL.get(device)
-    if ctl is None:
+    if ctl is None and create:
+        if torch.cuda.is_current_stream_capturing():
+            return None
         ctl = _XDEC_CTL[device] = torch.zeros(_lib.XDEC_CTL_WORDS, dtype=torch.int32, device=device)
     return ctl
 
 
-def xdec_supported(B, Q, S, L):
+def _ranks_share_a_device():
+    """True when the ranks of this job on this node cannot have one GPU each (the XCD-resident launches need all 256 CUs to themselves).  LOCAL_WORLD_SIZE is
+    what torchrun / the driver's launch line export; without it (a hand-made rendezvous) the world size is the best bound there is."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    local = os.environ.get("LOCAL_WORLD_SIZE")
+    local = int(local) if local and local.isdigit() else dist.get_world_size()
+    return local > torch.cuda.device_count()
+
+
+def xdec_supported(B, Q, S, L, ff=2048):
     """The XCD-resident decoder launches need all 256 CUs of the device to themselves (one 147 KB workgroup per CU, 32 co-resident per image): not
     when several ranks of one job share a GPU (the one-GPU multi-rank tests; two such launches from two processes would starve each other until their
-    bounded spins expire)."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > torch.cuda.device_count():
+    bounded spins expire), not after a launch has reported an expired spin (XDEC_FAILED), not for a dim_feedforward other than the compiled-in 2048
+    (ADVICE r5), and never with TOIST_XDEC=0 (the opt-out for a GPU shared with another process or a CU-masked queue: INTEGRATION.md)."""
+    if XDEC_FAILED or ff != 2048 or _ranks_share_a_device():
         return False
-    return bool(_lib.lib().toist_xdec_supported(B, Q, S, L))
+    if not _lib.lib().toist_xdec_supported(B, Q, S, L):
+        return False
+    return _xdec_ctl(torch.device("cuda", torch.cuda.current_device())) is not None
 
 
 def xdec_fwd(B, Q, S, x0, qpos, kv, key_pad, drop_p, eps, out, layers, part):
@@ -753,6 +774,8 @@ def xdec_fwd(B, Q, S, x0, qpos, kv, key_pad, drop_p, eps, out, layers, part):
     descriptor's fields; `layers` = one dict per layer with the 18 parameter tensors + "seed" (6 ints)."""
     d = _lib.Xdec()
     d.B, d.Q, d.S, d.L = B, Q, S, len(layers)
+    d.ff, d.test_absent = int(layers[0]["w1"].shape[0]), XDEC_TEST_ABSENT
+    assert all(tuple(ly["w1"].shape) == (d.ff, 256) and tuple(ly["w2"].shape) == (256, d.ff) for ly in layers)
     d.x0, d.qpos, d.kv, d.ldkv = _p(x0, torch.bfloat16), _p(qpos, torch.bfloat16), _p(kv, torch.bfloat16), kv.stride(0)
     d.key_pad = _p(key_pad, torch.uint8) if key_pad is not None else None
     d.drop_p, d.eps = drop_p, eps
@@ -767,7 +790,7 @@ def xdec_fwd(B, Q, S, x0, qpos, kv, key_pad, drop_p, eps, out, layers, part):
         setattr(d, name, _p(t, torch.float32))
     assert part.is_contiguous() and part.numel() >= B * 32 * 128 * 256
     d.part = _p(part, torch.bfloat16)
-    d.ctl = _xdec_ctl(x0.device).data_ptr()
+    d.ctl = _xdec_ctl(x0.device).data_ptr()       # (never None here: xdec_supported() said yes)
     d.prof = XDEC_PROF.data_ptr() if XDEC_PROF is not None else None      # diagnostics (tools/r5/xdec_bench.py): int64 [256, L, 8]
     for i, ly in enumerate(layers):
         e = d.layer[i]
@@ -781,6 +804,8 @@ def xdec_fwd(B, Q, S, x0, qpos, kv, key_pad, drop_p, eps, out, layers, part):
             setattr(e, name, _p(t, torch.float32))
         for j in range(6):
             e.seed[j] = ly["seed"][j]
+    global XDEC_LAUNCHES
+    XDEC_LAUNCHES += 1
     _lib.check(_lib.lib().toist_xdec_fwd(ctypes.byref(d), _stream()), "toist_xdec_fwd")
 
 
@@ -789,6 +814,7 @@ def xdec_bwd(B, Q, S, kv, key_pad, drop_p, saved, g_out, outs, layers, scratch):
     g_out bf16 [L, B*Q, 256], outs = dict(gb4, dh, go3, go1, sink, dkv, ln_part), scratch = dict(dctx, part, dq_part)."""
     d = _lib.XdecBwd()
     d.B, d.Q, d.S, d.L = B, Q, S, len(layers)
+    d.ff, d.test_absent = int(layers[0]["w1"].shape[0]), XDEC_TEST_ABSENT
     d.kv, d.ldkv = _p(kv, torch.bfloat16), kv.stride(0)
     d.key_pad = _p(key_pad, torch.uint8) if key_pad is not None else None
     d.drop_p = drop_p
@@ -835,11 +861,27 @@ def queue_fold(partials, out, splits, keep=()):
     _PENDING.setdefault(key, []).append((rd, (out, partials) + tuple(keep)))
 
 
-def xdec_check():
-    """Raises when a bounded spin of an XCD-resident launch expired (synchronises: call it from tests / at the end of a run)."""
-    for key, ctl in _XDEC_CTL.items():
+def xdec_check(raise_on_failure=True):
+    """The sticky status words of the XCD-resident launches (synchronises: one 4-byte read per device).  A set word means a bounded spin expired -- the 32
+    workgroups of an image were not co-resident (a second process on the GPU, a CU-masked queue, an unexpected dispatch order) -- and that launch's
+    results are invalid (the launch also turned them into NaN, so the losses of that step are NaN).  The word is cleared, XDEC_FAILED is set so that
+    every later decoder forward / backward runs on the per-op launches (graphs captured with the launches inside must be re-captured:
+    harness.CapturedTrainStep does), and RuntimeError is raised unless raise_on_failure is False (then the return value says whether a launch failed).
+    Called by harness.finite_or_exit, CapturedTrainStep when a replayed loss is not finite, harness.evaluate, Transformer's eval-mode decode, bench.py,
+    smoke()."""
+    global XDEC_FAILED
+    failed = False
+    for dev, ctl in _XDEC_CTL.items():
         if int(ctl[_lib.XDEC_CTL_WORDS - 1].item()) != 0:
-            raise RuntimeError("toist_xdec: a workgroup gave up waiting for its XCD group (the 32 workgroups of an image were not co-resident); results are invalid")
+            failed = True
+            ctl[_lib.XDEC_CTL_WORDS - 1] = 0
+    if failed:
+        XDEC_FAILED = True
+        if raise_on_failure:
+            raise RuntimeError("toist_xdec: a workgroup gave up waiting for its XCD group (the 32 workgroups of an image were not co-resident); the results of "
+                               "that step are invalid (NaN).  The XCD-resident decoder launches are now off for this process: repeat the step (per-op launches), "
+                               "or start with TOIST_XDEC=0 when the GPU is shared")
+    return failed
 
 
 def kmeans(banks, centers, group_task, group_off, members, features, tol, max_iter, pick, chosen_center, iters=None):

@@ -46,7 +46,9 @@ class StaticTargets:
     batch * max_per_image targets; the number of targets per image may change from step to step.
 
     Layout of the arena (bytes): boxes f32 [cap,4] | positive_map f32 [cap,K] | token masks i64 [cap,2] | tgt_off i32 [B+1] |
-    match_off i32 [B+1] | num_boxes f32 [1] (local sum of targets; the world mean, clamped to >= 1, is formed on the device)."""
+    match_off i32 [B+1] | num_boxes f32 [1] (local sum of targets; the world mean, clamped to >= 1, is formed on the device) |
+    valid_hw i32 [2] (with mask_hw: the largest ground-truth mask of the batch = the size the reference pads the batch's masks to and resizes the
+    predictions to, mdetr.py:839-843; the mask losses count the target pixels inside it and normalise by it -- ADVICE r5)."""
 
     def __init__(self, batch, max_per_image, num_queries, K=256, device="cuda", mask_hw=None):
         self.B, self.max_per_image, self.Q, self.K = batch, max_per_image, num_queries, K
@@ -59,7 +61,7 @@ class StaticTargets:
             self._mask_host = torch.zeros(batch * max_per_image, *self.mask_hw, dtype=torch.uint8).pin_memory()
         self.cap = cap = batch * max_per_image
         self.device = torch.device(device)
-        sizes = [cap * 4 * 4, cap * K * 4, cap * TOKEN_MASK_WORDS * 8, (batch + 1) * 4, (batch + 1) * 4, 4]
+        sizes = [cap * 4 * 4, cap * K * 4, cap * TOKEN_MASK_WORDS * 8, (batch + 1) * 4, (batch + 1) * 4, 4, 8]
         offs, total = [], 0
         for n in sizes:
             offs.append(total)
@@ -70,10 +72,12 @@ class StaticTargets:
         def views(buf):
             cut = lambda i, dt, shape: buf[offs[i]:offs[i] + sizes[i]].view(dt).view(shape)
             return (cut(0, torch.float32, (cap, 4)), cut(1, torch.float32, (cap, K)), cut(2, torch.int64, (cap, TOKEN_MASK_WORDS)), cut(3, torch.int32, (batch + 1,)),
-                    cut(4, torch.int32, (batch + 1,)), cut(5, torch.float32, (1,)))
+                    cut(4, torch.int32, (batch + 1,)), cut(5, torch.float32, (1,)), cut(6, torch.int32, (2,)))
 
         self._views = views
-        self.boxes, self.positive_map, self.tok_mask, self.tgt_off, self.match_off, self._nb_local = views(self._dev)
+        self.boxes, self.positive_map, self.tok_mask, self.tgt_off, self.match_off, self._nb_local, self.valid_hw = views(self._dev)
+        if self.mask_hw is None:
+            self.valid_hw = None
         self.num_boxes = torch.ones(1, dtype=torch.float32, device=self.device)
         self.sizes = [0] * batch
         self._out = {}        # L -> (src [L, cap], tgt [L, cap], status [L*B])
@@ -87,7 +91,7 @@ class StaticTargets:
         if len(sizes) != self.B or max(sizes, default=0) > self.max_per_image:
             raise ValueError(f"StaticTargets holds {self.B} images x <= {self.max_per_image} targets; got sizes {sizes}")
         host = out if out is not None else torch.zeros(self._host.numel(), dtype=torch.uint8).pin_memory()
-        hb, hp, hm, hto, hmo, hnb = self._views(host)
+        hb, hp, hm, hto, hmo, hnb, hvalid = self._views(host)
         tot = sum(sizes)
         if tot:
             hb[:tot] = torch.cat([t["boxes"].float().cpu() for t in targets])
@@ -105,15 +109,17 @@ class StaticTargets:
             return host, sizes
         TH, TW = self.mask_hw
         mh = self._mask_host if out is not None else torch.zeros(self.cap, TH, TW, dtype=torch.uint8).pin_memory()
-        row = 0
+        row, vh, vw = 0, 0, 0
         for t in targets:
             m = t["masks"].to(torch.uint8).cpu()
             n, h, w = m.shape
             if h > TH or w > TW:
                 raise ValueError(f"StaticTargets(mask_hw={self.mask_hw}) got a {h} x {w} mask")
+            vh, vw = max(vh, h), max(vw, w)         # (an image without targets still carries its [0, h, w] mask tensor)
             mh[row:row + n].zero_()
             mh[row:row + n, :h, :w] = m
             row += n
+        hvalid[0], hvalid[1] = (vh or TH), (vw or TW)
         return host, sizes, mh
 
     def load_packed(self, packed):

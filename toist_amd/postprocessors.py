@@ -23,8 +23,13 @@ class PostProcess(nn.Module):
         boxes = box_ops.box_cxcywh_to_xyxy(out_bbox.float())
         img_h, img_w = target_sizes.unbind(1)
         boxes = boxes * torch.stack([img_w, img_h, img_w, img_h], dim=1)[:, None, :]
-        # (the reference also forwards an MDETR "pred_isfinal" head; no TOIST model produces that key)
-        return [{"scores": s, "labels": l, "boxes": b} for s, l, b in zip(scores, labels, boxes)]
+        results = [{"scores": s, "labels": l, "boxes": b} for s, l, b in zip(scores, labels, boxes)]
+        final = outputs.get("pred_isfinal")                # MDETR's referring-expression head (postprocessors.py:49-54); no TOIST recipe emits it
+        if final is not None:
+            refexp = scores * final.float().sigmoid().view_as(scores)
+            for r, s in zip(results, refexp):
+                r["scores_refexp"] = s
+        return results
 
 
 class PostProcessSegm(nn.Module):

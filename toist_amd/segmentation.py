@@ -74,14 +74,29 @@ FUSED_TAIL = True
 
 
 class _MatchedRows:
-    __slots__ = ("grad", "rows", "seg", "dense_ptr")
+    """Hand-off between `_MaskLossFn.backward` and the mask program's backward: pair t's gradient in row t of `grad`, the prediction rows in
+    `rows`, and the zero SENTINEL autograd carried in place of the dense gradient (held here, so autograd can never accumulate into it in
+    place; it is a stride-0 expansion of one element, so no dense sum can alias it either)."""
+    __slots__ = ("grad", "rows", "seg", "sentinel", "version")
 
     def __init__(self):
         self.clear()
 
     def clear(self):
-        self.grad = self.rows = self.seg = None
-        self.dense_ptr = 0
+        self.grad = self.rows = self.seg = self.sentinel = None
+        self.version = -1
+
+
+_ZERO = {}
+
+
+def _zero_sentinel(dev):
+    """One f32 zero per device.  `z.expand(shape)` is the gradient autograd carries when only the matched rows are non-zero: no kernel ever
+    reads or writes it (the 82 MB `zeros_like(pred)` of round 5 is gone), and anything autograd adds to it lands in a NEW dense tensor."""
+    z = _ZERO.get(str(dev))
+    if z is None:
+        z = _ZERO[str(dev)] = torch.zeros(1, dtype=torch.float32, device=dev)
+    return z
 
 
 def _krsc_bf16(w):
@@ -284,21 +299,26 @@ class DETRsegm(nn.Module):
                                      (B * Q, 2 * H_, 2 * W_, Cx), pick=pick)[0]
 
             def matched_rows_of(g):
-                """g = gradient of the mask logits [BQ,8h,8w] as autograd delivered it -> the rows the backward has to run on (sets `sel`)."""
-                g = g.view(BQ, 8 * h, 8 * w)
+                """g = gradient of the mask logits [B,Q,8h,8w] exactly as autograd delivered it (Var.raw_grad) -> the rows the backward has to run on
+                (sets `sel`).  "Nothing but the mask losses consumed pred_masks" is decided by IDENTITY of the zero sentinel `_MaskLossFn.backward`
+                returned: same address, every stride zero, version counter untouched.  The sink holds a reference to the sentinel, so autograd's
+                input buffer cannot add another consumer's gradient into it in place (it only does that to a tensor it owns alone), whichever
+                consumer was created first: any sum is a new dense tensor and takes the dense path."""
                 sel["rows"] = sel["scatter"] = sel["seg"] = None
+                zero = sink.sentinel
                 if sink.grad is not None:
                     rows = sink.rows
-                    if g.data_ptr() == sink.dense_ptr:
-                        # nothing but the mask losses looked at pred_masks: the gradient is sink.grad in rows `rows`, zero elsewhere
+                    if (zero is not None and g.data_ptr() == zero.data_ptr() and not any(g.stride()) and zero._version == sink.version):
+                        # the gradient is sink.grad in rows `rows`, zero elsewhere
                         sel["rows"] = rows.clamp(min=0).to(torch.int64)
                         sel["scatter"] = torch.where(rows < 0, torch.full_like(rows, BQ), rows).to(torch.int64)
                         sel["seg"] = sink.seg
                         g = sink.grad
                     else:                        # another consumer added its gradient: dense backward of the sum (unused slots hold zeros)
-                        g.index_add_(0, rows.clamp(min=0).to(torch.int64), sink.grad)
+                        g = g.to(torch.float32).contiguous().view(BQ, 8 * h, 8 * w).index_add(0, rows.clamp(min=0).to(torch.int64), sink.grad)
                     sink.clear()
-                return g
+                    return g
+                return g.to(torch.float32).contiguous().view(BQ, 8 * h, 8 * w)
 
             def out_lay_grads(g, a5_rows, Wo, bo, wo8):
                 """Backward of out_lay (one output channel, padded to 8 for the GEMM operands) for the logit gradient g [n,8h,8w] f32."""
@@ -337,6 +357,7 @@ class DETRsegm(nn.Module):
                 masks = torch.empty(B, Q, H5, W5_, dtype=torch.float32, device=dev)
                 k.mask_stage_fwd(pre5, st5, g5w.f32, g5b.f32, None, Wo.w, bo.f32, masks, None, BQ, Q, H5, W5_, C5, 1, 1, True, False)
                 mv = engine.Var(masks)
+                mv.raw_grad = True
 
                 def norm_rows(pre, st, gw, gb, HW_, C):
                     """relu(GroupNorm(pre)) of the rows the backward runs on, from the forward's statistics."""
@@ -406,6 +427,7 @@ class DETRsegm(nn.Module):
             o8 = ops.conv2d(a5.data, wo8, pad=1, shift=bo8)                         # [BQ,8h,8w,8] bf16
             masks = o8[..., 0].float().view(B, Q, 8 * h, 8 * w).contiguous()
             mv = engine.Var(masks)
+            mv.raw_grad = True
 
             def out_bwd():
                 g = mv.take_grad()
@@ -459,34 +481,39 @@ class _MaskLossFn(torch.autograd.Function):
     """(loss_mask, loss_dice) of SetCriterion.loss_masks for the matched (prediction, target) pairs."""
 
     @staticmethod
-    def forward(ctx, pred, pred_row, gt, gt_row, num_boxes, TH, TW, sink=None, seg=None):
+    def forward(ctx, pred, pred_row, gt, gt_row, num_boxes, TH, TW, sink=None, seg=None, valid=None):
+        """valid: optional device int32 [2] -- the batch's own padded mask size inside a [TH, TW] bucket (matcher.StaticTargets.valid_hw): the
+        target pixels beyond it take no part and loss_mask is the mean over valid[0] * valid[1] pixels, as mdetr.py:843-851 on that batch."""
         T = pred_row.numel()
         ctx.sink, ctx.seg = sink, seg
         h, w = pred.shape[-2:]
         sums = torch.zeros(T, 4, dtype=torch.float32, device=pred.device)
-        k.mask_loss_fwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, 0.25, sums)
-        focal = (sums[:, 0] / float(TH * TW)).sum() / num_boxes
+        k.mask_loss_fwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, 0.25, sums, valid_hw=valid)
+        area = torch.full((), float(TH * TW), device=pred.device) if valid is None else (valid[0] * valid[1]).float()
+        focal = (sums[:, 0] / area).sum() / num_boxes
         dice = (1 - (2 * sums[:, 1] + 1) / (sums[:, 2] + sums[:, 3] + 1)).sum() / num_boxes
-        ctx.save_for_backward(pred, pred_row, gt, gt_row, sums, num_boxes)
+        ctx.save_for_backward(pred, pred_row, gt, gt_row, sums, num_boxes, area, valid)
         ctx.dims = (T, h, w, TH, TW)
         return torch.stack([focal, dice])
 
     @staticmethod
     def backward(ctx, g):
-        pred, pred_row, gt, gt_row, sums, num_boxes = ctx.saved_tensors
+        pred, pred_row, gt, gt_row, sums, num_boxes, area, valid = ctx.saved_tensors
         T, h, w, TH, TW = ctx.dims
-        coef = torch.stack([g[0] / (float(TH * TW) * num_boxes), g[1] / num_boxes]).float().contiguous()
-        dpred = torch.zeros_like(pred)
+        coef = torch.stack([g[0] / (area * num_boxes), g[1] / num_boxes]).float().contiguous()
         sink = ctx.sink
+        none = (None,) * 9
         if sink is not None and sink.grad is None:
             # matched maps only: pair t's gradient goes to row t of a [T,h,w] buffer that the mask head's backward picks up together with the
-            # row indices; autograd carries the all-zero dense tensor, whose address tells the mask program that nobody added to it
+            # row indices; autograd carries a zero SENTINEL (one element, expanded) that the sink keeps alive -- see matched_rows_of
             rows_grad = torch.zeros(T, h, w, dtype=torch.float32, device=pred.device)
-            k.mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, 0.25, sums, coef, rows_grad, compact=True)
-            sink.grad, sink.rows, sink.seg, sink.dense_ptr = rows_grad, pred_row, ctx.seg, dpred.data_ptr()
-        else:
-            k.mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, 0.25, sums, coef, dpred)
-        return dpred, None, None, None, None, None, None, None, None
+            k.mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, 0.25, sums, coef, rows_grad, compact=True, valid_hw=valid)
+            zero = _zero_sentinel(pred.device)
+            sink.grad, sink.rows, sink.seg, sink.sentinel, sink.version = rows_grad, pred_row, ctx.seg, zero, zero._version
+            return (zero.expand(pred.shape),) + none
+        dpred = torch.zeros_like(pred)
+        k.mask_loss_bwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, 0.25, sums, coef, dpred, valid_hw=valid)
+        return (dpred,) + none
 
 
 _OFFSETS = {}
@@ -536,7 +563,7 @@ def mask_losses_static(outputs, st, match, layer, L):
     sink = getattr(outputs["pred_masks"], "toist_matched_rows", None)
     seg = mo[:B + 1].to(torch.int32).contiguous() if sink is not None else None      # slots [match_off[i], match_off[i+1]) belong to image i
     vals = _MaskLossFn.apply(pred.view(B * Q, pred.shape[-2], pred.shape[-1]), pred_row.contiguous(), st.masks, gt_row.contiguous(), st.num_boxes.reshape(()).float(), TH, TW,
-                             sink, seg)
+                             sink, seg, st.valid_hw)
     return {"loss_mask": vals[0], "loss_dice": vals[1]}
 
 

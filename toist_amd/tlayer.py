@@ -15,6 +15,7 @@ gradient of a LayerNorm input appears directly; every stand-alone LayerNorm laun
 output gradient arrives from outside the program (last encoder layer, last decoder layer) and the shared final decoder norm.
 Weight gradients go to the tape's grouped launches exactly as in toist_amd.engine."""
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -30,7 +31,9 @@ ENABLED = knob("TOIST_ROWS", True)          # tests flip this to compare with th
 FUSE_FWD_MAX_K = knob("TOIST_ROWS_FWD_MAX_K", 768)      # forward sub-layers with a longer reduction run as GEMM + LayerNorm launch ...
 FUSE_FWD_MAX_M = knob("TOIST_ROWS_FWD_MAX_M", 0)        # ... (a row-count exception for the decoder's 800 queries was measured and dropped, see _ln_fwd)
 XDEC_BWD = knob("TOIST_XDEC_BWD", True)     # ... and the data-gradient chain of the decoder backward as one launch (toist_xdec_bwd)
-XDEC = knob("TOIST_XDEC", True)             # decoder forward as ONE XCD-resident launch (csrc/xdec.hip) when the shape and the device allow it
+# decoder forward as ONE XCD-resident launch (csrc/xdec.hip) when the shape and the device allow it.  TOIST_XDEC=0 is a PRODUCT switch (read without
+# TOIST_KNOBS): the opt-out for a GPU this process does not own alone -- a second process, a CU-masked queue
+XDEC = os.environ.get("TOIST_XDEC", "1") != "0"
 
 
 def supported(d, H, Sk):
@@ -310,7 +313,8 @@ def decoder_program(tape, ps, mem, qe, pos, key_pad, B, S, Q, H, n_layers):
     cur = torch.zeros(M, d, dtype=BF16, device=dev)
     cur_e = qpos
     layers = []
-    fused = XDEC and k.xdec_supported(B, Q, S, L_)
+    ff = ps["layers.0.linear1.weight"].w.shape[0]
+    fused = XDEC and all(ps[f"layers.{i}.linear1.weight"].w.shape[0] == ff for i in range(L_)) and k.xdec_supported(B, Q, S, L_, ff=ff)
     fw = None
     if fused:
         layers, fw = _decoder_layers_xcd(tape, ps, Wself, Wcross, cur, qpos, kv, key_pad, tgt_stack, B, S, Q, H, L_)
