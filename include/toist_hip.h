@@ -339,9 +339,10 @@ TOIST_API int toist_mask_loss_bwd(const float* pred, const int32_t* pred_row, co
                         int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred, const int32_t* valid_hw, void* stream);
 TOIST_API int toist_mask_loss_bwd_compact(const float* pred, const int32_t* pred_row, const uint8_t* gt, const int32_t* gt_row, int T, int h, int w,
                         int TH, int TW, float alpha, const float* sums, const float* coef, float* dpred_rows, const int32_t* valid_hw, void* stream);
-/* valid_hw (all three; NULL = the whole [TH, TW]): device int32 [2] = the batch's own padded mask size inside a larger bucket (a captured graph's
- * static shape): target pixels at y >= valid_hw[0] or x >= valid_hw[1] take no part (the reference resizes to the batch's largest image,
- * mdetr.py:843, and the caller divides loss_mask by valid_hw[0] * valid_hw[1]); the pixel grid stays the bucket's (scale h / TH). */
+/* valid_hw (all three; NULL = everything): device int32 [4] = {VH, VW, hs, ws} for a batch that sits in the corner of a larger bucket (a captured graph's
+ * static shape).  The reference resizes its [hs, ws] prediction to the batch's largest image [VH, VW] (mdetr.py:843) and averages loss_mask over
+ * those pixels: prediction rows / columns [0, hs) x [0, ws) are mapped onto target pixels [0, VH) x [0, VW) (align_corners = False grid of that
+ * pair of sizes), nothing else takes part, and the caller divides loss_mask by VH * VW.  gt keeps its row stride TW. */
 
 /* ---- optimizer tail: clip_grad_norm_ + AdamW + EMA + bf16 compute-copy refresh in one multi-tensor pass ------------
  * Replaces engine.py:87-101 of the reference (torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm);

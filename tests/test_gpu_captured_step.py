@@ -160,8 +160,13 @@ def test_caption_length_is_not_padded_by_default(dev):
         assert abs(g - want) <= 2e-3 * abs(want), (got, want)
 
 
-def test_captured_step_with_mask_losses(dev):
-    """configs[2] through CapturedTrainStep: the ground-truth masks travel in StaticTargets(mask_hw=...), the mask losses run on a
+@pytest.mark.parametrize("hw,tol", [((128, 192), 3e-3), ((120, 180), 4e-2)])
+def test_captured_step_with_mask_losses(dev, hw, tol):
+    """(120 x 180: image sides that are NOT multiples of pad_hw -- ADVICE r5.  The bucket is 128 x 192; StaticTargets.valid_hw makes the mask losses
+    those of the 120 x 180 batch (geometry and normalisation: tests/test_gpu_segm.py::test_mask_losses_of_a_batch_do_not_depend_on_its_bucket is the
+    exact statement), what remains is the padded margin seen by the convolutions next to the image border -- the same effect a smaller image has
+    inside a reference batch; bounded here.)
+    configs[2] through CapturedTrainStep: the ground-truth masks travel in StaticTargets(mask_hw=...), the mask losses run on a
     fixed-capacity pair table whose live slots / image indices are computed on the device (segmentation.mask_losses_static), so ONE graph serves
     batches with different numbers of targets.  Each step is compared with the same step launched eagerly through the LIST-of-dicts criterion path
     (segmentation.mask_losses: an independent implementation of the pair tables) from the same weights."""
@@ -190,7 +195,7 @@ def test_captured_step_with_mask_losses(dev):
         eag_opt = opt_of(eag_model)
         cap_opt = cap.optimizer
         # one bucket (128 x 192, 12 tokens: sides are multiples of pad_hw, so the padded batch IS the batch), 0 .. 5 targets per image
-        stream = [harness.synthetic_batch(2, 128, 192, tokens=12, seed=70 + i, max_targets=mt, with_masks=True) for i, mt in enumerate((4, 5, 0, 2, 5, 3))]
+        stream = [harness.synthetic_batch(2, hw[0], hw[1], tokens=12, seed=70 + i, max_targets=mt, with_masks=True) for i, mt in enumerate((4, 5, 0, 2, 5, 3))]
         got, ref = [], []
         for samples, tok, targets, pmap in stream:
             with torch.no_grad():
@@ -212,8 +217,9 @@ def test_captured_step_with_mask_losses(dev):
             eag_opt.step()
             ref.append(float(total.detach()))
         assert cap.captures == 1 and cap.replays == len(stream) - 1
+        print("captured vs eager totals", hw, [round(a / b - 1, 5) for a, b in zip(got, ref)])
         for i, (a, b) in enumerate(zip(got, ref)):
-            assert abs(a - b) <= 3e-3 * abs(b) + 1e-4, (i, got, ref)
+            assert abs(a - b) <= tol * abs(b) + 1e-4, (i, got, ref)
         assert len(set(round(v, 3) for v in got)) > 3
     finally:
         engine.REUSE_GRAD_BUFFERS = old_reuse

@@ -99,6 +99,45 @@ def test_mask_losses(dev):
     assert err <= 1e-3 * float(pred.grad.abs().max()) + 1e-8, err
 
 
+@pytest.mark.parametrize("VH,VW,TH,TW", [(120, 180, 128, 192), (134, 201, 192, 256), (96, 128, 96, 128)])
+def test_mask_losses_of_a_batch_do_not_depend_on_its_bucket(dev, VH, VW, TH, TW):
+    """harness.CapturedTrainStep pads a batch to its bucket's (Hp, Wp); the reference resizes the [ceil(H/4), ceil(W/4)]
+    prediction to the batch's own largest image (H, W) and averages loss_mask over H * W (/root/reference/models/mdetr.py:839-851).  With
+    StaticTargets.valid_hw = {VH, VW, hs, ws} the bucket-sized call must give EXACTLY what the batch-sized call gives on the corresponding
+    corners -- the reference-pinned path of test_mask_losses -- values and gradients, with zero gradient outside the corner."""
+    from oracle import model_ref
+    from toist_amd.segmentation import _MaskLossFn
+    g = torch.Generator().manual_seed(VH + TW)
+    B, Q = 2, 5
+    hs, ws, h, w = (VH + 3) // 4, (VW + 3) // 4, TH // 4, TW // 4
+    pred_big = (torch.randn(B * Q, h, w, generator=g) * 2)
+    sizes = [2, 1]
+    gt_small = (torch.rand(sum(sizes), VH, VW, generator=g) > 0.6)
+    gt_big = torch.zeros(sum(sizes), TH, TW, dtype=torch.bool)
+    gt_big[:, :VH, :VW] = gt_small
+    gt_big[:, VH:, :] = True                      # garbage outside the batch's corner must not matter
+    gt_big[:, :, VW:] = True
+    indices = [(torch.tensor([1, 4]), torch.tensor([1, 0])), (torch.tensor([3]), torch.tensor([0]))]
+    # the reference-pinned oracle on the batch-sized tensors
+    p_ref = pred_big[:, :hs, :ws].reshape(B, Q, hs, ws).clone().requires_grad_(True)
+    targets = [{"masks": gt_small[:2], "boxes": torch.zeros(2, 4)}, {"masks": gt_small[2:], "boxes": torch.zeros(1, 4)}]
+    ref = model_ref.loss_masks(p_ref, targets, indices, 3.0)
+    (ref["loss_mask"] * 1.5 + ref["loss_dice"] * 0.7).backward()
+    pred_row = torch.tensor([1, 4, Q + 3, -1], dtype=torch.int32, device=dev)          # one unused slot, as in a fixed-capacity pair table
+    gt_row = torch.tensor([1, 0, 2, 0], dtype=torch.int32, device=dev)
+    p2 = pred_big.to(dev).requires_grad_(True)
+    valid = torch.tensor([VH, VW, hs, ws], dtype=torch.int32, device=dev)
+    vals = _MaskLossFn.apply(p2, pred_row, gt_big.to(torch.uint8).to(dev), gt_row, torch.tensor(3.0, device=dev), TH, TW, None, None, valid)
+    (vals[0] * 1.5 + vals[1] * 0.7).backward()
+    assert abs(float(vals[0]) - float(ref["loss_mask"])) <= 1e-4 * abs(float(ref["loss_mask"])) + 1e-6, (float(vals[0]), float(ref["loss_mask"]))
+    assert abs(float(vals[1]) - float(ref["loss_dice"])) <= 1e-4 * abs(float(ref["loss_dice"])) + 1e-6
+    got = p2.grad.cpu().reshape(B, Q, h, w)
+    assert float((got[:, :, :hs, :ws] - p_ref.grad).abs().max()) <= 1e-3 * float(p_ref.grad.abs().max()) + 1e-8
+    outside = got.clone()
+    outside[:, :, :hs, :ws] = 0
+    assert float(outside.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("N,HW,C", [(6, 400, 264), (4, 1600, 64), (3, 6400, 16)])
 def test_groupnorm_backward_rederives_the_relu_mask(dev, N, HW, C):
     """toist_groupnorm_bwd without y (round 5: the mask y > 0 of relu(GroupNorm(x)) re-derived from x, stats, gamma, beta -- two passes over

@@ -178,7 +178,8 @@ def test_expired_spin_is_loud_and_falls_back_to_the_per_op_launches(dev):
             model.zero_grad(set_to_none=True)
             mc = model(samples.to(dev), tok.to(dev), encode_and_save=True)
             out = model(samples.to(dev), tok.to(dev), encode_and_save=False, memory_cache=mc)
-            assert torch.isnan(out["pred_logits"]).all() and torch.isnan(out["pred_boxes"]).all()
+            assert torch.isnan(out["pred_logits"]).all()          # (the box head's ReLUs are IEEE maxnum: they turn NaN into 0, the class head is linear)
+            assert all(torch.isnan(a["pred_logits"]).all() for a in out["aux_outputs"])
             assert k.xdec_check(raise_on_failure=False) and k.XDEC_FAILED
             # (a) the next step: per-op launches, finite, equal to the reference run
             k.XDEC_TEST_ABSENT = 0

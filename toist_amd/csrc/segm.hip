@@ -417,9 +417,12 @@ __global__ __launch_bounds__(256) void mask_loss_fwd_kernel(const float* __restr
     __shared__ float red[4];
     const int t = blockIdx.y;
     if (pred_row[t] < 0) return;          // an unused slot of a fixed-capacity pair table (matcher.StaticTargets): its sums stay 0 -> both losses 0
-    // valid_hw (device, optional): the batch's own padded size inside a larger [TH, TW] bucket (harness.CapturedTrainStep) -- target pixels beyond it
-    // are not part of the reference's loss (mdetr.py:843 resizes to the batch's largest image); the pixel grid (scale h / TH) is the bucket's
+    // valid_hw (device int32 [4], optional) = {VH, VW, hs, ws}: the batch's own padded size inside a larger [TH, TW] bucket (harness.CapturedTrainStep) and
+    // the part of the prediction the reference would have had for that batch.  The reference resizes its [hs, ws] prediction to the batch's largest
+    // image [VH, VW] (mdetr.py:843): here prediction rows / columns [0, hs) x [0, ws) are mapped onto target pixels [0, VH) x [0, VW) with the
+    // same align_corners=False grid, and nothing else takes part.
     const int VH = valid_hw ? min(valid_hw[0], TH) : TH, VW = valid_hw ? min(valid_hw[1], TW) : TW;
+    const int hs = valid_hw ? min(valid_hw[2], h) : h, ws = valid_hw ? min(valid_hw[3], w) : w;
     const float* pm = pred + (size_t)pred_row[t] * h * w;
     const unsigned char* gm = gt + (size_t)gt_row[t] * TH * TW;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -428,8 +431,8 @@ __global__ __launch_bounds__(256) void mask_loss_fwd_kernel(const float* __restr
         const int Y = i / TW, X = i - Y * TW;
         if (Y >= VH || X >= VW) continue;
         int y0, y1, x0, x1; float wy, wx;
-        bilinear_src(Y, h, TH, y0, y1, wy);
-        bilinear_src(X, w, TW, x0, x1, wx);
+        bilinear_src(Y, hs, VH, y0, y1, wy);
+        bilinear_src(X, ws, VW, x0, x1, wx);
         const float v = (1.f - wy) * ((1.f - wx) * pm[y0 * w + x0] + wx * pm[y0 * w + x1]) + wy * ((1.f - wx) * pm[y1 * w + x0] + wx * pm[y1 * w + x1]);
         const float tg = gm[i] ? 1.f : 0.f;
         const float p = 1.f / (1.f + __expf(-v));
@@ -469,22 +472,23 @@ __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restr
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int Y0 = ty * MLB_TILE, X0 = tx * MLB_TILE;
     const int VH = valid_hw ? min(valid_hw[0], TH) : TH, VW = valid_hw ? min(valid_hw[1], TW) : TW;      // as in the forward kernel
+    const int hs = valid_hw ? min(valid_hw[2], h) : h, ws = valid_hw ? min(valid_hw[3], w) : w;
     if (Y0 >= VH || X0 >= VW) return;
     // source origin of this tile (first source row / column any of its pixels touches)
     int sy0, sx0, dummy; float wdummy;
-    bilinear_src(Y0, h, TH, sy0, dummy, wdummy);
-    bilinear_src(X0, w, TW, sx0, dummy, wdummy);
+    bilinear_src(Y0, hs, VH, sy0, dummy, wdummy);
+    bilinear_src(X0, ws, VW, sx0, dummy, wdummy);
     // Up-sampling ratios in [1.9, 5.5] (the reference predicts masks at 1/4 of the padded image): the tile's footprint fits the LDS window and a
     // source pixel is touched by at most MLB_CAND target rows / columns -> GATHER: per-target-pixel gradients go to LDS with plain stores and
     // every source pixel of the window sums its own contributions (the scatter form below spent 420 of its 520 us in same-address LDS float
     // atomics: measured 110 us with the atomics replaced by stores).  Other ratios keep the scatter form.
-    const float sc_y = (float)TH / (float)h, sc_x = (float)TW / (float)w;
+    const float sc_y = (float)VH / (float)hs, sc_x = (float)VW / (float)ws;
     const bool gather = sc_y >= 1.9f && sc_y <= 5.5f && sc_x >= 1.9f && sc_x <= 5.5f;     // 2 * 5.5 + 5 = MLB_CAND candidate columns
     // the prediction window under this tile goes to LDS once
     for (int i = threadIdx.x; i < MLB_SRC * MLB_SRC; i += 256) {
         acc[i] = 0.f;
         const int y = sy0 + i / MLB_SRC, x = sx0 + i % MLB_SRC;
-        win[i] = (y < h && x < w) ? pm[y * w + x] : 0.f;
+        win[i] = (y < hs && x < ws) ? pm[y * w + x] : 0.f;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < MLB_TILE * MLB_TILE; i += 256) {
@@ -494,8 +498,8 @@ __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restr
             continue;
         }
         int y0, y1, x0, x1; float wy, wx;
-        bilinear_src(Y, h, TH, y0, y1, wy);
-        bilinear_src(X, w, TW, x0, x1, wx);
+        bilinear_src(Y, hs, VH, y0, y1, wy);
+        bilinear_src(X, ws, VW, x0, x1, wx);
         const int ly0 = y0 - sy0, ly1 = y1 - sy0, lx0 = x0 - sx0, lx1 = x1 - sx0;
         const bool inside = ly1 < MLB_SRC && lx1 < MLB_SRC;      // always true in gather mode
         float p00, p01, p10, p11;
@@ -534,16 +538,16 @@ __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restr
         for (int i = threadIdx.x; i < MLB_SRC * MLB_SRC; i += 256) {
             const float a = acc[i];
             const int y = sy0 + i / MLB_SRC, x = sx0 + i % MLB_SRC;
-            if (a != 0.f && y < h && x < w) atomicAdd(dp + y * w + x, a);
+            if (a != 0.f && y < hs && x < ws) atomicAdd(dp + y * w + x, a);
         }
         return;
     }
     // gather: source pixel (gy, gx) of the window receives sum over the tile's target pixels of gv * Wy(Y -> gy) * Wx(X -> gx), where a target row
     // Y gives weight (1 - wy) to its upper source row y0 and wy to y1 (both to the same row at the image border) -- the scatter form's weights
-    const int Yend = min(Y0 + MLB_TILE, TH) - 1, Xend = min(X0 + MLB_TILE, TW) - 1;
+    const int Yend = min(Y0 + MLB_TILE, VH) - 1, Xend = min(X0 + MLB_TILE, VW) - 1;
     for (int s = threadIdx.x; s < MLB_SRC * MLB_SRC; s += 256) {
         const int gy = sy0 + s / MLB_SRC, gx = sx0 + s % MLB_SRC;
-        if (gy >= h || gx >= w) continue;
+        if (gy >= hs || gx >= ws) continue;
         // targets whose bilinear support can contain this source pixel: (o + 0.5) / sc - 0.5 in [g - 1, g + 1), widened by one each side
         const int Ylo = max(Y0, (int)floorf(((float)gy - 0.5f) * sc_y - 0.5f) - 1), Yhi = min(Yend, (int)ceilf(((float)gy + 1.5f) * sc_y - 0.5f) + 1);
         const int Xlo = max(X0, (int)floorf(((float)gx - 0.5f) * sc_x - 0.5f) - 1), Xhi = min(Xend, (int)ceilf(((float)gx + 1.5f) * sc_x - 0.5f) + 1);
@@ -552,13 +556,13 @@ __global__ __launch_bounds__(256) void mask_loss_bwd_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < MLB_CAND; ++j) {
             int x0, x1; float wx;
-            bilinear_src(Xlo + j, w, TW, x0, x1, wx);
+            bilinear_src(Xlo + j, ws, VW, x0, x1, wx);
             wxv[j] = (Xlo + j <= Xhi) ? ((x0 == gx ? 1.f - wx : 0.f) + (x1 == gx ? wx : 0.f)) : 0.f;
         }
         float total = 0.f;
         for (int Y = Ylo; Y <= Yhi; ++Y) {
             int y0, y1; float wy;
-            bilinear_src(Y, h, TH, y0, y1, wy);
+            bilinear_src(Y, hs, VH, y0, y1, wy);
             const float wyk = (y0 == gy ? 1.f - wy : 0.f) + (y1 == gy ? wy : 0.f);
             if (wyk == 0.f) continue;
             const float* row = gvs + (Y - Y0) * MLB_TILE + (Xlo - X0);

@@ -242,10 +242,10 @@ class CapturedTrainStep:
         det = getattr(model, "detr", model)
         self.num_queries = det.query_embed.weight.shape[0]
         self.contrastive = bool(getattr(det, "contrastive_align_loss", False)) if contrastive is None else bool(contrastive)
-        # configs[2]: the ground-truth masks travel in the bucket's StaticTargets, zero-padded to the bucket's (Hp, Wp) -- the reference pads them to the
-        # batch's largest image (util/misc.py:185-209) and resizes the predicted masks to that size (mdetr.py:843): with image sides that are
-        # multiples of pad_hw the two coincide; otherwise the padded margin enters the mask losses as background (targets 0), like the margin
-        # of a smaller image inside a reference batch
+        # configs[2]: the ground-truth masks travel in the bucket's StaticTargets, zero-padded to the bucket's (Hp, Wp).  The reference pads them to the
+        # batch's largest image (util/misc.py:185-209) and resizes the [ceil(H/4), ceil(W/4)] predictions to that size (mdetr.py:843):
+        # StaticTargets.valid_hw carries the batch's own sizes to the mask-loss kernels, which map that corner of the prediction onto that corner of
+        # the targets and normalise by H * W -- the same mask losses in any bucket (round 6).
         self.masks = "masks" in getattr(criterion, "losses", ())
         self._buckets = OrderedDict()          # (Hp, Wp, Lp) -> dict(graph, images, mask, ids, att, targets, loss)
         self._side = torch.cuda.Stream(device=self.device)

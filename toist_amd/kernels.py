@@ -585,7 +585,7 @@ def sum_queries(inp, B, Q, per, out):
 
 
 def mask_loss_fwd(pred, pred_row, gt, gt_row, T, h, w, TH, TW, alpha, sums, valid_hw=None):
-    """valid_hw: optional device int32 [2], the batch's own padded mask size inside the [TH, TW] bucket (include/toist_hip.h)."""
+    """valid_hw: optional device int32 [4] = {VH, VW, hs, ws}, the batch's own corner of a larger bucket (include/toist_hip.h)."""
     _lib.check(_lib.lib().toist_mask_loss_fwd(_p(pred, F32), _p(pred_row, torch.int32), _p(gt, torch.uint8), _p(gt_row, torch.int32), T, h, w, TH,
                                               TW, alpha, _p(sums, F32), _p(valid_hw, torch.int32), _stream()), "toist_mask_loss_fwd")
 

@@ -47,21 +47,24 @@ class StaticTargets:
 
     Layout of the arena (bytes): boxes f32 [cap,4] | positive_map f32 [cap,K] | token masks i64 [cap,2] | tgt_off i32 [B+1] |
     match_off i32 [B+1] | num_boxes f32 [1] (local sum of targets; the world mean, clamped to >= 1, is formed on the device) |
-    valid_hw i32 [2] (with mask_hw: the largest ground-truth mask of the batch = the size the reference pads the batch's masks to and resizes the
-    predictions to, mdetr.py:839-843; the mask losses count the target pixels inside it and normalise by it -- ADVICE r5)."""
+    valid_hw i32 [4] (with mask_hw) = {VH, VW, hs, ws}: the largest ground-truth mask of the batch = the size the reference pads the batch's masks to
+    and resizes its predictions to (mdetr.py:839-843), and the size of the prediction the reference would have had for that batch (DETRsegm's
+    maps have the size of the ResNet C2 feature: ceil(side / 4), `mask_pred_of`); the mask losses map that corner of the bucket's prediction onto that corner of the bucket's targets and
+    normalise by VH * VW, so a batch gives the same mask losses in any bucket."""
 
-    def __init__(self, batch, max_per_image, num_queries, K=256, device="cuda", mask_hw=None):
+    def __init__(self, batch, max_per_image, num_queries, K=256, device="cuda", mask_hw=None, mask_pred_of=lambda side: (side + 3) // 4):
         self.B, self.max_per_image, self.Q, self.K = batch, max_per_image, num_queries, K
         # mask_hw = (TH, TW): the ground-truth masks of the targets travel too (uint8 [cap, TH, TW], zero-padded to the padded batch size like
         # NestedTensor.from_tensor_list, util/misc.py:185-209) -- the mask losses of configs[2] then replay from the same graph as the detection losses
         self.mask_hw = None if mask_hw is None else (int(mask_hw[0]), int(mask_hw[1]))
+        self.mask_pred_of = mask_pred_of          # image side -> side of pred_masks (the mask head resizes to each FPN level and ends at C2's size: segmentation.py:223-240)
         self.masks = self._mask_host = None
         if self.mask_hw is not None:
             self.masks = torch.zeros(batch * max_per_image, *self.mask_hw, dtype=torch.uint8, device=device)
             self._mask_host = torch.zeros(batch * max_per_image, *self.mask_hw, dtype=torch.uint8).pin_memory()
         self.cap = cap = batch * max_per_image
         self.device = torch.device(device)
-        sizes = [cap * 4 * 4, cap * K * 4, cap * TOKEN_MASK_WORDS * 8, (batch + 1) * 4, (batch + 1) * 4, 4, 8]
+        sizes = [cap * 4 * 4, cap * K * 4, cap * TOKEN_MASK_WORDS * 8, (batch + 1) * 4, (batch + 1) * 4, 4, 16]
         offs, total = [], 0
         for n in sizes:
             offs.append(total)
@@ -72,7 +75,7 @@ class StaticTargets:
         def views(buf):
             cut = lambda i, dt, shape: buf[offs[i]:offs[i] + sizes[i]].view(dt).view(shape)
             return (cut(0, torch.float32, (cap, 4)), cut(1, torch.float32, (cap, K)), cut(2, torch.int64, (cap, TOKEN_MASK_WORDS)), cut(3, torch.int32, (batch + 1,)),
-                    cut(4, torch.int32, (batch + 1,)), cut(5, torch.float32, (1,)), cut(6, torch.int32, (2,)))
+                    cut(4, torch.int32, (batch + 1,)), cut(5, torch.float32, (1,)), cut(6, torch.int32, (4,)))
 
         self._views = views
         self.boxes, self.positive_map, self.tok_mask, self.tgt_off, self.match_off, self._nb_local, self.valid_hw = views(self._dev)
@@ -119,7 +122,8 @@ class StaticTargets:
             mh[row:row + n].zero_()
             mh[row:row + n, :h, :w] = m
             row += n
-        hvalid[0], hvalid[1] = (vh or TH), (vw or TW)
+        vh, vw = (vh or TH), (vw or TW)
+        hvalid[0], hvalid[1], hvalid[2], hvalid[3] = vh, vw, self.mask_pred_of(vh), self.mask_pred_of(vw)
         return host, sizes, mh
 
     def load_packed(self, packed):

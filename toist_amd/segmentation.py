@@ -482,8 +482,9 @@ class _MaskLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pred, pred_row, gt, gt_row, num_boxes, TH, TW, sink=None, seg=None, valid=None):
-        """valid: optional device int32 [2] -- the batch's own padded mask size inside a [TH, TW] bucket (matcher.StaticTargets.valid_hw): the
-        target pixels beyond it take no part and loss_mask is the mean over valid[0] * valid[1] pixels, as mdetr.py:843-851 on that batch."""
+        """valid: optional device int32 [4] = {VH, VW, hs, ws} -- the batch's own padded mask size inside a [TH, TW] bucket and the prediction size
+        the reference would have had for it (matcher.StaticTargets.valid_hw, include/toist_hip.h): that corner of the prediction is resized onto
+        that corner of the targets and loss_mask is the mean over VH * VW pixels, as mdetr.py:843-851 does on that batch."""
         T = pred_row.numel()
         ctx.sink, ctx.seg = sink, seg
         h, w = pred.shape[-2:]
@@ -563,7 +564,7 @@ def mask_losses_static(outputs, st, match, layer, L):
     sink = getattr(outputs["pred_masks"], "toist_matched_rows", None)
     seg = mo[:B + 1].to(torch.int32).contiguous() if sink is not None else None      # slots [match_off[i], match_off[i+1]) belong to image i
     vals = _MaskLossFn.apply(pred.view(B * Q, pred.shape[-2], pred.shape[-1]), pred_row.contiguous(), st.masks, gt_row.contiguous(), st.num_boxes.reshape(()).float(), TH, TW,
-                             sink, seg, st.valid_hw)
+                             sink, seg, getattr(st, "valid_hw", None))
     return {"loss_mask": vals[0], "loss_dice": vals[1]}
 
 
