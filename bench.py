@@ -214,6 +214,42 @@ def pmc_traffic_live(families, timeout=300):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def kernel_stats_live(families, steps, warmup, timeout=300, keep=None):
+    """Average launch duration of the roofline kernel families in the REPLAYED step: one `rocprofv3 --kernel-trace --stats` pass (no counters)
+    over this script's own default timed loop (hipGraph replay), i.e. the command whose summary is committed as profiles/rNN_bench_kernel_stats.csv.
+    Returns ({family: (avg_us, calls)}, note).  `keep`: a path that receives a copy of the kernel_stats CSV."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="toist_kt_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+               "--no-cpu-baseline", "--no-roofline", "--no-secondary", "--steps", str(steps), "--warmup", str(warmup)]
+        subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=timeout)
+        path = os.path.join(tmp, "p_kernel_stats.csv")
+        acc = {fam: [0.0, 0] for fam in families}
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                kn = row.get("Name", "")
+                for fam, subs in families.items():
+                    if any(k_ in kn for k_ in subs):
+                        acc[fam][0] += float(row["TotalDurationNs"])
+                        acc[fam][1] += int(row["Calls"])
+        if keep:
+            os.makedirs(os.path.dirname(keep), exist_ok=True)
+            shutil.copyfile(path, keep)
+        out = {fam: (t / n / 1000.0, n) for fam, (t, n) in acc.items() if n}
+        return out, (None if out else "no dispatch of %s in the kernel trace" % (sorted(families),))
+    except Exception as e:  # profiler missing / timed out / unreadable output: the HIP-event timing of the eager pass is reported instead
+        return {}, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def bench_distillation(a, dev, rank, world):
     """BASELINE configs[4] per GPU: noun-pronoun distillation step (engine.py:119-250) -- teacher and student forward,
     memory-bank update + k-means prototypes, paired criterion with softkd / nsthl2, backward through both models, one
@@ -790,6 +826,8 @@ def main():
                                    "clip 0.1 + AdamW + EMA" + (" (torch)" if a.torch_optimizer else " (fused HIP tail)") + "; random-init weights; " +
                                    ("every step a different batch (4 resident batches, 0..10 targets per image) through fixed-address inputs" if dynamic else "one fixed batch"),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 4), "launch": ("%d hipGraphs (head | text || backbone layer4 | layer3 | layer2 | tail), gradient all-reduces under the backbone backward" % (3 + len(bb_graphs)) if split_graph else "hipGraph replay") if use_graph else "eager",
+                       "decoder": ("2 XCD-resident launches (toist_xdec_fwd / toist_xdec_bwd, one image per XCD)" if kernels.XDEC_LAUNCHES > 0 else
+                                   "per-op launches (the XCD-resident launches need the GPU to themselves: ranks share a device, TOIST_XDEC=0, or not 8 XCDs x 32 CUs)"),
                        "gflop_per_image": gflop_img,
                        "mfma_frac_whole_step": round(ips / world * gflop_img / 1000.0 / PEAK_BF16_TFLOPS, 5)},
         }
@@ -817,8 +855,15 @@ def main():
             pmc, why = {}, "PMC passes skipped (--no-pmc / N > 1)"
             if world == 1 and not a.no_pmc:
                 pmc, why = pmc_traffic_live({fam: subs for fam, (_, subs) in FAMS.items()})
+            # launch durations: the family's average in a rocprofv3 kernel trace of the REPLAYED step (what profiles/rNN_bench_kernel_stats.csv holds);
+            # the HIP events around the eager launches of the pass above stay in the entry as `avg_launch_us_hip_events` (they read 10-20 % longer:
+            # a launch between two event records on an otherwise idle stream starts cold)
+            ktrace, why_kt = {}, "kernel-trace pass skipped (--no-pmc / N > 1)"
+            if world == 1 and not a.no_pmc and use_graph:
+                ktrace, why_kt = kernel_stats_live({fam: subs for fam, (_, subs) in FAMS.items()}, a.steps, a.warmup,
+                                                   keep=os.path.join("gpurun_out", "bench_kernel_stats.csv") if os.path.isdir("gpurun_out") else None)
             pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            pname = next((n_ for n_ in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(pdir, n_))), None)
+            pname = next((n_ for n_ in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(pdir, n_))), None)
             KERNEL_TEXT = {"generic": "gemm_kernel<64,64,64,A kind,B kind,ring slots,lean epilogue> (tile code 65: the generic 64x64x64 tile -- linears of the cross-modal transformer and of RoBERTa, their data and weight gradients, small convolutions)",
                            "hbm": "panel2_kernel<{B_ROWK,B_KROW},act,BM> (tile code 135: 1x1 convolutions / linears with K <= 256 and their data gradients)",
                            "mfma": "gemm128_kernel<A kind, B kind, NS> (tile code 136: 3x3 convolutions of ResNet layers 2-4, their data gradients, 1x1 / linear launches with K >= 768; 128x128 tiles, 64x64 wave tiles)"}
@@ -828,6 +873,12 @@ def main():
                     continue
                 ms = sum(r[0].elapsed_time(r[1]) for r in recs)
                 fl, nb, n = sum(r[2] for r in recs), sum(r[5] for r in recs), len(recs)
+                ms_events = ms
+                timed = "HIP events around each launch, %d eager steps %s" % (a.steps, "after the graph-replayed timed region" if use_graph else "inside the timed region")
+                if fam in ktrace:          # per-launch flops / bytes from the eager pass's records, duration from the replayed step's kernel trace
+                    ms = ktrace[fam][0] * 1e-3 * n
+                    timed = ("rocprofv3 --kernel-trace --stats of `bench.py --no-cpu-baseline --no-roofline --no-secondary --steps %d --warmup %d` (hipGraph replay): "
+                             "family TotalDurationNs / Calls over %d dispatches; algorithmic flops / bytes per launch from the eager pass" % (a.steps, a.warmup, ktrace[fam][1]))
                 fam_ms[fam] = ms / a.steps
                 tfl, gbs = fl / (ms * 1e-3) / 1e12, nb / (ms * 1e-3) / 1e9
                 subs = FAMS[fam][1]
@@ -846,8 +897,8 @@ def main():
                                        + " (2*FETCH_SIZE + WRITE_SIZE per launch, gfx950 correction applied); not re-measured in this run -- " + str(why))
                 common = {"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src if traffic is not None else str(why),
                           "algorithmic_bytes_per_launch": round(nb / n), "launches": n, "launches_per_step": n // a.steps, "ms_per_step": round(ms / a.steps, 3),
-                          "avg_launch_us": round(1000 * ms / n, 2), "avg_gflop_per_launch": round(fl / n / 1e9, 3),
-                          "timed": "HIP events around each launch, %d eager steps %s" % (a.steps, "after the graph-replayed timed region" if use_graph else "inside the timed region")}
+                          "avg_launch_us": round(1000 * ms / n, 2), "avg_launch_us_hip_events": round(1000 * ms_events / n, 2),
+                          "avg_gflop_per_launch": round(fl / n / 1e9, 3), "timed": timed if fam in ktrace else timed + " (" + str(why_kt) + ")"}
                 # which roofline bounds the family: flop per algorithmic byte against the ridge (dense bf16 MFMA peak / HBM peak = 312)
                 bound = "hbm" if fam == "hbm" or (fam == "generic" and fl / max(nb, 1) < PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS) else "mfma"
                 if bound == "hbm":

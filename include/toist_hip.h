@@ -328,6 +328,12 @@ TOIST_API int toist_groupnorm_bwd(const void* dy, const void* y, const void* x, 
 TOIST_API int toist_upsample_add(const void* in, const void* fpn, int BQ, int Q, int H, int W, int C, void* out, void* stream);
 TOIST_API int toist_upsample_add_rows(const void* in, const void* fpn, const int64_t* rows, int n, int Q, int H, int W, int C, void* out, void* stream);
 TOIST_API int toist_upsample_add_bwd(const void* dout, int BQ, int H, int W, int C, void* din, void* stream);
+/* The same three for ANY target size (/root/reference/models/segmentation.py:218, 225, 232: `cur_fpn + F.interpolate(x, size=cur_fpn.shape[-2:],
+ * mode="nearest")` -- the FPN level's size is 2H x 2W only for image sides that are multiples of 32): out [n, OH, OW, C] = fpn[image] + in[n, src(Y), src(X)]
+ * with torch's source index min(floor(dst * (float)in / out), in - 1); rows = NULL (map i is map i, n % Q == 0) or the gathered subset as in
+ * toist_upsample_add_rows.  toist_resize_add_bwd: din[n, y, x] = sum of the dout pixels that read it. */
+TOIST_API int toist_resize_add(const void* in, const void* fpn, const int64_t* rows, int n, int Q, int H, int W, int OH, int OW, int C, void* out, void* stream);
+TOIST_API int toist_resize_add_bwd(const void* dout, int BQ, int H, int W, int OH, int OW, int C, void* din, void* stream);
 TOIST_API int toist_sum_queries(const void* in, int B, int Q, int64_t per, void* out, void* stream);
 TOIST_API int toist_mask_stage_fwd(const void* src, const float* src_stats, const float* gamma, const float* beta, const void* fpn_conv, const void* w,
                         const float* bias, void* out, float* out_stats, int N, int Q, int H, int W, int c_in, int c_out, int w_rows, int gn_in, int up,

@@ -146,3 +146,29 @@ def test_bench_ranks_on_one_gpu_gloo(dev, world, steps):
     sizes = [res["collectives"]["backbone stage %d of 3 (layer4 first)" % i]["bytes"] for i in (1, 2, 3)]
     assert sizes[0] > 50e6 and sizes[1] > 90e6 and sizes[2] < 10e6, sizes       # layer4 ~ 60 MB, layer3 ~ 104 MB, layer2 ~ 5 MB of fp32 gradients
     assert res["config"]["parameters_identical_across_ranks"] is True
+    # ranks that share a device must not use the XCD-resident decoder launches (each needs all 256 CUs) -- the head segment's
+    # graph then holds the per-op decoder kernels; one rank per GPU (the driver's 8-GPU run, test_bench_split_graphs_on_one_rank below) uses them
+    assert res["config"]["decoder"].startswith("per-op launches"), res["config"]["decoder"]
+
+
+def test_bench_split_graphs_on_one_rank(dev):
+    """The configuration the first real multi-GPU run executes on every rank -- six hipGraphs with the XCD-resident decoder launches inside the
+    head segment -- on the one GPU of the test box (`--split-graph`: the N > 1 graph structure at world size 1).  Asserted: the structure, that the
+    decoder really ran as the two XCD-resident launches (no expired spin: bench.py calls kernels.xdec_check), a finite loss."""
+    import json
+    import math
+    import subprocess
+    import sys
+    from toist_amd import kernels as k
+    if not k.xdec_supported(8, 100, 416, 6):
+        pytest.skip("device without 8 XCDs x 32 CUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--split-graph", "--steps", "3", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--no-roofline",
+           "--no-secondary"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, out.stderr[-3000:]
+    res = json.loads(lines[-1])
+    assert "6 hipGraphs" in res["config"]["launch"], res["config"]["launch"]
+    assert res["config"]["decoder"].startswith("2 XCD-resident launches"), res["config"]["decoder"]
+    assert res["n_gpus"] == 1 and res["value"] > 0 and math.isfinite(res["config"]["final_loss"])

@@ -136,3 +136,55 @@ def test_generic_lsap_committed_known_answers(dev):
     got = linear_sum_assignment_batch(costs)
     for i, (c, (r, k_)) in enumerate(zip(cases, got)):
         assert r.cpu().tolist() == c["row_ind"] and k_.cpu().tolist() == c["col_ind"], (i, c["rows"], c["cols"])
+
+
+def test_register_resident_lsap_on_ties_shapes_and_infinities(dev):
+    """Round 6: the solver keeps a column's path cost / dual / owner / POSITION in SciPy's `remaining` list in registers (csrc/matcher.hip
+    lsap_solve_wave_reg, 2 .. 16 columns per lane) and resolves ties at the minimum by position.  300 problems chosen to stress exactly that --
+    integer costs in {0..3} and {0, 1} (ties at every step), duplicated rows and columns, every lane-count bracket (<= 128, 256, 512, 1024
+    columns), tall ones (solved on the transpose), +inf entries (feasible and infeasible) -- against oracle/lsap.c (pinned to SciPy): the
+    assignments must be bit-identical, infeasible problems must be reported as such."""
+    import numpy as np
+    from oracle import lsap as oracle_lsap
+    from toist_amd import matcher as tm
+    g = torch.Generator().manual_seed(2026)
+    costs = []
+    for k_ in range(300):
+        kind = k_ % 6
+        r = int(torch.randint(1, 130, (1,), generator=g))
+        c = int(torch.randint(1, 130, (1,), generator=g))
+        if k_ % 25 == 0:
+            c = [200, 256, 300, 512, 700, 1024][(k_ // 25) % 6]
+            r = int(torch.randint(1, 9, (1,), generator=g))
+        if kind == 0:
+            m = torch.randint(0, 4, (r, c), generator=g).float()
+        elif kind == 1:
+            m = torch.randint(0, 2, (r, c), generator=g).float()
+        elif kind == 2:
+            m = torch.rand(r, c, generator=g)
+            m[:, c // 2:] = m[:, :c - c // 2]                       # duplicated columns
+        elif kind == 3:
+            m = torch.rand(r, c, generator=g).round(decimals=1)
+            m[r // 2:] = m[:r - r // 2]                             # duplicated rows
+        elif kind == 4:
+            m = torch.rand(r, c, generator=g) - 0.5
+            m[torch.rand(r, c, generator=g) < 0.3] = float("inf")
+        else:
+            m = torch.rand(r, c, generator=g) * 100 - 50
+        costs.append(m)
+    shapes = [(int(m.shape[0]), int(m.shape[1])) for m in costs]
+    sizes = [a * b for a, b in shapes]
+    flat = torch.cat([m.reshape(-1) for m in costs]).to(dev)
+    ri, ci, out_off, pairs, status = tm.lsap_blocks(flat, shapes, [sum(sizes[:i]) for i in range(len(sizes))], 0)
+    ri, ci, status = ri.cpu().numpy(), ci.cpu().numpy(), status.cpu().tolist()
+    n_inf = 0
+    for m, o, n, st in zip(costs, out_off, pairs, status):
+        try:
+            rr, cc = oracle_lsap.linear_sum_assignment(m.double().numpy())
+        except ValueError:
+            assert st == 2, (m.shape, st)                           # infeasible
+            n_inf += 1
+            continue
+        assert st == 0, (m.shape, st)
+        assert np.array_equal(ri[o:o + n], rr) and np.array_equal(ci[o:o + n], cc), m.shape
+    assert 0 < n_inf < 60

@@ -154,8 +154,13 @@ def test_criterion_and_gradients(dev, setup):
     assert frozen.grad is None and not frozen.requires_grad
 
 
-def test_segmentation_model_end_to_end(dev):
-    """Config 3: build_model(masks=True) -> DETRsegm; pred_masks vs the oracle, mask losses, a backward pass."""
+@pytest.mark.parametrize("hw", [(128, 160), (120, 180), (104, 136)])
+def test_segmentation_model_end_to_end(dev, hw):
+    """Config 3: build_model(masks=True) -> DETRsegm; pred_masks vs the oracle, mask losses, a backward pass.
+    (120, 180) / (104, 136): image sides that are NOT multiples of 32 -- what the reference's data pipeline delivers (datasets/tdod.py:305-319 resizes to
+    arbitrary sizes).  The FPN levels then are not exact doublings of each other (4 x 6 -> 8 x 12 -> 15 x 23 -> 30 x 45) and the head resizes its maps to
+    each level's own size with F.interpolate(mode="nearest") (/root/reference/models/segmentation.py:218, 225, 232); pred_masks has C2's size
+    ceil(side / 4).  Round 6: these sizes used to raise in the mask program (it assumed 2x steps)."""
     import toist_amd
     from oracle import model_ref
     from toist_amd import harness
@@ -169,12 +174,13 @@ def test_segmentation_model_end_to_end(dev):
     sd = {k_: v.detach().clone().float() for k_, v in model.state_dict().items()}
     assert "mask_head.adapter3.bias" in sd and "detr.transformer.encoder.layers.0.linear1.weight" in sd
     model.to(dev).eval()
-    samples, tok, targets, pmap = harness.synthetic_batch(2, 128, 160, tokens=12, seed=9, max_targets=4, with_masks=True)
+    samples, tok, targets, pmap = harness.synthetic_batch(2, hw[0], hw[1], tokens=12, seed=9, max_targets=4, with_masks=True)
     t_dev = [{k_: (v.to(dev) if torch.is_tensor(v) else v) for k_, v in t.items()} for t in targets]
     mc = model(samples.to(dev), tok.to(dev), encode_and_save=True)
     out = model(samples.to(dev), tok.to(dev), encode_and_save=False, memory_cache=mc)
-    assert out["pred_masks"].shape == (2, 100, 32, 40)
-    assert len(mc["features_4_mask"]) == 4 and mc["src_proj_4_mask"].shape == (2, 256, 4, 5)
+    up = lambda v, s_: (v + s_ - 1) // s_
+    assert out["pred_masks"].shape == (2, 100, up(hw[0], 4), up(hw[1], 4))
+    assert len(mc["features_4_mask"]) == 4 and mc["src_proj_4_mask"].shape == (2, 256, up(hw[0], 32), up(hw[1], 32))
     losses = criterion(mc, out, t_dev, pmap.to(dev), None)
     assert {"loss_mask", "loss_dice"} <= set(losses)
     total = sum(losses[k_] * weight_dict[k_] for k_ in losses if k_ in weight_dict)

@@ -450,3 +450,29 @@ def test_static_pair_table_matches_the_eager_pairs(dev, sizes):
     for n, a, b in zip(["hs", "memory", "src_proj", "c4", "c3", "c2"], ge, gs):
         ratio = float(b.norm() / a.norm())
         assert cos(a, b) > 0.9995 and 0.99 < ratio < 1.01, (n, cos(a, b), ratio)
+
+
+@pytest.mark.parametrize("H,W,OH,OW", [(4, 6, 8, 12), (8, 12, 15, 23), (15, 23, 30, 45), (7, 5, 13, 10), (25, 42, 50, 84), (50, 84, 100, 167)])
+def test_resize_add_matches_torch_nearest(dev, H, W, OH, OW):
+    """toist_resize_add / toist_resize_add_bwd (round 6: FPN levels of any size) against `fpn + F.interpolate(x, size=..., mode="nearest")` and its autograd
+    (/root/reference/models/segmentation.py:218, 225, 232) -- exact: both only move and add bf16 values (the sums of <= 9 terms are formed in f32 here)."""
+    from toist_amd import kernels as k
+    g = torch.Generator().manual_seed(H * 131 + OW)
+    B, Q, C = 2, 3, 16
+    x = torch.randn(B * Q, H, W, C, generator=g).to(BF)
+    f = torch.randn(B, OH, OW, C, generator=g).to(BF)
+    out = torch.empty(B * Q, OH, OW, C, dtype=BF, device=dev)
+    k.resize_add(x.to(dev), f.to(dev), None, B * Q, Q, H, W, OH, OW, C, out)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    up = torch.nn.functional.interpolate(xr, size=(OH, OW), mode="nearest")
+    ref = (up + f.float().permute(0, 3, 1, 2).repeat_interleave(Q, 0)).permute(0, 2, 3, 1)
+    assert torch.equal(out.float().cpu(), ref.detach().to(BF).float())
+    rows = torch.tensor([4, 1, 5], dtype=torch.int64, device=dev)              # a gathered subset: maps 4, 1, 5 (images 1, 0, 1)
+    sub = torch.empty(3, OH, OW, C, dtype=BF, device=dev)
+    k.resize_add(x.to(dev)[rows].contiguous(), f.to(dev), rows, 3, Q, H, W, OH, OW, C, sub)
+    assert torch.equal(sub, out[rows])
+    dy = torch.randn(B * Q, OH, OW, C, generator=g).to(BF)
+    dx = torch.empty(B * Q, H, W, C, dtype=BF, device=dev)
+    k.resize_add_bwd(dy.to(dev), B * Q, H, W, OH, OW, C, dx)
+    up.backward(dy.float().permute(0, 3, 1, 2))
+    assert torch.equal(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1).to(BF).float())

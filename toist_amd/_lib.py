@@ -134,6 +134,8 @@ _SIGNATURES = {
     "toist_upsample_add_bwd": ([c_void_p] + [c_int32] * 4 + [c_void_p, c_void_p], ctypes.c_int),
     "toist_sum_queries": ([c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p], ctypes.c_int),
     "toist_upsample_add_rows": ([c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p, c_void_p], ctypes.c_int),
+    "toist_resize_add": ([c_void_p, c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p, c_void_p], ctypes.c_int),
+    "toist_resize_add_bwd": ([c_void_p] + [c_int32] * 6 + [c_void_p, c_void_p], ctypes.c_int),
     "toist_mask_stage_fwd": ([c_void_p] * 9 + [c_int32] * 9 + [c_float, c_void_p], ctypes.c_int),
     "toist_sum_segments": ([c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p], ctypes.c_int),
     "toist_mask_loss_fwd": ([c_void_p] * 4 + [c_int32] * 5 + [c_float, c_void_p, c_void_p, c_void_p], ctypes.c_int),

@@ -126,6 +126,158 @@ __device__ __forceinline__ int lsap_solve_wave(const float* cw, const int R, con
     return st;
 }
 
+// ---- the same traversal with the column state in REGISTERS (round 6) ---------------------------------------------------------------------
+// lsap_solve_wave keeps spc / dv / path / row4col / remaining in LDS and walks `remaining` by position: every scan step is five dependent LDS
+// reads per candidate plus a six-stage shuffle of a 16-byte key -- ~1.2 ms for one 95 x 95 softkd problem, 5.9 ms of the 26 ms distillation step
+// (profiles/r05_distill_timeline.txt).  Here lane l OWNS columns l, l + 64, ... (CPL of them): shortest path cost, dual variable, predecessor,
+// owner row and the column's POSITION in SciPy's `remaining` list live in its registers.  The list itself is never materialised: removing the
+// element at position p moves the element at position live - 1 to p, i.e. one compare-and-set per owned column.  A scan step is then one LDS
+// read per owned column (the cost row), a DPP min-reduction of one double, and -- only when several columns tie at the minimum -- the
+// reference's tie rule on positions (an unassigned column wins, the LAST such in scan order; otherwise the FIRST in scan order).  Same
+// arithmetic, same order of floating-point operations per column, same tie rules: bit-identical assignments (tests/golden/lsap_kat.json,
+// oracle/lsap.c on the step's own matrices in tests/test_gpu_distill_fullsize.py).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {     // lanes without a source (or outside ROW_MASK) receive +inf, the identity of min
+    const int inf_hi = 0x7ff00000;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(inf_hi, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+    v = fmin(v, dpp_f64<0x111, 0xf>(v));      // row_shr:1
+    v = fmin(v, dpp_f64<0x112, 0xf>(v));      // row_shr:2
+    v = fmin(v, dpp_f64<0x114, 0xf>(v));      // row_shr:4
+    v = fmin(v, dpp_f64<0x118, 0xf>(v));      // row_shr:8   -> lane 15 of every row holds its row's minimum
+    v = fmin(v, dpp_f64<0x142, 0xa>(v));      // row_bcast:15 into rows 1 and 3
+    v = fmin(v, dpp_f64<0x143, 0xc>(v));      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <int CPL>
+__device__ __forceinline__ int lsap_solve_wave_reg(const float* cw, const int R, const int C, double* du, double* spc_lds, int* col4row, int* in_sr,
+                                                   const int lane) {
+    double dv[CPL], spc[CPL];
+    int path[CPL], r4c[CPL], pos[CPL];
+    bool gone[CPL];                       // the column has left `remaining` in this augmentation (= SciPy's SC), or does not exist (j >= C)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { dv[c] = 0.0; path[c] = -1; r4c[c] = -1; }
+    for (int i = lane; i < R; i += 64) { du[i] = 0.0; col4row[i] = -1; }
+    wave_lds_fence();
+
+    for (int cur = 0; cur < R; ++cur) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = lane + 64 * c;
+            spc[c] = INFINITY;
+            pos[c] = C - 1 - j;           // `remaining` starts in descending column order
+            gone[c] = j >= C;
+        }
+        for (int i = lane; i < R; i += 64) in_sr[i] = 0;
+        wave_lds_fence();
+
+        int live = C, sink = -1, i = cur;
+        double floor_val = 0.0;
+        while (sink < 0) {
+            if (lane == 0) in_sr[i] = 1;
+            const double ui = du[i];
+            const float* crow = cw + (size_t)i * C;
+            double mine = INFINITY;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                if (!gone[c]) {
+                    const double r = ((floor_val + (double)crow[lane + 64 * c]) - ui) - dv[c];
+                    if (r < spc[c]) { path[c] = i; spc[c] = r; }
+                    mine = fmin(mine, spc[c]);
+                }
+            }
+            const double m = wave_min_f64(mine);
+            if (!(m < INFINITY)) return ST_INFEASIBLE;
+            floor_val = m;
+            // which column: the ties at the minimum, resolved as the sequential scan over `remaining` resolves them
+            unsigned long long tie[CPL];
+            int ties = 0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                tie[c] = __ballot(!gone[c] && spc[c] == m);
+                ties += __popcll(tie[c]);
+            }
+            int pc = 0, pl = 0;           // the picked column's register slot and lane (wave-uniform)
+            if (ties == 1) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c)
+                    if (tie[c]) { pc = c; pl = __ffsll((long long)tie[c]) - 1; }
+            } else {
+                unsigned long long anyu = 0;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) anyu |= __ballot(!gone[c] && spc[c] == m && r4c[c] < 0);
+                int key = -1;             // unassigned ties: the largest position; none: the smallest position
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const bool t = !gone[c] && spc[c] == m;
+                    if (anyu) { if (t && r4c[c] < 0) key = max(key, pos[c]); }
+                    else if (t) key = max(key, 0x7fffffff - pos[c]);
+                }
+                const int best = wave_max_i32(key);
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const bool t = !gone[c] && spc[c] == m && (anyu ? (r4c[c] < 0 && pos[c] == best) : (0x7fffffff - pos[c] == best));
+                    const unsigned long long b = __ballot(t);
+                    if (b) { pc = c; pl = __ffsll((long long)b) - 1; }
+                }
+            }
+            pc = __builtin_amdgcn_readfirstlane(pc);
+            pl = __builtin_amdgcn_readfirstlane(pl);
+            int ppos = 0, owner = -1;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (c == pc) { ppos = __builtin_amdgcn_readlane(pos[c], pl); owner = __builtin_amdgcn_readlane(r4c[c], pl); }
+            // remaining[pick] = remaining[--live]
+            --live;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                if (!gone[c] && pos[c] == live) pos[c] = ppos;
+                if (c == pc && lane == pl) gone[c] = true;
+            }
+            if (owner < 0) sink = pl + 64 * pc; else i = owner;
+            wave_lds_fence();             // in_sr[i] of this step is written before the next step's (other) row is marked
+        }
+
+        // dual variables (the columns' shortest path costs go through LDS once: rows look their column up)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+            if (lane + 64 * c < C) spc_lds[lane + 64 * c] = spc[c];
+        wave_lds_fence();
+        if (lane == 0) du[cur] += floor_val;
+        for (int r = lane; r < R; r += 64)
+            if (in_sr[r] && r != cur) du[r] += floor_val - spc_lds[col4row[r]];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+            if (gone[c] && lane + 64 * c < C) dv[c] -= floor_val - spc[c];
+        wave_lds_fence();
+        // augment along the path (serial, short): every lane follows it, the owning lane records the new row of each column
+        int j = sink;
+        for (;;) {
+            const int jc = j >> 6, jl = j & 63;
+            int pi = -1;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (c == jc) { pi = __builtin_amdgcn_readlane(path[c], jl); if (lane == jl) r4c[c] = pi; }
+            const int prev = col4row[pi];
+            wave_lds_fence();
+            if (lane == 0) col4row[pi] = j;
+            j = prev;
+            if (pi == cur) break;
+        }
+        wave_lds_fence();
+    }
+    return ST_OK;
+}
+
 static constexpr int MATCH_THREADS = 1024;   // 16 waves build the cost block (one query per wave at a time); wave 0 solves
 
 __global__ __launch_bounds__(MATCH_THREADS) void matcher_kernel(
@@ -329,7 +481,12 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
         if (lane == 0) status[p] = ST_INVALID;
         return;
     }
-    const int st = lsap_solve_wave(cw, R, C, du, dv, spc, path, row4col, remaining, col4row, in_sr, in_sc, lane);
+    int st;
+    if (C <= 128) st = lsap_solve_wave_reg<2>(cw, R, C, du, spc, col4row, in_sr, lane);
+    else if (C <= 256) st = lsap_solve_wave_reg<4>(cw, R, C, du, spc, col4row, in_sr, lane);
+    else if (C <= 512) st = lsap_solve_wave_reg<8>(cw, R, C, du, spc, col4row, in_sr, lane);
+    else if (C <= 1024) st = lsap_solve_wave_reg<16>(cw, R, C, du, spc, col4row, in_sr, lane);
+    else st = lsap_solve_wave(cw, R, C, du, dv, spc, path, row4col, remaining, col4row, in_sr, in_sc, lane);
     if (lane == 0) status[p] = st;
     if (st != ST_OK) return;
     long long* ro = row_idx + out_off[p];

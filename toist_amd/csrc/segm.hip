@@ -317,12 +317,20 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restr
         *reinterpret_cast<uint4*>(dx + off) = pack8(d);
     }
 }
-// ------------------------------------------------------------------------------- nearest 2x upsample + shared FPN term
-// out[bq, Y, X, :] = fpn[bq / Q, Y, X, :] + in[bq, Y/2, X/2, :]   (in is [BQ, H, W, C], out [BQ, 2H, 2W, C])
+// ------------------------------------------------------------------------------- nearest resize + shared FPN term
+// out[bq, Y, X, :] = fpn[bq / Q, Y, X, :] + in[bq, src(Y), src(X), :]   (in is [BQ, H, W, C], out [BQ, OH, OW, C]) with F.interpolate(mode="nearest")'s
+// source index min(floor(dst * (float)in / out), in - 1) (segmentation.py:218, 225, 232: the maps are resized to the FPN level's own size, which is
+// 2H x 2W only when the image sides are multiples of 32).
 // rows != nullptr: map i of `in` / `out` is map rows[i] of the batch (a gathered subset), its image rows[i] / Q
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in) {
+    const int s = (int)floorf((float)dst * scale);
+    return s < in - 1 ? s : in - 1;
+}
 __global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ fpn, const long long* __restrict__ rows,
-                                                            int BQ, int Q, int H, int W, int C, bf16_t* __restrict__ out) {
-    const int c8 = C >> 3, OH = 2 * H, OW = 2 * W;
+                                                            int BQ, int Q, int H, int W, int OH, int OW, int C, bf16_t* __restrict__ out) {
+    const int c8 = C >> 3;
+    const bool twice = OH == 2 * H && OW == 2 * W;
+    const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
     const long long total = (long long)BQ * OH * OW * c8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int cc = (int)(i % c8);
@@ -330,8 +338,9 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restr
         const int X = (int)(p % OW); p /= OW;
         const int Y = (int)(p % OH);
         const int bq = (int)(p / OH);
+        const int ys = twice ? (Y >> 1) : nearest_src(Y, sy, H), xs = twice ? (X >> 1) : nearest_src(X, sx, W);
         float a[8], f[8];
-        unpack8(*reinterpret_cast<const uint4*>(in + ((((size_t)bq * H + (Y >> 1)) * W + (X >> 1)) * C) + cc * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(in + ((((size_t)bq * H + ys) * W + xs) * C) + cc * 8), a);
         const int img = (int)((rows != nullptr ? rows[bq] : (long long)bq) / Q);
         unpack8(*reinterpret_cast<const uint4*>(fpn + ((((size_t)img * OH + Y) * OW + X) * C) + cc * 8), f);
 #pragma unroll
@@ -339,9 +348,11 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restr
         *reinterpret_cast<uint4*>(out + (size_t)i * 8) = pack8(a);
     }
 }
-// din[bq, y, x, :] = sum of the 4 output pixels that read it
-__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const bf16_t* __restrict__ dout, int BQ, int H, int W, int C, bf16_t* __restrict__ din) {
-    const int c8 = C >> 3, OW = 2 * W;
+// din[bq, y, x, :] = sum of the output pixels that read it (the transpose of the map above: 4 of them for the exact doubling)
+__global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const bf16_t* __restrict__ dout, int BQ, int H, int W, int OH, int OW, int C, bf16_t* __restrict__ din) {
+    const int c8 = C >> 3;
+    const bool twice = OH == 2 * H && OW == 2 * W;
+    const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
     const long long total = (long long)BQ * H * W * c8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int cc = (int)(i % c8);
@@ -350,15 +361,23 @@ __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const bf16_t* __r
         const int y = (int)(p % H);
         const int bq = (int)(p / H);
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
+        int Y0, Y1, X0, X1;
+        if (twice) {
+            Y0 = 2 * y; Y1 = 2 * y + 1; X0 = 2 * x; X1 = 2 * x + 1;
+        } else {       // candidates: a window that certainly holds every Y with src(Y) == y; membership is tested with the forward map itself
+            Y0 = max(0, (int)((float)y / sy) - 2); Y1 = min(OH - 1, (int)((float)(y + 1) / sy) + 2);
+            X0 = max(0, (int)((float)x / sx) - 2); X1 = min(OW - 1, (int)((float)(x + 1) / sx) + 2);
+        }
+        for (int Y = Y0; Y <= Y1; ++Y) {
+            if (!twice && nearest_src(Y, sy, H) != y) continue;
+            for (int X = X0; X <= X1; ++X) {
+                if (!twice && nearest_src(X, sx, W) != x) continue;
                 float v[8];
-                unpack8(*reinterpret_cast<const uint4*>(dout + ((((size_t)bq * 2 * H + 2 * y + dy) * OW + 2 * x + dx) * C) + cc * 8), v);
+                unpack8(*reinterpret_cast<const uint4*>(dout + ((((size_t)bq * OH + Y) * OW + X) * C) + cc * 8), v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) a[j] += v[j];
             }
+        }
         *reinterpret_cast<uint4*>(din + (size_t)i * 8) = pack8(a);
     }
 }
@@ -661,23 +680,33 @@ extern "C" int toist_groupnorm_bwd(const void* dy, const void* y, const void* x,
     return check_launch("toist_groupnorm_bwd");
 }
 
+static int launch_resize_add(const char* what, const void* in, const void* fpn, const int64_t* rows, int n, int Q, int H, int W, int OH, int OW, int C, void* out, void* stream) {
+    TOIST_REQUIRE(in && fpn && out && n > 0 && Q > 0 && H > 0 && W > 0 && OH >= H && OW >= W && (C % 8) == 0 && (rows || (n % Q) == 0), "%s: bad shape", what);
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_cap((long long)n * OH * OW * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, (const bf16_t*)fpn, (const long long*)rows, n, Q, H, W, OH, OW, C, (bf16_t*)out);
+    return check_launch(what);
+}
 extern "C" int toist_upsample_add(const void* in, const void* fpn, int BQ, int Q, int H, int W, int C, void* out, void* stream) {
-    TOIST_REQUIRE(BQ > 0 && Q > 0 && (BQ % Q) == 0 && H > 0 && W > 0 && (C % 8) == 0, "toist_upsample_add: bad shape");
-    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_cap((long long)BQ * 4 * H * W * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)in, (const bf16_t*)fpn, (const long long*)nullptr, BQ, Q, H, W, C, (bf16_t*)out);
-    return check_launch("toist_upsample_add");
+    return launch_resize_add("toist_upsample_add", in, fpn, nullptr, BQ, Q, H, W, 2 * H, 2 * W, C, out, stream);
 }
 extern "C" int toist_upsample_add_rows(const void* in, const void* fpn, const int64_t* rows, int n, int Q, int H, int W, int C, void* out, void* stream) {
-    TOIST_REQUIRE(in && fpn && rows && out && n > 0 && Q > 0 && H > 0 && W > 0 && (C % 8) == 0, "toist_upsample_add_rows: bad shape");
-    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_cap((long long)n * 4 * H * W * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)in, (const bf16_t*)fpn, (const long long*)rows, n, Q, H, W, C, (bf16_t*)out);
-    return check_launch("toist_upsample_add_rows");
+    TOIST_REQUIRE(rows != nullptr, "toist_upsample_add_rows: rows is required");
+    return launch_resize_add("toist_upsample_add_rows", in, fpn, rows, n, Q, H, W, 2 * H, 2 * W, C, out, stream);
+}
+extern "C" int toist_resize_add(const void* in, const void* fpn, const int64_t* rows, int n, int Q, int H, int W, int OH, int OW, int C, void* out, void* stream) {
+    return launch_resize_add("toist_resize_add", in, fpn, rows, n, Q, H, W, OH, OW, C, out, stream);
+}
+static int launch_resize_add_bwd(const char* what, const void* dout, int BQ, int H, int W, int OH, int OW, int C, void* din, void* stream) {
+    TOIST_REQUIRE(dout && din && BQ > 0 && H > 0 && W > 0 && OH >= H && OW >= W && (C % 8) == 0, "%s: bad shape", what);
+    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_cap((long long)BQ * H * W * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dout, BQ, H, W, OH, OW, C, (bf16_t*)din);
+    return check_launch(what);
 }
 extern "C" int toist_upsample_add_bwd(const void* dout, int BQ, int H, int W, int C, void* din, void* stream) {
-    TOIST_REQUIRE(BQ > 0 && H > 0 && W > 0 && (C % 8) == 0, "toist_upsample_add_bwd: bad shape");
-    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_cap((long long)BQ * H * W * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)dout, BQ, H, W, C, (bf16_t*)din);
-    return check_launch("toist_upsample_add_bwd");
+    return launch_resize_add_bwd("toist_upsample_add_bwd", dout, BQ, H, W, 2 * H, 2 * W, C, din, stream);
+}
+extern "C" int toist_resize_add_bwd(const void* dout, int BQ, int H, int W, int OH, int OW, int C, void* din, void* stream) {
+    return launch_resize_add_bwd("toist_resize_add_bwd", dout, BQ, H, W, OH, OW, C, din, stream);
 }
 extern "C" int toist_sum_queries(const void* in, int B, int Q, int64_t per, void* out, void* stream) {
     TOIST_REQUIRE(B > 0 && Q > 0 && per > 0 && (per % 8) == 0, "toist_sum_queries: bad shape");

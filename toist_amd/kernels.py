@@ -561,6 +561,15 @@ def upsample_add(inp, fpn, BQ, Q, H, W, C, out):
     _lib.check(_lib.lib().toist_upsample_add(_p(inp, BF16), _p(fpn, BF16), BQ, Q, H, W, C, _p(out, BF16), _stream()), "toist_upsample_add")
 
 
+def resize_add(inp, fpn, rows, n, Q, H, W, OH, OW, C, out):
+    """out [n, OH, OW, C] = fpn[image] + nearest-resized inp [n, H, W, C] (any target size; rows = None or the int64 map indices of a gathered subset)."""
+    _lib.check(_lib.lib().toist_resize_add(_p(inp, BF16), _p(fpn, BF16), _p(rows, torch.int64), n, Q, H, W, OH, OW, C, _p(out, BF16), _stream()), "toist_resize_add")
+
+
+def resize_add_bwd(dout, BQ, H, W, OH, OW, C, din):
+    _lib.check(_lib.lib().toist_resize_add_bwd(_p(dout, BF16), BQ, H, W, OH, OW, C, _p(din, BF16), _stream()), "toist_resize_add_bwd")
+
+
 def upsample_add_rows(inp, fpn, rows, n, Q, H, W, C, out):
     """upsample_add on gathered maps: map i of inp / out is map rows[i] (int64, device) of the batch."""
     _lib.check(_lib.lib().toist_upsample_add_rows(_p(inp, BF16), _p(fpn, BF16), _p(rows, torch.int64), n, Q, H, W, C, _p(out, BF16), _stream()),

@@ -262,17 +262,17 @@ class DETRsegm(nn.Module):
                 return ops.linear(feat.data.view(-1, Cin_f), wa, ba.f32), wa
 
             def up_grads(g, x, feat, i, wa, H_, W_):
-                """Backward of `adapter{i}(feat) + upsample2(x)` for the gradient g [n,2H_,2W_,Cx] of the sum."""
+                """Backward of `adapter{i}(feat) + nearest_resize(x)` for the gradient g [n,OH,OW,Cx] of the sum (OH x OW = the FPN level's size)."""
                 Wa, ba = M(f"adapter{i}.weight"), M(f"adapter{i}.bias")
                 Cx, Cin_f = wa.shape
-                n = g.shape[0]
+                n, OH, OW = g.shape[0], g.shape[1], g.shape[2]
                 if x.needs_grad:
                     gx = torch.empty(n, H_, W_, Cx, dtype=BF16, device=dev)
-                    k.upsample_add_bwd(g, n, H_, W_, Cx, gx)
+                    k.resize_add_bwd(g, n, H_, W_, OH, OW, Cx, gx)
                     engine.accumulate(x, gx)
                 if Wa.g is not None or feat.needs_grad:
-                    gf = torch.empty(B * 4 * H_ * W_, Cx, dtype=BF16, device=dev)
-                    image_sum(g, 4 * H_ * W_ * Cx, gf)
+                    gf = torch.empty(B * OH * OW, Cx, dtype=BF16, device=dev)
+                    image_sum(g, OH * OW * Cx, gf)
                     if Wa.g is not None:
                         tmp = torch.zeros(Cx, Cin_f, dtype=torch.float32, device=dev)
                         ops.linear_wgrad(gf, feat.data.view(-1, Cin_f), out=tmp, bias_out=ba.g)
@@ -282,11 +282,13 @@ class DETRsegm(nn.Module):
                         engine.accumulate(feat, gfeat.view(feat.data.shape))
 
             def fpn_stage(x, feat, i, H_, W_):
-                """x [BQ,H_,W_,C] -> relu(GN(lay(adapter(feat) + up2(x))))"""
+                """x [BQ,H_,W_,C] -> relu(GN(lay(adapter(feat) + nearest_resize(x)))) at the FPN level's own size (segmentation.py:216-234: 2H_ x 2W_
+                for image sides that are multiples of 32, otherwise whatever the backbone's ceil-divisions left)"""
                 Cx = x.data.shape[-1]
-                f, wa = adapter(feat, i)                                             # [B*2H*2W, Cx]
-                up = torch.empty(B * Q, 2 * H_, 2 * W_, Cx, dtype=BF16, device=dev)
-                k.upsample_add(x.data, f, B * Q, Q, H_, W_, Cx, up)
+                OH, OW = feat.data.shape[1], feat.data.shape[2]
+                f, wa = adapter(feat, i)                                             # [B*OH*OW, Cx]
+                up = torch.empty(B * Q, OH, OW, Cx, dtype=BF16, device=dev)
+                k.resize_add(x.data, f, None, B * Q, Q, H_, W_, OH, OW, Cx, up)
                 uv = engine.Var(up)
 
                 def up_bwd():
@@ -296,7 +298,7 @@ class DETRsegm(nn.Module):
 
                 tape.record(up_bwd)
                 return _conv_gn_relu(tape, uv, M(f"lay{i + 2}.weight"), M(f"lay{i + 2}.bias"), M(f"gn{i + 2}.weight"), M(f"gn{i + 2}.bias"),
-                                     (B * Q, 2 * H_, 2 * W_, Cx), pick=pick)[0]
+                                     (B * Q, OH, OW, Cx), pick=pick)[0]
 
             def matched_rows_of(g):
                 """g = gradient of the mask logits [B,Q,8h,8w] exactly as autograd delivered it (Var.raw_grad) -> the rows the backward has to run on
@@ -315,15 +317,15 @@ class DETRsegm(nn.Module):
                         sel["seg"] = sink.seg
                         g = sink.grad
                     else:                        # another consumer added its gradient: dense backward of the sum (unused slots hold zeros)
-                        g = g.to(torch.float32).contiguous().view(BQ, 8 * h, 8 * w).index_add(0, rows.clamp(min=0).to(torch.int64), sink.grad)
+                        g = g.to(torch.float32).contiguous().view(BQ, Hm, Wm).index_add(0, rows.clamp(min=0).to(torch.int64), sink.grad)
                     sink.clear()
                     return g
-                return g.to(torch.float32).contiguous().view(BQ, 8 * h, 8 * w)
+                return g.to(torch.float32).contiguous().view(BQ, Hm, Wm)
 
             def out_lay_grads(g, a5_rows, Wo, bo, wo8):
-                """Backward of out_lay (one output channel, padded to 8 for the GEMM operands) for the logit gradient g [n,8h,8w] f32."""
+                """Backward of out_lay (one output channel, padded to 8 for the GEMM operands) for the logit gradient g [n,Hm,Wm] f32."""
                 n = g.shape[0]
-                g8 = torch.zeros(n, 8 * h, 8 * w, 8, dtype=BF16, device=dev)
+                g8 = torch.zeros(n, Hm, Wm, 8, dtype=BF16, device=dev)
                 g8[..., 0] = g.to(BF16)
                 if Wo.g is not None:
                     tmp = ops.conv2d_wgrad(g8, a5_rows, wo8.shape, pad=1)
@@ -331,13 +333,16 @@ class DETRsegm(nn.Module):
                     bo.g.add_(g.sum().reshape(1))
                 return g8
 
+            # sizes of the three FPN levels the maps are resized to; the logits have the last one's (C2: ceil(side / 4))
+            (h4, w4), (h3, w3), (Hm, Wm) = f4.data.shape[1:3], f3.data.shape[1:3], f2.data.shape[1:3]
+            doubling = (h4, w4, h3, w3, Hm, Wm) == (2 * h, 2 * w, 4 * h, 4 * w, 8 * h, 8 * w)      # image sides are multiples of 32
             a3 = fpn_stage(a2, f4, 1, h, w)
             Wo, bo = M("out_lay.weight"), M("out_lay.bias")
             W4, W5 = M("lay4.weight"), M("lay5.weight")
             C3, C4, C5 = a3.data.shape[-1], W4.w.shape[0], W5.w.shape[0]
             wo8 = torch.zeros(8, 3, 3, C5, dtype=BF16, device=dev)   # out_lay: Cout = 1 padded to 8 output channels (16-byte rows for the backward GEMM operands)
             wo8[:1] = Wo.w
-            if FUSED_TAIL and (C3, C4, C5) == (64, 32, 16) and W4.w.shape[-1] == 64 and W5.w.shape[-1] == 32 and Wo.w.shape[0] == 1:
+            if FUSED_TAIL and doubling and (C3, C4, C5) == (64, 32, 16) and W4.w.shape[-1] == 64 and W5.w.shape[-1] == 32 and Wo.w.shape[0] == 1:
                 # ---- lay4 / lay5 / out_lay as one launch each (csrc/maskstage.hip): the upsampled sums, the normalised activations and the padded
                 # out_lay output are never written; the backward re-creates them for the maps it runs on (the matched ones)
                 b4, b5 = M("lay4.bias"), M("lay5.bias")
@@ -420,12 +425,12 @@ class DETRsegm(nn.Module):
                 tape.record(tail_bwd)
                 return [mv], None
 
-            a4 = fpn_stage(a3, f3, 2, 2 * h, 2 * w)
-            a5 = fpn_stage(a4, f2, 3, 4 * h, 4 * w)
+            a4 = fpn_stage(a3, f3, 2, h4, w4)
+            a5 = fpn_stage(a4, f2, 3, h3, w3)
             bo8 = torch.zeros(8, dtype=torch.float32, device=dev)
             bo8[:1] = bo.f32
-            o8 = ops.conv2d(a5.data, wo8, pad=1, shift=bo8)                         # [BQ,8h,8w,8] bf16
-            masks = o8[..., 0].float().view(B, Q, 8 * h, 8 * w).contiguous()
+            o8 = ops.conv2d(a5.data, wo8, pad=1, shift=bo8)                         # [BQ,Hm,Wm,8] bf16
+            masks = o8[..., 0].float().view(B, Q, Hm, Wm).contiguous()
             mv = engine.Var(masks)
             mv.raw_grad = True
 
@@ -435,7 +440,7 @@ class DETRsegm(nn.Module):
                     return
                 g = matched_rows_of(g)
                 g8 = out_lay_grads(g, pick(a5.data), Wo, bo, wo8)
-                a5.grad = ops.conv2d_dgrad(g8, wo8, (8 * h, 8 * w), pad=1, res=a5.grad)
+                a5.grad = ops.conv2d_dgrad(g8, wo8, (Hm, Wm), pad=1, res=a5.grad)
 
             tape.record(out_bwd)
             return [mv], None
