@@ -14,6 +14,7 @@ this box's host cores at N = 1.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -162,7 +163,7 @@ def secondary_legs():
             d = json.loads(line)
             out[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "launch": d["config"].get("launch"),
                          "mfma_frac_whole_step": d["config"].get("mfma_frac_whole_step"), "workload": d["config"]["workload"]}
-            for extra in ("eager_pairs_per_s", "graph_replay_fixed_batch_pairs_per_s"):
+            for extra in ("eager_pairs_per_s", "graph_replay_any_batch_pairs_per_s"):
                 if extra in d["config"]:
                     out[name][extra] = d["config"][extra]
         except Exception as e:
@@ -325,32 +326,38 @@ def bench_distillation(a, dev, rank, world):
     launch, eager_rate, graph_rate = "eager", round(a.batch * world * a.steps / dt, 3), None
     final_loss = round(float(last.detach()), 4)
     del last
+    any_rate = None
     if world == 1 and not a.no_graph:
-        # The same step replayed from a hipGraph.  Every per-batch table of the step (noun / pronoun token weights, substitution masks, task columns,
-        # k-means groups, matcher offsets, softkd index vectors) is cached on the device after the warm-up steps, so the captured step reads no host
-        # data -- but the graph is THIS batch's: a new batch (other captions / target counts) needs its tables rebuilt and a new capture.  The number is
-        # the GPU-side cost of the step without Python's launch path; it is reported as such.
+        # Round 6: ONE hipGraph of the step for ANY batch (toist_amd.harness.CapturedDistillStep): every per-batch table -- target counts / LSAP problem
+        # sizes, the grouping of the images by task, the token tables of the captions -- lives at fixed device addresses (matcher.StaticTargets +
+        # distill.DistillTables per side) that are refilled before each replay.  The timed loop feeds a DIFFERENT batch every step (a pool of resident
+        # batches with other images, captions, target counts and tasks, their host tables packed ahead as a loader worker would).
         try:
-            with kernels.tables_beside_graph():
-                for _ in range(max(a.warmup, 2)):       # on the capturing stream: its scratch arenas and the pointer tables of grouped launches exist before the capture
-                    step()
-                for o in opts:
-                    o.zero_grad(set_to_none=True)
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
-                    static_loss = step()
-            for _ in range(max(a.warmup, 1)):
-                graph.replay()
+            torch.cuda.synchronize()
+            cap = harness.CapturedDistillStep(model, model_noun, criterion, cluster_criterion, opts, weight_dict, batch=a.batch, image_hw=(a.size, a.size), tokens=16,
+                                              max_targets_per_image=10, stream=side)
+            pool = []
+            for j in range(4):
+                b_j = harness.synthetic_distill_batch(a.batch, a.size, a.size, tokens=16, seed=2000 + 7919 * j + rank, device=dev)
+                for side_t in b_j["targets"]:
+                    for i, t in enumerate(side_t):
+                        t["dataset_name"] = f"task_{1 + (i * (j + 1) + 3 * j) % 14}_train.json"
+                pool.append(cap.pack(b_j))
+            it = [0]
 
             def replayed():
-                graph.replay()
-                return static_loss
+                it[0] += 1
+                return cap.step(packed=pool[it[0] % len(pool)])
+            for _ in range(max(a.warmup, 2) + 1):
+                replayed()
             dt_g, last_g = timed(replayed)
-            # `value` stays the EAGER rate -- what a training loop over new batches gets; the replay of one fixed batch (host-side queue
-            # bookkeeping frozen at capture: not a usable training step) is the GPU-side cost of the step and is reported beside it
-            graph_rate = round(a.batch * world * a.steps / dt_g, 3)
-            launch = "eager (every batch builds its caption-driven tables on the host); hipGraph replay of ONE fixed batch: %.1f pairs/s, %.2f ms/step (a new batch needs a new capture)" % (graph_rate, 1000 * dt_g / a.steps)
+            from toist_amd.matcher import check_lsap_pending
+            check_lsap_pending()
+            assert cap.captures == 1 and math.isfinite(float(last_g))
+            any_rate = graph_rate = round(a.batch * world * a.steps / dt_g, 3)
+            launch = ("hipGraph replay, every step a different batch (harness.CapturedDistillStep: 1 graph, %d replays; 4 resident batches with different images, captions, "
+                      "0..10 targets per image and tasks); eager list-of-dicts step: %.1f pairs/s" % (cap.replays, eager_rate))
+            dt, final_loss = dt_g, round(float(last_g.detach()), 4)
         except Exception as e:      # stays on the eager number, loudly
             print(f"[bench] distillation: hipGraph capture failed ({type(e).__name__}: {e}); reporting the eager step", file=sys.stderr)
             torch.cuda.synchronize()
@@ -361,7 +368,7 @@ def bench_distillation(a, dev, rank, world):
                           "config": {"workload": f"configs[4]: noun-pronoun distillation, teacher + student (ResNet-101 + RoBERTa-base + 6+6 each), batch {a.batch} pairs/GPU "
                                                  f"{a.size}x{a.size}, cluster memory 1024 x 14 tasks + k-means(3), softkd + nsthl2 + cluster losses, two fused optimizer tails",
                                      "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": final_loss, "launch": launch, "eager_pairs_per_s": eager_rate,
-                                     "graph_replay_fixed_batch_pairs_per_s": graph_rate}}))
+                                     "graph_replay_any_batch_pairs_per_s": any_rate}}))
     if world > 1:
         torch.distributed.destroy_process_group()
 

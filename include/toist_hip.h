@@ -581,6 +581,11 @@ typedef struct toist_xdec_bwd_desc {
 
 TOIST_API int toist_xdec_bwd(const toist_xdec_bwd_desc* d, void* stream);
 
+/* ---- masked row scatter (the nearest-replacement memory-bank update, /root/reference/models/mdetr.py:98-103, when the pair table has a fixed
+ * capacity and the live slots are only known on the device: hipGraph replay of the distillation step).  dst[dst_row[i]] = src[src_row[i]] (rows of d
+ * floats) for every i < m with src_row[i] >= 0 and dst_row[i] >= 0; live destinations must be distinct. */
+TOIST_API int toist_scatter_rows_f32(const float* src, const int64_t* src_row, float* dst, const int64_t* dst_row, int m, int d, void* stream);
+
 /* ---- k-means of the distillation step on the device (models/kmeans.py:21-96 as mdetr.py:213-234 calls it).  One workgroup per
  * distinct task of the batch: group g covers samples members[group_off[g] .. group_off[g+1]) (batch order), all of task
  * group_task[g]; for each sample: Lloyd iterations over banks[task] ([N, D] f32, stride bank_stride elements) from

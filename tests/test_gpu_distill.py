@@ -228,6 +228,76 @@ def test_distillation_step_replayed_from_a_hipgraph(dev):
         engine.REUSE_GRAD_BUFFERS = saved
 
 
+def test_captured_distill_step_serves_any_batch(dev):
+    """harness.CapturedDistillStep -- ONE hipGraph of the whole distillation step replayed on batches that differ in everything the graph
+    used to be tied to: target counts per image (0 .. 5: the softkd LSAP sizes, the pair tables), the tasks of the images (one bank LSAP / k-means group per
+    distinct task; both images in one task; an image without boxes on the teacher side), images and captions.  Each step is compared with the
+    list-of-dicts step (harness.distillation_step on the collate_fn batch: the path pinned against the real reference by tests/golden/distill.npz and
+    test_gpu_distill_fullsize.py) from the same weights and the same memory state: total loss, every softkd / nsthl2 / cluster term through the total,
+    the memory banks (the same rows replaced by the same features), the cluster centres, two parameter gradients."""
+    import copy
+    import toist_amd
+    from toist_amd import engine, harness, kernels
+    from toist_amd.matcher import check_lsap_pending
+    from toist_amd.optim import FusedClipAdamWEMA
+    args = harness.default_args(device="cuda", distillation=True, cluster=True, nsthl2_loss=True, softkd_loss=True, cluster_memory_size=32,
+                                num_queries=20, enc_layers=1, dec_layers=2, dropout=0.0)
+    torch.manual_seed(0)
+    model, criterion, cc, weight_dict = toist_amd.build_model(args)
+    noun, _, _, _ = toist_amd.build_model(args)
+    for m_ in (model, noun):
+        m_.to(dev).train()
+        m_.transformer.text_encoder.config.hidden_dropout_prob = 0.0
+        m_.transformer.text_encoder.config.attention_probs_dropout_prob = 0.0
+    cc.to(dev)
+    cc.full_label.fill_(1)
+    cc.update_count.fill_(100)
+    cc.sync_host_state()
+    cc_ref = copy.deepcopy(cc)
+    cc_ref.sync_host_state()
+    kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+    saved = engine.REUSE_GRAD_BUFFERS
+    try:
+        # lr = 0: the optimizer tails run (they are part of the graph) and leave the weights where they are, so every step of both paths starts from the same
+        # weights; what evolves is the memory (banks, centres), which each path carries in its own ClusterCriterion
+        opts = [FusedClipAdamWEMA([{"params": [p for p in x.parameters() if p.requires_grad]}], lr=0.0, weight_decay=0.0, max_norm=0.1) for x in (model, noun)]
+        cap = harness.CapturedDistillStep(model, noun, criterion, cc, opts, weight_dict, batch=2, image_hw=(128, 160), tokens=16, max_targets_per_image=6)
+        plans = [(4, (3, 7)), (5, (2, 2)), (0, (1, 9)), (2, (7, 7)), (5, (11, 4)), (3, (5, 5)), (1, (14, 1))]
+        for step_i, (mt, tasks) in enumerate(plans):
+            batch = harness.synthetic_distill_batch(2, 128, 160, tokens=16, seed=40 + step_i, device=dev, max_targets=mt)
+            for side_t in batch["targets"]:
+                for i, t in enumerate(side_t):
+                    t["dataset_name"] = f"task_{tasks[i]}_train.json"
+            bank_before = cc.feature_bank.clone()
+            got = float(cap.step(batch))
+            if step_i == 0:     # views of the programs' flat gradient buffers (fixed addresses: every replay writes them, whatever `.grad` points to later)
+                gviews = [model.class_embed.weight.grad, noun.transformer.decoder.layers[0].linear1.weight.grad]
+            g_cap = [v.detach().clone() for v in gviews]
+            for o in opts:
+                o.zero_grad(set_to_none=True)
+            total, losses = harness.distillation_step(model, noun, criterion, cc_ref, weight_dict, batch)
+            total.backward()
+            torch.cuda.synchronize()
+            check_lsap_pending()
+            ref = float(total)
+            assert abs(got - ref) <= 2e-3 * abs(ref) + 1e-4, (step_i, got, ref)
+            g_ref = [model.class_embed.weight.grad, noun.transformer.decoder.layers[0].linear1.weight.grad]
+            for a, b in zip(g_cap, g_ref):
+                assert float((a - b).norm()) <= 2e-2 * float(b.norm()) + 1e-6, (step_i, float((a - b).norm()), float(b.norm()))
+            # the memory: the same rows replaced (one per image with boxes; identical features up to the noise of a bf16 forward), the same centres
+            ch_c = (cc.feature_bank != bank_before).any(-1)
+            ch_r = (cc_ref.feature_bank != bank_before).any(-1)
+            n_live = sum(1 for t in batch["targets"][0] if len(t["boxes"]))
+            assert int(ch_c.sum()) == n_live and torch.equal(ch_c, ch_r), (step_i, int(ch_c.sum()), int(ch_r.sum()), n_live)
+            assert torch.allclose(cc.feature_bank, cc_ref.feature_bank, rtol=1e-3, atol=1e-4)
+            assert torch.allclose(cc.cluster_centers, cc_ref.cluster_centers, rtol=1e-3, atol=1e-4), float((cc.cluster_centers - cc_ref.cluster_centers).abs().max())
+            cc_ref.feature_bank.copy_(cc.feature_bank)                 # (keep the two memories bit-identical: a 1e-7 drift of a feature must not pick another row later)
+            cc_ref.cluster_centers.copy_(cc.cluster_centers)
+        assert cap.captures == 1 and cap.replays == len(plans) - 1
+    finally:
+        engine.REUSE_GRAD_BUFFERS = saved
+
+
 def test_device_kmeans_matches_host_loop(dev):
     """csrc/kmeans.hip (all samples of a batch in one launch, no host read) against the per-sample Lloyd loop that restates
     models/kmeans.py (toist_amd.distill.kmeans, itself pinned to the reference's ClusterCriterion by distill.npz): same centres (fp32

@@ -162,13 +162,15 @@ def test_register_resident_lsap_on_ties_shapes_and_infinities(dev):
             m = torch.randint(0, 2, (r, c), generator=g).float()
         elif kind == 2:
             m = torch.rand(r, c, generator=g)
-            m[:, c // 2:] = m[:, :c - c // 2]                       # duplicated columns
+            m[:, c // 2:] = m[:, :c - c // 2].clone()               # duplicated columns
         elif kind == 3:
             m = torch.rand(r, c, generator=g).round(decimals=1)
-            m[r // 2:] = m[:r - r // 2]                             # duplicated rows
+            m[r // 2:] = m[:r - r // 2].clone()                     # duplicated rows
         elif kind == 4:
             m = torch.rand(r, c, generator=g) - 0.5
             m[torch.rand(r, c, generator=g) < 0.3] = float("inf")
+            if (k_ // 6) % 3 == 0:
+                m[0, :] = float("inf")                              # a row that cannot be assigned: infeasible whenever rows <= columns
         else:
             m = torch.rand(r, c, generator=g) * 100 - 50
         costs.append(m)
@@ -187,4 +189,4 @@ def test_register_resident_lsap_on_ties_shapes_and_infinities(dev):
             continue
         assert st == 0, (m.shape, st)
         assert np.array_equal(ri[o:o + n], rr) and np.array_equal(ci[o:o + n], cc), m.shape
-    assert 0 < n_inf < 60
+    assert n_inf > 0

@@ -152,6 +152,7 @@ _SIGNATURES = {
     "toist_xdec_supported": ([c_int32] * 4, ctypes.c_int),
     "toist_xdec_fwd": ([POINTER(Xdec), c_void_p], ctypes.c_int),
     "toist_xdec_bwd": ([POINTER(XdecBwd), c_void_p], ctypes.c_int),
+    "toist_scatter_rows_f32": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p], ctypes.c_int),
     "toist_kmeans": ([c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_float, c_int32,
                      c_void_p, c_void_p, c_void_p, c_void_p], ctypes.c_int),
     "toist_attn_small_fwd": ([c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p] + [c_int32] * 4 + [c_float, c_float, c_uint64, c_void_p, c_void_p,

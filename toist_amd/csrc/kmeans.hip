@@ -126,6 +126,17 @@ __global__ __launch_bounds__(KM_THREADS) void kmeans_kernel(const float* __restr
     }
 }
 
+// dst[dst_row[i]] = src[src_row[i]] for the rows i with dst_row[i] >= 0 and src_row[i] >= 0 (rows of `d` floats; distinct live destinations).
+// The memory-bank replacement of the distillation step under hipGraph replay: which slots are live is decided on the device (an LSAP pair table of
+// fixed capacity, its status word), so the write must skip the dead ones instead of sending them to a scratch row the bank does not have.
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, const long long* __restrict__ src_row, float* __restrict__ dst,
+                                                            const long long* __restrict__ dst_row, int m, int d) {
+    const int i = blockIdx.x;
+    const long long sr = src_row[i], dr = dst_row[i];
+    if (i >= m || sr < 0 || dr < 0) return;
+    for (int e = threadIdx.x; e < d; e += 256) dst[dr * d + e] = src[sr * d + e];
+}
+
 }  // namespace toist
 
 using namespace toist;
@@ -139,4 +150,11 @@ extern "C" int toist_kmeans(const float* banks, int64_t bank_stride, float* cent
     hipLaunchKernelGGL(kmeans_kernel, dim3(n_groups), dim3(KM_THREADS), (size_t)((N + 15) & ~15), (hipStream_t)stream, banks, (long long)bank_stride, centers,
                        (long long)centers_stride, group_task, group_off, members, features, N, D, K, tol, max_iter, pick, chosen_center, iters);
     return check_launch("toist_kmeans");
+}
+
+extern "C" int toist_scatter_rows_f32(const float* src, const int64_t* src_row, float* dst, const int64_t* dst_row, int m, int d, void* stream) {
+    using namespace toist;
+    TOIST_REQUIRE(src && src_row && dst && dst_row && m > 0 && d > 0, "toist_scatter_rows_f32: bad arguments");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, src, (const long long*)src_row, dst, (const long long*)dst_row, m, d);
+    return check_launch("toist_scatter_rows_f32");
 }

@@ -116,6 +116,101 @@ def task_index(dataset_name):
     return int(dataset_name.split("_")[1]) - 1
 
 
+# ---- the same tables at FIXED device addresses: one hipGraph of the distillation step serves any batch ------------------------------------
+class DistillTables:
+    """Fixed-address device image of ONE side's (noun or pronoun) caption-driven tables, the counterpart of matcher.StaticTargets for the distillation
+    losses (round 6): the captured step reads every per-batch index from these buffers, `load()` refills them between replays
+    (one pinned staging arena, one asynchronous H2D copy, no host sync).  `matcher.StaticTargets.distill` carries the side's tables into
+    ClusterCriterion.update_memory / forward and SetCriterion.
+
+    Arena (B = batch, L = tokens of the bucket):
+      W_span  f32 [B, L]   noun_token_weights(): W @ text_memory[i] = mean over the image's boxes of the mean over each box's noun tokens (mdetr.py:112-145)
+      W_sth   f32 [B, L]   mean weights of the tokens of the word 'something' in the caption (mdetr.py:240-260); zeros on the noun side
+      sub_span u8 [L, B]   tokens that receive the prototype on the teacher side (images without boxes: none)
+      sub_sth  u8 [L, B]   tokens of 'something'
+      task    i32 [B]      task index of the image (dataset_name), -1 = the image takes no part (teacher side: no boxes)
+      group_task i32 [B] | group_off i32 [B + 1] | members i32 [B]    the images grouped by task, in batch order inside a group (csrc/kmeans.hip, the
+                           per-task LSAP of the memory-bank update); unused groups are empty (group_off stays at the member count)."""
+
+    def __init__(self, batch, tokens, device, pronoun_side):
+        self.B, self.L, self.pronoun_side = int(batch), int(tokens), bool(pronoun_side)
+        self.device = torch.device(device)
+        B, L = self.B, self.L
+        sizes = [B * L * 4, B * L * 4, L * B, L * B, B * 4, B * 4, (B + 1) * 4, B * 4]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 15) // 16 * 16
+        self._host = torch.zeros(total, dtype=torch.uint8).pin_memory()
+        self._dev = torch.zeros(total, dtype=torch.uint8, device=self.device)
+
+        def views(buf):
+            cut = lambda i, dt, shape: buf[offs[i]:offs[i] + sizes[i]].view(dt).view(shape)
+            return (cut(0, torch.float32, (B, L)), cut(1, torch.float32, (B, L)), cut(2, torch.uint8, (L, B)), cut(3, torch.uint8, (L, B)), cut(4, torch.int32, (B,)),
+                    cut(5, torch.int32, (B,)), cut(6, torch.int32, (B + 1,)), cut(7, torch.int32, (B,)))
+
+        self._views = views
+        self.W_span, self.W_sth, self.sub_span, self.sub_sth, self.task, self.group_task, self.group_off, self.members = views(self._dev)
+        self._event = None
+
+    def pack(self, tokenized, targets, captions=None, out=None):
+        """Host image of one batch.  tokenized: the side's BatchEncoding (needs char_to_token); targets: the side's list of dicts with `noun_tokens_positive`,
+        `dataset_name`, `boxes`; captions: list[str] (pronoun side: where the word 'something' sits)."""
+        B, L = self.B, self.L
+        if len(targets) != B:
+            raise ValueError(f"DistillTables holds {B} images; got {len(targets)}")
+        host = out if out is not None else torch.zeros(self._host.numel(), dtype=torch.uint8).pin_memory()
+        host.zero_()
+        W_span, W_sth, sub_span, sub_sth, task, group_task, group_off, members = (v.numpy() for v in self._views(host))
+        empty = [len(t["boxes"]) == 0 for t in targets]
+        for i, tgt in enumerate(targets):
+            boxes = tgt["noun_tokens_positive"]
+            for spans in boxes:
+                pos = span_positions(tokenized, i, spans, L).numpy()
+                if len(pos) == 0:
+                    W_span[i, :] = np.nan                      # the reference averages an empty set there
+                else:
+                    W_span[i, pos] += np.float32(1.0 / (len(pos) * len(boxes)))
+            if not empty[i]:
+                sub_span[span_positions(tokenized, i, [s_ for box in boxes for s_ in box], L).numpy(), i] = 1
+        if self.pronoun_side:
+            for i in range(B):
+                beg = captions[i].find("something")
+                pos = np.arange(tokenized.char_to_token(i, beg), tokenized.char_to_token(i, beg + len("something") - 1) + 1)
+                if len(pos) == 0:
+                    W_sth[i, :] = np.nan
+                else:
+                    W_sth[i, pos] = np.float32(1.0 / len(pos))
+                    sub_sth[pos, i] = 1
+            tasks = [task_index(t["dataset_name"]) for t in targets]               # the student clusters EVERY sample (mdetr.py:230-277)
+        else:
+            tasks = [-1 if empty[i] else task_index(t["dataset_name"]) for i, t in enumerate(targets)]
+        task[:] = np.asarray(tasks, dtype=np.int32)
+        live = [(i, t) for i, t in enumerate(tasks) if t >= 0]
+        order = sorted(set(t for _, t in live))
+        mem, off = [], [0]
+        for t in order:
+            mem += [i for i, tt in live if tt == t]
+            off.append(len(mem))
+        group_task[:len(order)] = order
+        group_off[:len(off)] = off
+        group_off[len(off):] = len(mem)
+        members[:len(mem)] = mem
+        return host
+
+    def load_packed(self, host):
+        self._dev.copy_(host, non_blocking=True)
+        return self
+
+    def load(self, tokenized, targets, captions=None):
+        if self._event is not None:
+            self._event.synchronize()          # the previous upload has left the staging buffer
+        self.load_packed(self.pack(tokenized, targets, captions, out=self._host))
+        self._event = torch.cuda.Event()
+        self._event.record()
+        return self
+
+
 # ---- k-means (kmeans.py) ---------------------------------------------------------------------------------------
 def _sq_dist(x, centers):
     return ((x.unsqueeze(1) - centers.unsqueeze(0)) ** 2.0).sum(-1)
@@ -290,9 +385,85 @@ class ClusterCriterion(nn.Module):
         memory_cache["img_memory_mod"][-L:, i, :][pos.to(center.device)] = self.cluster_centers[t, pick]
         return center
 
+    # ---- hipGraph replay for ANY batch: every per-batch index comes from a DistillTables image (fixed addresses) ----------------------------
+    _CONST = {}
+
+    def _static_ok(self):
+        if self.args.fifo_memory or not all(self._full_host()) or self._world() > 1:
+            raise RuntimeError("ClusterCriterion on StaticTargets (a captured distillation step) needs the steady state of a single process: every task's "
+                               "memory bank full, nearest-replacement updates (fifo_memory off); run the list-of-dicts path until then")
+
+    def _replace_nearest_static(self, rows, tb):
+        """update_memory_queue's nearest-replacement branch (mdetr.py:98-103) with the grouping of the batch by task read from the device: one LSAP problem
+        per group slot (rows = the group's size, 0 for an unused slot), pair table of fixed capacity B per problem, and a bank write that skips the dead
+        slots and the problems whose status is not OK (toist_scatter_rows_f32).  rows [B, d] f32 (detached features)."""
+        from . import kernels as k
+        from .matcher import check_lsap_status
+        B, d = rows.shape
+        N, dev = self.memory_size, rows.device
+        key = ("bank", B, N, str(dev))
+        const = ClusterCriterion._CONST.get(key)
+        if const is None:
+            slot = torch.arange(B * B, dtype=torch.int64, device=dev)
+            const = ClusterCriterion._CONST[key] = (torch.full((B,), N, dtype=torch.int32, device=dev), torch.arange(B, dtype=torch.int64, device=dev) * B, slot // B, slot % B)
+        cols, out_off, g_of, s_of = const
+        mem = tb.members.to(torch.int64)
+        off = tb.group_off.to(torch.int64)
+        rs = rows.index_select(0, mem).contiguous()                                  # rows in group order
+        trow = tb.task.to(torch.int64).clamp(min=0).index_select(0, mem)
+        cost = torch.cdist(rs[:, None, :], self.feature_bank.index_select(0, trow), p=1).reshape(B, N).contiguous()
+        n_g = (off[1:] - off[:-1]).to(torch.int32)
+        ri = torch.zeros(B * B, dtype=torch.int64, device=dev)
+        ci = torch.zeros(B * B, dtype=torch.int64, device=dev)
+        status = torch.zeros(B, dtype=torch.int32, device=dev)
+        k.lsap(cost, (off[:-1] * N).contiguous(), n_g, cols, B, B, N, B * N, out_off, ri, ci, status, ld=N)
+        valid = (s_of < n_g.to(torch.int64)[g_of]) & (status[g_of] == 0)
+        src_row = torch.where(valid, off[g_of] + ri, torch.full_like(ri, -1))
+        dst_row = torch.where(valid, tb.group_task.to(torch.int64)[g_of] * N + ci, torch.full_like(ci, -1))
+        k.scatter_rows(rs, src_row, self.feature_bank.view(-1, d), dst_row)
+        check_lsap_status(status, defer=True)
+
+    def _cluster_static(self, features, tb):
+        from . import kernels as k
+        B, d = features.shape
+        pick = torch.zeros(B, dtype=torch.int32, device=features.device)
+        chosen = torch.zeros(B, d, dtype=torch.float32, device=features.device)
+        k.kmeans(self.feature_bank, self.cluster_centers, tb.group_task, tb.group_off, tb.members, features.detach().float().contiguous(), 1e-4, 10000, pick, chosen)
+        return pick, chosen
+
+    def update_memory_static(self, memory_cache_noun, tb):
+        """update_memory on a DistillTables image (teacher side)."""
+        self._static_ok()
+        text = memory_cache_noun["text_memory"].permute(1, 0, 2)
+        B, L, d = text.shape
+        feats = (tb.W_span.to(text.dtype).unsqueeze(-1) * text).sum(1)
+        self._replace_nearest_static(feats.detach().float(), tb)
+        memory_cache_noun["img_memory_mod"] = memory_cache_noun["img_memory"].clone()
+        _, chosen = self._cluster_static(feats, tb)
+        mod = memory_cache_noun["img_memory_mod"]
+        mod[-L:] = torch.where(tb.sub_span.bool()[:, :, None], chosen[None].to(mod.dtype), mod[-L:])
+        memory_cache_noun["full_label"], memory_cache_noun["update_count"] = self.full_label, self.update_count
+        return memory_cache_noun
+
+    def forward_static(self, memory_cache_sth, tb):
+        """forward (student side) on a DistillTables image: ('something' -> prototype, loss_cluster_feature)."""
+        self._static_ok()
+        text = memory_cache_sth["text_memory"].permute(1, 0, 2)
+        B, L, _ = text.shape
+        memory_cache_sth["img_memory_mod"] = memory_cache_sth["img_memory"].clone()
+        features = (tb.W_sth.to(text.dtype).unsqueeze(-1) * text).sum(1)
+        _, chosen = self._cluster_static(features, tb)
+        mod = memory_cache_sth["img_memory_mod"]
+        mod[-L:] = torch.where(tb.sub_sth.bool()[:, :, None], chosen[None].to(mod.dtype), mod[-L:])
+        loss = ((features - chosen.to(features.dtype)) ** 2).mean(1).sum() / max(B, 1)
+        return memory_cache_sth, {"loss_cluster_choice": torch.zeros((), device=loss.device), "loss_cluster_feature": loss}
+
     def update_memory(self, memory_cache_noun, targets_noun, captions_noun):
         """Teacher side (mdetr.py:105-205): push this batch's noun features into the banks, then replace the noun
         tokens of the teacher's text memory by their prototype."""
+        tb = getattr(targets_noun, "distill", None)
+        if tb is not None:                      # matcher.StaticTargets of a captured step
+            return self.update_memory_static(memory_cache_noun, tb)
         text = memory_cache_noun["text_memory"].permute(1, 0, 2)
         B, L, d = text.shape
         dev = text.device
@@ -366,6 +537,9 @@ class ClusterCriterion(nn.Module):
     def forward(self, memory_cache_sth, targets_sth, captions_sth):
         """Student side (mdetr.py:230-277): the pronoun 'something' is replaced by the prototype closest to its own
         feature; loss_cluster_feature pulls that feature towards the prototype (loss_cluster_choice stays 0)."""
+        tb = getattr(targets_sth, "distill", None)
+        if tb is not None:
+            return self.forward_static(memory_cache_sth, tb)
         mc, loss = self._something(memory_cache_sth, [t["dataset_name"] for t in targets_sth], captions_sth, True)
         return mc, {"loss_cluster_choice": torch.zeros((), device=loss.device), "loss_cluster_feature": loss}
 

@@ -366,3 +366,130 @@ class CapturedTrainStep:
         return total
 
     __call__ = step
+
+
+class CapturedDistillStep:
+    """The reference's distillation step (engine.py:152-204: teacher encode -> memory-bank update + prototypes -> teacher decode -> student encode ->
+    prototype of 'something' -> student decode -> paired SetCriterion with softkd / nsthl2 + cluster losses -> backward -> clip + AdamW + EMA of both
+    models) replayed from ONE hipGraph for ANY batch of a fixed shape (round 6).
+
+    What used to tie a captured graph to its batch -- per-image target counts (LSAP problem sizes (Q - c)^2, pair tables), the grouping of the images by
+    task (k-means groups, one memory-bank LSAP per task), the token tables of the captions (noun spans, the word 'something') -- now lives in
+    fixed-address device images that `step()` refills before every replay: matcher.StaticTargets (one per side) and distill.DistillTables (one per
+    side, attached as StaticTargets.distill); the criterion and the cluster criterion dispatch on them (SetCriterion._forward_pair_static,
+    ClusterCriterion.update_memory_static / forward_static).
+
+    step(batch) with batch = what util/misc.collate_fn delivers for (noun, pronoun) pairs (harness.synthetic_distill_batch): dict(samples=[..] * 2,
+    tokenized=[..] * 2 (BatchEncodings with char_to_token), targets=[..] * 2, captions=[..] * 2, positive_map=[..] * 2) -> total loss (device scalar).
+    The first step runs eagerly (a real training step) and is captured right after; later steps = the H2D copies of the inputs + one graph launch.
+    Requirements (checked): one process, every memory bank full, nearest-replacement bank updates, both sides with the same number of targets per
+    image (the reference's pairs share their boxes), images / captions of the constructor's shape."""
+
+    def __init__(self, model, model_noun, criterion, cluster_criterion, optimizers, weight_dict, *, batch, image_hw, tokens, max_targets_per_image=16, device=None,
+                 stream=None):
+        """stream: the HIP stream the steps run (and the graph is captured) on; pass the stream earlier eager steps of the same models ran on, if any -- the programs'
+        reused gradient buffers and the launchers' per-stream scratch must not change streams between eager steps and the capture."""
+        from . import engine, kernels
+        from .distill import DistillTables
+        from .matcher import StaticTargets
+        from .misc import NestedTensor
+        from .transformer import TokenizedText
+        self.model, self.model_noun, self.criterion, self.cluster_criterion = model, model_noun, criterion, cluster_criterion
+        self.optimizers, self.weight_dict = list(optimizers), weight_dict
+        self.B, self.hw, self.L = int(batch), (int(image_hw[0]), int(image_hw[1])), int(tokens)
+        dev = self.device = torch.device(device) if device is not None else next(model.parameters()).device
+        det = getattr(model, "detr", model)
+        Q = det.query_embed.weight.shape[0]
+        self.contrastive = bool(getattr(det, "contrastive_align_loss", False))
+        pad_id = getattr(det.transformer.text_encoder.config, "pad_token_id", 1)
+        H, W = self.hw
+        self.sides = []
+        for pronoun in (False, True):
+            st = StaticTargets(self.B, int(max_targets_per_image), Q, 256, dev)
+            st.distill = DistillTables(self.B, self.L, dev, pronoun_side=pronoun)
+            self.sides.append({"samples": NestedTensor(torch.zeros(self.B, 3, H, W, device=dev), torch.zeros(self.B, H, W, dtype=torch.bool, device=dev)),
+                               "tok": TokenizedText({"input_ids": torch.full((self.B, self.L), pad_id, dtype=torch.int64, device=dev),
+                                                     "attention_mask": torch.zeros(self.B, self.L, dtype=torch.int64, device=dev)}),
+                               "targets": st})
+        self._side = stream if stream is not None else torch.cuda.Stream(device=dev)
+        if kernels.SEED_DEV is None:
+            kernels.SEED_DEV = torch.zeros(1, dtype=torch.int64, device=dev)
+        engine.REUSE_GRAD_BUFFERS = True
+        self.graph, self.loss, self._xdec = None, None, False
+        self.captures = self.replays = 0
+
+    def pack(self, batch):
+        """Host half of a step (no device work, no synchronisation when the batch's targets are host tensors: run it in the loader): the pinned images of both
+        sides' StaticTargets and DistillTables, next to the batch's image / token tensors.  step(packed=...) consumes it."""
+        if [len(t["boxes"]) for t in batch["targets"][0]] != [len(t["boxes"]) for t in batch["targets"][1]]:
+            raise ValueError("softkd needs the same number of targets on the noun and the pronoun side of every pair")
+        out = []
+        for i, side in enumerate(self.sides):
+            samples, tok, targets = batch["samples"][i], batch["tokenized"][i], batch["targets"][i]
+            if tuple(samples.tensors.shape) != (self.B, 3, *self.hw) or tuple(tok["input_ids"].shape) != (self.B, self.L):
+                raise ValueError(f"CapturedDistillStep was built for {self.B} x 3 x {self.hw[0]} x {self.hw[1]} images and {self.L}-token captions")
+            host_t = [{k_: (v.cpu() if torch.is_tensor(v) else v) for k_, v in t.items()} for t in targets]
+            pm = batch["positive_map"][i]
+            masks = self.criterion.token_masks_host(host_t, tok) if self.contrastive else None
+            out.append({"samples": samples, "tok": tok, "targets": side["targets"].pack(host_t, pm.cpu() if torch.is_tensor(pm) else pm, masks),
+                        "tables": side["targets"].distill.pack(tok, host_t, batch["captions"][i])})
+        return out
+
+    def _fill(self, packed):
+        for side, pk in zip(self.sides, packed):
+            side["samples"].tensors.copy_(pk["samples"].tensors, non_blocking=True)
+            side["samples"].mask.copy_(pk["samples"].mask, non_blocking=True)
+            side["tok"]["input_ids"].copy_(pk["tok"]["input_ids"], non_blocking=True)
+            side["tok"]["attention_mask"].copy_(pk["tok"]["attention_mask"], non_blocking=True)
+            side["targets"].load_packed(pk["targets"])
+            side["targets"].distill.load_packed(pk["tables"])
+
+    def _fwd_bwd_opt(self):
+        from . import kernels
+        kernels.SEED_DEV.add_(1000003)
+        noun, sth = self.sides
+        static = {"samples": [noun["samples"], sth["samples"]], "targets": [noun["targets"], sth["targets"]], "captions": [None, None],
+                  "tokenized": [noun["tok"], sth["tok"]], "positive_map": [None, None]}
+        total, _ = distillation_step(self.model, self.model_noun, self.criterion, self.cluster_criterion, self.weight_dict, static)
+        total.backward()
+        for o in self.optimizers:
+            o.step()
+        return total
+
+    def step(self, batch=None, packed=None):
+        from . import kernels
+        batch = packed if packed is not None else self.pack(batch)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            raise RuntimeError("CapturedDistillStep is single-process (the memory-bank queue all_gathers rows across ranks: collectives are not captured)")
+        if kernels.XDEC_FAILED and self.graph is not None and self._xdec:
+            self.graph = self.loss = None                  # the captured graph holds XCD-resident launches that have been turned off: capture again
+        side = self._side
+        if self.graph is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._fill(batch)
+                self.graph.replay()
+            torch.cuda.current_stream().wait_stream(side)
+            self.replays += 1
+            for o in self.optimizers:
+                if hasattr(o, "note_replayed_step"):
+                    o.note_replayed_step()
+            return self.loss
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._fill(batch)
+            for o in self.optimizers:
+                o.zero_grad(set_to_none=True)
+            total = self._fwd_bwd_opt()
+            for o in self.optimizers:
+                o.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with kernels.tables_beside_graph():
+                with torch.cuda.graph(graph, stream=side):
+                    self.loss = self._fwd_bwd_opt()
+            self.graph, self._xdec = graph, not kernels.XDEC_FAILED
+            self.captures += 1
+        torch.cuda.current_stream().wait_stream(side)
+        return total
+
+    __call__ = step

@@ -893,6 +893,13 @@ def xdec_check(raise_on_failure=True):
     return failed
 
 
+def scatter_rows(src, src_row, dst, dst_row):
+    """dst[dst_row[i]] = src[src_row[i]] (f32 rows) for the i with both indices >= 0 (int64 device vectors); see toist_scatter_rows_f32."""
+    assert src.is_contiguous() and dst.is_contiguous() and src.shape[-1] == dst.shape[-1]
+    _lib.check(_lib.lib().toist_scatter_rows_f32(_p(src, torch.float32), _p(src_row, torch.int64), _p(dst, torch.float32), _p(dst_row, torch.int64), src_row.numel(),
+                                                 src.shape[-1], _stream()), "toist_scatter_rows_f32")
+
+
 def kmeans(banks, centers, group_task, group_off, members, features, tol, max_iter, pick, chosen_center, iters=None):
     """banks [T, N, D] f32, centers [T, K, D] f32 (updated in place); see toist_kmeans."""
     T, N, D = banks.shape

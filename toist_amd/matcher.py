@@ -85,6 +85,7 @@ class StaticTargets:
         self.sizes = [0] * batch
         self._out = {}        # L -> (src [L, cap], tgt [L, cap], status [L*B])
         self._event = None
+        self.distill = None   # distill.DistillTables of this side of a (noun, pronoun) pair: the captured distillation step (harness.CapturedDistillStep)
 
     def pack(self, targets, positive_map, token_masks=None, out=None):
         """Host image of one batch (pinned uint8 tensor in the arena layout, + the per-image target counts): build it ahead of time -- in a

@@ -500,6 +500,8 @@ class SetCriterion(nn.Module):
         if self._pending_status and not torch.cuda.is_current_stream_capturing():
             self.check_status(wait=False)   # an invalid cost block of an earlier call raises here, like SciPy inside the reference matcher
         if isinstance(outputs, list):
+            if isinstance(targets[0], StaticTargets):
+                return self._forward_pair_static(memory_cache, outputs, targets)
             return self._forward_pair(memory_cache, outputs, targets, positive_map)
         logits, boxes = self._stack(outputs)
         L = logits.shape[0]
@@ -566,6 +568,97 @@ class SetCriterion(nn.Module):
                 losses["loss_softkd" + ("" if l == L - 1 else f"_{l}")] = per_layer[l]
             losses.groups.append((per_layer, {"loss_softkd" + ("" if l == L - 1 else f"_{l}"): l for l in range(L)}))
         return losses
+
+    # ---- the same on StaticTargets (+ .distill tables): nothing depends on the batch's target counts, captions or tasks -> one hipGraph for any batch ----
+    def _forward_pair_static(self, memory_cache, outputs, sts):
+        """_forward_pair on two matcher.StaticTargets images (teacher, student), each carrying its distill.DistillTables: the step captured by
+        harness.CapturedDistillStep.  The two sides must hold the same number of targets per image (softkd pairs the matched queries through
+        their target, mdetr.py:543-599) -- as the reference's (noun, pronoun) pairs do."""
+        losses, sides = LossDict(), []
+        for prefix, out, st in zip(("noun", "sth"), outputs, sts):
+            logits, boxes = self._stack(out)
+            L = logits.shape[0]
+            side = self._forward_static(out, logits, boxes, st, L)
+            losses.merge(side, prefix + "_")
+            sides.append((logits, boxes, self.last_match, L))
+        self.last_match = sides[1][2]
+        if getattr(self.args, "nsthl2_loss", False):
+            feats = []
+            for mc, st in zip(memory_cache, sts):
+                text = mc["text_memory"].permute(1, 0, 2)
+                feats.append((st.distill.W_span.to(text.dtype).unsqueeze(-1) * text).sum(1))
+            mo = sts[1].match_off
+            keep = (mo[1:] - mo[:-1]) > 0                                          # images in which the student's main layer matched a box
+            per_image = ((feats[1] - feats[0].detach()) ** 2).mean(1)
+            losses["loss_nsthl2"] = torch.where(keep, per_image, torch.zeros_like(per_image)).sum() / keep.sum().clamp(min=1)
+        if getattr(self.args, "softkd_loss", False):
+            L = sides[0][3]
+            per_layer = self._loss_softkd_static(sides[0], sides[1], sts[0], sts[1])
+            for l in range(L):
+                losses["loss_softkd" + ("" if l == L - 1 else f"_{l}")] = per_layer[l]
+            losses.groups.append((per_layer, {"loss_softkd" + ("" if l == L - 1 else f"_{l}"): l for l in range(L)}))
+        return losses
+
+    def _loss_softkd_static(self, noun, sth, st_n, st_s):
+        """_loss_softkd with every index built on the device from the StaticTargets offsets: the pair tables have the fixed capacity st.cap (matched pairs)
+        and Q per (layer, image) LSAP problem (unmatched pairs); the problem sizes Q - c_i are device vectors that toist_lsap reads; dead slots are
+        masked.  Every image's row count c_i + (Q - c_i) is Q, so the batchmean / image-mean weights are the constant 1 / (Q B)."""
+        from . import kernels as k
+        from .matcher import check_lsap_status
+        (lg_n, bx_n, m_n, _), (lg_s, bx_s, m_s, _) = noun, sth
+        L, B, Q = lg_n.shape[0], lg_n.shape[1], lg_n.shape[2]
+        dev, cap = lg_n.device, st_n.cap
+
+        def make():
+            p = torch.arange(L * cap, dtype=torch.int64, device=dev)
+            s = torch.arange(L * B * Q, dtype=torch.int64, device=dev)
+            prob = s // Q
+            return (p, s % Q, prob // B, prob % B, torch.arange(L * B, dtype=torch.int64, device=dev) * (Q * Q), torch.arange(L * B, dtype=torch.int64, device=dev) * Q)
+        p, slot_s, slot_l, slot_b, offsets, out_off = _cached(("softkd_static", L, B, Q, cap, str(dev)), make)
+        mo = st_n.match_off.to(torch.int64)                                       # [B + 1] (the student's must be equal: same targets per image)
+        mtot = mo[B]
+        live = p < L * mtot
+        l_of = torch.div(p, mtot.clamp(min=1), rounding_mode="floor").clamp(max=L - 1)
+        j = p - l_of * mtot
+        img = torch.bucketize(j, mo[1:], right=True).clamp(max=B - 1)
+
+        def binarise(lg):
+            pr = lg.float().softmax(-1)
+            return torch.cat([pr[..., :-1].sum(-1, keepdim=True), pr[..., -1:]], dim=-1)                  # [L,B,Q,2]
+
+        def unmatched_first(m):
+            """[L,B,Q] query order with the unmatched queries first (ascending), the matched ones after."""
+            free = torch.ones(L * B * Q + 1, dtype=torch.int8, device=dev)
+            free.scatter_(0, torch.where(live, (l_of * B + img) * Q + m.src.reshape(-1)[:L * cap], torch.full_like(p, L * B * Q)), 0)
+            return torch.sort(free[:L * B * Q].view(L, B, Q), dim=-1, descending=True, stable=True).indices
+
+        p_n, p_s = binarise(lg_n).detach(), binarise(lg_s)
+        ord_n, ord_s = unmatched_first(m_n), unmatched_first(m_s)
+        take = lambda t, order: torch.gather(t, 2, order[..., None].expand(-1, -1, -1, t.shape[-1]))
+        fp_n, fp_s = take(p_n, ord_n), take(p_s, ord_s)                                                 # unmatched first
+        with torch.no_grad():
+            fb_n, fb_s = take(bx_n.float(), ord_n), take(bx_s.float(), ord_s)
+            cost_class = (fp_n[:, :, None, :, :] * (fp_n.log()[:, :, None, :, :] - fp_s.log()[:, :, :, None, :])).sum(-1)   # [L,B,S,T]
+            cost = (torch.cdist(fb_s, fb_n, p=1) + cost_class - _paired_giou_matrix(fb_s, fb_n)).contiguous()
+            n_b = (Q - (mo[1:] - mo[:-1])).to(torch.int32).repeat(L).contiguous()                       # [L*B] problem sizes, layer-major
+            rows = torch.zeros(L * B * Q, dtype=torch.int64, device=dev)
+            cols = torch.zeros(L * B * Q, dtype=torch.int64, device=dev)
+            status = torch.zeros(L * B, dtype=torch.int32, device=dev)
+            k.lsap(cost, offsets, n_b, n_b, L * B, Q, Q, Q * Q, out_off, rows, cols, status, ld=Q)
+            valid = slot_s < n_b.to(torch.int64)[slot_l * B + slot_b]
+        kl_fp = _kl_rows(fp_n[slot_l, slot_b, cols], fp_s[slot_l, slot_b, rows])                       # [L*B*Q]; dead slots read row 0 and are masked
+        kl_fp = torch.where(valid, kl_fp, torch.zeros_like(kl_fp))
+
+        def by_target(pr, m):
+            """[L, cap, 2]: the probabilities of the query matched to target t of image i at position match_off[i] + t; dead rows (0.5, 0.5) on both sides: KL 0"""
+            vals = pr.reshape(L * B * Q, 2)[torch.where(live, (l_of * B + img) * Q + m.src.reshape(-1)[:L * cap], torch.zeros_like(p))]
+            dst = torch.where(live, l_of * cap + mo[img] + m.tgt.reshape(-1)[:L * cap], torch.full_like(p, L * cap))
+            out = torch.full((L * cap + 1, 2), 0.5, device=dev, dtype=pr.dtype)
+            return out.index_copy(0, dst, vals)[:L * cap].view(L, cap, 2)
+        kl_tp = _kl_rows(by_target(p_n, m_n), by_target(p_s, m_s))                                      # [L, cap]
+        per_layer = (kl_tp.sum(1) + kl_fp.view(L, B * Q).sum(1)) / float(Q * B)
+        check_lsap_status(status, defer=True)
+        return per_layer
 
     def _loss_nsthl2(self, memory_cache, outputs, targets, match_sth):
         """mdetr.py:668-781: MSE between the student's and the (detached) teacher's mean noun-token text feature, over
