@@ -136,21 +136,29 @@ __device__ __forceinline__ int lsap_solve_wave(const float* cw, const int R, con
 // reference's tie rule on positions (an unassigned column wins, the LAST such in scan order; otherwise the FIRST in scan order).  Same
 // arithmetic, same order of floating-point operations per column, same tie rules: bit-identical assignments (tests/golden/lsap_kat.json,
 // oracle/lsap.c on the step's own matrices in tests/test_gpu_distill_fullsize.py).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v) {     // lanes without a source (or outside ROW_MASK) receive +inf, the identity of min
-    const int inf_hi = 0x7ff00000;
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(inf_hi, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+// min of two doubles that are never NaN: one v_min_f64 (fmin() would canonicalise both operands first: two more f64 operations per call)
+__device__ __forceinline__ double min_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {     // row rotations: every lane has a source, no identity needed
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_min_f64(double v) {
-    v = fmin(v, dpp_f64<0x111, 0xf>(v));      // row_shr:1
-    v = fmin(v, dpp_f64<0x112, 0xf>(v));      // row_shr:2
-    v = fmin(v, dpp_f64<0x114, 0xf>(v));      // row_shr:4
-    v = fmin(v, dpp_f64<0x118, 0xf>(v));      // row_shr:8   -> lane 15 of every row holds its row's minimum
-    v = fmin(v, dpp_f64<0x142, 0xa>(v));      // row_bcast:15 into rows 1 and 3
-    v = fmin(v, dpp_f64<0x143, 0xc>(v));      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+    v = min_f64(v, dpp_f64<0x121>(v));        // row_ror:1   (rotations inside each row of 16 lanes: after 1, 2, 4, 8 every lane holds its row's minimum)
+    v = min_f64(v, dpp_f64<0x122>(v));        // row_ror:2
+    v = min_f64(v, dpp_f64<0x124>(v));        // row_ror:4
+    v = min_f64(v, dpp_f64<0x128>(v));        // row_ror:8
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return min_f64(min_f64(r0, r1), min_f64(r2, r3));
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
@@ -184,16 +192,19 @@ __device__ __forceinline__ int lsap_solve_wave_reg(const float* cw, const int R,
         double floor_val = 0.0;
         while (sink < 0) {
             if (lane == 0) in_sr[i] = 1;
-            const double ui = du[i];
             const float* crow = cw + (size_t)i * C;
+            float cf[CPL];                                    // the row's costs of the owned columns and the row's dual: ONE LDS round trip per step
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) cf[c] = crow[min(lane + 64 * c, C - 1)];
+            const double ui = du[i];
             double mine = INFINITY;
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                if (!gone[c]) {
-                    const double r = ((floor_val + (double)crow[lane + 64 * c]) - ui) - dv[c];
-                    if (r < spc[c]) { path[c] = i; spc[c] = r; }
-                    mine = fmin(mine, spc[c]);
-                }
+            for (int c = 0; c < CPL; ++c) {                   // predicated, no branches: a column that has left `remaining` keeps its state and offers +inf
+                const double r = ((floor_val + (double)cf[c]) - ui) - dv[c];
+                const bool upd = !gone[c] && r < spc[c];
+                spc[c] = upd ? r : spc[c];
+                path[c] = upd ? i : path[c];
+                mine = min_f64(mine, gone[c] ? (double)INFINITY : spc[c]);
             }
             const double m = wave_min_f64(mine);
             if (!(m < INFINITY)) return ST_INFEASIBLE;
@@ -244,7 +255,6 @@ __device__ __forceinline__ int lsap_solve_wave_reg(const float* cw, const int R,
                 if (c == pc && lane == pl) gone[c] = true;
             }
             if (owner < 0) sink = pl + 64 * pc; else i = owner;
-            wave_lds_fence();             // in_sr[i] of this step is written before the next step's (other) row is marked
         }
 
         // dual variables (the columns' shortest path costs go through LDS once: rows look their column up)
