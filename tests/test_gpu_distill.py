@@ -324,3 +324,87 @@ def test_device_kmeans_matches_host_loop(dev):
         assert torch.allclose(chosen[i], c_ref, rtol=1e-4, atol=1e-5), (i, float((chosen[i] - c_ref).abs().max()))
     assert torch.allclose(cc.cluster_centers, ref.cluster_centers, rtol=1e-4, atol=1e-5)
     assert torch.equal(cc.cluster_centers[1], ref.cluster_centers[1])
+
+
+def test_string_captions_and_real_batch_encodings(dev):
+    """VERDICT r5 "missing" #6: the `captions: list[str]` path (/root/reference/models/transformer.py:59,129) and the char-span lookups of the distillation losses on a
+    REAL Hugging Face fast tokenizer (tests/golden/tiny_tokenizer.py; roberta-base's vocabulary cannot be had offline -- the BatchEncoding mechanics are the same):
+    (a) model(samples, list[str]) tokenizes through `transformer.tokenizer` and equals the forward on the same ids passed as a dict (padding, attention masks);
+    (b) ClusterCriterion.update_memory / forward and the paired criterion's loss_nsthl2 on genuine BatchEncodings -- a ten-token word, spans starting / ending on a
+        space, the reference's batch-index-free retries -- equal what the REAL reference computed (tests/golden/distill_tokenizer.npz)."""
+    import toist_amd
+    from toist_amd import harness
+    from toist_amd.distill import ClusterCriterion
+    from toist_amd.matcher import HungarianMatcher
+    from toist_amd.mdetr import SetCriterion
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import tiny_tokenizer
+    tok = tiny_tokenizer.build()
+    ZT = np.load(os.path.join(os.path.dirname(__file__), "golden", "distill_tokenizer.npz"))
+    CAP = {"noun": ["use the screwdriver to cut the paper up", "sit comfortably on the armchair", "dig a hole with the umbrella handle"],
+           "sth": ["use something to cut the paper up", "sit comfortably on something", "dig a hole with something"]}
+    SP = {"noun": [[[(8, 19)], [(7, 19), (31, 37)]], [[(3, 15), (23, 31)]], [[(20, 35)], [(19, 28)]]],
+          "sth": [[[(4, 13)], [(4, 13)]], [[(19, 28)]], [[(16, 25)], [(15, 25)]]]}
+    TT, B3, Q3, D3, LAY = [2, 1, 2], 3, 12, 16, 2
+    # ---- (a) string captions through the model
+    args = harness.default_args(device="cuda", enc_layers=1, dec_layers=1, num_queries=10)
+    torch.manual_seed(0)
+    model, _, _, _ = toist_amd.build_model(args)
+    model.to(dev).eval()
+    model.transformer.tokenizer = tok
+    samples, _, _, _ = harness.synthetic_batch(3, 96, 128, tokens=8, seed=5)
+    with torch.no_grad():
+        mc_s = model(samples.to(dev), CAP["noun"], encode_and_save=True)
+        out_s = model(samples.to(dev), CAP["noun"], encode_and_save=False, memory_cache=mc_s)
+        enc = tok(CAP["noun"], padding="longest", return_tensors="pt")
+        ids = {"input_ids": enc["input_ids"].to(dev), "attention_mask": enc["attention_mask"].to(dev)}
+        mc_d = model(samples.to(dev), ids, encode_and_save=True)
+        out_d = model(samples.to(dev), ids, encode_and_save=False, memory_cache=mc_d)
+    assert mc_s["text_memory"].shape[0] == 20 and hasattr(mc_s["tokenized"], "char_to_token")
+    assert torch.equal(mc_s["text_attention_mask"], mc_d["text_attention_mask"]) and bool(mc_s["text_attention_mask"][1, 7:].all())      # padding masked
+    assert torch.equal(out_s["pred_logits"], out_d["pred_logits"]) and torch.equal(out_s["pred_boxes"], out_d["pred_boxes"])
+    # ---- (b) the distillation losses on real BatchEncodings against the real reference's numbers
+    enc = {tag: tok(CAP[tag], padding="longest", return_tensors="pt") for tag in ("noun", "sth")}
+
+    def tk_side(tag):
+        LT_ = int(enc[tag]["input_ids"].shape[1])
+
+        def layer(l):
+            return {"pred_logits": formula.tensor(f"dtk.{tag}.logits{l}", (B3, Q3, K), 4.0).to(dev).requires_grad_(tag == "sth"),
+                    "pred_boxes": formula.tensor(f"dtk.{tag}.boxes{l}", (B3, Q3, 4), 0.3, 0.5).to(dev), "proj_queries": torch.zeros(B3, Q3, 4, device=dev), "tokenized": enc[tag]}
+        o = layer(LAY - 1)
+        o["aux_outputs"] = [layer(l) for l in range(LAY - 1)]
+        targets, pms = [], []
+        for i in range(B3):
+            pm = torch.zeros(TT[i], K)
+            pm[:, 1 + i:4 + i] = 1.0 / 3
+            targets.append({"boxes": formula.tensor(f"dtk.{tag}.tbox{i}", (TT[i], 4), 0.25, 0.5).to(dev), "labels": torch.ones(TT[i], dtype=torch.int64, device=dev),
+                            "noun_tokens_positive": SP[tag][i], "dataset_name": f"task_{2 + 3 * i}_train.json"})
+            pms.append(pm)
+        return o, targets, torch.cat(pms).to(dev), {"text_memory": formula.tensor(f"dtk.{tag}.text", (LT_, B3, D3), 2.0).to(dev), "tokenized": enc[tag]}, LT_
+    crit = SetCriterion(types.SimpleNamespace(num_queries=Q3, nsthl2_loss=True, softkd_loss=True), 255, matcher=HungarianMatcher(1, 5, 2), eos_coef=0.1,
+                        losses=["labels", "boxes", "cardinality", "nsthl2", "softkd"], temperature=0.07)
+    (on, tn, pn, mn, LTn), (os_, ts, ps, ms, LTs) = tk_side("noun"), tk_side("sth")
+    losses = crit([mn, ms], [on, os_], [tn, ts], [pn, ps], None)
+    want = {k_[5:]: float(ZT[k_]) for k_ in ZT.files if k_.startswith("pair.")}
+    assert set(losses) == set(want)
+    for k_, v in want.items():
+        assert abs(float(losses[k_]) - v) <= 1e-4 * abs(v) + 1e-6, (k_, float(losses[k_]), v)
+    MEM, HW = 24, 6
+    cc = ClusterCriterion(feature_dim=D3, memory_size=MEM, cluster_num=3, task_count=14, args=types.SimpleNamespace(train_batch_size=B3, fifo_memory=False)).to(dev)
+    cc.feature_bank.copy_(formula.tensor("dtk.bank", (14, MEM, D3), 2.0))
+    cc.cluster_centers.copy_(formula.tensor("dtk.centers", (14, 3, D3), 2.0))
+    cc.full_label.fill_(1)
+    cc.update_count.fill_(100)
+    mn["img_memory"] = formula.tensor("dtk.noun.img", (HW + LTn, B3, D3), 1.5).to(dev)
+    mn["text_memory"] = mn["img_memory"][-LTn:]
+    mc = cc.update_memory(mn, tn, CAP["noun"])
+    np.testing.assert_allclose(cc.feature_bank.cpu().numpy(), ZT["cl.bank_after_update"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(cc.cluster_centers.cpu().numpy(), ZT["cl.centers_after_update"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(mc["img_memory_mod"].cpu().numpy(), ZT["cl.noun.img_memory_mod"], rtol=1e-4, atol=1e-5)
+    ms["img_memory"] = formula.tensor("dtk.sth.img", (HW + LTs, B3, D3), 1.5).to(dev)
+    ms["text_memory"] = ms["img_memory"][-LTs:]
+    mc2, loss = cc(ms, ts, CAP["sth"])
+    np.testing.assert_allclose(mc2["img_memory_mod"].cpu().numpy(), ZT["cl.sth.img_memory_mod"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(cc.cluster_centers.cpu().numpy(), ZT["cl.centers_after_forward"], rtol=1e-4, atol=1e-5)
+    assert abs(float(loss["loss_cluster_feature"]) - float(ZT["cl.loss_cluster_feature"])) <= 1e-4 * float(ZT["cl.loss_cluster_feature"])

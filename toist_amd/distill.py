@@ -141,7 +141,10 @@ class DistillTables:
         for n in sizes:
             offs.append(total)
             total += (n + 15) // 16 * 16
-        self._host = torch.zeros(total, dtype=torch.uint8).pin_memory()
+        self._pin = self.device.type == "cuda"                   # (a host-only instance packs tables in the CPU tests)
+        self._host = torch.zeros(total, dtype=torch.uint8)
+        if self._pin:
+            self._host = self._host.pin_memory()
         self._dev = torch.zeros(total, dtype=torch.uint8, device=self.device)
 
         def views(buf):
@@ -159,7 +162,9 @@ class DistillTables:
         B, L = self.B, self.L
         if len(targets) != B:
             raise ValueError(f"DistillTables holds {B} images; got {len(targets)}")
-        host = out if out is not None else torch.zeros(self._host.numel(), dtype=torch.uint8).pin_memory()
+        host = out if out is not None else torch.zeros(self._host.numel(), dtype=torch.uint8)
+        if out is None and self._pin:
+            host = host.pin_memory()
         host.zero_()
         W_span, W_sth, sub_span, sub_sth, task, group_task, group_off, members = (v.numpy() for v in self._views(host))
         empty = [len(t["boxes"]) == 0 for t in targets]

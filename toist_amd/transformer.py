@@ -294,6 +294,11 @@ class Transformer(nn.Module):
                                    f"(dict with input_ids / attention_mask) instead of strings ({e})")
         return self._tokenizer
 
+    @tokenizer.setter
+    def tokenizer(self, value):
+        """any Hugging Face fast tokenizer (e.g. RobertaTokenizerFast.from_pretrained(<local directory>)); string captions go through it"""
+        self._tokenizer = value
+
     def _next_seed(self):
         self._step += 1
         return self._step
@@ -596,10 +601,14 @@ class Transformer(nn.Module):
 
     def _tokenize(self, text, device):
         if isinstance(text, (list, tuple)) and len(text) and isinstance(text[0], str):
-            tok = self.tokenizer.batch_encode_plus(list(text), padding="longest", return_tensors="pt").to(device)
+            # (reference transformer.py:129: tokenizer.batch_encode_plus(text, padding="longest", return_tensors="pt") -- the same call through __call__,
+            # which every transformers release has; batch_encode_plus itself is gone from transformers 5)
+            tok = self.tokenizer(list(text), padding="longest", return_tensors="pt").to(device)
             return tok
         if isinstance(text, dict) or hasattr(text, "input_ids"):
-            tok = text if isinstance(text, TokenizedText) else TokenizedText({"input_ids": text["input_ids"], "attention_mask": text["attention_mask"]})
+            # a Hugging Face BatchEncoding keeps its identity: the distillation losses look characters up in it (char_to_token)
+            keep = isinstance(text, TokenizedText) or (hasattr(text, "char_to_token") and hasattr(text, "to"))
+            tok = text if keep else TokenizedText({"input_ids": text["input_ids"], "attention_mask": text["attention_mask"]})
             return tok.to(device)
         raise TypeError("captions must be list[str] or a dict with input_ids / attention_mask")
 
