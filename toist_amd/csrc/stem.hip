@@ -29,7 +29,10 @@ constexpr int ST_MF = (ST_NPIX + 15) / 16;     // 19 row blocks
 constexpr int ST_KS = 13;                      // k-steps of 32 (49 taps x 8 channels = 392, padded to 416)
 constexpr int ST_WB_BYTES = ST_KS * 4 * 64 * 16;         // 53 248
 constexpr int ST_PATCH_BYTES = ST_IT * ST_IT * 16;       // 24 336
-constexpr int ST_CONV_BYTES = ST_NPIX * 64 * 2;          // 36 992
+constexpr int ST_CP = 72;                      // elements per pixel of the convolution tile in LDS: 64 channels + 8 of padding (144 bytes).  With 128-byte pixels the
+                                               // 16 lanes of a fragment column wrote 8 bytes each at a 128-byte stride: 16 of the 64 banks, an 8-way conflict on all 12
+                                               // stores per lane and tile (63 % of the LDS-active cycles, profiles/r05_pmc_lds_conflicts.txt); 144 bytes spread them over all banks
+constexpr int ST_CONV_BYTES = ST_NPIX * ST_CP * 2;       // 41 616
 constexpr int ST_LDS = ST_WB_BYTES + ST_PATCH_BYTES + ST_CONV_BYTES;
 
 __global__ __launch_bounds__(512) void stem_kernel(const float* __restrict__ img, const bf16_t* __restrict__ w, const float* __restrict__ shift,
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(512) void stem_kernel(const float* __restrict__ img
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     uint4* const sW = reinterpret_cast<uint4*>(lds);                                   // [ks][nb][lane] B fragments
     bf16_t* const sP = reinterpret_cast<bf16_t*>(lds + ST_WB_BYTES);                   // [39*39][8]
-    bf16_t* const sC = reinterpret_cast<bf16_t*>(lds + ST_WB_BYTES + ST_PATCH_BYTES);  // [289][64]
+    bf16_t* const sC = reinterpret_cast<bf16_t*>(lds + ST_WB_BYTES + ST_PATCH_BYTES);  // [289][ST_CP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
 
     // ---- once per workgroup: weights as B fragments (lane (column c16, k group g) of step ks = tap 4 ks + g, its 8 channels), zeroed patch ----
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(512) void stem_kernel(const float* __restrict__ img
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = inside ? fmaxf(acc[u][nb][j] + sh[nb][j], 0.f) : 0.f;
-                *reinterpret_cast<uint2*>(sC + p * 64 + nb * 16 + g * 4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                *reinterpret_cast<uint2*>(sC + p * ST_CP + nb * 16 + g * 4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
             }
         }
         __syncthreads();
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(512) void stem_kernel(const float* __restrict__ img
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(sC + ((2 * py + dy) * ST_CT + 2 * px + dx) * 64 + c8 * 8);
+                        const uint4 v = *reinterpret_cast<const uint4*>(sC + ((2 * py + dy) * ST_CT + 2 * px + dx) * ST_CP + c8 * 8);
                         asm("v_pk_max_i16 %0, %0, %1" : "+v"(m.x) : "v"(v.x));
                         asm("v_pk_max_i16 %0, %0, %1" : "+v"(m.y) : "v"(v.y));
                         asm("v_pk_max_i16 %0, %0, %1" : "+v"(m.z) : "v"(v.z));
