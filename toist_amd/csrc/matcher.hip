@@ -429,7 +429,11 @@ __global__ __launch_bounds__(MATCH_THREADS) void matcher_kernel(
     }
     if (wave != 0) return;
 
-    const int st = lsap_solve_wave(cw, R, C, du, dv, spc, path, row4col, remaining, col4row, in_sr, in_sc, lane);
+    // (round 6) the register-resident solver for up to 256 columns: Q = 100 queries x T <= Q targets is solved on the transpose, C = Q (82 VGPRs, no spills)
+    int st;
+    if (C <= 128) st = lsap_solve_wave_reg<2>(cw, R, C, du, spc, col4row, in_sr, lane);
+    else if (C <= 256) st = lsap_solve_wave_reg<4>(cw, R, C, du, spc, col4row, in_sr, lane);
+    else st = lsap_solve_wave(cw, R, C, du, dv, spc, path, row4col, remaining, col4row, in_sr, in_sc, lane);
 
     if (lane == 0) status[lb] = st;
     if (st != ST_OK) return;

@@ -326,10 +326,10 @@ __device__ __forceinline__ int nearest_src(int dst, float scale, int in) {
     const int s = (int)floorf((float)dst * scale);
     return s < in - 1 ? s : in - 1;
 }
+template <bool twice>        // twice: OH = 2 H and OW = 2 W (image sides that are multiples of 32: the shift form, no float index arithmetic)
 __global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ fpn, const long long* __restrict__ rows,
                                                             int BQ, int Q, int H, int W, int OH, int OW, int C, bf16_t* __restrict__ out) {
     const int c8 = C >> 3;
-    const bool twice = OH == 2 * H && OW == 2 * W;
     const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
     const long long total = (long long)BQ * OH * OW * c8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -349,9 +349,9 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const bf16_t* __restr
     }
 }
 // din[bq, y, x, :] = sum of the output pixels that read it (the transpose of the map above: 4 of them for the exact doubling)
+template <bool twice>
 __global__ __launch_bounds__(256) void upsample_add_bwd_kernel(const bf16_t* __restrict__ dout, int BQ, int H, int W, int OH, int OW, int C, bf16_t* __restrict__ din) {
     const int c8 = C >> 3;
-    const bool twice = OH == 2 * H && OW == 2 * W;
     const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
     const long long total = (long long)BQ * H * W * c8;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -682,8 +682,12 @@ extern "C" int toist_groupnorm_bwd(const void* dy, const void* y, const void* x,
 
 static int launch_resize_add(const char* what, const void* in, const void* fpn, const int64_t* rows, int n, int Q, int H, int W, int OH, int OW, int C, void* out, void* stream) {
     TOIST_REQUIRE(in && fpn && out && n > 0 && Q > 0 && H > 0 && W > 0 && OH >= H && OW >= W && (C % 8) == 0 && (rows || (n % Q) == 0), "%s: bad shape", what);
-    hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_cap((long long)n * OH * OW * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)in, (const bf16_t*)fpn, (const long long*)rows, n, Q, H, W, OH, OW, C, (bf16_t*)out);
+    if (OH == 2 * H && OW == 2 * W)
+        hipLaunchKernelGGL(upsample_add_kernel<true>, dim3(grid_cap((long long)n * OH * OW * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)in, (const bf16_t*)fpn, (const long long*)rows, n, Q, H, W, OH, OW, C, (bf16_t*)out);
+    else
+        hipLaunchKernelGGL(upsample_add_kernel<false>, dim3(grid_cap((long long)n * OH * OW * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)in, (const bf16_t*)fpn, (const long long*)rows, n, Q, H, W, OH, OW, C, (bf16_t*)out);
     return check_launch(what);
 }
 extern "C" int toist_upsample_add(const void* in, const void* fpn, int BQ, int Q, int H, int W, int C, void* out, void* stream) {
@@ -698,8 +702,12 @@ extern "C" int toist_resize_add(const void* in, const void* fpn, const int64_t* 
 }
 static int launch_resize_add_bwd(const char* what, const void* dout, int BQ, int H, int W, int OH, int OW, int C, void* din, void* stream) {
     TOIST_REQUIRE(dout && din && BQ > 0 && H > 0 && W > 0 && OH >= H && OW >= W && (C % 8) == 0, "%s: bad shape", what);
-    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_cap((long long)BQ * H * W * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)dout, BQ, H, W, OH, OW, C, (bf16_t*)din);
+    if (OH == 2 * H && OW == 2 * W)
+        hipLaunchKernelGGL(upsample_add_bwd_kernel<true>, dim3(grid_cap((long long)BQ * H * W * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dout, BQ, H, W, OH, OW, C, (bf16_t*)din);
+    else
+        hipLaunchKernelGGL(upsample_add_bwd_kernel<false>, dim3(grid_cap((long long)BQ * H * W * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dout, BQ, H, W, OH, OW, C, (bf16_t*)din);
     return check_launch(what);
 }
 extern "C" int toist_upsample_add_bwd(const void* dout, int BQ, int H, int W, int C, void* din, void* stream) {
