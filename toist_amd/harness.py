@@ -113,9 +113,9 @@ def synthetic_distill_batch(batch, height=640, width=640, tokens=16, seed=1000, 
     return out
 
 
-def distillation_step(model, model_noun, criterion, cluster_criterion, weight_dict, batch):
-    """Forward half of engine.py:152-190 (train_one_epoch_distillation): teacher and student encode, memory-bank update
-    and prototype substitution, both decodes, the paired criterion.  Returns (total loss, loss dict)."""
+def distillation_losses(model, model_noun, criterion, cluster_criterion, batch):
+    """Forward half of engine.py:152-190 (train_one_epoch_distillation) up to the loss dict: teacher and student encode, memory-bank update and prototype
+    substitution, both decodes, the paired criterion (+ the cluster losses)."""
     s_noun, s_sth = batch["samples"]
     t_noun, t_sth = batch["targets"]
     c_noun, c_sth = batch["captions"]
@@ -131,7 +131,16 @@ def distillation_step(model, model_noun, criterion, cluster_criterion, weight_di
     out_sth = model(s_sth, k_sth, encode_and_save=False, memory_cache=mc_sth)
     losses = criterion([mc_noun, mc_sth], [out_noun, out_sth], [t_noun, t_sth], batch["positive_map"], batch.get("example_rel"))
     losses.update(loss_cluster)
+    return losses
+
+
+def distillation_step(model, model_noun, criterion, cluster_criterion, weight_dict, batch):
+    """distillation_losses + the weighted total (engine.py:227).  Returns (total loss, loss dict)."""
+    losses = distillation_losses(model, model_noun, criterion, cluster_criterion, batch)
     from .mdetr import weighted_total
+    join = getattr(losses, "join", None)
+    if join is not None:                       # (only inside a capture: part of the dict was produced on a side stream)
+        torch.cuda.current_stream().wait_stream(join)
     total = weighted_total(losses, weight_dict)
     return total, losses
 
@@ -445,16 +454,29 @@ class CapturedDistillStep:
             side["targets"].distill.load_packed(pk["tables"])
 
     def _fwd_bwd_opt(self):
+        """One step.  The backward pass is issued in TWO calls -- the teacher's total (the noun_ keys) first, then everything else (sth_, softkd, nsthl2, cluster:
+        the student's) -- which changes no gradient (the two models' graphs are disjoint: the teacher enters the cross losses detached, mdetr.py:520-599, 668-781)
+        but lets a captured step run the teacher's backward beside the softkd assignment problems, which occupy 24 CUs for ~3.6 ms on a side stream
+        (SetCriterion._forward_pair_static)."""
         from . import kernels
+        from .mdetr import weighted_total
         kernels.SEED_DEV.add_(1000003)
         noun, sth = self.sides
         static = {"samples": [noun["samples"], sth["samples"]], "targets": [noun["targets"], sth["targets"]], "captions": [None, None],
                   "tokenized": [noun["tok"], sth["tok"]], "positive_map": [None, None]}
-        total, _ = distillation_step(self.model, self.model_noun, self.criterion, self.cluster_criterion, self.weight_dict, static)
-        total.backward()
+        losses = distillation_losses(self.model, self.model_noun, self.criterion, self.cluster_criterion, static)
+        w_noun = {k_: v for k_, v in self.weight_dict.items() if k_.startswith("noun_")}
+        w_rest = {k_: v for k_, v in self.weight_dict.items() if not k_.startswith("noun_")}
+        total_noun = weighted_total(losses, w_noun)
+        total_noun.backward()
+        join = getattr(losses, "join", None)
+        if join is not None:
+            torch.cuda.current_stream().wait_stream(join)
+        total_rest = weighted_total(losses, w_rest)
+        total_rest.backward()
         for o in self.optimizers:
             o.step()
-        return total
+        return (total_noun + total_rest).detach()
 
     def step(self, batch=None, packed=None):
         from . import kernels

@@ -593,7 +593,18 @@ class SetCriterion(nn.Module):
             losses["loss_nsthl2"] = torch.where(keep, per_image, torch.zeros_like(per_image)).sum() / keep.sum().clamp(min=1)
         if getattr(self.args, "softkd_loss", False):
             L = sides[0][3]
-            per_layer = self._loss_softkd_static(sides[0], sides[1], sts[0], sts[1])
+            if engine.overlap_enabled():
+                # inside a captured step the softkd block -- cost matrices, 24 LSAP problems on 24 CUs for ~3.6 ms, the KL terms -- goes to a side stream: the
+                # caller (harness.CapturedDistillStep) starts the TEACHER's backward pass beside it (the teacher is detached in softkd / nsthl2: its gradients come
+                # from the noun_ losses alone) and joins `losses.join` before it forms the student's total
+                main = torch.cuda.current_stream()
+                side = engine.side_stream(sides[0][0].device, "softkd")
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    per_layer = self._loss_softkd_static(sides[0], sides[1], sts[0], sts[1])
+                losses.join = side
+            else:
+                per_layer = self._loss_softkd_static(sides[0], sides[1], sts[0], sts[1])
             for l in range(L):
                 losses["loss_softkd" + ("" if l == L - 1 else f"_{l}")] = per_layer[l]
             losses.groups.append((per_layer, {"loss_softkd" + ("" if l == L - 1 else f"_{l}"): l for l in range(L)}))
@@ -803,6 +814,7 @@ class LossDict(dict):
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self.groups = []
+        self.join = None        # a side stream some of the values were produced on: the consumer's stream must wait for it (SetCriterion._forward_pair_static)
 
     def merge(self, other, prefix=""):
         self.update({prefix + k_: v for k_, v in other.items()})
@@ -820,6 +832,9 @@ def weighted_total(loss_dict, weight_dict):
     for stacked, index in getattr(loss_dict, "groups", ()):
         flat = stacked.reshape(-1)
         key = (str(flat.device), flat.numel(), tuple(sorted((i, float(weight_dict[k_])) for k_, i in index.items() if k_ in weight_dict)))
+        covered.update(index)
+        if not key[2]:           # none of the group's keys is weighted: no term (and no backward pass through the group's graph for a sum of zeros)
+            continue
         w = _WEIGHT_VECTORS.get(key)
         if w is None:
             host = torch.zeros(flat.numel(), dtype=torch.float32)
@@ -828,7 +843,6 @@ def weighted_total(loss_dict, weight_dict):
             w = _WEIGHT_VECTORS[key] = host.to(flat.device)
         term = (flat.float() * w).sum()        # (torch.dot would put a rocBLAS launch into the replayed step)
         total = term if total is None else total + term
-        covered.update(index)
     for k_, v in loss_dict.items():
         if k_ in weight_dict and k_ not in covered:
             total = v * weight_dict[k_] if total is None else total + v * weight_dict[k_]
