@@ -353,6 +353,7 @@ def bench_distillation(a, dev, rank, world):
             dt_g, last_g = timed(replayed)
             from toist_amd.matcher import check_lsap_pending
             check_lsap_pending()
+            kernels.xdec_check()      # (the XCD-resident decoder launches of the teacher's backward run beside the softkd solve: no bounded spin may have expired)
             assert cap.captures == 1 and math.isfinite(float(last_g))
             any_rate = graph_rate = round(a.batch * world * a.steps / dt_g, 3)
             launch = ("hipGraph replay, every step a different batch (harness.CapturedDistillStep: 1 graph, %d replays; 4 resident batches with different images, captions, "
