@@ -464,7 +464,11 @@ class CapturedDistillStep:
         noun, sth = self.sides
         static = {"samples": [noun["samples"], sth["samples"]], "targets": [noun["targets"], sth["targets"]], "captions": [None, None],
                   "tokenized": [noun["tok"], sth["tok"]], "positive_map": [None, None]}
-        losses = distillation_losses(self.model, self.model_noun, self.criterion, self.cluster_criterion, static)
+        self.criterion.defer_pair_join = True          # the softkd block may go to a side stream: this method joins it (below) before the student's total
+        try:
+            losses = distillation_losses(self.model, self.model_noun, self.criterion, self.cluster_criterion, static)
+        finally:
+            self.criterion.defer_pair_join = False
         w_noun = {k_: v for k_, v in self.weight_dict.items() if k_.startswith("noun_")}
         w_rest = {k_: v for k_, v in self.weight_dict.items() if not k_.startswith("noun_")}
         total_noun = weighted_total(losses, w_noun)

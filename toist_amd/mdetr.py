@@ -593,7 +593,9 @@ class SetCriterion(nn.Module):
             losses["loss_nsthl2"] = torch.where(keep, per_image, torch.zeros_like(per_image)).sum() / keep.sum().clamp(min=1)
         if getattr(self.args, "softkd_loss", False):
             L = sides[0][3]
-            if engine.overlap_enabled():
+            if engine.overlap_enabled() and getattr(self, "defer_pair_join", False):
+                # (opt-in: the CALLER must wait for `losses.join` before it reads a softkd value -- harness.CapturedDistillStep sets defer_pair_join around its own call; any
+                # other caller gets the whole dict on its own stream)
                 # inside a captured step the softkd block -- cost matrices, 24 LSAP problems on 24 CUs for ~3.6 ms, the KL terms -- goes to a side stream: the
                 # caller (harness.CapturedDistillStep) starts the TEACHER's backward pass beside it (the teacher is detached in softkd / nsthl2: its gradients come
                 # from the noun_ losses alone) and joins `losses.join` before it forms the student's total
