@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/r6/gpu_f.sh <tag>  -- static distillation: tests + the distill bench leg (+ its kernel timeline)
+# usage (GPU box): bash tools/r6/distill_round.sh <tag>  -- static distillation: tests + the distill bench leg (+ its kernel timeline)
 TAG=${1:-r6f}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp

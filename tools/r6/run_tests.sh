@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/r6/gpu_g.sh <tag> <pytest args>
+# usage (GPU box): bash tools/r6/run_tests.sh <tag> <pytest args>
 TAG=${1:-r6g}
 shift
 cd $GRAFT_REPO_ROOT
