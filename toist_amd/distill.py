@@ -181,7 +181,10 @@ class DistillTables:
         if self.pronoun_side:
             for i in range(B):
                 beg = captions[i].find("something")
-                pos = np.arange(tokenized.char_to_token(i, beg), tokenized.char_to_token(i, beg + len("something") - 1) + 1)
+                first, last = (tokenized.char_to_token(i, beg), tokenized.char_to_token(i, beg + len("something") - 1)) if beg >= 0 else (None, None)
+                if first is None or last is None:      # (the reference fails here too: mdetr.py:240-246 indexes with the None it gets back)
+                    raise ValueError(f"pronoun caption {i} ({captions[i]!r}) has no token for the word 'something'")
+                pos = np.arange(first, last + 1)
                 if len(pos) == 0:
                     W_sth[i, :] = np.nan
                 else:

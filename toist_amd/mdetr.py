@@ -670,6 +670,10 @@ class SetCriterion(nn.Module):
             return out.index_copy(0, dst, vals)[:L * cap].view(L, cap, 2)
         kl_tp = _kl_rows(by_target(p_n, m_n), by_target(p_s, m_s))                                      # [L, cap]
         per_layer = (kl_tp.sum(1) + kl_fp.view(L, B * Q).sum(1)) / float(Q * B)
+        # the list path raises when the two sides of a pair hold different numbers of targets; here the counts live on the device: poison instead (NaN losses trip
+        # the loop's finite-loss guard, engine.py:212-215) -- harness.CapturedDistillStep.pack() already refuses such a batch on the host
+        same = (st_n.match_off == st_s.match_off).all()
+        per_layer = torch.where(same, per_layer, torch.full_like(per_layer, float("nan")))
         check_lsap_status(status, defer=True)
         return per_layer
 
