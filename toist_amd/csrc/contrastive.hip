@@ -17,7 +17,7 @@
 
 namespace toist {
 
-static constexpr int CA_THREADS = 256;
+static constexpr int CA_THREADS = 1024;   // 16 waves: the loops below are chains of LDS reads per thread -- four waves per SIMD hide their latency (round 6: 28.9 + 44.6 -> 28.2 + 35.0 us)
 static constexpr int CA_MW = 4;          // 64-bit mask words per target row
 static constexpr int CA_MAX_TOK = 64 * CA_MW;   // 256 = the reference's max_text_len (models/mdetr.py:601-666 pads captions to it at most)
 static constexpr int CA_LDS_MAX = 160 * 1024 - 256;   // dynamic LDS the kernels may ask for (they also hold a few static words)
