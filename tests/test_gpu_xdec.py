@@ -204,3 +204,54 @@ def test_expired_spin_is_loud_and_falls_back_to_the_per_op_launches(dev):
         torch.cuda.synchronize()
         k.xdec_check(raise_on_failure=False)
         k.XDEC_FAILED = False
+
+
+def test_xcd_resident_launch_beside_a_saturating_second_stream(dev):
+    """the launches assume the 32 workgroups of an image are co-resident.  A second stream of the SAME process that saturates HBM (large device
+    copies: workgroups without LDS, so they share CUs with the 147 KB decoder workgroups) must not break that: either the launch succeeds (the XCD barriers just
+    take longer: 0.84 -> 1.6 us in profiles/r05_xcd_barrier.txt) or the inference path notices an expired spin and repeats the decoder on the per-op launches --
+    in both cases the result equals the undisturbed per-op forward."""
+    import warnings
+    from toist_amd import harness
+    from toist_amd import kernels as k
+    from toist_amd import tlayer
+    if not k.xdec_supported(8, 100, 136, 6):
+        pytest.skip("device without 8 XCDs x 32 CUs")
+    model = _model(dev).eval()
+    samples, tok, _, _ = harness.synthetic_batch(8, 256, 480, tokens=16, seed=12, max_targets=4)
+    s_dev, t_dev = samples.to(dev), tok.to(dev)
+
+    def forward(fused):
+        old = tlayer.XDEC
+        tlayer.XDEC = fused
+        try:
+            with torch.no_grad():
+                mc = model(s_dev, t_dev, encode_and_save=True)
+                return model(s_dev, t_dev, encode_and_save=False, memory_cache=mc)["pred_logits"].float().clone()
+        finally:
+            tlayer.XDEC = old
+    ref = forward(False)
+    torch.cuda.synchronize()
+    big = torch.empty(1 << 27, dtype=torch.float32, device=dev)            # 512 MB: one copy = 1 GB of HBM traffic
+    dst = torch.empty_like(big)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    launches = k.XDEC_LAUNCHES
+    with torch.cuda.stream(side):
+        for _ in range(60):                                                  # ~ 15 ms of saturated HBM beside the forward pass
+            dst.copy_(big, non_blocking=True)
+    try:
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            got = forward(True)
+        torch.cuda.synchronize()
+        assert k.XDEC_LAUNCHES > launches                                    # the fused launch was issued beside the copies
+        fell_back = any("per-op" in str(m.message) for m in seen)
+        assert fell_back == k.XDEC_FAILED
+        assert torch.isfinite(got).all()
+        assert float((got - ref).norm() / ref.norm()) < 1.5e-2, float((got - ref).norm() / ref.norm())
+    finally:
+        k.XDEC_FAILED = False
+        torch.cuda.synchronize()
+        k.xdec_check(raise_on_failure=False)
+        k.XDEC_FAILED = False
